@@ -1,0 +1,496 @@
+"""ORACLE — test infrastructure only.  NOT part of the product path.
+
+A plain PyTorch-CPU, functional restatement of the SAST hot path (SURVEY.md
+§8a rows a1..a13): STP scoring / window+token selection, masked sparse window
+self-attention (MS-WSA) in the reference's padded top-k formulation, the
+window/grid partitions, GLU-MLP, conv-downsample + LayerNorm, ConvLSTM and the
+YOLOX PAFPN.  Every function cites the reference file:line it follows.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module; `sast_amd/` never does (tests/test_no_oracle_in_product.py
+enforces it).
+
+Parity pin: the reference ships no tests or golden vectors, so
+this oracle is pinned against outputs of the reference itself, imported in the
+build container by `tests/golden/make_golden.py`; the captured vectors live in
+`tests/golden/*.npz` and `tests/test_oracle_golden.py` checks the oracle against
+them (indices exact, floating point `torch.equal` or <=1e-6).
+
+Parameters are passed as a flat dict keyed by the reference's state_dict names
+(SURVEY.md App. D-10), so a reference checkpoint can be used unchanged.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+@dataclass
+class AttnCfg:
+    """attention_cfg keys read by SAST_block.__init__ (SAST.py:34-44,60,79-80)."""
+    partition_size: Tuple[int, int]
+    dim_head: int = 32
+    norm_eps: float = 1e-5
+    amp: float = 2e-4
+    bounce: float = 1e-3
+    enable_cb: bool = False
+
+
+@dataclass
+class BackboneCfg:
+    """mdl_config keys read by RNNDetector.__init__ (sast_rnn.py:68-130)."""
+    in_res_hw: Tuple[int, int]
+    partition_size: Tuple[int, int]
+    input_channels: int = 20
+    embed_dim: int = 64
+    dim_multiplier: Tuple[int, ...] = (1, 2, 4, 8)
+    num_blocks: Tuple[int, ...] = (1, 1, 1, 1)
+    patch_size: int = 4
+    attn: AttnCfg = field(init=False)
+    amp: float = 2e-4
+    bounce: float = 1e-3
+    enable_cb: bool = False
+
+    def __post_init__(self):
+        self.attn = AttnCfg(partition_size=tuple(self.partition_size), amp=self.amp,
+                            bounce=self.bounce, enable_cb=self.enable_cb)
+
+    @property
+    def stage_dims(self):
+        return [self.embed_dim * m for m in self.dim_multiplier]
+
+
+# --------------------------------------------------------------------------- a1
+def non_zero_ratio(x: Tensor) -> Tensor:
+    """sast_rnn.py:45-60.  (B,Cin,H,W) any dtype -> (B,4,Cin) fp32."""
+    pooled = []
+    cur = F.max_pool2d(x.float(), kernel_size=4, stride=4)
+    pooled.append(cur)
+    for _ in range(3):
+        cur = F.max_pool2d(cur, kernel_size=2, stride=2)
+        pooled.append(cur)
+    out = []
+    for p in pooled:
+        cnt = torch.sum(torch.sum(p != 0, dtype=torch.int16, dim=[2]), dtype=torch.int16, dim=-1)
+        out.append(x.shape[0] / p.numel() * cnt.float())
+    return torch.stack(out, dim=1)
+
+
+# --------------------------------------------------------------------------- a3
+def position_embedding_sine(H: int, W: int, C: int, temperature: float = 10000.0) -> Tensor:
+    """sast_rnn.py:180-213 with num_pos_feats=C/2, normalize=True, scale=2pi.  -> (1,H,W,C)."""
+    nf = C // 2
+    ones = torch.ones(1, H, W, dtype=torch.bool)
+    ye = ones.cumsum(1, dtype=torch.float32)
+    xe = ones.cumsum(2, dtype=torch.float32)
+    eps, scale = 1e-6, 2 * math.pi
+    ye = (ye - 0.5) / (ye[:, -1:, :] + eps) * scale
+    xe = (xe - 0.5) / (xe[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(nf, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / nf)
+    px = xe[:, :, :, None] / dim_t
+    py = ye[:, :, :, None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3)
+
+
+# --------------------------------------------------------------------------- a4
+def window_partition(x: Tensor, hw: Tuple[int, int]) -> Tensor:
+    """ops.py:189-195.  (B,H,W,C) -> (B*N,h,w,C), windows are contiguous h x w tiles."""
+    B, H, W, C = x.shape
+    h, w = hw
+    assert H % h == 0 and W % w == 0
+    return x.reshape(B, H // h, h, W // w, w, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, h, w, C)
+
+
+def window_reverse(win: Tensor, hw: Tuple[int, int], img: Tuple[int, int]) -> Tensor:
+    """ops.py:198-203."""
+    H, W = img
+    h, w = hw
+    C = win.shape[-1]
+    return win.reshape(-1, H // h, W // w, h, w, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, H, W, C)
+
+
+def grid_partition(x: Tensor, hw: Tuple[int, int]) -> Tensor:
+    """ops.py:206-212.  A grid group takes one token from each of the h x w coarse cells."""
+    B, H, W, C = x.shape
+    h, w = hw
+    assert H % h == 0 and W % w == 0
+    return x.reshape(B, h, H // h, w, W // w, C).permute(0, 2, 4, 1, 3, 5).reshape(-1, h, w, C)
+
+
+def grid_reverse(win: Tensor, hw: Tuple[int, int], img: Tuple[int, int]) -> Tensor:
+    """ops.py:215-220."""
+    H, W = img
+    h, w = hw
+    C = win.shape[-1]
+    return win.reshape(-1, H // h, W // w, h, w, C).permute(0, 3, 1, 4, 2, 5).reshape(-1, H, W, C)
+
+
+# --------------------------------------------------------------------------- a2
+def conv_downsample_cf2cl(x: Tensor, p: Params, pre: str, factor: int) -> Tensor:
+    """ops.py:54-95: conv k=2f-1, stride f, replicate pad f-1, no bias -> NHWC -> LayerNorm(1e-5)."""
+    w = p[pre + "conv.weight"]
+    pad = (2 * (factor - 1) + 1) // 2
+    y = F.conv2d(F.pad(x, (pad, pad, pad, pad), mode="replicate"), w, None, stride=factor)
+    y = y.permute(0, 2, 3, 1).contiguous()
+    return F.layer_norm(y, (y.shape[-1],), p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5)
+
+
+# --------------------------------------------------------------------------- a6-a8
+def select_windows(scores: Tensor, B: int, N: int, T: int, bounce: float) -> Tensor:
+    """SAST.py:84-89 + :258-267.  scores (B,N,T,C) -> flat ascending window ids (M,)."""
+    nw = (torch.norm(scores, dim=[2, 3], p=1) / T).softmax(-1).view(B, N)
+    thr = (1 / N) / (1 + bounce)
+    nz = torch.nonzero(nw >= thr)
+    if B == 1:
+        return nz[:, 1]
+    return nz[:, 0] * N + nz[:, 1]
+
+
+def select_tokens(scores: Tensor, index_window: Tensor, B: int, N: int, T: int, bounce: float):
+    """SAST.py:91-96 + :270-281.  -> index_token (M*Kmax,), asy_index (sum K,), K (M,)."""
+    nt = torch.norm(scores, dim=[3], p=1).view(B * N, -1)[index_window].softmax(-1)
+    thr = (1 / T) / (1 + bounce)
+    gt = nt >= thr
+    K = gt.sum(dim=1)
+    top = torch.topk(nt, k=int(K.max()), dim=1, largest=True, sorted=False)[1]
+    base = torch.arange(0, nt.shape[0] * nt.shape[1], nt.shape[1]).view(-1, 1)
+    nz = torch.nonzero(gt)
+    asy = nz[:, 0] * nt.shape[1] + nz[:, 1]
+    return (top + base).view(-1), asy, K
+
+
+def selection_margins(scores: Tensor, B: int, N: int, T: int, bounce: float):
+    """relative distance of every softmax value to its threshold; test diagnostics."""
+    nw = (torch.norm(scores, dim=[2, 3], p=1) / T).softmax(-1).view(B, N)
+    thr_n = torch.tensor((1 / N) / (1 + bounce), dtype=nw.dtype)
+    nt = torch.norm(scores, dim=[3], p=1).view(B * N, -1).softmax(-1)
+    thr_t = torch.tensor((1 / T) / (1 + bounce), dtype=nt.dtype)
+    return ((nw - thr_n).abs() / thr_n), ((nt - thr_t).abs() / thr_t)
+
+
+# --------------------------------------------------------------------------- a9
+def mlp_glu(x: Tensor, p: Params, pre: str) -> Tensor:
+    """ops.py:111-175: Linear(C->2*inner) -> value * GELU_erf(gate) -> Linear(inner->C)."""
+    y = F.linear(x, p[pre + "net.0.proj.weight"], p[pre + "net.0.proj.bias"])
+    val, gate = torch.tensor_split(y, 2, dim=-1)
+    return F.linear(val * F.gelu(gate), p[pre + "net.2.weight"], p[pre + "net.2.bias"])
+
+
+def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: AttnCfg) -> Tensor:
+    """SAST.py:199-255 (padded top-k formulation, column mask -1e4).  x (B*N,T,C) -> same."""
+    index_window, index_token, padding_index, asy_index, _K = idx
+    M = len(index_window)
+    shape = x.shape
+    Nw, C = x.shape[0], x.shape[-1]
+    heads, dh = C // cfg.dim_head, cfg.dim_head
+    x = F.layer_norm(x.view(Nw, -1, C), (C,), p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.norm_eps)
+    if len(index_token) == 0:
+        return x.view(*shape)
+    X = x.clone()
+    x = x[index_window].view(-1, C)
+    XX = x.clone()
+    x[asy_index] = F.layer_norm(x[asy_index], (C,), p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.norm_eps)
+    shortcut = x[asy_index]
+    x = x[index_token].view(M, -1, C)
+
+    qkv = F.linear(x, p[pre + "qkv.weight"], p[pre + "qkv.bias"])
+    q, k, v = qkv.view(M, -1, heads, dh * 3).transpose(1, 2).chunk(3, dim=3)
+    attn = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
+    Kmax = q.shape[2]
+    amap = torch.zeros((XX.shape[0], Kmax, heads), dtype=attn.dtype)
+    amap[index_token] = attn.transpose(1, 3).reshape(-1, Kmax, heads)
+    amap[padding_index] = -1e4
+    attn = amap[index_token].view(M, -1, Kmax, heads).transpose(1, 3)
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2)
+    x = F.linear(x.reshape(M, -1, C), p[pre + "proj.weight"], p[pre + "proj.bias"])
+
+    XX[index_token] = x.view(-1, C)
+    x = XX[asy_index]
+    x = shortcut + x * p[pre + "ls1.gamma"]
+    shortcut = x
+    x = mlp_glu(x, p, pre + "mlp.")
+    if cfg.enable_cb:  # SAST.py:240-246
+        tX, tXX = torch.zeros_like(X), torch.zeros_like(XX)
+        tXX[asy_index] = x
+        tX[index_window] = tXX.view(M, -1, C)
+        tX = tX.view(B, -1, C)
+        tX = (0.5 * tX + (1 - 0.5) * tX.mean(dim=1, keepdim=True)).view(*shape)
+        x = tX[index_window].view(-1, C)[asy_index]
+    x = shortcut + x * p[pre + "ls2.gamma"]
+    XX[asy_index] = x.view(-1, C)
+    XX[padding_index] = X[index_window].view(-1, C)[padding_index]
+    X[index_window] = XX.view(M, -1, C)
+    return X.view(*shape)
+
+
+# --------------------------------------------------------------------------- a5,a10
+def _padding_index(index_token: Tensor, asy_index: Tensor) -> Tensor:
+    return index_token[torch.isin(index_token, asy_index, assume_unique=True, invert=True)]
+
+
+def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnCfg,
+               index_list=None, first_block: bool = True, return_scores: bool = False):
+    """SAST.py:98-164.  x (B,H,W,C) NHWC, pe (1,H,W,C), r (B,20) -> (x, index_count, [list1,list2])."""
+    B, H, W, C = x.shape
+    h, w = cfg.partition_size
+    T = h * w
+    N = H * W // T
+    count = 0
+    x = x + pe[:, :H, :W, :].repeat(B, 1, 1, 1)
+    x = window_partition(x, (h, w)).view(B, N, -1, C)
+    scores = None
+    if first_block:
+        scale = F.linear(r + 1e-6, torch.exp(p[pre + "to_controls.weight"]))[:, None, None, :]
+        scores = F.relu(F.linear(x, p[pre + "to_scores.weight"], p[pre + "to_scores.bias"]))
+        weight = scale.sigmoid() * scores.sigmoid()
+        x = (weight * x).view(B * N, -1, C)
+        scale = cfg.amp / scale
+        scale[scale == torch.inf] = 0
+        scores = scale * scores
+        iw = select_windows(scores, B, N, T, cfg.bounce)
+        it, asy, K = select_tokens(scores, iw, B, N, T, cfg.bounce)
+        list1 = [iw, it, _padding_index(it, asy), asy, K]
+    else:
+        x = x.view(B * N, -1, C)
+        list1, list2 = index_list
+    if len(list1[1]):
+        x = ms_wsa(x, list1, B, p, pre + "win_attn.", cfg)
+    x = window_reverse(x, (h, w), (H, W))
+    count += len(list1[3]) // B
+    scores_win = scores
+    if first_block:
+        scores = window_reverse(scores.view_as(x), (h, w), (H, W))
+        scores = grid_partition(scores, (h, w)).view(B, N, -1, C)
+        iw = select_windows(scores, B, N, T, cfg.bounce)
+        it, asy, K = select_tokens(scores, iw, B, N, T, cfg.bounce)
+        list2 = [iw, it, _padding_index(it, asy), asy, K]
+    x = grid_partition(x.view(B, H, W, C), (h, w)).view(B * N, -1, C)
+    if len(list2[1]):
+        x = ms_wsa(x, list2, B, p, pre + "grid_attn.", cfg)
+    x = grid_reverse(x, (h, w), (H, W))
+    count += len(list2[3]) // B
+    if return_scores:
+        return x, count, [list1, list2], scores_win
+    return x, count, [list1, list2]
+
+
+# --------------------------------------------------------------------------- a12
+def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: str):
+    """rnn.py:36-69 with dws_conv=False.  NCHW."""
+    C = x.shape[1]
+    if hc is None:
+        hc = (torch.zeros_like(x), torch.zeros_like(x))
+    h0, c0 = hc
+    mix = F.conv2d(torch.cat((x, h0), dim=1), p[pre + "conv1x1.weight"], p[pre + "conv1x1.bias"])
+    gates, cin = torch.tensor_split(mix, [C * 3], dim=1)
+    f, i, o = torch.tensor_split(torch.sigmoid(gates), 3, dim=1)
+    c1 = f * c0 + i * torch.tanh(cin)
+    h1 = o * torch.tanh(c1)
+    return h1, c1
+
+
+# --------------------------------------------------------------------------- a11
+def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: BackboneCfg, stage_idx: int,
+                   pe: Optional[Tensor] = None):
+    """sast_rnn.py:265-287 (enable_masking False).  NCHW in -> (h NCHW, (h,c), P, index lists)."""
+    factor = cfg.patch_size if stage_idx == 0 else 2
+    x = conv_downsample_cf2cl(x, p, pre + "downsample_cf2cl.", factor)
+    B, H, W, C = x.shape
+    if pe is None:
+        pe = position_embedding_sine(H, W, C)
+    P = 0
+    lists = None
+    all_lists = []
+    for bi in range(cfg.num_blocks[stage_idx]):
+        x, cnt, lists = sast_block(x, pe, r, p, f"{pre}att_blocks.{bi}.att.", cfg.attn,
+                                   index_list=lists, first_block=(bi == 0))
+        all_lists.append(lists)
+        P += cnt
+    x = x.permute(0, 3, 1, 2).contiguous()
+    hc = conv_lstm(x, state, p, pre + "lstm.")
+    return hc[0], hc, P, all_lists
+
+
+def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "", return_lists: bool = False):
+    """sast_rnn.py:144-162.  x (B,20,H,W) -> ({1..4: h}, states, P)."""
+    if prev_states is None:
+        prev_states = [None] * 4
+    r = non_zero_ratio(x)
+    x = x.float()
+    out, states, P, lists = {}, [], [], []
+    for s in range(4):
+        x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s)
+        states.append(st)
+        out[s + 1] = st[0]
+        P.append(cnt)
+        lists.append(ls)
+    if return_lists:
+        return out, states, P, lists
+    return out, states, P
+
+
+# --------------------------------------------------------------------------- a13
+def base_conv(x: Tensor, p: Params, pre: str, stride: int, training: bool, bufs: Optional[Params] = None):
+    """network_blocks.py:29-54: conv(no bias, same pad) + BatchNorm2d(eps 1e-5, mom 0.1) + SiLU."""
+    w = p[pre + "conv.weight"]
+    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2)
+    src = bufs if bufs is not None else p
+    rm, rv = src.get(pre + "bn.running_mean"), src.get(pre + "bn.running_var")
+    if training and bufs is None:  # do not mutate the caller's buffers unless asked to
+        rm = rm.clone() if rm is not None else None
+        rv = rv.clone() if rv is not None else None
+    y = F.batch_norm(y, rm, rv, p[pre + "bn.weight"], p[pre + "bn.bias"], training, 0.1, 1e-5)
+    return F.silu(y)
+
+
+def csp_layer(x: Tensor, p: Params, pre: str, n: int, training: bool, bufs=None):
+    """network_blocks.py:104-141 with shortcut=False, expansion 0.5, Bottleneck expansion 1.0."""
+    x1 = base_conv(x, p, pre + "conv1.", 1, training, bufs)
+    x2 = base_conv(x, p, pre + "conv2.", 1, training, bufs)
+    for i in range(n):
+        x1 = base_conv(base_conv(x1, p, f"{pre}m.{i}.conv1.", 1, training, bufs), p,
+                       f"{pre}m.{i}.conv2.", 1, training, bufs)
+    return base_conv(torch.cat((x1, x2), dim=1), p, pre + "conv3.", 1, training, bufs)
+
+
+def pafpn(feats: Dict[int, Tensor], p: Params, pre: str = "", depth: float = 0.67,
+          in_stages=(2, 3, 4), training: bool = True, bufs=None):
+    """yolo_pafpn.py:109-139."""
+    n = round(3 * depth)
+    x2, x1, x0 = (feats[s] for s in in_stages)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="nearest-exact")
+    fpn0 = base_conv(x0, p, pre + "lateral_conv0.", 1, training, bufs)
+    f0 = csp_layer(torch.cat([up(fpn0), x1], 1), p, pre + "C3_p4.", n, training, bufs)
+    fpn1 = base_conv(f0, p, pre + "reduce_conv1.", 1, training, bufs)
+    pan2 = csp_layer(torch.cat([up(fpn1), x2], 1), p, pre + "C3_p3.", n, training, bufs)
+    d1 = base_conv(pan2, p, pre + "bu_conv2.", 2, training, bufs)
+    pan1 = csp_layer(torch.cat([d1, fpn1], 1), p, pre + "C3_n3.", n, training, bufs)
+    d0 = base_conv(pan1, p, pre + "bu_conv1.", 2, training, bufs)
+    pan0 = csp_layer(torch.cat([d0, fpn0], 1), p, pre + "C3_n4.", n, training, bufs)
+    return pan2, pan1, pan0
+
+
+# --------------------------------------------------------------------------- init helpers
+def mlp_inner_dim(C: int, ratio: int = 4) -> int:
+    """ops.py:157."""
+    return math.floor(int(C * ratio) * 2 / 3 / 32) * 32
+
+
+def init_backbone_params(cfg: BackboneCfg, seed: int = 0, ls_init: float = 1e-5) -> Params:
+    """random-init parameter dict with the reference's names/shapes.
+
+    The draw order is NOT the reference's (App. D-15); weights always travel by dict, never by seed.
+    """
+    g = torch.Generator().manual_seed(seed)
+
+    def U(shape, fan_in):
+        b = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(shape, generator=g) * 2 - 1) * b
+
+    p: Params = {}
+    cin = cfg.input_channels
+    for s, C in enumerate(cfg.stage_dims):
+        f = cfg.patch_size if s == 0 else 2
+        k = 2 * (f - 1) + 1
+        pre = f"stages.{s}."
+        p[pre + "downsample_cf2cl.conv.weight"] = U((C, cin, k, k), cin * k * k)
+        p[pre + "downsample_cf2cl.norm.weight"] = torch.ones(C)
+        p[pre + "downsample_cf2cl.norm.bias"] = torch.zeros(C)
+        inner = mlp_inner_dim(C)
+        for bi in range(cfg.num_blocks[s]):
+            a = f"{pre}att_blocks.{bi}.att."
+            for m in ("win_attn.", "grid_attn."):
+                p[a + m + "qkv.weight"] = U((3 * C, C), C)
+                p[a + m + "qkv.bias"] = U((3 * C,), C)
+                p[a + m + "proj.weight"] = U((C, C), C)
+                p[a + m + "proj.bias"] = U((C,), C)
+                for nm in ("norm1", "norm2"):
+                    p[a + m + nm + ".weight"] = torch.ones(C)
+                    p[a + m + nm + ".bias"] = torch.zeros(C)
+                p[a + m + "ls1.gamma"] = torch.full((C,), ls_init)
+                p[a + m + "ls2.gamma"] = torch.full((C,), ls_init)
+                p[a + m + "mlp.net.0.proj.weight"] = U((2 * inner, C), C)
+                p[a + m + "mlp.net.0.proj.bias"] = U((2 * inner,), C)
+                p[a + m + "mlp.net.2.weight"] = U((C, inner), inner)
+                p[a + m + "mlp.net.2.bias"] = U((C,), inner)
+            if bi == 0:
+                p[a + "to_scores.weight"] = U((C, C), C)
+                p[a + "to_scores.bias"] = U((C,), C)
+                p[a + "to_controls.weight"] = torch.ones(C, 20)
+        p[pre + "lstm.conv1x1.weight"] = U((4 * C, 2 * C, 1, 1), 2 * C)
+        p[pre + "lstm.conv1x1.bias"] = U((4 * C,), 2 * C)
+        cin = C
+    return p
+
+
+def pafpn_conv_list(in_channels=(128, 256, 512), depth: float = 0.67):
+    """(name, cin, cout, ksize, stride) for all conv-BN-SiLU units of YOLOPAFPN (yolo_pafpn.py:50-98)."""
+    c0, c1, c2 = in_channels
+    n = round(3 * depth)
+    out = [("lateral_conv0", c2, c1, 1, 1)]
+
+    def csp(name, ci, co):
+        hid = int(co * 0.5)
+        l = [(f"{name}.conv1", ci, hid, 1, 1), (f"{name}.conv2", ci, hid, 1, 1)]
+        for i in range(n):
+            l += [(f"{name}.m.{i}.conv1", hid, hid, 1, 1), (f"{name}.m.{i}.conv2", hid, hid, 3, 1)]
+        l.append((f"{name}.conv3", 2 * hid, co, 1, 1))
+        return l
+
+    out += csp("C3_p4", 2 * c1, c1)
+    out.append(("reduce_conv1", c1, c0, 1, 1))
+    out += csp("C3_p3", 2 * c0, c0)
+    out.append(("bu_conv2", c0, c0, 3, 2))
+    out += csp("C3_n3", 2 * c0, c1)
+    out.append(("bu_conv1", c1, c1, 3, 2))
+    out += csp("C3_n4", 2 * c1, c2)
+    return out
+
+
+def init_pafpn_params(in_channels=(128, 256, 512), depth: float = 0.67, seed: int = 1):
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, ci, co, k, _s in pafpn_conv_list(in_channels, depth):
+        b = 1.0 / math.sqrt(ci * k * k)
+        p[name + ".conv.weight"] = (torch.rand((co, ci, k, k), generator=g) * 2 - 1) * b
+        p[name + ".bn.weight"] = torch.ones(co)
+        p[name + ".bn.bias"] = torch.zeros(co)
+        p[name + ".bn.running_mean"] = torch.zeros(co)
+        p[name + ".bn.running_var"] = torch.ones(co)
+    return p
+
+
+def proxy_loss(outs: Sequence[Tensor]) -> Tensor:
+    """sum_k mean(out_k^2)."""
+    return sum((o.float() ** 2).mean() for o in outs)
+
+
+def synthetic_events(B: int, hw: Tuple[int, int], seed: int = 0, sparsity: float = 0.0,
+                     channels: int = 20) -> Tensor:
+    """benchmark.py:58-60 protocol: (rand > sparsity).int(), already-padded size."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, channels, hw[0], hw[1], generator=g) > sparsity).int()
+
+
+def count_events(B: int, hw: Tuple[int, int], seed: int = 0, density: float = 0.1,
+                 valid_hw: Optional[Tuple[int, int]] = None, channels: int = 20) -> Tensor:
+    """dataset-like count-valued input: uint8 counts 1..10 at `density`, zero pad region."""
+    g = torch.Generator().manual_seed(seed)
+    on = torch.rand(B, channels, hw[0], hw[1], generator=g) < density
+    val = torch.randint(1, 11, (B, channels, hw[0], hw[1]), generator=g)
+    x = (on * val).to(torch.uint8)
+    if valid_hw is not None:
+        x[:, :, valid_hw[0]:, :] = 0
+        x[:, :, :, valid_hw[1]:] = 0
+    return x

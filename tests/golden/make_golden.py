@@ -1,0 +1,293 @@
+"""Generate the golden fixtures in tests/golden/ by running the upstream reference.
+
+Runs ONLY in the build container (needs /root/reference, never present on the GPU
+box).  It imports the reference (with the omegaconf/strenum stubs of
+`_ref_import.py`), feeds it seeded inputs and parameters drawn by
+`oracle.sast_oracle.init_*_params(seed)` (so fixtures do not have to carry the
+weights), and stores inputs + expected outputs as .npz.  Fixtures are data only.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import _ref_import as RI  # noqa: E402
+from oracle import sast_oracle as O  # noqa: E402
+
+torch.set_num_threads(8)
+MIN_MARGIN = 3e-5  # >= 300x the fp32 rounding noise on tok/softmax (~1e-7)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def load_into(module, params, prefix=""):
+    """copy an oracle param dict into a reference module (handles the aliased sub_layers.* keys)."""
+    sd = module.state_dict()
+    new = {}
+    for k in sd:
+        kk = k
+        for a, b in ((".sub_layers.0.", ".ls1."), (".sub_layers.2.", ".norm2."),
+                     (".sub_layers.3.", ".mlp."), (".sub_layers.4.", ".ls2.")):
+            kk = kk.replace(a, b)
+        if kk.endswith("num_batches_tracked"):
+            new[k] = sd[k]
+            continue
+        new[k] = params[prefix + kk].clone()
+    module.load_state_dict(new, strict=True)
+
+
+def param_checksum(params):
+    return float(sum(float(v.double().abs().sum()) for v in params.values()))
+
+
+def lists_to_np(lists, tag):
+    out = {}
+    for li, l in enumerate(lists):
+        for name, t in zip(("index_window", "index_token", "padding_index", "asy_index", "K"), l):
+            out[f"{tag}l{li}_{name}"] = np_(t).astype(np.int64)
+    return out
+
+
+def block_params(C, seed, ls_init, nblocks=1):
+    cfg = O.BackboneCfg(in_res_hw=(64, 80), partition_size=(4, 5), embed_dim=C, num_blocks=(nblocks, 1, 1, 1))
+    p = O.init_backbone_params(cfg, seed=seed, ls_init=ls_init)
+    return {k[len("stages.0."):]: v for k, v in p.items() if k.startswith("stages.0.att_blocks.")}
+
+
+def gen_nzr(ref):
+    x = O.count_events(2, (64, 96), seed=3, density=0.02)
+    r = ref.sast_rnn.non_zero_ratio(x)
+    assert torch.equal(r, O.non_zero_ratio(x))
+    xb = O.synthetic_events(2, (64, 96), seed=4, sparsity=0.97)
+    rb = ref.sast_rnn.non_zero_ratio(xb)
+    np.savez_compressed(os.path.join(HERE, "nzr.npz"), x=np_(x), r=np_(r), xb=np_(xb).astype(np.int32), rb=np_(rb))
+    print("nzr ok")
+
+
+def run_ref_block(ref, params, x, r, pe_mod, acfg, first=True, index_list=None, pre="att_blocks.0.att."):
+    blk = ref.SAST.SAST_block(x.shape[-1], RI.to_cfg(acfg), first_block=first)
+    load_into(blk, params, pre)
+    xx = x.clone().requires_grad_(True)
+    out, cnt, lists = blk(xx, pe_mod, r, index_list)
+    return blk, xx, out, cnt, lists
+
+
+def gen_block(ref, name, B, amp, enable_cb=False, seed0=0):
+    C, H, W, part = 64, 16, 20, (4, 5)
+    acfg = dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
+                mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=0.5, enable_CB=enable_cb, AMP=amp, BOUNCE=1e-3)
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb)
+    pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    pe = O.position_embedding_sine(H, W, C)
+    assert torch.equal(pe, pe_mod.pos_embedding)
+    for seed in range(seed0, seed0 + 200):
+        g = torch.Generator().manual_seed(1000 + seed)
+        x = torch.randn(B, H, W, C, generator=g)
+        r = torch.rand(B, 20, generator=g) * 0.05
+        params = block_params(C, seed, 0.5)
+        blk, xx, out, cnt, lists = run_ref_block(ref, params, x, r, pe_mod, acfg)
+        # margins via the oracle's scores
+        _o, _c, _l, sc = O.sast_block(x, pe, r, params, "att_blocks.0.att.", ocfg, return_scores=True)
+        T = part[0] * part[1]
+        N = H * W // T
+        mw, mt = O.selection_margins(sc, B, N, T, 1e-3)
+        scg = O.grid_partition(O.window_reverse(sc.view(B * N, part[0], part[1], C), part, (H, W)), part).view(B, N, -1, C)
+        mw2, mt2 = O.selection_margins(scg, B, N, T, 1e-3)
+        margin = float(min(mw.min(), mt.min(), mw2.min(), mt2.min()))
+        kept = [len(l[3]) for l in lists]
+        if margin >= MIN_MARGIN and all(0 < k for k in kept):
+            break
+    else:
+        raise RuntimeError("no seed with a safe margin")
+    loss = (out ** 2).mean()
+    loss.backward()
+    # oracle must agree
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    oo, oc, ol = O.sast_block(xo, pe, r, po, "att_blocks.0.att.", ocfg)
+    assert oc == cnt
+    for a, b in zip(sum(lists, []), sum(ol, [])):
+        assert torch.equal(a, b)
+    assert torch.equal(oo, out), float((oo - out).abs().max())
+    (oo ** 2).mean().backward()
+    assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
+    d = dict(x=np_(x), r=np_(r), out=np_(out), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
+             margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)),
+             enable_cb=np.int64(enable_cb))
+    d.update(lists_to_np(lists, ""))
+    named = dict(blk.named_parameters())
+    for k, v in named.items():
+        if "sub_layers" in k:
+            continue
+        gk = "g_" + k
+        gv = v.grad if v.grad is not None else torch.zeros_like(v)
+        ref_g = po["att_blocks.0.att." + k].grad
+        assert torch.allclose(ref_g, gv, atol=1e-7, rtol=1e-4), k
+        d[gk] = np_(gv)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(f"{name}: seed {seed} margin {margin:.2e} kept {kept} of {B * H * W} count {cnt}")
+
+
+def gen_two_blocks(ref):
+    """one stage with num_blocks=2: second block reuses the first block's index lists (SAST.py:124-128)."""
+    C, H, W, part = 64, 16, 20, (4, 5)
+    amp = 2e-2
+    acfg = dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
+                mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=0.5, enable_CB=False, AMP=amp, BOUNCE=1e-3)
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3)
+    pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    pe = O.position_embedding_sine(H, W, C)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(2, H, W, C, generator=g)
+    r = torch.rand(2, 20, generator=g) * 0.05
+    params = block_params(C, 5, 0.5, nblocks=2)
+    _b, _xx, o1, c1, l1 = run_ref_block(ref, params, x, r, pe_mod, acfg, True, None, "att_blocks.0.att.")
+    _b, _xx, o2, c2, l2 = run_ref_block(ref, params, o1.detach(), r, pe_mod, acfg, False, l1, "att_blocks.1.att.")
+    a1, ac1, al1 = O.sast_block(x, pe, r, params, "att_blocks.0.att.", ocfg)
+    a2, ac2, al2 = O.sast_block(a1, pe, r, params, "att_blocks.1.att.", ocfg, index_list=al1, first_block=False)
+    assert torch.equal(a2, o2) and ac2 == c2
+    d = dict(x=np_(x), r=np_(r), out1=np_(o1), out2=np_(o2), count1=np.int64(c1), count2=np.int64(c2),
+             seed=np.int64(5), amp=np.float64(amp), param_checksum=np.float64(param_checksum(params)))
+    d.update(lists_to_np(l1, ""))
+    np.savez_compressed(os.path.join(HERE, "stage_two_blocks.npz"), **d)
+    print("two blocks ok", c1, c2)
+
+
+def gen_backbone_tiny(ref):
+    """F-4: embed_dim 32, (128,160) input, partition (4,5), B=2, two timesteps (second with LSTM state)."""
+    hw, part, E = (128, 160), (4, 5), 32
+    for amp, tag in ((2e-4, "dense"), (2e-2, "sparse")):
+        rcfg = RI.backbone_cfg(hw, part, embed_dim=E, amp=amp, ls_init=0.5)
+        ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=amp)
+        params = O.init_backbone_params(ocfg, seed=11, ls_init=0.5)
+        net = ref.sast_rnn.RNNDetector(rcfg)
+        load_into(net, params)
+        x0 = O.count_events(2, hw, seed=21, density=0.05)
+        x1 = O.count_events(2, hw, seed=22, density=0.05)
+        out0, st0, P0 = net(x0)
+        out1, st1, P1 = net(x1, [(h.detach(), c.detach()) for h, c in st0])
+        loss = sum((out1[k] ** 2).mean() for k in (1, 2, 3, 4))
+        loss.backward()
+        oo0, os0, oP0 = O.backbone(x0, None, params, ocfg)
+        oo1, os1, oP1 = O.backbone(x1, os0, params, ocfg)
+        assert oP0 == P0 and oP1 == P1, (oP0, P0, oP1, P1)
+        for k in (1, 2, 3, 4):
+            assert torch.equal(oo0[k], out0[k]) and torch.equal(oo1[k], out1[k]), k
+        d = dict(x0=np_(x0), x1=np_(x1), P0=np.array(P0), P1=np.array(P1), seed=np.int64(11), amp=np.float64(amp),
+                 param_checksum=np.float64(param_checksum(params)), loss=np.float64(float(loss)))
+        for k in (1, 2, 3, 4):
+            d[f"h0_{k}"] = np_(out0[k])
+            d[f"h1_{k}"] = np_(out1[k])
+            d[f"c1_{k}"] = np_(st1[k - 1][1])
+        gn = {}
+        for k, v in net.named_parameters():
+            if "sub_layers" in k or v.grad is None:
+                continue
+            gn[k] = [float(v.grad.double().norm()), float(v.grad.double().sum())]
+        d["grad_stats_json"] = np.array(json.dumps(gn))
+        for k in ("stages.0.att_blocks.0.att.to_scores.bias", "stages.3.lstm.conv1x1.bias",
+                  "stages.1.downsample_cf2cl.norm.weight", "stages.2.att_blocks.0.att.grid_attn.ls2.gamma"):
+            d["g_" + k] = np_(dict(net.named_parameters())[k].grad)
+        np.savez_compressed(os.path.join(HERE, f"backbone_tiny_{tag}.npz"), **d)
+        print(f"backbone_tiny_{tag}: P0 {P0} P1 {P1}")
+
+
+def gen_pafpn(ref):
+    chans = (64, 128, 256)
+    params = O.init_pafpn_params(chans, seed=31)
+    net = ref.yolo_pafpn.YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans, depthwise=False, act="silu")
+    sd = {k: (params[k].clone() if not k.endswith("num_batches_tracked") else v) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(32)
+    feats = {2: torch.randn(2, 64, 16, 20, generator=g), 3: torch.randn(2, 128, 8, 10, generator=g),
+             4: torch.randn(2, 256, 4, 5, generator=g)}
+    fin = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    net.train()
+    outs = net(fin)
+    loss = sum((o ** 2).mean() for o in outs)
+    loss.backward()
+    oo = O.pafpn(feats, params, training=True)
+    for a, b in zip(outs, oo):
+        assert torch.equal(a, b)
+    d = dict(seed=np.int64(31), param_checksum=np.float64(param_checksum(params)))
+    for k, v in feats.items():
+        d[f"in{k}"] = np_(v)
+        d[f"din{k}"] = np_(fin[k].grad)
+    for i, o in enumerate(outs):
+        d[f"train_out{i}"] = np_(o)
+    d["rm_lateral"] = np_(net.lateral_conv0.bn.running_mean)
+    d["rv_lateral"] = np_(net.lateral_conv0.bn.running_var)
+    gn = {k: [float(v.grad.double().norm()), float(v.grad.double().sum())] for k, v in net.named_parameters()}
+    d["grad_stats_json"] = np.array(json.dumps(gn))
+    d["g_C3_p3.conv3.conv.weight"] = np_(net.C3_p3.conv3.conv.weight.grad)
+    d["g_bu_conv2.bn.weight"] = np_(net.bu_conv2.bn.weight.grad)
+    net.eval()
+    with torch.no_grad():
+        eo = net(feats)
+    bufs = {k: v.clone() for k, v in net.state_dict().items()}
+    ee = O.pafpn(feats, bufs, training=False)
+    for i, (a, b) in enumerate(zip(eo, ee)):
+        assert torch.equal(a, b)
+        d[f"eval_out{i}"] = np_(a)
+    np.savez_compressed(os.path.join(HERE, "pafpn.npz"), **d)
+    print("pafpn ok")
+
+
+def gen_full_stats(ref):
+    """F-7: full-size M1 / G1 statistics (tensors too large to commit)."""
+    res = {}
+    for tag, hw, part, B in (("M1", (384, 640), (6, 10), 4), ("G1", (256, 320), (8, 10), 4)):
+        rcfg = RI.backbone_cfg(hw, part)
+        ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part)
+        params = O.init_backbone_params(ocfg, seed=0)
+        net = ref.sast_rnn.RNNDetector(rcfg)
+        load_into(net, params)
+        x = O.synthetic_events(B, hw, seed=0, sparsity=0.9)
+        with torch.no_grad():
+            out, st, P = net(x)
+            oo, os_, oP, lists = O.backbone(x, None, params, ocfg, return_lists=True)
+        assert oP == P
+        ent = {"P": [int(v) for v in P], "param_checksum": param_checksum(params)}
+        for k in (1, 2, 3, 4):
+            assert torch.equal(oo[k], out[k])
+            t = out[k].double()
+            ent[f"h{k}"] = {"mean": float(t.mean()), "absmean": float(t.abs().mean()), "maxabs": float(t.abs().max()),
+                            "sha256": hashlib.sha256(np_(out[k]).tobytes()).hexdigest()}
+        ent["index_sha256"] = [[hashlib.sha256(np_(l[3]).astype(np.int64).tobytes()).hexdigest() for l in ls[0]]
+                               for ls in lists]
+        ent["M"] = [[int(len(l[0])) for l in ls[0]] for ls in lists]
+        ent["sumK"] = [[int(len(l[3])) for l in ls[0]] for ls in lists]
+        res[tag] = ent
+        print(tag, ent["P"], ent["M"], ent["sumK"])
+    with open(os.path.join(HERE, "full_stats.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def main():
+    ref = RI.import_reference()
+    gen_nzr(ref)
+    gen_block(ref, "block_amp2e-4", 2, 2e-4)
+    gen_block(ref, "block_amp2e-2", 2, 2e-2)
+    gen_block(ref, "block_amp1", 2, 1.0)
+    gen_block(ref, "block_b1", 1, 2e-2)
+    gen_block(ref, "block_cb", 2, 2e-2, enable_cb=True)
+    gen_two_blocks(ref)
+    gen_backbone_tiny(ref)
+    gen_pafpn(ref)
+    gen_full_stats(ref)
+
+
+if __name__ == "__main__":
+    main()

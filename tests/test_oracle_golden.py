@@ -1,0 +1,165 @@
+"""CPU: the oracle (oracle/sast_oracle.py) against the fixtures captured from the reference.
+
+Fixtures were produced by tests/golden/make_golden.py by importing /root/reference in the
+build container; parameters are re-drawn here from the recorded seed (checksum-guarded).
+Bar: index lists exact; floating point torch.equal (same ATen op sequence) -- we allow
+1e-6 in case a BLAS build differs between boxes.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sast_oracle as O
+
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+
+ATOL = 1e-6
+LIST_NAMES = ("index_window", "index_token", "padding_index", "asy_index", "K")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _block_params(C, seed, nblocks=1):
+    cfg = O.BackboneCfg(in_res_hw=(64, 80), partition_size=(4, 5), embed_dim=C, num_blocks=(nblocks, 1, 1, 1))
+    p = O.init_backbone_params(cfg, seed=seed, ls_init=0.5)
+    return {k[len("stages.0."):]: v for k, v in p.items() if k.startswith("stages.0.att_blocks.")}
+
+
+def _checksum(params):
+    return float(sum(float(v.double().abs().sum()) for v in params.values()))
+
+
+def test_non_zero_ratio(golden_dir):
+    g = _load(golden_dir, "nzr")
+    assert torch.equal(O.non_zero_ratio(torch.from_numpy(g["x"])), torch.from_numpy(g["r"]))
+    assert torch.equal(O.non_zero_ratio(torch.from_numpy(g["xb"])), torch.from_numpy(g["rb"]))
+
+
+@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb"])
+def test_sast_block(golden_dir, name):
+    g = _load(golden_dir, name)
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    params = _block_params(64, int(g["seed"]))
+    assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]))
+    pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out, cnt, lists = O.sast_block(xo, pe, r, po, "att_blocks.0.att.", cfg)
+    assert cnt == int(g["count"])
+    for li, l in enumerate(lists):
+        for nm, t in zip(LIST_NAMES, l):
+            assert np.array_equal(t.numpy(), g[f"l{li}_{nm}"]), (li, nm)
+    assert torch.allclose(out, torch.from_numpy(g["out"]), atol=ATOL, rtol=0)
+    (out ** 2).mean().backward()
+    assert torch.allclose(xo.grad, torch.from_numpy(g["dx"]), atol=1e-7, rtol=1e-4)
+    for k, v in po.items():
+        gk = "g_" + k[len("att_blocks.0.att."):]
+        assert torch.allclose(v.grad, torch.from_numpy(g[gk]), atol=1e-7, rtol=1e-3), k
+
+
+def test_two_blocks_reuse_index_lists(golden_dir):
+    g = _load(golden_dir, "stage_two_blocks")
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    params = _block_params(64, int(g["seed"]), nblocks=2)
+    cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]))
+    pe = O.position_embedding_sine(16, 20, 64)
+    a1, c1, l1 = O.sast_block(x, pe, r, params, "att_blocks.0.att.", cfg)
+    a2, c2, _ = O.sast_block(a1, pe, r, params, "att_blocks.1.att.", cfg, index_list=l1, first_block=False)
+    assert (c1, c2) == (int(g["count1"]), int(g["count2"]))
+    assert torch.allclose(a1, torch.from_numpy(g["out1"]), atol=ATOL, rtol=0)
+    assert torch.allclose(a2, torch.from_numpy(g["out2"]), atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["dense", "sparse"])
+def test_backbone_tiny(golden_dir, tag):
+    g = _load(golden_dir, f"backbone_tiny_{tag}")
+    cfg = O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=32, amp=float(g["amp"]))
+    params = O.init_backbone_params(cfg, seed=int(g["seed"]), ls_init=0.5)
+    assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o0, s0, P0 = O.backbone(torch.from_numpy(g["x0"]), None, po, cfg)
+    o1, s1, P1 = O.backbone(torch.from_numpy(g["x1"]), [(h.detach(), c.detach()) for h, c in s0], po, cfg)
+    assert P0 == list(g["P0"]) and P1 == list(g["P1"])
+    for k in (1, 2, 3, 4):
+        assert torch.allclose(o0[k].detach(), torch.from_numpy(g[f"h0_{k}"]), atol=ATOL, rtol=0)
+        assert torch.allclose(o1[k].detach(), torch.from_numpy(g[f"h1_{k}"]), atol=ATOL, rtol=0)
+        assert torch.allclose(s1[k - 1][1].detach(), torch.from_numpy(g[f"c1_{k}"]), atol=ATOL, rtol=0)
+    loss = sum((o1[k] ** 2).mean() for k in (1, 2, 3, 4))
+    assert abs(float(loss) - float(g["loss"])) < 1e-6 * abs(float(g["loss"]))
+    loss.backward()
+    stats = json.loads(str(g["grad_stats_json"]))
+    for k, (nrm, _sm) in stats.items():
+        got = float(po[k].grad.double().norm())
+        assert abs(got - nrm) <= 1e-4 * nrm + 1e-10, k
+    for key in g.files:
+        if key.startswith("g_"):
+            assert torch.allclose(po[key[2:]].grad, torch.from_numpy(g[key]), atol=1e-7, rtol=1e-3), key
+
+
+def test_pafpn(golden_dir):
+    g = _load(golden_dir, "pafpn")
+    chans = (64, 128, 256)
+    params = O.init_pafpn_params(chans, seed=int(g["seed"]))
+    assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    feats = {k: torch.from_numpy(g[f"in{k}"]).requires_grad_(True) for k in (2, 3, 4)}
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in params.items()}
+    outs = O.pafpn(feats, po, training=True, bufs=po)
+    for i, o in enumerate(outs):
+        assert torch.allclose(o.detach(), torch.from_numpy(g[f"train_out{i}"]), atol=ATOL, rtol=0)
+    assert torch.allclose(po["lateral_conv0.bn.running_mean"], torch.from_numpy(g["rm_lateral"]), atol=1e-7)
+    assert torch.allclose(po["lateral_conv0.bn.running_var"], torch.from_numpy(g["rv_lateral"]), atol=1e-7)
+    sum((o ** 2).mean() for o in outs).backward()
+    for k in (2, 3, 4):
+        assert torch.allclose(feats[k].grad, torch.from_numpy(g[f"din{k}"]), atol=1e-7, rtol=1e-3)
+    stats = json.loads(str(g["grad_stats_json"]))
+    for k, (nrm, _sm) in stats.items():
+        got = float(po[k].grad.double().norm())
+        assert abs(got - nrm) <= 1e-4 * nrm + 1e-10, k
+    with torch.no_grad():
+        ev = O.pafpn({k: v.detach() for k, v in feats.items()}, po, training=False)
+    for i, o in enumerate(ev):
+        assert torch.allclose(o, torch.from_numpy(g[f"eval_out{i}"]), atol=ATOL, rtol=0)
+
+
+def test_full_size_stats_g1(golden_dir):
+    """F-7 (Gen1 size; the 1Mpx twin runs on the GPU box next to the HIP path)."""
+    with open(os.path.join(golden_dir, "full_stats.json")) as f:
+        ref = json.load(f)["G1"]
+    cfg = O.BackboneCfg(in_res_hw=(256, 320), partition_size=(8, 10))
+    params = O.init_backbone_params(cfg, seed=0)
+    x = O.synthetic_events(4, (256, 320), seed=0, sparsity=0.9)
+    with torch.no_grad():
+        out, _st, P, lists = O.backbone(x, None, params, cfg, return_lists=True)
+    assert P == ref["P"]
+    assert [[len(l[3]) for l in ls[0]] for ls in lists] == ref["sumK"]
+    for k in (1, 2, 3, 4):
+        t = out[k].double()
+        assert abs(float(t.abs().mean()) - ref[f"h{k}"]["absmean"]) < 1e-6
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference only exists in the build container")
+def test_oracle_equals_reference_live():
+    """container-only: run the imported reference next to the oracle on a fresh seed."""
+    import _ref_import as RI
+    ref = RI.import_reference()
+    hw, part = (128, 160), (4, 5)
+    rcfg = RI.backbone_cfg(hw, part, embed_dim=32, amp=2e-3, ls_init=0.5)
+    cfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=32, amp=2e-3)
+    params = O.init_backbone_params(cfg, seed=5, ls_init=0.5)
+    net = ref.sast_rnn.RNNDetector(rcfg)
+    from make_golden import load_into
+    load_into(net, params)
+    x = O.count_events(3, hw, seed=9, density=0.03)
+    with torch.no_grad():
+        a, _, Pa = net(x)
+        b, _, Pb = O.backbone(x, None, params, cfg)
+    assert Pa == Pb
+    for k in (1, 2, 3, 4):
+        assert torch.equal(a[k], b[k])
