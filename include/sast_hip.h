@@ -1,0 +1,172 @@
+/* sast_hip.h -- C ABI of libsast_hip.so: the MI355X (gfx950) implementation of the SAST hot path.
+ *
+ * The reference (Peterande/SAST) has no FFI: its hot path is plain torch.nn.Module code under
+ * models/layers.  Each entry point below replaces the ATen op sequence of the
+ * cited reference lines; the Python modules in sast_amd/ bind them with ctypes (see
+ * INTEGRATION.md for the reference-side binding a maintainer would add).
+ *
+ * Conventions
+ *  - all tensors are device pointers owned by the CALLER (PyTorch caching allocator); the library
+ *    never allocates, frees or retains pointers;  workspaces are caller-provided.
+ *  - activations are fp32, channels-last: "image layout" = [B*H*W, C] rows (NHWC).
+ *  - conv weights are [Cout][KH][KW][Cin] (torch channels_last storage of a [Cout,Cin,KH,KW] param).
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t); no host synchronisation, so a whole
+ *    training step is hipGraph-capturable.  Data-dependent sizes (number of kept windows/tokens)
+ *    stay on the device in SastSel.counts.
+ *  - return 0 on success, negative errno-style code otherwise (-22 bad argument, -5 launch failure).
+ *  - *_bwd calls ACCUMULATE (+=) into parameter-gradient buffers and OVERWRITE activation gradients.
+ */
+#ifndef SAST_HIP_H
+#define SAST_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sast_stream_t; /* hipStream_t */
+
+enum { SAST_DT_F32 = 0, SAST_DT_I32 = 1, SAST_DT_U8 = 2 };
+
+int sast_version(void);
+
+/* a1  non_zero_ratio -- models/detection/recurrent_backbone/sast_rnn.py:45-60.
+ * x: (B,Cin,H,W) NCHW of `dtype`; cnt_ws: int32[B*4*Cin] scratch; r: fp32 (B,4,Cin). H,W multiples of 32. */
+int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream);
+
+/* layout changes at the NCHW API boundary (reference: ops.py:19-30 nChw_2_nhwC / nhwC_2_nChw, x.float() sast_rnn.py:153) */
+int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream);
+int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream);
+
+/* a3  x + pos_emb(x) -- SAST.py:105 with the constant sine table of sast_rnn.py:180-219: y[row] = x[row] + table[row % table_rows] */
+int sast_add_rows(const float* x, const float* table, float* y, int rows, int C, int table_rows, sast_stream_t stream);
+
+/* a2  ConvDownsampling_Cf2Cl -- models/layers/SAST/ops.py:54-95 (+ the pos-emb add of SAST.py:105 when pe != NULL) */
+typedef struct SastDownArgs {
+  int32_t B, H, W, Cin, Cout, factor;
+  const float* x;        /* [B*H*W, Cin] NHWC */
+  const float* w;        /* [Cout][k][k][Cin], k = 2*factor-1, replicate padding factor-1 */
+  const float* ln_w; const float* ln_b;
+  const float* pe;       /* [Ho*Wo, Cout] or NULL */
+  float* conv_out;       /* [B*Ho*Wo, Cout] saved for backward */
+  float* mean; float* rstd; /* [B*Ho*Wo] */
+  float* y;              /* [B*Ho*Wo, Cout] = LN(conv) (+ pe) */
+  /* backward */
+  const float* dy; float* dx; /* dx may be NULL (stem) */
+  float* dw; float* d_ln_w; float* d_ln_b;
+  float* ws;             /* fp32[B*Ho*Wo*Cout] */
+} SastDownArgs;
+int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream);
+int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream);
+
+/* a5  scoring + STP weighting -- SAST.py:109-119 and PositiveLinear :305-328.
+ * xw = sigmoid(scale)*sigmoid(s)*xp,  s = relu(xp Ws^T + bs),  tok[b,l] = sum_c (AMP/scale[b,c]) * s */
+typedef struct SastScoreArgs {
+  int32_t B, L, C, r_stride;
+  float amp;
+  const float* xp;       /* [B*L, C] = x + pos-emb */
+  const float* r;        /* r[b*r_stride + j], j < 20 */
+  const float* ws_w; const float* ws_b; /* to_scores */
+  const float* wc;       /* to_controls.weight [C,20] */
+  float* scale;          /* [B,C] saved */
+  float* s;              /* [B*L,C] saved */
+  float* xw;             /* [B*L,C] out */
+  float* tok;            /* [B*L] out (not differentiable) */
+  /* backward */
+  const float* dxw; float* dxp;
+  float* d_ws_w; float* d_ws_b; float* d_wc;
+  float* ws;             /* fp32[B*L*C + B*C] */
+} SastScoreArgs;
+int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream);
+int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream);
+
+/* a6-a8  window / token selection -- SAST.py:84-96, :258-281, :122.  All buffers caller-allocated. */
+typedef struct SastSel {
+  int32_t* win_keep;   /* [B*N] 0/1 */
+  uint64_t* mask;      /* [B*N][2] kept-token bitmask of each group (T <= 128) */
+  int32_t* K;          /* [B*N] kept tokens (0 for dropped windows) */
+  int32_t* row_off;    /* [B*N] first compact row of the group */
+  int32_t* win_rank;   /* [B*N] index among kept windows or -1 */
+  int32_t* counts;     /* [4] sum K (= len(asy_index)), M (= len(index_window)), sumK / B, 0 */
+  int32_t* tok_slot;   /* [B*L] compact row of a token or -1 */
+  int32_t* row_tok;    /* [B*L] token (b*L + y*W + x) of a compact row */
+} SastSel;
+/* mode 0: window partition (ops.py:189-195), 1: grid partition (ops.py:206-212) */
+int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode, double bounce, const SastSel* sel,
+                sast_stream_t stream);
+
+/* a9  MS_WSA -- SAST.py:199-255 with LayerScale (ops.py:178-186) and GLU-MLP (ops.py:111-175). */
+typedef struct SastMswsaArgs {
+  int32_t B, H, W, C, ph, pw, mode, inner;
+  float eps;
+  const float* xin;      /* [B*L, C] image layout */
+  float* out;            /* [B*L, C] */
+  SastSel sel;
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ls1;
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b, *ls2;
+  /* saved for backward; R = B*L rows upper bound */
+  float *mean1, *rstd1;  /* [B*L] */
+  float *mean2, *rstd2;  /* [R] */
+  float *S, *QKV, *O, *lse, *Y, *UG, *Hh; /* [R,C] [R,3C] [R,C] [R,C/32] [R,C] [R,2*inner] [R,inner] */
+  /* backward */
+  const float* dout; float* dxin;
+  float *d_ln1_w, *d_ln1_b, *d_ln2_w, *d_ln2_b, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_ls1;
+  float *d_fc1_w, *d_fc1_b, *d_fc2_w, *d_fc2_b, *d_ls2;
+  float* ws;             /* sast_mswsa_bwd_ws_floats() */
+} SastMswsaArgs;
+size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner);
+int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream);
+int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream);
+
+/* a12  DWSConvLSTM2d (dws_conv=False) -- models/layers/rnn.py:36-69, on NHWC rows */
+typedef struct SastLstmArgs {
+  int32_t B, L, C;
+  const float* x; const float* h0; const float* c0;   /* h0/c0 NULL = zero state */
+  const float* w; const float* b;                      /* conv1x1 [4C,2C], [4C] */
+  float* h1; float* c1;
+  float* gates;          /* [B*L,4C] saved: sigmoid(f,i,o), tanh(g) */
+  /* backward */
+  const float* dh1; const float* dc1;                  /* dc1 may be NULL */
+  float* dx; float* dh0; float* dc0;                   /* dh0/dc0 may be NULL */
+  float* dw; float* db;
+  float* ws;             /* fp32[B*L*4C] */
+} SastLstmArgs;
+int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream);
+int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);
+
+/* a13  BaseConv = Conv2d(no bias, same pad) + BatchNorm2d + SiLU -- yolox/models/network_blocks.py:29-54 */
+typedef struct SastConvBnArgs {
+  int32_t B, H, W, Cin, Cout, ksize, stride, training;
+  int32_t ldx, ldy, lddy, lddx;   /* channel strides of x, y, dy, dx rows (slices of concat buffers) */
+  float momentum, eps;
+  const float* x; const float* w; const float* bn_w; const float* bn_b;
+  float* run_mean; float* run_var;  /* updated in training mode */
+  float* conv_out;       /* [M,Cout] saved, M = B*Ho*Wo */
+  float* stats;          /* [2*Cout] saved: mean, rstd actually used */
+  float* y;
+  /* backward */
+  const float* dy; float* dx; float* dw; float* d_bn_w; float* d_bn_b;
+  float* ws;             /* fp32[M*Cout + 4*Cout] (fwd uses the first 4*Cout as fp64[2*Cout]) */
+} SastConvBnArgs;
+int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
+int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);
+
+/* a13  nearest-exact x2 upsample + channel concat -- yolo_pafpn.py:49,119-120.
+ * out[B,2H,2W,C1+C2] = cat(up2(a[B,H,W,C1]), b[B,2H,2W,C2]) ; backward splits/sums. */
+int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream);
+int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H, int W, int C1, int C2, sast_stream_t stream);
+/* plain channel concat of two NHWC row sets and its split (yolo_pafpn.py:129,134; network_blocks.py:140) */
+int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream);
+int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int C2, sast_stream_t stream);
+
+/* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441) */
+int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,
+               const float* lr_step /* device fp32[2]: learning rate, step count (already incremented) */,
+               float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+               float clip_value /* <=0: off; reference clips by value 1.0, train.py:156-157 */, sast_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAST_HIP_H */

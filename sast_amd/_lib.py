@@ -1,0 +1,108 @@
+"""ctypes binding of libsast_hip.so (include/sast_hip.h).  Fails loudly when the library is missing:
+there is NO CPU / PyTorch fallback for the hot path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsast_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sast_hip.h")
+
+P = C.c_void_p
+I32 = C.c_int32
+F32 = C.c_float
+
+DT_F32, DT_I32, DT_U8 = 0, 1, 2
+
+
+def _struct(name, spec):
+    """spec: list of (ctype, 'a b c') -> ctypes.Structure with fields in order."""
+    fields = []
+    for ct, names in spec:
+        for n in names.split():
+            fields.append((n, ct))
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+SastDownArgs = _struct("SastDownArgs", [
+    (I32, "B H W Cin Cout factor"),
+    (P, "x w ln_w ln_b pe conv_out mean rstd y dy dx dw d_ln_w d_ln_b ws"),
+])
+SastScoreArgs = _struct("SastScoreArgs", [
+    (I32, "B L C r_stride"), (F32, "amp"),
+    (P, "xp r ws_w ws_b wc scale s xw tok dxw dxp d_ws_w d_ws_b d_wc ws"),
+])
+SastSel = _struct("SastSel", [(P, "win_keep mask K row_off win_rank counts tok_slot row_tok")])
+SastMswsaArgs = _struct("SastMswsaArgs", [
+    (I32, "B H W C ph pw mode inner"), (F32, "eps"),
+    (P, "xin out"), (SastSel, "sel"),
+    (P, "ln1_w ln1_b ln2_w ln2_b qkv_w qkv_b proj_w proj_b ls1 fc1_w fc1_b fc2_w fc2_b ls2"),
+    (P, "mean1 rstd1 mean2 rstd2 S QKV O lse Y UG Hh"),
+    (P, "dout dxin"),
+    (P, "d_ln1_w d_ln1_b d_ln2_w d_ln2_b d_qkv_w d_qkv_b d_proj_w d_proj_b d_ls1 d_fc1_w d_fc1_b d_fc2_w d_fc2_b d_ls2"),
+    (P, "ws"),
+])
+SastLstmArgs = _struct("SastLstmArgs", [
+    (I32, "B L C"),
+    (P, "x h0 c0 w b h1 c1 gates dh1 dc1 dx dh0 dc0 dw db ws"),
+])
+SastConvBnArgs = _struct("SastConvBnArgs", [
+    (I32, "B H W Cin Cout ksize stride training ldx ldy lddy lddx"), (F32, "momentum eps"),
+    (P, "x w bn_w bn_b run_mean run_var conv_out stats y dy dx dw d_bn_w d_bn_b ws"),
+])
+
+_SIGNATURES = {
+    "sast_version": (C.c_int, []),
+    "sast_nzratio": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
+    "sast_nchw_to_nhwc": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    "sast_nhwc_to_nchw": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    "sast_add_rows": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
+    "sast_downsample_ln_fwd": (C.c_int, [C.POINTER(SastDownArgs), P]),
+    "sast_downsample_ln_bwd": (C.c_int, [C.POINTER(SastDownArgs), P]),
+    "sast_score_stp_fwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
+    "sast_score_stp_bwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
+    "sast_select": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), P]),
+    "sast_mswsa_bwd_ws_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sast_mswsa_fwd": (C.c_int, [C.POINTER(SastMswsaArgs), P]),
+    "sast_mswsa_bwd": (C.c_int, [C.POINTER(SastMswsaArgs), P]),
+    "sast_lstm_fwd": (C.c_int, [C.POINTER(SastLstmArgs), P]),
+    "sast_lstm_bwd": (C.c_int, [C.POINTER(SastLstmArgs), P]),
+    "sast_conv_bn_silu_fwd": (C.c_int, [C.POINTER(SastConvBnArgs), P]),
+    "sast_conv_bn_silu_bwd": (C.c_int, [C.POINTER(SastConvBnArgs), P]),
+    "sast_upsample_cat_fwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]),
+    "sast_upsample_cat_bwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]),
+    "sast_cat2_fwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
+    "sast_cat2_bwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
+    "sast_adamw": (C.c_int, [P, P, P, P, C.c_size_t, P, F32, F32, F32, F32, F32, F32, P]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """every function name declared in include/sast_hip.h"""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    return sorted(set(re.findall(r"\b(sast_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m sast_amd.build` (needs hipcc, gfx950). "
+                "sast_amd has no CPU/PyTorch fallback for the SAST hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"libsast_hip: {what} failed with code {rc}")

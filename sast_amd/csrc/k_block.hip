@@ -1,0 +1,301 @@
+// C-ABI entry points of the SAST block: STP scoring, MS-WSA (fwd/bwd) and the ConvLSTM.
+// Each entry point enqueues a short chain of kernels on the caller's stream; the GEMMs are
+// the fp32-MFMA template of gemm.cuh with op-specific loaders / fused epilogues.
+#include "gemm.cuh"
+#include "kernels.h"
+
+using namespace sast;
+
+namespace {
+
+template <class LA, class LB, class EP>
+int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
+  if (NJ <= 64) return launch_gemm<TileN64>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  const long nb_big = (long)((M + 127) / 128) * ((NJ + 127) / 128);
+  if (nb_big >= 512) return launch_gemm<TileBig>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+}
+
+// weight-gradient form: out[Mo, NJ] += A^T B over R (device-side count dR) rows
+template <class LA, class LB>
+int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, hipStream_t st) {
+  const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
+  int splits = (1024 + nb - 1) / nb;
+  const int max_splits = (R + 127) / 128;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, st);
+}
+
+// ---------------------------------------------------------------- epilogues
+struct EpBiasRelu {
+  float* c; int ldc; const float* bias;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    c[(size_t)m * ldc + j] = fmaxf(v[0] + bias[j], 0.f);
+  }
+};
+struct EpResidualLS {  // y = res + gamma * (v + bias)
+  float* y; const float* res; const float* bias; const float* gamma; int C;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    const float z = v[0] + bias[j];
+    y[(size_t)m * C + j] = res[(size_t)m * C + j] + (gamma ? gamma[j] * z : z);
+  }
+};
+struct EpResidualLSScatter {  // out[row_tok[m]] = res + gamma * (v + bias)
+  float* out; const float* res; const float* bias; const float* gamma; const int* row_tok; int C;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    const float z = v[0] + bias[j];
+    out[(size_t)row_tok[m] * C + j] = res[(size_t)m * C + j] + (gamma ? gamma[j] * z : z);
+  }
+};
+struct EpGlu {  // ops.py:136-137: value = first half, gate = second half, exact-erf GELU
+  float* ug; float* h; const float* bias; int inner;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[2]) const {
+    const float u = v[0] + bias[j], g = v[1] + bias[inner + j];
+    ug[(size_t)m * 2 * inner + j] = u;
+    ug[(size_t)m * 2 * inner + inner + j] = g;
+    h[(size_t)m * inner + j] = u * gelu_erf(g);
+  }
+};
+struct EpDGlu {  // v = dH -> d(value), d(gate)
+  const float* ug; float* dug; int inner;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    const float u = ug[(size_t)m * 2 * inner + j], g = ug[(size_t)m * 2 * inner + inner + j];
+    dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(g);
+    dug[(size_t)m * 2 * inner + inner + j] = v[0] * u * gelu_erf_grad(g);
+  }
+};
+struct EpAddGather {  // c[m,j] = v + src[idx[m], j]
+  float* c; int ldc; const float* src; const int* idx; int lds;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    c[(size_t)m * ldc + j] = v[0] + src[(size_t)idx[m] * lds + j];
+  }
+};
+struct EpLstm {  // rnn.py:57-67
+  const float* bias; const float* c0; float* h1; float* c1; float* gates; int C;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[4]) const {
+    const float f = sigmoid_exact(v[0] + bias[j]), i = sigmoid_exact(v[1] + bias[C + j]);
+    const float o = sigmoid_exact(v[2] + bias[2 * C + j]), g = tanhf(v[3] + bias[3 * C + j]);
+    const float c = f * (c0 ? c0[(size_t)m * C + j] : 0.f) + i * g;
+    c1[(size_t)m * C + j] = c;
+    h1[(size_t)m * C + j] = o * tanhf(c);
+    float* gp = gates + (size_t)m * 4 * C + j;
+    gp[0] = f; gp[C] = i; gp[2 * C] = o; gp[3 * C] = g;
+  }
+};
+struct EpSplit2 {  // j < C1 -> a, else b
+  float* a; float* b; int C1, C2;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    if (j < C1) a[(size_t)m * C1 + j] = v[0];
+    else if (b) b[(size_t)m * C2 + (j - C1)] = v[0];
+  }
+};
+
+__global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c0,
+                                                                 const float* __restrict__ c1, const float* __restrict__ dh1,
+                                                                 const float* __restrict__ dc1, float* __restrict__ dmix,
+                                                                 float* __restrict__ dc0, size_t n, int C) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const size_t m = e / C; const int j = (int)(e % C);
+  const float* gp = gates + m * 4 * C + j;
+  const float f = gp[0], i = gp[C], o = gp[2 * C], g = gp[3 * C];
+  const float tc = tanhf(c1[e]);
+  const float dh = dh1[e];
+  const float dc = (dc1 ? dc1[e] : 0.f) + dh * o * (1.f - tc * tc);
+  const float cp = c0 ? c0[e] : 0.f;
+  float* dp = dmix + m * 4 * C + j;
+  dp[0] = dc * cp * f * (1.f - f);
+  dp[C] = dc * g * i * (1.f - i);
+  dp[2 * C] = dh * tc * o * (1.f - o);
+  dp[3 * C] = dc * i * (1.f - g * g);
+  if (dc0) dc0[e] = dc * f;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sast_version(void) { return 100; }
+
+int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream) {
+  if (!x || !cnt_ws || !r || H % 32 || W % 32) return SAST_EINVAL;
+  return nzr_dispatch(x, dtype, cnt_ws, r, B, Cin, H, W, (hipStream_t)stream);
+}
+int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream) {
+  return nchw_to_nhwc_dispatch(x, dtype, y, B, C, H, W, (hipStream_t)stream);
+}
+int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream) {
+  return nhwc_to_nchw_launch(x, y, B, C, H * W, (hipStream_t)stream);
+}
+
+int sast_add_rows(const float* x, const float* table, float* y, int rows, int C, int table_rows, sast_stream_t stream) {
+  if (C % 4) return SAST_EINVAL;
+  return add_rows_launch(x, table, y, rows, C, table_rows, (hipStream_t)stream);
+}
+
+int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode, double bounce, const SastSel* s,
+                sast_stream_t stream) {
+  if (!tok || !s) return SAST_EINVAL;
+  const int N = (H / ph) * (W / pw), T = ph * pw;
+  // thresholds are evaluated in double and rounded to fp32 once, exactly like the reference's
+  // `x >= d / (1 + b)` tensor-vs-python-scalar compare (SAST.py:264,272)
+  const float thr_w = (float)((1.0 / N) / (1.0 + bounce));
+  const float thr_t = (float)((1.0 / T) / (1.0 + bounce));
+  return select_launch(tok, B, H, W, ph, pw, mode, thr_w, thr_t, s->win_keep, (unsigned long long*)s->mask, s->K, s->row_off,
+                       s->win_rank, s->counts, s->tok_slot, s->row_tok, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------ scoring + STP
+int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || a->C % 32) return SAST_EINVAL;
+  const int M = a->B * a->L, C = a->C;
+  int rc = controls_fwd_launch(a->wc, a->r, a->r_stride, a->scale, a->B, C, 20, st);
+  if (rc) return rc;
+  rc = gemm_auto(LdRows{a->xp, C, nullptr}, LdWeightNT{a->ws_w, C, 0}, EpBiasRelu{a->s, C, a->ws_b}, M, C, C, nullptr, st);
+  if (rc) return rc;
+  return stp_fwd_launch(a->xp, a->s, a->scale, a->amp, a->xw, a->tok, a->B, a->L, C, st);
+}
+
+int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int M = a->B * a->L, C = a->C;
+  float* dz = a->ws;
+  float* dscale = a->ws + (size_t)M * C;
+  hipMemsetAsync(dscale, 0, sizeof(float) * a->B * C, st);
+  int rc = stp_bwd_launch(a->xp, a->s, a->scale, a->dxw, a->dxp, dz, dscale, a->B, a->L, C, st);
+  if (rc) return rc;
+  // dxp = direct + dz Ws
+  rc = gemm_auto(LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C, nullptr}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
+  if (rc) return rc;
+  rc = gemm_tn(LdRowsT{dz, C, nullptr}, LdRowsT{a->xp, C, nullptr}, a->d_ws_w, C, C, C, M, nullptr, st);
+  if (rc) return rc;
+  rc = colsum_launch(dz, C, nullptr, M, nullptr, C, a->d_ws_b, st);
+  if (rc) return rc;
+  return controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, st);
+}
+
+// ------------------------------------------------------------------ MS-WSA
+size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
+  return (size_t)rows * (2 * inner + C + C + 3 * C + C) + (size_t)C * inner + (size_t)C * C + 2 * C;
+}
+
+int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || a->C % 32 || a->inner % 32) return SAST_EINVAL;
+  const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
+  const int T = a->ph * a->pw, NW = a->B * (L / T);
+  const int* dR = a->sel.counts;  // device-side number of kept tokens
+  int rc = ln1_gather_fwd_launch(a->xin, a->out, a->S, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->ln2_b, a->mean1,
+                                 a->rstd1, a->mean2, a->rstd2, R, C, a->eps, st);
+  if (rc) return rc;
+  rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
+  if (rc) return rc;
+  rc = attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, st);
+  if (rc) return rc;
+  rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
+  if (rc) return rc;
+  {
+    const LdRows la{a->Y, C, nullptr};
+    const LdWeightNT lb{a->fc1_w, C, inner};
+    const EpGlu ep{a->UG, a->Hh, a->fc1_b, inner};
+    const long nb_big = (long)((R + 127) / 128) * ((inner + 63) / 64);
+    rc = nb_big >= 512 ? launch_gemm<TileG2Big>(la, lb, ep, R, inner, C, dR, nullptr, st)
+                       : launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    if (rc) return rc;
+  }
+  return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
+                   EpResidualLSScatter{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C}, R, C, inner, dR, st);
+}
+
+int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
+  const int T = a->ph * a->pw, NW = a->B * (L / T);
+  const int* dR = a->sel.counts;
+  const int* row_tok = a->sel.row_tok;
+  float* dUG = a->ws;
+  float* dY = dUG + (size_t)R * 2 * inner;
+  float* dO = dY + (size_t)R * C;
+  float* dQKV = dO + (size_t)R * C;
+  float* dS = dQKV + (size_t)R * 3 * C;
+  float* raw2 = dS + (size_t)R * C;
+  float* raw1 = raw2 + (size_t)C * inner;
+  float* s2 = raw1 + (size_t)C * C;
+  float* s1 = s2 + C;
+  hipMemsetAsync(raw2, 0, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
+  int rc;
+  // dH = (gamma2 * dZ) W2 ; fused: dUG from the saved pre-activations
+  rc = gemm_auto(LdRows{a->dout, C, row_tok}, LdWeightNN{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+  if (rc) return rc;
+  // fc2 grads (raw, LayerScale applied in the finish kernel)
+  rc = gemm_tn(LdRowsT{a->dout, C, row_tok}, LdRowsT{a->Hh, inner, nullptr}, raw2, inner, C, inner, R, dR, st);
+  if (rc) return rc;
+  rc = colsum_launch(a->dout, C, row_tok, R, dR, C, s2, st);
+  if (rc) return rc;
+  rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, st);
+  if (rc) return rc;
+  // dY = dZ + dUG W1
+  rc = gemm_auto(LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C, nullptr}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C,
+                 2 * inner, dR, st);
+  if (rc) return rc;
+  rc = gemm_tn(LdRowsT{dUG, 2 * inner, nullptr}, LdRowsT{a->Y, C, nullptr}, a->d_fc1_w, C, 2 * inner, C, R, dR, st);
+  if (rc) return rc;
+  rc = colsum_launch(dUG, 2 * inner, nullptr, R, dR, 2 * inner, a->d_fc1_b, st);
+  if (rc) return rc;
+  // dO = (gamma1 * dY) Wp ; proj grads
+  rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+  if (rc) return rc;
+  rc = gemm_tn(LdRowsT{dY, C, nullptr}, LdRowsT{a->O, C, nullptr}, raw1, C, C, C, R, dR, st);
+  if (rc) return rc;
+  rc = colsum_launch(dY, C, nullptr, R, dR, C, s1, st);
+  if (rc) return rc;
+  rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
+  if (rc) return rc;
+  // attention backward
+  rc = attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, st);
+  if (rc) return rc;
+  // dS = dY + dQKV Wqkv ; qkv grads
+  rc = gemm_auto(LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C, nullptr}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
+  if (rc) return rc;
+  rc = gemm_tn(LdRowsT{dQKV, 3 * C, nullptr}, LdRowsT{a->S, C, nullptr}, a->d_qkv_w, C, 3 * C, C, R, dR, st);
+  if (rc) return rc;
+  rc = colsum_launch(dQKV, 3 * C, nullptr, R, dR, 3 * C, a->d_qkv_b, st);
+  if (rc) return rc;
+  // LN2 (kept rows) + LN1 (all tokens) backward
+  return ln1_gather_bwd_launch(a->xin, a->dout, dS, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->mean1, a->rstd1, a->mean2,
+                               a->rstd2, a->dxin, a->d_ln1_w, a->d_ln1_b, a->d_ln2_w, a->d_ln2_b, R, C, st);
+}
+
+// ------------------------------------------------------------------ ConvLSTM (1x1 conv on [x|h])
+int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || a->C % 32) return SAST_EINVAL;
+  const int M = a->B * a->L, C = a->C;
+  const int Kred = a->h0 ? 2 * C : C;   // zero hidden state: skip the h half of the reduction
+  const LdRows2 la{a->x, C, C, a->h0, C};
+  const LdWeightNT lb{a->w, 2 * C, C};
+  const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C};
+  const long nb_big = (long)((M + 127) / 128) * ((C + 31) / 32);
+  return nb_big >= 512 ? launch_gemm<TileG4Big>(la, lb, ep, M, C, Kred, nullptr, nullptr, st)
+                       : launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
+}
+
+int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int M = a->B * a->L, C = a->C;
+  float* dmix = a->ws;
+  const size_t n = (size_t)M * C;
+  hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
+                     a->dc1, dmix, a->dc0, n, C);
+  const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
+  int rc = gemm_auto(LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C, nullptr}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C,
+                     nullptr, st);
+  if (rc) return rc;
+  rc = gemm_tn(LdRowsT{dmix, 4 * C, nullptr}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, st);
+  if (rc) return rc;
+  return colsum_launch(dmix, 4 * C, nullptr, M, nullptr, 4 * C, a->db, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,370 @@
+// Convolution-shaped entry points (implicit GEMM on NHWC through gemm.cuh loaders):
+//   - ConvDownsampling_Cf2Cl (+LayerNorm, + pos-emb)     ops.py:54-95
+//   - BaseConv = conv + BatchNorm2d + SiLU                network_blocks.py:29-54
+//   - nearest x2 upsample + concat, concat                yolo_pafpn.py:117-137
+//   - fused AdamW on the flat parameter buffer
+#include "gemm.cuh"
+#include "kernels.h"
+
+using namespace sast;
+
+namespace {
+
+template <class LA, class LB, class EP>
+int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
+  if (NJ <= 64) return launch_gemm<TileN64>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
+  const long nb_big = (long)((M + 127) / 128) * ((NJ + 127) / 128);
+  if (nb_big >= 512) return launch_gemm<TileBig>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
+  return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
+}
+template <class LA, class LB>
+int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
+  const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
+  int splits = (1024 + nb - 1) / nb;
+  const int max_splits = (R + 127) / 128;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, st);
+}
+
+// ---------------------------------------------------------------- BatchNorm pieces
+// per-channel sum / sum of squares of x[M, C] in fp64
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
+                                                       int rows_per_block) {
+  const int c4 = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+  if (c4 * 4 < C)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = ld4(x + (size_t)r * C + c4 * 4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+  __shared__ double red[4][64][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[rl][threadIdx.x & 63][e] = s[e]; red[rl][threadIdx.x & 63][4 + e] = q[e]; }
+  __syncthreads();
+  if (rl == 0 && c4 * 4 < C) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      double a = 0, b = 0;
+      for (int k = 0; k < 4; ++k) { a += red[k][threadIdx.x][e]; b += red[k][threadIdx.x][4 + e]; }
+      atomicAdd(sums + c4 * 4 + e, a);
+      atomicAdd(sums + C + c4 * 4 + e, b);
+    }
+  }
+}
+// batch statistics -> (mean, rstd) + running-stat update (momentum, unbiased variance), torch BatchNorm2d semantics
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int M, int C, float eps, float momentum,
+                                   float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sums[c] / M;
+  double var = sums[C + c] / M - mean * mean;
+  if (var < 0) var = 0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unb = M > 1 ? var * M / (M - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+}
+__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float eps,
+                                     float* __restrict__ stats) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  stats[c] = run_mean[c];
+  stats[C + c] = 1.0f / sqrtf(run_var[c] + eps);
+}
+// y = silu((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ y, int ldy, size_t n4, int C) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const int c4 = C / 4;
+  const size_t m = e / c4; const int c = (int)(e % c4) * 4;
+  const float4 v = ld4(x + m * C + c), mu = ld4(stats + c), rs = ld4(stats + C + c), g = ld4(gamma + c), b = ld4(beta + c);
+  float4 z = make_float4((v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z,
+                         (v.w - mu.w) * rs.w * g.w + b.w);
+  z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
+  st4(y + m * ldy + c, z);
+}
+// backward pass 1: sums[c] += dz, sums[C+c] += dz * xhat, with dz = dy * silu'(z)
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ dy, int lddy, int M, int C,
+                                                            float* __restrict__ sums, int rows_per_block) {
+  const int c4 = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float4 a = zero4(), b = zero4();
+  if (c4 * 4 < C) {
+    const int c = c4 * 4;
+    const float4 mu = ld4(stats + c), rs = ld4(stats + C + c), g = ld4(gamma + c), bt = ld4(beta + c);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = ld4(x + (size_t)r * C + c), d = ld4(dy + (size_t)r * lddy + c);
+      const float xh[4] = {(v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w};
+      const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w}, dd[4] = {d.x, d.y, d.z, d.w};
+      float* ap = &a.x; float* bp = &b.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = xh[e] * gg[e] + bb[e], sg = sigmoid_exact(z);
+        const float dz = dd[e] * sg * (1.f + z * (1.f - sg));
+        ap[e] += dz; bp[e] += dz * xh[e];
+      }
+    }
+  }
+  __shared__ float4 red[4][64][2];
+  red[rl][threadIdx.x & 63][0] = a; red[rl][threadIdx.x & 63][1] = b;
+  __syncthreads();
+  if (rl == 0 && c4 * 4 < C) {
+    for (int k = 1; k < 4; ++k) {
+      const float4 t = red[k][threadIdx.x][0], u = red[k][threadIdx.x][1];
+      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; b.x += u.x; b.y += u.y; b.z += u.z; b.w += u.w;
+    }
+    const int c = c4 * 4;
+    atomicAdd(sums + c, a.x); atomicAdd(sums + c + 1, a.y); atomicAdd(sums + c + 2, a.z); atomicAdd(sums + c + 3, a.w);
+    atomicAdd(sums + C + c, b.x); atomicAdd(sums + C + c + 1, b.y); atomicAdd(sums + C + c + 2, b.z); atomicAdd(sums + C + c + 3, b.w);
+  }
+}
+// backward pass 2: dconv = gamma * rstd * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ dy, int lddy, const float* __restrict__ sums,
+                                                           float* __restrict__ dconv, size_t n4, int C, float invM, int training) {
+  const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e4 >= n4) return;
+  const int c4 = C / 4;
+  const size_t m = e4 / c4; const int c = (int)(e4 % c4) * 4;
+  const float4 v = ld4(x + m * C + c), d = ld4(dy + m * lddy + c);
+  float out[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float mu = stats[c + e], rs = stats[C + c + e], g = gamma[c + e];
+    const float xh = ((&v.x)[e] - mu) * rs;
+    const float z = xh * g + beta[c + e], sg = sigmoid_exact(z);
+    const float dz = (&d.x)[e] * sg * (1.f + z * (1.f - sg));
+    out[e] = training ? g * rs * (dz - sums[c + e] * invM - xh * sums[C + c + e] * invM) : g * rs * dz;
+  }
+  st4(dconv + m * C + c, make_float4(out[0], out[1], out[2], out[3]));
+}
+__global__ void bn_bwd_finish_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] += sums[c];
+  dgamma[c] += sums[C + c];
+}
+
+// ---------------------------------------------------------------- upsample / concat
+__global__ __launch_bounds__(256) void upsample_cat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               float* __restrict__ out, int H, int W, int C1, int C2, size_t n4) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const int Ct = C1 + C2, c4n = Ct / 4;
+  const size_t row = e / c4n; const int c = (int)(e % c4n) * 4;
+  float4 v;
+  if (c < C1) {
+    const int W2 = 2 * W, H2 = 2 * H;
+    const int x = (int)(row % W2); const size_t t = row / W2; const int y = (int)(t % H2); const size_t bb = t / H2;
+    v = ld4(a + ((bb * H + (y >> 1)) * W + (x >> 1)) * C1 + c);
+  } else {
+    v = ld4(b + row * C2 + (c - C1));
+  }
+  st4(out + row * Ct + c, v);
+}
+__global__ __launch_bounds__(256) void upsample_cat_bwd_a_kernel(const float* __restrict__ dout, float* __restrict__ da, int H, int W,
+                                                                 int C1, int Ct, size_t n4) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const int c4n = C1 / 4;
+  const size_t row = e / c4n; const int c = (int)(e % c4n) * 4;
+  const int x = (int)(row % W); const size_t t = row / W; const int y = (int)(t % H); const size_t bb = t / H;
+  const size_t base = ((bb * 2 * H + 2 * y) * 2 * W + 2 * x);
+  const float4 p = ld4(dout + base * Ct + c), q = ld4(dout + (base + 1) * Ct + c);
+  const float4 r = ld4(dout + (base + 2 * W) * Ct + c), s = ld4(dout + (base + 2 * W + 1) * Ct + c);
+  st4(da + row * C1 + c, make_float4((p.x + q.x) + (r.x + s.x), (p.y + q.y) + (r.y + s.y), (p.z + q.z) + (r.z + s.z), (p.w + q.w) + (r.w + s.w)));
+}
+// copy a channel slice: dst[row, 0:Cs] = src[row*lds + off : +Cs]   (or the reverse with dst stride)
+__global__ __launch_bounds__(256) void slice_copy_kernel(const float* __restrict__ src, int lds, int soff, float* __restrict__ dst,
+                                                         int ldd, int doff, int Cs, size_t n4) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const int c4n = Cs / 4;
+  const size_t row = e / c4n; const int c = (int)(e % c4n) * 4;
+  st4(dst + row * ldd + doff + c, ld4(src + row * lds + soff + c));
+}
+int slice_copy(const float* src, int lds, int soff, float* dst, int ldd, int doff, int Cs, size_t rows, hipStream_t st) {
+  const size_t n4 = rows * (Cs / 4);
+  if (!n4) return SAST_OK;
+  hipLaunchKernelGGL(slice_copy_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, lds, soff, dst, ldd, doff, Cs, n4);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ---------------------------------------------------------------- AdamW
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, size_t n4, const float* __restrict__ lr_step, float b1,
+                                                    float b2, float eps, float wd, float gscale, float clip) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const float lr = lr_step[0], step = lr_step[1];
+  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
+  float4 pv = ld4(p + e * 4), gv = ld4(g + e * 4), mv = ld4(m + e * 4), vv = ld4(v + e * 4);
+  float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float gr = gp[k] * gscale;
+    if (clip > 0.f) gr = fminf(fmaxf(gr, -clip), clip);
+    pp[k] *= 1.f - lr * wd;
+    mp[k] = b1 * mp[k] + (1.f - b1) * gr;
+    vp[k] = b2 * vp[k] + (1.f - b2) * gr * gr;
+    const float denom = sqrtf(vp[k]) / bc2s + eps;
+    pp[k] -= (lr / bc1) * (mp[k] / denom);
+  }
+  st4(p + e * 4, pv); st4(m + e * 4, mv); st4(v + e * 4, vv);
+}
+
+inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad, int replicate, int ldx) {
+  ConvGeom g;
+  g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad; g.replicate = replicate; g.ldx = ldx;
+  g.Ho = (H + 2 * pad - k) / stride + 1;
+  g.Wo = (W + 2 * pad - k) / stride + 1;
+  return g;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ downsample conv + LayerNorm
+int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || a->Cin % 4 || a->Cout % 32) return SAST_EINVAL;
+  const int k = 2 * a->factor - 1;
+  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
+  const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
+  int rc = gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
+  if (rc) return rc;
+  return ln_fwd_launch(a->conv_out, a->y, a->ln_w, a->ln_b, a->pe, g.Ho * g.Wo, a->mean, a->rstd, M, a->Cout, 1e-5f, st);
+}
+
+int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int k = 2 * a->factor - 1;
+  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
+  const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
+  float* dconv = a->ws;
+  int rc = ln_bwd_launch(a->conv_out, a->dy, a->ln_w, a->mean, a->rstd, dconv, a->d_ln_w, a->d_ln_b, M, a->Cout, st);
+  if (rc) return rc;
+  rc = gemm_tn(LdRowsT{dconv, a->Cout, nullptr}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, st);
+  if (rc) return rc;
+  if (a->dx) {
+    const int Min = a->B * a->H * a->W;
+    rc = gemm_auto(LdConvDx{dconv, g, a->Cout, a->Cout}, LdWeightConvDx{a->w, a->Cout, k * k, a->Cin}, EpStore{a->dx, a->Cin, nullptr},
+                   Min, a->Cin, k * k * a->Cout, st);
+  }
+  return rc;
+}
+
+// ------------------------------------------------------------------ conv + BN + SiLU
+int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || a->Cin % 4 || a->Cout % 4 || (a->ksize != 1 && a->ksize != 3)) return SAST_EINVAL;
+  const int k = a->ksize, pad = (k - 1) / 2;
+  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
+  const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
+  int rc;
+  if (k == 1 && a->stride == 1)
+    rc = gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, C, nullptr}, M, C, K, st);
+  else
+    rc = gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, C, nullptr}, M, C, K, st);
+  if (rc) return rc;
+  if (a->training) {
+    double* sums = (double*)a->ws;
+    hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
+    const int rpb = 128;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C / 4 + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, a->conv_out, M, C, sums, rpb);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, M, C, a->eps, a->momentum, a->run_mean,
+                       a->run_var, a->stats);
+  } else {
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a->run_mean, a->run_var, C, a->eps, a->stats);
+  }
+  const size_t n4 = (size_t)M * (C / 4);
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
+                     a->y, a->ldy, n4, C);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int k = a->ksize, pad = (k - 1) / 2;
+  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
+  const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
+  float* sums = a->ws;                 // [2C]
+  float* dconv = a->ws + 4 * C;        // [M, C]
+  hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
+  const int rpb = 128;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C / 4 + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w,
+                     a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
+  const size_t n4 = (size_t)M * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
+                     a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, a->d_bn_w, a->d_bn_b, C);
+  SAST_CHECK_LAUNCH();
+  int rc;
+  if (k == 1 && a->stride == 1) {
+    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdRowsT{a->x, a->ldx, nullptr}, a->dw, K, C, K, M, st);
+    if (rc) return rc;
+    if (a->dx) rc = gemm_auto(LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K, nullptr}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, st);
+  } else {
+    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, st);
+    if (rc) return rc;
+    if (a->dx)
+      rc = gemm_auto(LdConvDx{dconv, g, C, C}, LdWeightConvDx{a->w, C, k * k, a->Cin}, EpStore{a->dx, a->lddx, nullptr},
+                     a->B * a->H * a->W, a->Cin, k * k * C, st);
+  }
+  return rc;
+}
+
+// ------------------------------------------------------------------ upsample / concat
+int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream) {
+  if (C1 % 4 || C2 % 4) return SAST_EINVAL;
+  const size_t n4 = (size_t)B * 4 * H * W * ((C1 + C2) / 4);
+  hipLaunchKernelGGL(upsample_cat_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H, int W, int C1, int C2, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n4 = (size_t)B * H * W * (C1 / 4);
+  hipLaunchKernelGGL(upsample_cat_bwd_a_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dout, da, H, W, C1, C1 + C2, n4);
+  SAST_CHECK_LAUNCH();
+  return slice_copy(dout, C1 + C2, C1, db, C2, 0, C2, (size_t)B * 4 * H * W, st);
+}
+int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (C1 % 4 || C2 % 4) return SAST_EINVAL;
+  int rc = slice_copy(a, C1, 0, out, C1 + C2, 0, C1, rows, st);
+  if (rc) return rc;
+  return slice_copy(b, C2, 0, out, C1 + C2, C1, C2, rows, st);
+}
+int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int C2, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = slice_copy(dout, C1 + C2, 0, da, C1, 0, C1, rows, st);
+  if (rc) return rc;
+  return slice_copy(dout, C1 + C2, C1, db, C2, 0, C2, rows, st);
+}
+
+int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* lr_step, float beta1, float beta2, float eps,
+               float weight_decay, float grad_scale, float clip_value, sast_stream_t stream) {
+  if (n % 4) return SAST_EINVAL;
+  const size_t n4 = n / 4;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
+                     beta2, eps, weight_decay, grad_scale, clip_value);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,639 @@
+// Row-wise (per token) HBM-bound kernels: event-tensor statistics, layout change,
+// LayerNorm family, STP weighting, column reductions.  One sub-group of GL lanes owns
+// one token row of C channels (C = 4*GL*VPL), float4 accesses, wave shuffles only.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sast {
+
+// ============================================================ non_zero_ratio (a1)
+// reference: sast_rnn.py:45-60.  One block = 32 rows x 128 cols of one (b, c) plane:
+// thread -> one 4x4 cell max, then the 2x2 max cascade through LDS (8x8, 16x16, 32x32).
+template <typename T>
+__global__ __launch_bounds__(256) void nzr_count_kernel(const T* __restrict__ x, int* __restrict__ cnt, int C, int H, int W) {
+  __shared__ float cell[8][33];
+  const int plane = blockIdx.z;                 // b*C + c
+  const int cy = threadIdx.x >> 5, cx = threadIdx.x & 31;
+  const int y0 = blockIdx.y * 32 + cy * 4, x0 = blockIdx.x * 128 + cx * 4;
+  float mx = -INFINITY;
+  bool valid = (y0 < H) && (x0 < W);
+  if (valid) {
+    const T* p = x + ((size_t)plane * H + y0) * W + x0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, (float)p[(size_t)r * W + q]);
+  }
+  cell[cy][cx] = mx;
+  const int b = plane / C, c = plane % C;
+  int* out = cnt + ((size_t)b * 4) * C + c;   // cnt[b][level][c]
+  unsigned long long m1 = __ballot(valid && mx != 0.f);
+  __syncthreads();
+  // level 2: 4 x 16 cells of 8x8 px, level 3: 2 x 8, level 4: 1 x 4
+  bool v2 = false, v3 = false, v4 = false;
+  float a = -INFINITY;
+  if (threadIdx.x < 64) {
+    const int yy = threadIdx.x >> 4, xx = threadIdx.x & 15;
+    a = fmaxf(fmaxf(cell[2 * yy][2 * xx], cell[2 * yy][2 * xx + 1]), fmaxf(cell[2 * yy + 1][2 * xx], cell[2 * yy + 1][2 * xx + 1]));
+    v2 = (blockIdx.y * 32 + yy * 8 < H) && (blockIdx.x * 128 + xx * 8 < W);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) cell[threadIdx.x >> 4][threadIdx.x & 15] = a;
+  unsigned long long m2 = __ballot(v2 && a != 0.f);
+  __syncthreads();
+  float a3 = -INFINITY;
+  if (threadIdx.x < 16) {
+    const int yy = threadIdx.x >> 3, xx = threadIdx.x & 7;
+    a3 = fmaxf(fmaxf(cell[2 * yy][2 * xx], cell[2 * yy][2 * xx + 1]), fmaxf(cell[2 * yy + 1][2 * xx], cell[2 * yy + 1][2 * xx + 1]));
+    v3 = (blockIdx.y * 32 + yy * 16 < H) && (blockIdx.x * 128 + xx * 16 < W);
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) cell[threadIdx.x >> 3][threadIdx.x & 7] = a3;
+  unsigned long long m3 = __ballot(v3 && a3 != 0.f);
+  __syncthreads();
+  float a4 = -INFINITY;
+  if (threadIdx.x < 4) {
+    const int xx = threadIdx.x;
+    a4 = fmaxf(fmaxf(cell[0][2 * xx], cell[0][2 * xx + 1]), fmaxf(cell[1][2 * xx], cell[1][2 * xx + 1]));
+    v4 = (blockIdx.y * 32 < H) && (blockIdx.x * 128 + xx * 32 < W);
+  }
+  unsigned long long m4 = __ballot(v4 && a4 != 0.f);
+  if ((threadIdx.x & 63) == 0) {
+    if (m1) atomicAdd(out + 0 * C, __popcll(m1));
+    if (threadIdx.x == 0) {
+      if (m2) atomicAdd(out + 1 * C, __popcll(m2));
+      if (m3) atomicAdd(out + 2 * C, __popcll(m3));
+      if (m4) atomicAdd(out + 3 * C, __popcll(m4));
+    }
+  }
+}
+
+__global__ void nzr_finish_kernel(const int* __restrict__ cnt, float* __restrict__ r, int n, int C, float s0, float s1, float s2, float s3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int lvl = (i / C) & 3;
+  const float s = lvl == 0 ? s0 : lvl == 1 ? s1 : lvl == 2 ? s2 : s3;
+  r[i] = s * (float)cnt[i];   // fp32(B/numel) * fp32(count), as the reference's scalar*tensor
+}
+
+template <typename T>
+int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, hipStream_t st) {
+  hipMemsetAsync(cnt, 0, sizeof(int) * B * 4 * C, st);
+  dim3 grid((W + 127) / 128, (H + 31) / 32, B * C);
+  hipLaunchKernelGGL((nzr_count_kernel<T>), grid, dim3(256), 0, st, (const T*)x, cnt, C, H, W);
+  float s[4];
+  int f = 4;
+  for (int l = 0; l < 4; ++l) {
+    const double numel = (double)B * C * (H / f) * (W / f);
+    s[l] = (float)((double)B / numel);
+    f *= 2;
+  }
+  const int n = B * 4 * C;
+  hipLaunchKernelGGL(nzr_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cnt, r, n, C, s[0], s[1], s[2], s[3]);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int H, int W, hipStream_t st) {
+  switch (dtype) {
+    case SAST_DT_F32: return nzr_launch<float>(x, cnt, r, B, C, H, W, st);
+    case SAST_DT_I32: return nzr_launch<int>(x, cnt, r, B, C, H, W, st);
+    case SAST_DT_U8:  return nzr_launch<unsigned char>(x, cnt, r, B, C, H, W, st);
+    default: return SAST_EINVAL;
+  }
+}
+
+// ============================================================ NCHW (any dtype) -> NHWC fp32
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int HW) {
+  extern __shared__ float tile[];  // [64][C+1]
+  const int b = blockIdx.y, p0 = blockIdx.x * 64;
+  const int ldt = C + 1;
+  for (int e = threadIdx.x; e < 64 * C; e += 256) {
+    const int c = e >> 6, p = e & 63;
+    if (p0 + p < HW) tile[p * ldt + c] = (float)x[((size_t)b * C + c) * HW + p0 + p];
+  }
+  __syncthreads();
+  const int np = min(64, HW - p0);
+  float* o = y + ((size_t)b * HW + p0) * C;
+  for (int e = threadIdx.x; e < np * C; e += 256) o[e] = tile[(e / C) * ldt + (e % C)];
+}
+
+int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int H, int W, hipStream_t st) {
+  const int HW = H * W;
+  dim3 grid((HW + 63) / 64, B);
+  const size_t sh = sizeof(float) * 64 * (C + 1);
+  switch (dtype) {
+    case SAST_DT_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, HW); break;
+    case SAST_DT_I32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, HW); break;
+    case SAST_DT_U8:  hipLaunchKernelGGL((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, HW); break;
+    default: return SAST_EINVAL;
+  }
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// NHWC fp32 -> NCHW fp32 (API boundary only) and back
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int p = e >> 6, c = e & 63;
+    if (p0 + p < HW && c0 + c < C) tile[p][c] = x[((size_t)b * HW + p0 + p) * C + c0 + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int c = e >> 6, p = e & 63;
+    if (p0 + p < HW && c0 + c < C) y[((size_t)b * C + c0 + c) * HW + p0 + p] = tile[p][c];
+  }
+}
+int nhwc_to_nchw_launch(const float* x, float* y, int B, int C, int HW, hipStream_t st) {
+  dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, x, y, C, HW);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ============================================================ LayerNorm rows
+template <int GL, int VPL>
+struct RowIO {
+  static constexpr int C = GL * VPL * 4;
+  static constexpr int ROWS_PER_WAVE = 64 / GL;
+  __device__ static void load(const float* p, float4 (&v)[VPL], int gl) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) v[i] = ld4(p + (i * GL + gl) * 4);
+  }
+  __device__ static void store(float* p, const float4 (&v)[VPL], int gl) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) st4(p + (i * GL + gl) * 4, v[i]);
+  }
+  __device__ static float sum(const float4 (&v)[VPL]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    return group_sum<GL>(s);
+  }
+};
+
+template <int GL, int VPL>
+__device__ __forceinline__ void ln_row(float4 (&v)[VPL], const float4 (&gm)[VPL], const float4 (&bt)[VPL], float eps,
+                                       float& mean, float& rstd) {
+  using IO = RowIO<GL, VPL>;
+  mean = IO::sum(v) * (1.0f / IO::C);
+  float4 d[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    d[i] = make_float4(v[i].x - mean, v[i].y - mean, v[i].z - mean, v[i].w - mean);
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) ss += (d[i].x * d[i].x + d[i].y * d[i].y) + (d[i].z * d[i].z + d[i].w * d[i].w);
+  ss = group_sum<GL>(ss);
+  rstd = 1.0f / sqrtf(ss * (1.0f / IO::C) + eps);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    v[i].x = d[i].x * rstd * gm[i].x + bt[i].x; v[i].y = d[i].y * rstd * gm[i].y + bt[i].y;
+    v[i].z = d[i].z * rstd * gm[i].z + bt[i].z; v[i].w = d[i].w * rstd * gm[i].w + bt[i].w;
+  }
+}
+
+// y = LN(x) (+ add[(row % add_rows)]) ; saves mean / rstd
+template <int GL, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ add, int add_rows,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o, int rows, float eps) {
+  using IO = RowIO<GL, VPL>;
+  const int gl = threadIdx.x % GL;
+  const int row = (blockIdx.x * 256 + threadIdx.x) / GL;
+  if (row >= rows) return;
+  float4 v[VPL], gm[VPL], bt[VPL];
+  IO::load(x + (size_t)row * IO::C, v, gl);
+  IO::load(gamma, gm, gl);
+  IO::load(beta, bt, gl);
+  float mean, rstd;
+  ln_row<GL, VPL>(v, gm, bt, eps, mean, rstd);
+  if (add) {
+    float4 a[VPL];
+    IO::load(add + (size_t)(row % add_rows) * IO::C, a, gl);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { v[i].x += a[i].x; v[i].y += a[i].y; v[i].z += a[i].z; v[i].w += a[i].w; }
+  }
+  IO::store(y + (size_t)row * IO::C, v, gl);
+  if (gl == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// LN backward for one row held in registers.  dy in/out -> dx ; accumulates dgamma/dbeta partials
+template <int GL, int VPL>
+__device__ __forceinline__ void ln_row_bwd(const float4 (&x)[VPL], float4 (&dy)[VPL], const float4 (&gm)[VPL], float mean,
+                                           float rstd, float4 (&dg)[VPL], float4 (&db)[VPL]) {
+  using IO = RowIO<GL, VPL>;
+  float4 xh[VPL], gy[VPL];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    xh[i] = make_float4((x[i].x - mean) * rstd, (x[i].y - mean) * rstd, (x[i].z - mean) * rstd, (x[i].w - mean) * rstd);
+    gy[i] = make_float4(dy[i].x * gm[i].x, dy[i].y * gm[i].y, dy[i].z * gm[i].z, dy[i].w * gm[i].w);
+    s1 += (gy[i].x + gy[i].y) + (gy[i].z + gy[i].w);
+    s2 += (gy[i].x * xh[i].x + gy[i].y * xh[i].y) + (gy[i].z * xh[i].z + gy[i].w * xh[i].w);
+    dg[i].x += dy[i].x * xh[i].x; dg[i].y += dy[i].y * xh[i].y; dg[i].z += dy[i].z * xh[i].z; dg[i].w += dy[i].w * xh[i].w;
+    db[i].x += dy[i].x; db[i].y += dy[i].y; db[i].z += dy[i].z; db[i].w += dy[i].w;
+  }
+  s1 = group_sum<GL>(s1) * (1.0f / IO::C);
+  s2 = group_sum<GL>(s2) * (1.0f / IO::C);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    dy[i].x = rstd * (gy[i].x - s1 - xh[i].x * s2); dy[i].y = rstd * (gy[i].y - s1 - xh[i].y * s2);
+    dy[i].z = rstd * (gy[i].z - s1 - xh[i].z * s2); dy[i].w = rstd * (gy[i].w - s1 - xh[i].w * s2);
+  }
+}
+
+// block-level reduction of per-thread channel partials into global accumulators (atomicAdd)
+template <int GL, int VPL>
+__device__ __forceinline__ void flush_channel_partials(float* red /* [256/GL][C] in LDS */, const float4 (&p)[VPL],
+                                                       float* __restrict__ gout) {
+  using IO = RowIO<GL, VPL>;
+  const int gl = threadIdx.x % GL, grp = threadIdx.x / GL;
+  constexpr int NG = 256 / GL;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) st4(red + grp * IO::C + (i * GL + gl) * 4, p[i]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < IO::C; c += 256) {
+    float s = 0.f;
+    for (int g = 0; g < NG; ++g) s += red[g * IO::C + c];
+    atomicAdd(gout + c, s);
+  }
+}
+
+template <int GL, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                     const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+  using IO = RowIO<GL, VPL>;
+  extern __shared__ float red[];
+  const int gl = threadIdx.x % GL;
+  constexpr int RPB = 256 / GL;
+  float4 gm[VPL], dg[VPL], db[VPL];
+  IO::load(gamma, gm, gl);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) { dg[i] = zero4(); db[i] = zero4(); }
+  for (int row = blockIdx.x * RPB + threadIdx.x / GL; row < rows; row += gridDim.x * RPB) {
+    float4 xv[VPL], dv[VPL];
+    IO::load(x + (size_t)row * IO::C, xv, gl);
+    IO::load(dy + (size_t)row * IO::C, dv, gl);
+    ln_row_bwd<GL, VPL>(xv, dv, gm, mean_i[row], rstd_i[row], dg, db);
+    IO::store(dx + (size_t)row * IO::C, dv, gl);
+  }
+  flush_channel_partials<GL, VPL>(red, dg, dgamma);
+  flush_channel_partials<GL, VPL>(red, db, dbeta);
+}
+
+#define SAST_DISPATCH_C(C, CALL)                      \
+  switch (C) {                                        \
+    case 32:  { constexpr int GL = 8,  VPL = 1; CALL; } break;  \
+    case 64:  { constexpr int GL = 16, VPL = 1; CALL; } break;  \
+    case 128: { constexpr int GL = 32, VPL = 1; CALL; } break;  \
+    case 256: { constexpr int GL = 64, VPL = 1; CALL; } break;  \
+    case 512: { constexpr int GL = 64, VPL = 2; CALL; } break;  \
+    case 1024:{ constexpr int GL = 64, VPL = 4; CALL; } break;  \
+    default: return SAST_EINVAL;                      \
+  }
+
+static inline int bwd_grid(int rows, int rpb) {
+  int g = (rows + rpb - 1) / rpb;
+  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+}
+
+int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* beta, const float* add, int add_rows,
+                  float* mean, float* rstd, int rows, int C, float eps, hipStream_t st) {
+  if (rows <= 0) return SAST_OK;
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0, st,
+                                        x, y, gamma, beta, add, add_rows, mean, rstd, rows, eps));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+int ln_bwd_launch(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
+                  float* dgamma, float* dbeta, int rows, int C, hipStream_t st) {
+  if (rows <= 0) return SAST_OK;
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, 256 / GL)), dim3(256),
+                                        sizeof(float) * (256 / GL) * C, st, x, dy, gamma, mean, rstd, dx, dgamma, dbeta, rows));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ============================================================ MS-WSA: LN1 on every token, LN2 + compaction of kept tokens
+// reference: SAST.py:206-215 (norm1 on all tokens; norm2 only on the selected ones).
+template <int GL, int VPL>
+__global__ __launch_bounds__(256) void ln1_gather_fwd_kernel(const float* __restrict__ xin, float* __restrict__ out,
+                                                             float* __restrict__ sc, const int* __restrict__ tok_slot,
+                                                             const float* __restrict__ g1, const float* __restrict__ b1,
+                                                             const float* __restrict__ g2, const float* __restrict__ b2,
+                                                             float* __restrict__ mean1, float* __restrict__ rstd1,
+                                                             float* __restrict__ mean2, float* __restrict__ rstd2,
+                                                             int rows, float eps) {
+  using IO = RowIO<GL, VPL>;
+  const int gl = threadIdx.x % GL;
+  const int row = (blockIdx.x * 256 + threadIdx.x) / GL;
+  if (row >= rows) return;
+  float4 v[VPL], gm[VPL], bt[VPL];
+  IO::load(xin + (size_t)row * IO::C, v, gl);
+  IO::load(g1, gm, gl);
+  IO::load(b1, bt, gl);
+  float mean, rstd;
+  ln_row<GL, VPL>(v, gm, bt, eps, mean, rstd);
+  if (gl == 0) { mean1[row] = mean; rstd1[row] = rstd; }
+  const int slot = tok_slot[row];
+  // kept tokens are overwritten later by the MLP2 epilogue; everything else leaves the layer as LN1(x)
+  if (slot < 0) { IO::store(out + (size_t)row * IO::C, v, gl); return; }
+  IO::load(g2, gm, gl);
+  IO::load(b2, bt, gl);
+  ln_row<GL, VPL>(v, gm, bt, eps, mean, rstd);
+  IO::store(sc + (size_t)slot * IO::C, v, gl);
+  if (gl == 0) { mean2[slot] = mean; rstd2[slot] = rstd; }
+}
+
+// backward of the above.  dout: grad w.r.t. layer output (image layout); dsc: grad w.r.t. compact S rows.
+template <int GL, int VPL>
+__global__ __launch_bounds__(256) void ln1_gather_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dout,
+                                                             const float* __restrict__ dsc, const int* __restrict__ tok_slot,
+                                                             const float* __restrict__ g1, const float* __restrict__ b1,
+                                                             const float* __restrict__ g2,
+                                                             const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                             const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                             float* __restrict__ dxin, float* __restrict__ dg1, float* __restrict__ db1,
+                                                             float* __restrict__ dg2, float* __restrict__ db2, int rows) {
+  using IO = RowIO<GL, VPL>;
+  extern __shared__ float red[];
+  const int gl = threadIdx.x % GL;
+  constexpr int RPB = 256 / GL;
+  float4 gm1[VPL], bt1[VPL], gm2[VPL], a1[VPL], c1[VPL], a2[VPL], c2[VPL];
+  IO::load(g1, gm1, gl);
+  IO::load(b1, bt1, gl);
+  IO::load(g2, gm2, gl);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) { a1[i] = zero4(); c1[i] = zero4(); a2[i] = zero4(); c2[i] = zero4(); }
+  for (int row = blockIdx.x * RPB + threadIdx.x / GL; row < rows; row += gridDim.x * RPB) {
+    float4 xv[VPL], dv[VPL];
+    IO::load(xin + (size_t)row * IO::C, xv, gl);
+    const float m1 = mean1[row], r1 = rstd1[row];
+    const int slot = tok_slot[row];
+    if (slot >= 0) {
+      // recompute X1 = LN1(x) (input of LN2), then LN2 backward
+      float4 x1[VPL];
+#pragma unroll
+      for (int i = 0; i < VPL; ++i)
+        x1[i] = make_float4((xv[i].x - m1) * r1 * gm1[i].x + bt1[i].x, (xv[i].y - m1) * r1 * gm1[i].y + bt1[i].y,
+                            (xv[i].z - m1) * r1 * gm1[i].z + bt1[i].z, (xv[i].w - m1) * r1 * gm1[i].w + bt1[i].w);
+      IO::load(dsc + (size_t)slot * IO::C, dv, gl);
+      ln_row_bwd<GL, VPL>(x1, dv, gm2, mean2[slot], rstd2[slot], a2, c2);
+    } else {
+      IO::load(dout + (size_t)row * IO::C, dv, gl);
+    }
+    ln_row_bwd<GL, VPL>(xv, dv, gm1, m1, r1, a1, c1);
+    IO::store(dxin + (size_t)row * IO::C, dv, gl);
+  }
+  flush_channel_partials<GL, VPL>(red, a1, dg1);
+  flush_channel_partials<GL, VPL>(red, c1, db1);
+  flush_channel_partials<GL, VPL>(red, a2, dg2);
+  flush_channel_partials<GL, VPL>(red, c2, db2);
+}
+
+int ln1_gather_fwd_launch(const float* xin, float* out, float* sc, const int* tok_slot, const float* g1, const float* b1,
+                          const float* g2, const float* b2, float* mean1, float* rstd1, float* mean2, float* rstd2,
+                          int rows, int C, float eps, hipStream_t st) {
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0,
+                                        st, xin, out, sc, tok_slot, g1, b1, g2, b2, mean1, rstd1, mean2, rstd2, rows, eps));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc, const int* tok_slot, const float* g1,
+                          const float* b1, const float* g2, const float* mean1, const float* rstd1, const float* mean2,
+                          const float* rstd2, float* dxin, float* dg1, float* db1, float* dg2, float* db2, int rows, int C,
+                          hipStream_t st) {
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, 256 / GL)), dim3(256),
+                                        sizeof(float) * (256 / GL) * C, st, xin, dout, dsc, tok_slot, g1, b1, g2, mean1, rstd1,
+                                        mean2, rstd2, dxin, dg1, db1, dg2, db2, rows));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ============================================================ STP scoring (a5)
+// scale[b,c] = sum_j exp(Wc[c,j]) * (r[b,j] + 1e-6)      (SAST.py:109, :325-328)
+__global__ void controls_fwd_kernel(const float* __restrict__ wc, const float* __restrict__ r, int r_stride,
+                                    float* __restrict__ scale, int B, int C, int J) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  float s = 0.f;
+  for (int j = 0; j < J; ++j) s = fmaf(expf(wc[c * J + j]), r[b * r_stride + j] + 1e-6f, s);
+  scale[i] = s;
+}
+// dWc[c,j] += dscale[b,c] * exp(Wc[c,j]) * (r[b,j]+1e-6)
+__global__ void controls_bwd_kernel(const float* __restrict__ wc, const float* __restrict__ r, int r_stride,
+                                    const float* __restrict__ dscale, float* __restrict__ dwc, int B, int C, int J) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * J) return;
+  const int c = i / J, j = i % J;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dscale[b * C + c] * (r[b * r_stride + j] + 1e-6f);
+  dwc[i] += s * expf(wc[i]);
+}
+
+// xw = sigmoid(scale) * sigmoid(s) * xp ; tok = sum_c (AMP/scale) * s      (SAST.py:113-119, :94)
+template <int GL, int VPL>
+__global__ __launch_bounds__(256) void stp_fwd_kernel(const float* __restrict__ xp, const float* __restrict__ s,
+                                                      const float* __restrict__ scale, float amp, float* __restrict__ xw,
+                                                      float* __restrict__ tok, int rows, int L) {
+  using IO = RowIO<GL, VPL>;
+  const int gl = threadIdx.x % GL;
+  const int row = (blockIdx.x * 256 + threadIdx.x) / GL;
+  if (row >= rows) return;
+  const int b = row / L;
+  float4 xv[VPL], sv[VPL], sc[VPL];
+  IO::load(xp + (size_t)row * IO::C, xv, gl);
+  IO::load(s + (size_t)row * IO::C, sv, gl);
+  IO::load(scale + (size_t)b * IO::C, sc, gl);
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float* sp = &sv[i].x; const float* cp = &sc[i].x; float* xo = &xv[i].x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float inv = amp / cp[e];
+      if (isinf(inv)) inv = 0.f;
+      acc += (double)(inv * sp[e]);   // each product rounded to fp32 as in the reference, summed exactly-ish
+      xo[e] = (sigmoid_exact(cp[e]) * sigmoid_exact(sp[e])) * xo[e];
+    }
+  }
+#pragma unroll
+  for (int o = GL / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  IO::store(xw + (size_t)row * IO::C, xv, gl);
+  if (gl == 0) tok[row] = (float)acc;
+}
+
+// backward of the weighting: given g = dL/dxw
+//   direct[m,c] = g * sig(scale) * sig(s)                      (-> dxp, before the to_scores GEMM term)
+//   dz[m,c]     = g * xp * sig(scale) * sig(s) * (1 - sig(s)) * [s > 0]
+//   dscale[b,c]+= g * xp * sig(s) * sig(scale) * (1 - sig(scale))
+template <int GL, int VPL>
+__global__ __launch_bounds__(256) void stp_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ s,
+                                                      const float* __restrict__ scale, const float* __restrict__ g,
+                                                      float* __restrict__ direct, float* __restrict__ dz,
+                                                      float* __restrict__ dscale, int L, int rows_per_block) {
+  using IO = RowIO<GL, VPL>;
+  extern __shared__ float red[];
+  const int gl = threadIdx.x % GL;
+  constexpr int RPB = 256 / GL;
+  const int b = blockIdx.y;
+  float4 sc[VPL], ds[VPL];
+  IO::load(scale + (size_t)b * IO::C, sc, gl);
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ds[i] = zero4();
+    sc[i] = make_float4(sigmoid_exact(sc[i].x), sigmoid_exact(sc[i].y), sigmoid_exact(sc[i].z), sigmoid_exact(sc[i].w));
+  }
+  const int l0 = blockIdx.x * rows_per_block;
+  const int l1 = min(L, l0 + rows_per_block);
+  for (int l = l0 + threadIdx.x / GL; l < l1; l += RPB) {
+    const size_t row = (size_t)b * L + l;
+    float4 xv[VPL], sv[VPL], gv[VPL], dv[VPL];
+    IO::load(xp + row * IO::C, xv, gl);
+    IO::load(s + row * IO::C, sv, gl);
+    IO::load(g + row * IO::C, gv, gl);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const float* xs = &xv[i].x; const float* ss = &sv[i].x; float* gs = &gv[i].x; float* dd = &dv[i].x;
+      const float* cs = &sc[i].x; float* da = &ds[i].x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = sigmoid_exact(ss[e]);
+        const float gx = gs[e] * xs[e];
+        dd[e] = ss[e] > 0.f ? gx * cs[e] * sg * (1.f - sg) : 0.f;
+        da[e] += gx * sg;
+        gs[e] = gs[e] * cs[e] * sg;
+      }
+    }
+    IO::store(direct + row * IO::C, gv, gl);
+    IO::store(dz + row * IO::C, dv, gl);
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    ds[i].x *= sc[i].x * (1.f - sc[i].x); ds[i].y *= sc[i].y * (1.f - sc[i].y);
+    ds[i].z *= sc[i].z * (1.f - sc[i].z); ds[i].w *= sc[i].w * (1.f - sc[i].w);
+  }
+  flush_channel_partials<GL, VPL>(red, ds, dscale + (size_t)b * IO::C);
+}
+
+int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, hipStream_t st) {
+  hipLaunchKernelGGL(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, wc, r, r_stride, scale, B, C, J);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int controls_bwd_launch(const float* wc, const float* r, int r_stride, const float* dscale, float* dwc, int B, int C, int J,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(controls_bwd_kernel, dim3((C * J + 255) / 256), dim3(256), 0, st, wc, r, r_stride, dscale, dwc, B, C, J);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int stp_fwd_launch(const float* xp, const float* s, const float* scale, float amp, float* xw, float* tok, int B, int L, int C,
+                   hipStream_t st) {
+  const int rows = B * L;
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0, st, xp,
+                                        s, scale, amp, xw, tok, rows, L));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int stp_bwd_launch(const float* xp, const float* s, const float* scale, const float* g, float* direct, float* dz,
+                   float* dscale, int B, int L, int C, hipStream_t st) {
+  // dscale must be zeroed by the caller
+  const int rpb = 512;
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_bwd_kernel<GL, VPL>), dim3((L + rpb - 1) / rpb, B), dim3(256),
+                                        sizeof(float) * (256 / GL) * C, st, xp, s, scale, g, direct, dz, dscale, L, rpb));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ============================================================ y = x + table[row % table_rows]   (pos-emb add, SAST.py:105)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x, const float* __restrict__ t, float* __restrict__ y,
+                                                       size_t n4, int C4, int table_rows) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const size_t row = e / C4; const int c = (int)(e % C4);
+  const float4 a = ld4(x + e * 4), b = ld4(t + ((row % table_rows) * C4 + c) * 4);
+  st4(y + e * 4, make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w));
+}
+int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, int table_rows, hipStream_t st) {
+  const size_t n4 = (size_t)rows * (C / 4);
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, t, y, n4, C / 4, table_rows);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ============================================================ column sums: out[c] += sum_rows x[row(idx)][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, const int* __restrict__ idx,
+                                                     int rows, const int* __restrict__ drows, int C, float* __restrict__ out,
+                                                     int rows_per_block) {
+  const int R = drows ? min(rows, *drows) : rows;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  const int c4 = blockIdx.x * 64 + (threadIdx.x & 63);   // float4 column
+  const int rl = threadIdx.x >> 6;
+  float4 acc = zero4();
+  if (c4 * 4 < C)
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int row = idx ? idx[r] : r;
+      const float4 v = ld4(x + (size_t)row * ld + c4 * 4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  __shared__ float4 red[4][64];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c4 * 4 < C && r0 < r1) {
+    float4 s = red[0][threadIdx.x];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const float4 t = red[k][threadIdx.x]; s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w; }
+    atomicAdd(out + c4 * 4 + 0, s.x); atomicAdd(out + c4 * 4 + 1, s.y);
+    atomicAdd(out + c4 * 4 + 2, s.z); atomicAdd(out + c4 * 4 + 3, s.w);
+  }
+}
+int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* drows, int C, float* out, hipStream_t st) {
+  if (rows <= 0) return SAST_OK;
+  const int rpb = 256;
+  dim3 grid((C / 4 + 63) / 64, (rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, x, ld, idx, rows, drows, C, out, rpb);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// ============================================================ LayerScale'd linear: finalize grads from the raw (gamma-free) ones
+//   y = gamma * (x W^T + b):  raw = dy^T x, s = colsum(dy)
+//   dW += gamma[c]*raw[c,:]; db += gamma*s ; dgamma += <W[c,:], raw[c,:]> + b[c]*s[c]
+__global__ __launch_bounds__(64) void ls_linear_finish_kernel(const float* __restrict__ w, const float* __restrict__ b,
+                                                              const float* __restrict__ gamma, const float* __restrict__ raw,
+                                                              const float* __restrict__ s, float* __restrict__ dw,
+                                                              float* __restrict__ db, float* __restrict__ dgamma, int K) {
+  const int c = blockIdx.x;
+  const float g = gamma ? gamma[c] : 1.f;   // gamma == NULL: LayerScale disabled (ls_init_value <= 0, SAST.py:187)
+  float dot = 0.f;
+  for (int k = threadIdx.x; k < K; k += 64) {
+    const float rv = raw[(size_t)c * K + k];
+    dot += w[(size_t)c * K + k] * rv;
+    dw[(size_t)c * K + k] += g * rv;
+  }
+  dot = wave_sum(dot);
+  if (threadIdx.x == 0) {
+    db[c] += g * s[c];
+    if (gamma) dgamma[c] += dot + b[c] * s[c];
+  }
+}
+int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
+                            float* db, float* dgamma, int C, int K, hipStream_t st) {
+  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3(C), dim3(64), 0, st, w, b, gamma, raw, s, dw, db, dgamma, K);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+}  // namespace sast

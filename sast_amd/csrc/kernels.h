@@ -1,0 +1,46 @@
+// internal launcher declarations shared by the translation units of libsast_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/sast_hip.h"
+
+namespace sast {
+
+// k_rows.hip
+int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int H, int W, hipStream_t st);
+int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int H, int W, hipStream_t st);
+int nhwc_to_nchw_launch(const float* x, float* y, int B, int C, int HW, hipStream_t st);
+int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* beta, const float* add, int add_rows,
+                  float* mean, float* rstd, int rows, int C, float eps, hipStream_t st);
+int ln_bwd_launch(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
+                  float* dgamma, float* dbeta, int rows, int C, hipStream_t st);
+int ln1_gather_fwd_launch(const float* xin, float* out, float* sc, const int* tok_slot, const float* g1, const float* b1,
+                          const float* g2, const float* b2, float* mean1, float* rstd1, float* mean2, float* rstd2,
+                          int rows, int C, float eps, hipStream_t st);
+int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc, const int* tok_slot, const float* g1,
+                          const float* b1, const float* g2, const float* mean1, const float* rstd1, const float* mean2,
+                          const float* rstd2, float* dxin, float* dg1, float* db1, float* dg2, float* db2, int rows, int C,
+                          hipStream_t st);
+int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, hipStream_t st);
+int controls_bwd_launch(const float* wc, const float* r, int r_stride, const float* dscale, float* dwc, int B, int C, int J,
+                        hipStream_t st);
+int stp_fwd_launch(const float* xp, const float* s, const float* scale, float amp, float* xw, float* tok, int B, int L, int C,
+                   hipStream_t st);
+int stp_bwd_launch(const float* xp, const float* s, const float* scale, const float* g, float* direct, float* dz,
+                   float* dscale, int B, int L, int C, hipStream_t st);
+int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, int table_rows, hipStream_t st);
+int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* drows, int C, float* out, hipStream_t st);
+int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
+                            float* db, float* dgamma, int C, int K, hipStream_t st);
+
+// k_select.hip
+int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mode, float thr_win, float thr_tok,
+                  int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,
+                  int* row_tok, hipStream_t st);
+
+// k_attn.hip
+int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C,
+                    hipStream_t st);
+int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
+                    const int* Kw, int W, int T, int C, hipStream_t st);
+
+}  // namespace sast

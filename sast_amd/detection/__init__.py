@@ -1,0 +1,10 @@
+from .sast_rnn import RNNDetector, RNNDetectorStage, SASTAttentionPairCl, PositionEmbeddingSine, non_zero_ratio  # noqa: F401
+from .yolo_pafpn import YOLOPAFPN  # noqa: F401
+from .network_blocks import BaseConv, Bottleneck, CSPLayer  # noqa: F401
+
+
+def build_recurrent_backbone(backbone_cfg):
+    """models/detection/recurrent_backbone/__init__.py:6"""
+    if backbone_cfg.name == 'SASTRNN':
+        return RNNDetector(backbone_cfg)
+    raise NotImplementedError

@@ -1,0 +1,74 @@
+"""Mirror of models/detection/yolox/models/network_blocks.py (BaseConv / Bottleneck / CSPLayer) on NHWC rows."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import functional as SF
+from ..layers.ops import channels_last_conv_weight
+
+
+class BaseConv(nn.Module):
+    """Conv2d(no bias, same pad) -> BatchNorm2d -> SiLU (network_blocks.py:29-54) as one fused op."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
+        super().__init__()
+        if groups != 1 or bias or act != "silu" or ksize not in (1, 3):
+            raise NotImplementedError("sast_amd: BaseConv implements groups=1, bias=False, act='silu', ksize in {1,3}")
+        self.ksize, self.stride = ksize, stride
+        self.conv = nn.Module()
+        self.conv.weight = channels_last_conv_weight(out_channels, in_channels, ksize)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward_nhwc(self, x):
+        bn = self.bn
+        y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
+                            self.training, bn.momentum, bn.eps)
+        if self.training and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        return y
+
+    def forward(self, x):
+        return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
+
+
+class Bottleneck(nn.Module):
+    """network_blocks.py:79-101"""
+
+    def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
+        super().__init__()
+        if depthwise:
+            raise NotImplementedError("sast_amd: depthwise PAFPN is not implemented (shipped config: depthwise False)")
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
+        self.use_add = shortcut and in_channels == out_channels
+
+    def forward_nhwc(self, x):
+        y = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x))
+        return y + x if self.use_add else y
+
+    def forward(self, x):
+        return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
+
+
+class CSPLayer(nn.Module):
+    """network_blocks.py:104-141"""
+
+    def __init__(self, in_channels, out_channels, n=1, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
+        super().__init__()
+        hidden = int(out_channels * expansion)
+        self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv2 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
+        self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
+        self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
+
+    def forward_nhwc(self, x):
+        x1 = self.conv1.forward_nhwc(x)
+        x2 = self.conv2.forward_nhwc(x)
+        for b in self.m:
+            x1 = b.forward_nhwc(x1)
+        return self.conv3.forward_nhwc(SF.cat2(x1, x2))
+
+    def forward(self, x):
+        return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))

@@ -1,0 +1,50 @@
+"""Mirror of models/detection/yolox_extension/models/yolo_pafpn.py (YOLOPAFPN) on NHWC rows."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch.nn as nn
+
+from .. import functional as SF
+from .network_blocks import BaseConv, CSPLayer
+
+
+class YOLOPAFPN(nn.Module):
+    """yolo_pafpn.py:18-139: top-down + bottom-up FPN over backbone stages (2,3,4)."""
+
+    def __init__(self, depth: float = 1.0, in_stages: Tuple[int, ...] = (2, 3, 4), in_channels: Tuple[int, ...] = (256, 512, 1024),
+                 depthwise: bool = False, act: str = "silu", compile_cfg: Optional[Dict] = None):
+        super().__init__()
+        assert len(in_stages) == len(in_channels) == 3, 'Current implementation only for 3 feature maps'
+        if depthwise:
+            raise NotImplementedError("sast_amd: depthwise PAFPN is not implemented")
+        if compile_cfg is not None and compile_cfg.get('enable', False):
+            raise NotImplementedError("sast_amd: torch.compile is not used; capture the step in a hipGraph instead")
+        self.in_features, self.in_channels = in_stages, in_channels
+        c0, c1, c2 = in_channels
+        n = round(3 * depth)
+        self.lateral_conv0 = BaseConv(c2, c1, 1, 1, act=act)
+        self.C3_p4 = CSPLayer(2 * c1, c1, n, False, depthwise=depthwise, act=act)
+        self.reduce_conv1 = BaseConv(c1, c0, 1, 1, act=act)
+        self.C3_p3 = CSPLayer(2 * c0, c0, n, False, depthwise=depthwise, act=act)
+        self.bu_conv2 = BaseConv(c0, c0, 3, 2, act=act)
+        self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
+        self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
+        self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
+
+    def forward_nhwc(self, feats: Dict[int, object]):
+        x2, x1, x0 = (feats[f] for f in self.in_features)
+        fpn_out0 = self.lateral_conv0.forward_nhwc(x0)
+        f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1))     # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
+        fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0)
+        pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2))
+        p_out1 = SF.cat2(self.bu_conv2.forward_nhwc(pan_out2), fpn_out1)
+        pan_out1 = self.C3_n3.forward_nhwc(p_out1)
+        p_out0 = SF.cat2(self.bu_conv1.forward_nhwc(pan_out1), fpn_out0)
+        pan_out0 = self.C3_n4.forward_nhwc(p_out0)
+        return pan_out2, pan_out1, pan_out0
+
+    def forward(self, input):
+        """input: {stage: (B,C,H,W)} -> 3-tuple of (B,C,H,W) maps (channels-last memory)."""
+        feats = {f: SF.as_nhwc(input[f]) for f in self.in_features}
+        return tuple(SF.as_nchw_view(o) for o in self.forward_nhwc(feats))

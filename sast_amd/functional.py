@@ -1,0 +1,571 @@
+"""torch.autograd bindings of the C-ABI ops (include/sast_hip.h).
+
+Layout: activations are fp32 NHWC ("image layout" rows [B*H*W, C]).  Parameter gradients are
+ACCUMULATED IN PLACE into `param.grad` by the backward kernels (atomicAdd, "+=" semantics, the
+buffer is created zero-filled when missing) and the autograd edge of a parameter returns None --
+the same contract as Megatron's fused gradient accumulation.  `loss.backward()` therefore fills
+`.grad` exactly like the reference; `torch.autograd.grad(..., params)` is not supported.
+
+There is no CPU implementation: every op raises if its tensors are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.DT_F32, torch.int32: L.DT_I32, torch.uint8: L.DT_U8}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sast_amd: tensors must live on a HIP device (no CPU fallback for the SAST hot path)")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _fill(struct, **kw):
+    for k, v in kw.items():
+        setattr(struct, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return struct
+
+
+def _gbuf(p: Optional[torch.Tensor]):
+    """gradient accumulation buffer of a parameter (created zero-filled with the parameter's strides)."""
+    if p is None or not p.requires_grad:
+        return None
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    g = p.grad
+    if g.stride() != p.stride():
+        raise RuntimeError("sast_amd: .grad must have the same memory layout as its parameter")
+    return g
+
+
+def _scratch_grad(p: torch.Tensor):
+    """for frozen parameters the kernels still need somewhere to accumulate; use a throw-away buffer."""
+    return torch.zeros_like(p)
+
+
+def _g(p):
+    g = _gbuf(p)
+    return g if g is not None else (_scratch_grad(p) if p is not None else None)
+
+
+def is_channels_last_weight(w: torch.Tensor) -> bool:
+    return w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()
+
+
+# ---------------------------------------------------------------------------------------------- a1
+@torch.no_grad()
+def non_zero_ratio(x: torch.Tensor) -> torch.Tensor:
+    """sast_rnn.py:45-60.  x (B,Cin,H,W) NCHW {uint8,int32,float32} -> (B,4,Cin) fp32."""
+    _need_gpu(x)
+    if x.dtype not in _DT:
+        x = x.float()
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    r = torch.empty(B, 4, Cin, device=x.device, dtype=torch.float32)
+    cnt = torch.empty(B * 4 * Cin, device=x.device, dtype=torch.int32)
+    L.check(L.lib().sast_nzratio(x.data_ptr(), _DT[x.dtype], B, Cin, H, W, cnt.data_ptr(), r.data_ptr(), _stream()), "nzratio")
+    return r
+
+
+@torch.no_grad()
+def nchw_to_nhwc_float(x: torch.Tensor) -> torch.Tensor:
+    """x.float() + nChw_2_nhwC (sast_rnn.py:153, ops.py:19-24) in one pass."""
+    _need_gpu(x)
+    if x.dtype not in _DT:
+        x = x.float()
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, Cc, device=x.device, dtype=torch.float32)
+    L.check(L.lib().sast_nchw_to_nhwc(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, y.data_ptr(), _stream()), "nchw_to_nhwc")
+    return y
+
+
+def as_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) logical NCHW -> (B,H,W,C) contiguous; zero-copy when x is already channels-last in memory."""
+    v = x.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """(B,H,W,C) contiguous -> logical (B,C,H,W) view (channels_last memory format, no copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+class _AddRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, table):
+        _need_gpu(x, table)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        L.check(L.lib().sast_add_rows(x.data_ptr(), table.data_ptr(), y.data_ptr(), rows, Cc, table.numel() // Cc, _stream()), "add_rows")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None
+
+
+def add_pos_embedding(x: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    return _AddRows.apply(x, table)
+
+
+# ---------------------------------------------------------------------------------------------- a2
+class _DownsampleLN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, ln_w, ln_b, pe, factor):
+        _need_gpu(x, w)
+        x = x.contiguous()
+        if not is_channels_last_weight(w):
+            raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        Ho, Wo = H // factor, W // factor
+        M = B * Ho * Wo
+        dev = x.device
+        conv_out = torch.empty(M, Cout, device=dev)
+        stats = torch.empty(2, M, device=dev)
+        y = torch.empty(B, Ho, Wo, Cout, device=dev)
+        a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
+                  pe=_ptr(pe), conv_out=conv_out, mean=stats[0], rstd=stats[1], y=y)
+        L.check(L.lib().sast_downsample_ln_fwd(C.byref(a), _stream()), "downsample_ln_fwd")
+        ctx.save_for_backward(x, conv_out, stats)
+        ctx.params = (w, ln_w, ln_b)
+        ctx.meta = (B, H, W, Cin, Cout, factor)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, conv_out, stats = ctx.saved_tensors
+        w, ln_w, ln_b = ctx.params
+        B, H, W, Cin, Cout, factor = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(conv_out.numel(), device=x.device)
+        a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
+                  conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=_g(w), d_ln_w=_g(ln_w), d_ln_b=_g(ln_b), ws=ws)
+        L.check(L.lib().sast_downsample_ln_bwd(C.byref(a), _stream()), "downsample_ln_bwd")
+        return dx, None, None, None, None, None
+
+
+def downsample_ln(x_nhwc, w, ln_w, ln_b, pe, factor):
+    return _DownsampleLN.apply(x_nhwc, w, ln_w, ln_b, pe, factor)
+
+
+# ---------------------------------------------------------------------------------------------- a5
+class _ScoreSTP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, r, ws_w, ws_b, wc, amp):
+        _need_gpu(xp, r, ws_w)
+        xp = xp.contiguous()
+        B = xp.shape[0]
+        Cc = xp.shape[-1]
+        Lt = xp.numel() // (B * Cc)
+        assert r.shape[-1] == 20 and r.stride(-1) == 1
+        dev = xp.device
+        scale = torch.empty(B, Cc, device=dev)
+        s = torch.empty(B * Lt, Cc, device=dev)
+        xw = torch.empty_like(xp)
+        tok = torch.empty(B, Lt, device=dev)
+        a = _fill(L.SastScoreArgs(), B=B, L=Lt, C=Cc, r_stride=r.stride(0), amp=amp, xp=xp, r=r, ws_w=ws_w, ws_b=ws_b, wc=wc,
+                  scale=scale, s=s, xw=xw, tok=tok)
+        L.check(L.lib().sast_score_stp_fwd(C.byref(a), _stream()), "score_stp_fwd")
+        ctx.save_for_backward(xp, r, scale, s)
+        ctx.params = (ws_w, ws_b, wc)
+        ctx.meta = (B, Lt, Cc, amp)
+        ctx.mark_non_differentiable(tok)
+        return xw, tok
+
+    @staticmethod
+    def backward(ctx, dxw, _dtok):
+        xp, r, scale, s = ctx.saved_tensors
+        ws_w, ws_b, wc = ctx.params
+        B, Lt, Cc, amp = ctx.meta
+        dxw = dxw.contiguous()
+        dxp = torch.empty_like(xp)
+        ws = torch.empty(B * Lt * Cc + B * Cc, device=xp.device)
+        a = _fill(L.SastScoreArgs(), B=B, L=Lt, C=Cc, r_stride=r.stride(0), amp=amp, xp=xp, r=r, ws_w=ws_w, ws_b=ws_b, wc=wc,
+                  scale=scale, s=s, dxw=dxw, dxp=dxp, d_ws_w=_g(ws_w), d_ws_b=_g(ws_b), d_wc=_g(wc), ws=ws)
+        L.check(L.lib().sast_score_stp_bwd(C.byref(a), _stream()), "score_stp_bwd")
+        return dxp, None, None, None, None, None
+
+
+def score_stp(xp, r, ws_w, ws_b, wc, amp) -> Tuple[torch.Tensor, torch.Tensor]:
+    return _ScoreSTP.apply(xp, r, ws_w, ws_b, wc, float(amp))
+
+
+# ---------------------------------------------------------------------------------------------- a6-a8
+class Selection:
+    """device-resident result of the window/token selection (SastSel).  No host sync unless a
+    reference-style index list is requested."""
+
+    def __init__(self, B, H, W, ph, pw, mode, device):
+        self.B, self.H, self.W, self.ph, self.pw, self.mode = B, H, W, ph, pw, mode
+        self.T = ph * pw
+        self.N = (H // ph) * (W // pw)
+        self.L = H * W
+        nw = B * self.N
+        buf = torch.empty(4 * nw + 4 + 2 * B * self.L, device=device, dtype=torch.int32)
+        self.win_keep, self.K, self.row_off, self.win_rank = (buf[i * nw:(i + 1) * nw] for i in range(4))
+        o = 4 * nw
+        self.counts = buf[o:o + 4]
+        self.tok_slot = buf[o + 4:o + 4 + B * self.L]
+        self.row_tok = buf[o + 4 + B * self.L:]
+        self.mask = torch.empty(nw, 2, device=device, dtype=torch.int64)
+        self._buf = buf
+        self.tok = None  # scores the selection was computed from (for index-list export)
+
+    def fill_struct(self, s):
+        _fill(s, win_keep=self.win_keep, mask=self.mask, K=self.K, row_off=self.row_off, win_rank=self.win_rank,
+              counts=self.counts, tok_slot=self.tok_slot, row_tok=self.row_tok)
+        return s
+
+    def struct(self):
+        return self.fill_struct(L.SastSel())
+
+    # ---- host-side views (synchronising; parity tests and the reference-style index_list only)
+    def num_kept_tokens(self) -> int:
+        return int(self.counts[0].item())
+
+    def index_window(self) -> torch.Tensor:
+        """ascending flat ids of kept windows (get_score_index_2d21d, SAST.py:258-267)."""
+        iw = torch.nonzero(self.win_keep).view(-1)
+        return iw
+
+    def K_list(self) -> torch.Tensor:
+        return self.K[self.win_keep.bool()].long()
+
+    def asy_index(self) -> torch.Tensor:
+        """ascending ids m*T+t of kept tokens in the compacted-window space (SAST.py:279-281)."""
+        bits = self._mask_bits()[self.win_keep.bool()]
+        return torch.nonzero(bits.reshape(-1)).view(-1)
+
+    def _mask_bits(self) -> torch.Tensor:
+        ar = torch.arange(64, device=self.mask.device, dtype=torch.int64)
+        lo = (self.mask[:, 0:1] >> ar) & 1
+        hi = (self.mask[:, 1:2] >> ar) & 1
+        return torch.cat([lo, hi], dim=1)[:, : self.T].bool()
+
+    def group_token_ids(self) -> torch.Tensor:
+        """(N, T) token index l = y*W + x of slot t of group n (ops.py:189-220 maps)."""
+        H, W, ph, pw = self.H, self.W, self.ph, self.pw
+        idx = torch.arange(H * W).view(1, H, W, 1)
+        if self.mode == 0:
+            g = idx.view(1, H // ph, ph, W // pw, pw, 1).permute(0, 1, 3, 2, 4, 5)
+        else:
+            g = idx.view(1, ph, H // ph, pw, W // pw, 1).permute(0, 2, 4, 1, 3, 5)
+        return g.reshape(self.N, self.T)
+
+    def to_index_list(self):
+        """[index_window, index_token, padding_index, asy_index, K] as the reference builds them
+        (SAST.py:120-123).  index_token / padding_index carry the top-k fillers, whose order is
+        unspecified in the reference (topk sorted=False); they are reproduced from the token scores."""
+        iw, asy, K = self.index_window(), self.asy_index(), self.K_list()
+        if self.tok is None:
+            return [iw, None, None, asy, K]
+        gid = self.group_token_ids().to(self.tok.device)
+        tokg = self.tok.view(self.B, self.L)[:, gid].reshape(self.B * self.N, self.T)
+        nt = tokg[iw].softmax(-1)
+        kmax = int(K.max().item()) if K.numel() else 0
+        top = torch.topk(nt, k=kmax, dim=1, largest=True, sorted=False)[1]
+        base = torch.arange(0, nt.shape[0] * self.T, self.T, device=nt.device).view(-1, 1)
+        it = (top + base).view(-1)
+        pad = it[torch.isin(it, asy, assume_unique=True, invert=True)]
+        return [iw, it, pad, asy, K]
+
+    def __iter__(self):
+        return iter(self.to_index_list())
+
+    def __getitem__(self, i):
+        return self.to_index_list()[i]
+
+    def __len__(self):
+        return 5
+
+
+@torch.no_grad()
+def select(tok: torch.Tensor, B, H, W, ph, pw, mode, bounce) -> Selection:
+    _need_gpu(tok)
+    if H % ph or W % pw:
+        raise AssertionError(f"map {H}x{W} must be divisible by partition ({ph},{pw})")  # ops.py:191-192
+    sel = Selection(B, H, W, ph, pw, mode, tok.device)
+    tok = tok.contiguous()
+    s = sel.struct()
+    L.check(L.lib().sast_select(tok.data_ptr(), B, H, W, ph, pw, mode, float(bounce), C.byref(s), _stream()), "select")
+    sel.tok = tok
+    return sel
+
+
+def selection_from_index_lists(index_window, asy_index, K, n_groups: int, T: int, device) -> Selection:
+    """build the device-side selection from reference-style lists in PARTITIONED layout
+    (token id = group*T + slot): used by the stand-alone MS_WSA.forward drop-in."""
+    sel = Selection.__new__(Selection)
+    sel.B, sel.H, sel.W, sel.ph, sel.pw, sel.mode = 1, n_groups * T, 1, T, 1, 0
+    sel.T, sel.N, sel.L = T, n_groups, n_groups * T
+    iw = index_window.to(device).long()
+    asy = asy_index.to(device).long()
+    Kl = K.to(device).long()
+    i32 = dict(device=device, dtype=torch.int32)
+    sel.win_keep = torch.zeros(n_groups, **i32)
+    sel.win_keep[iw] = 1
+    sel.K = torch.zeros(n_groups, **i32)
+    sel.K[iw] = Kl.int()
+    ro = torch.cumsum(Kl, 0) - Kl
+    sel.row_off = torch.zeros(n_groups, **i32)
+    sel.row_off[iw] = ro.int()
+    sel.win_rank = torch.full((n_groups,), -1, **i32)
+    sel.win_rank[iw] = torch.arange(len(iw), **i32)
+    total = int(asy.numel())
+    sel.counts = torch.tensor([total, len(iw), total, 0], **i32)
+    tokens = iw[asy // T] * T + asy % T          # partitioned-layout token of every compact row
+    sel.tok_slot = torch.full((n_groups * T,), -1, **i32)
+    sel.tok_slot[tokens] = torch.arange(total, **i32)
+    sel.row_tok = torch.zeros(n_groups * T, **i32)
+    sel.row_tok[:total] = tokens.int()
+    sel.mask = torch.zeros(n_groups, 2, device=device, dtype=torch.int64)
+    sel.tok = None
+    return sel
+
+
+# ---------------------------------------------------------------------------------------------- a9
+_MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
+                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")
+
+
+class _MSWSA(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xin, sel: Selection, eps, *params):
+        _need_gpu(xin)
+        xin = xin.contiguous()
+        p = dict(zip(_MSWSA_PARAMS, params))
+        Cc = xin.shape[-1]
+        R = xin.numel() // Cc
+        inner = p["fc2_w"].shape[1]
+        heads = Cc // 32
+        dev = xin.device
+        out = torch.empty_like(xin)
+        stats = torch.empty(4, R, device=dev)
+        big = torch.empty(R, Cc * 6 + 3 * inner + heads, device=dev)  # one allocation for all saved activations
+        # carve [R, width] blocks out of `big` as separate contiguous buffers
+        flat = big.view(-1)
+        off = 0
+
+        def carve(width):
+            nonlocal off
+            t = flat[off:off + R * width]
+            off += R * width
+            return t
+
+        S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
+        a = L.SastMswsaArgs()
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, xin=xin, out=out,
+              mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
+        sel.fill_struct(a.sel)
+        _fill(a, **{k: _ptr(v) for k, v in p.items()})
+        L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
+        ctx.save_for_backward(xin, stats, big)
+        ctx.sel, ctx.params, ctx.eps, ctx.inner = sel, params, eps, inner
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xin, stats, big = ctx.saved_tensors
+        sel, params, inner = ctx.sel, ctx.params, ctx.inner
+        p = dict(zip(_MSWSA_PARAMS, params))
+        Cc = xin.shape[-1]
+        R = xin.numel() // Cc
+        heads = Cc // 32
+        dout = dout.contiguous()
+        dxin = torch.empty_like(xin)
+        flat = big.view(-1)
+        off = 0
+
+        def carve(width):
+            nonlocal off
+            t = flat[off:off + R * width]
+            off += R * width
+            return t
+
+        S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
+        ws = torch.empty(L.lib().sast_mswsa_bwd_ws_floats(R, Cc, inner), device=xin.device)
+        a = L.SastMswsaArgs()
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, xin=xin,
+              mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh,
+              dout=dout, dxin=dxin, ws=ws)
+        sel.fill_struct(a.sel)
+        _fill(a, **{k: _ptr(v) for k, v in p.items()})
+        _fill(a, **{"d_" + k: _ptr(_g(v)) for k, v in p.items()})
+        L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
+        return (dxin, None, None) + (None,) * len(params)
+
+
+def mswsa(xin, sel: Selection, eps: float, params: dict) -> torch.Tensor:
+    """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled)."""
+    return _MSWSA.apply(xin, sel, float(eps), *[params[k] for k in _MSWSA_PARAMS])
+
+
+# ---------------------------------------------------------------------------------------------- a12
+class _LSTM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h0, c0, w, b):
+        _need_gpu(x, w)
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        h0 = h0.contiguous() if h0 is not None else None
+        c0 = c0.contiguous() if c0 is not None else None
+        Cc = x.shape[-1]
+        B = x.shape[0]
+        Lt = x.numel() // (B * Cc)
+        h1, c1 = torch.empty_like(x), torch.empty_like(x)
+        gates = torch.empty(B * Lt, 4 * Cc, device=x.device)
+        a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, h1=h1, c1=c1, gates=gates)
+        L.check(L.lib().sast_lstm_fwd(C.byref(a), _stream()), "lstm_fwd")
+        ctx.save_for_backward(x, h0, c0, c1, gates)
+        ctx.params = (w, b)
+        ctx.meta = (B, Lt, Cc)
+        return h1, c1
+
+    @staticmethod
+    def backward(ctx, dh1, dc1):
+        x, h0, c0, c1, gates = ctx.saved_tensors
+        w, b = ctx.params
+        B, Lt, Cc = ctx.meta
+        if dh1 is None:
+            dh1 = torch.zeros_like(x)
+        dh1 = dh1.contiguous()
+        dc1 = dc1.contiguous() if dc1 is not None else None
+        dx = torch.empty_like(x)
+        need_h = h0 is not None and ctx.needs_input_grad[1]
+        need_c = c0 is not None and ctx.needs_input_grad[2]
+        dh0 = torch.empty_like(x) if need_h else None
+        dc0 = torch.empty_like(x) if need_c else None
+        ws = torch.empty(B * Lt * 4 * Cc, device=x.device)
+        a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, c1=c1, gates=gates, dh1=dh1,
+                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=_g(w), db=_g(b), ws=ws)
+        L.check(L.lib().sast_lstm_bwd(C.byref(a), _stream()), "lstm_bwd")
+        return dx, dh0, dc0, None, None
+
+
+def conv_lstm(x_nhwc, h0, c0, w, b):
+    return _LSTM.apply(x_nhwc, h0, c0, w, b)
+
+
+# ---------------------------------------------------------------------------------------------- a13
+class _ConvBnSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps):
+        _need_gpu(x, w)
+        x = x.contiguous()
+        if not is_channels_last_weight(w):
+            raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
+        B, H, W, Cin = x.shape
+        Cout = w.shape[0]
+        pad = (ksize - 1) // 2
+        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        M = B * Ho * Wo
+        dev = x.device
+        conv_out = torch.empty(M, Cout, device=dev)
+        stats = torch.empty(2 * Cout, device=dev)
+        y = torch.empty(B, Ho, Wo, Cout, device=dev)
+        ws = torch.empty(4 * Cout, device=dev)
+        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin,
+                  ldy=Cout, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean), run_var=_ptr(run_var),
+                  conv_out=conv_out, stats=stats, y=y, ws=ws)
+        L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
+        ctx.save_for_backward(x, conv_out, stats)
+        ctx.params = (w, bn_w, bn_b)
+        ctx.meta = (B, H, W, Cin, Cout, ksize, stride, int(training), momentum, eps, M)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, conv_out, stats = ctx.saved_tensors
+        w, bn_w, bn_b = ctx.params
+        B, H, W, Cin, Cout, ksize, stride, training, momentum, eps, M = ctx.meta
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(M * Cout + 4 * Cout, device=x.device)
+        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin,
+                  ldy=Cout, lddy=Cout, lddx=Cin, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out,
+                  stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w), d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), ws=ws)
+        L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
+        return (dx,) + (None,) * 10
+
+
+def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5):
+    return _ConvBnSilu.apply(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps))
+
+
+class _UpsampleCat(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        B, H, W, C1 = a.shape
+        C2 = b.shape[-1]
+        assert b.shape[:3] == (B, 2 * H, 2 * W)
+        out = torch.empty(B, 2 * H, 2 * W, C1 + C2, device=a.device)
+        L.check(L.lib().sast_upsample_cat_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, C1, C2, _stream()), "upsample_cat_fwd")
+        ctx.meta = (B, H, W, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, H, W, C1, C2 = ctx.meta
+        dout = dout.contiguous()
+        da = torch.empty(B, H, W, C1, device=dout.device)
+        db = torch.empty(B, 2 * H, 2 * W, C2, device=dout.device)
+        L.check(L.lib().sast_upsample_cat_bwd(dout.data_ptr(), da.data_ptr(), db.data_ptr(), B, H, W, C1, C2, _stream()), "upsample_cat_bwd")
+        return da, db
+
+
+def upsample_cat(a, b):
+    return _UpsampleCat.apply(a, b)
+
+
+class _Cat2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        a, b = a.contiguous(), b.contiguous()
+        C1, C2 = a.shape[-1], b.shape[-1]
+        rows = a.numel() // C1
+        out = torch.empty(*a.shape[:-1], C1 + C2, device=a.device)
+        L.check(L.lib().sast_cat2_fwd(a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, C1, C2, _stream()), "cat2_fwd")
+        ctx.meta = (a.shape, b.shape, rows, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        sa, sb, rows, C1, C2 = ctx.meta
+        dout = dout.contiguous()
+        da, db = torch.empty(sa, device=dout.device), torch.empty(sb, device=dout.device)
+        L.check(L.lib().sast_cat2_bwd(dout.data_ptr(), da.data_ptr(), db.data_ptr(), rows, C1, C2, _stream()), "cat2_bwd")
+        return da, db
+
+
+def cat2(a, b):
+    return _Cat2.apply(a, b)
+
+
+@torch.no_grad()
+def adamw_step(p, g, m, v, lr_step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, clip_value=0.0):
+    """fused AdamW on flat fp32 buffers; lr_step = device tensor [lr, step]."""
+    _need_gpu(p, g, m, v, lr_step)
+    L.check(L.lib().sast_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_step.data_ptr(), beta1, beta2, eps,
+                               weight_decay, grad_scale, clip_value, _stream()), "adamw")

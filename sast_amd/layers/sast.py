@@ -1,0 +1,198 @@
+"""Host-side mirror of models/layers/SAST/SAST.py for the MI355X path.
+
+Same class names, constructor arguments, forward signatures and state_dict keys as the reference
+(SURVEY.md §8b, App. D-10); the arithmetic runs in the HIP kernels of libsast_hip.so:
+
+  SAST_block.forward  (SAST.py:98-164) ->  sast_add_rows -> sast_score_stp -> sast_select (window)
+                                           -> sast_mswsa (window) -> sast_select (grid) -> sast_mswsa (grid)
+
+Nothing is ever window/grid-partitioned in memory: tokens stay in image layout (B,H,W,C) and the
+kernels address them through the partition map, so the reference's five permute+contiguous round
+trips per block (ops.py:189-220) disappear.  Selection results stay on the device
+(functional.Selection); `index_count` is returned as a 0-dim device tensor unless
+`sync_index_count=True` (then a python int like the reference, at the price of a host sync).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import functional as SF
+from .ops import LayerNorm, LayerScale, MLP, cfg_get
+
+
+class PositiveLinear(nn.Module):
+    """SAST.py:305-328: linear layer whose effective weights are exp(weight).  Inside SAST_block it is
+    evaluated by the fused scoring kernel (csrc/k_rows.hip:controls_fwd_kernel)."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_features))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, input):
+        raise RuntimeError("PositiveLinear is evaluated inside the fused STP scoring kernel (SAST_block)")
+
+
+def get_score_index_2d21d(x: torch.Tensor, d: float, b: float) -> torch.Tensor:
+    """SAST.py:258-267 (host utility kept for API compatibility; the hot path uses sast_select)."""
+    nz = torch.nonzero(x >= d / (1 + b))
+    if x.shape[0] == 1:
+        return nz[:, 1]
+    return nz[:, 0] * x.shape[-1] + nz[:, 1]
+
+
+def get_score_index_with_padding(x: torch.Tensor, d: float, b: float):
+    """SAST.py:270-281 (host utility kept for API compatibility)."""
+    gt = x >= d / (1 + b)
+    K = torch.sum(gt, dim=1)
+    top = torch.topk(x, k=int(K.max()), dim=1, largest=True, sorted=False)[1]
+    base = torch.arange(0, x.shape[0] * x.shape[1], x.shape[1], device=x.device).view(-1, 1)
+    nz = torch.nonzero(gt)
+    return (top + base).view(-1), nz[:, 0] * x.shape[-1] + nz[:, 1], K
+
+
+class MS_WSA(nn.Module):
+    """Masked Sparse Window multi-head Self-Attention, channels-last (SAST.py:167-255)."""
+
+    def __init__(self, dim: int, dim_head: int = 32, bias: bool = True, sub_layer_params=None, norms=None):
+        super().__init__()
+        if dim_head != 32:
+            raise NotImplementedError("sast_amd: the attention kernels are built for dim_head = 32 (every shipped config)")
+        if not bias:
+            raise NotImplementedError("sast_amd: attention_bias=False is not implemented")
+        self.num_heads = dim // dim_head
+        self.dim_head = dim_head
+        self.scale = dim_head ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=bias)
+        self.proj = nn.Linear(dim, dim, bias=bias)
+        self.norm1 = norms[0]
+        ls_init_value, drop_path, mlp_expand_ratio, mlp_act_layer, mlp_bias, drop_mlp = sub_layer_params
+        if drop_path > 0:
+            raise NotImplementedError("sast_amd: drop_path > 0 is not implemented (reference default 0)")
+        if not mlp_bias:
+            raise NotImplementedError("sast_amd: mlp_bias=False is not implemented")
+        self.ls1 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
+        self.drop1 = nn.Identity()
+        self.norm2 = norms[1]
+        self.mlp = MLP(dim=dim, channel_last=True, expansion_ratio=mlp_expand_ratio, act_layer=mlp_act_layer, bias=mlp_bias,
+                       drop_prob=drop_mlp)
+        self.ls2 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
+        self.drop2 = nn.Identity()
+        # aliased container, same state_dict duplicates as the reference (SAST.py:194)
+        self.sub_layers = nn.ModuleList([self.ls1, self.drop1, self.norm2, self.mlp, self.ls2, self.drop2])
+        self.eps = 1e-6
+
+    def kernel_params(self) -> dict:
+        return dict(ln1_w=self.norm1.weight, ln1_b=self.norm1.bias, ln2_w=self.norm2.weight, ln2_b=self.norm2.bias,
+                    qkv_w=self.qkv.weight, qkv_b=self.qkv.bias, proj_w=self.proj.weight, proj_b=self.proj.bias,
+                    ls1=getattr(self.ls1, "gamma", None), fc1_w=self.mlp.net[0].proj.weight, fc1_b=self.mlp.net[0].proj.bias,
+                    fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias, ls2=getattr(self.ls2, "gamma", None))
+
+    def forward_image(self, x: torch.Tensor, sel: SF.Selection) -> torch.Tensor:
+        """fused path: x (B,H,W,C) in IMAGE layout + device-side selection."""
+        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params())
+
+    def forward(self, x: torch.Tensor, index_window: torch.Tensor, index_token: torch.Tensor, padding_index: torch.Tensor,
+                asy_index: torch.Tensor, M: int, B, enable_CB: bool) -> torch.Tensor:
+        """reference signature (SAST.py:199-201): x (B*N, T, C) already partitioned, reference index lists.
+        The top-k fillers (index_token / padding_index) are semantically inert and ignored."""
+        if enable_CB:
+            raise NotImplementedError("sast_amd: Context Broadcasting (enable_CB=True, SAST.py:240-246) is not implemented yet")
+        shape = x.shape
+        N, C = x.shape[0], x.shape[-1]
+        x3 = x.reshape(N, -1, C)
+        T = x3.shape[1]
+        K = torch.bincount(torch.div(asy_index, T, rounding_mode='floor'), minlength=len(index_window)) if len(index_window) \
+            else torch.zeros(0, dtype=torch.long, device=x.device)
+        sel = SF.selection_from_index_lists(index_window, asy_index, K, N, T, x.device)
+        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params())
+        return out.view(*shape)
+
+
+class SAST_block(nn.Module):
+    """SAST block = two SAST layers (window, then grid) sharing one scoring module (SAST.py:24-164)."""
+
+    def __init__(self, dim: int, attention_cfg, first_block: bool = False, sync_index_count: bool = False):
+        super().__init__()
+        norm_eps = cfg_get(attention_cfg, 'norm_eps', 1e-5)
+        partition_size = cfg_get(attention_cfg, 'partition_size', required=True)
+        dim_head = cfg_get(attention_cfg, 'dim_head', 32)
+        attention_bias = cfg_get(attention_cfg, 'attention_bias', True)
+        mlp_act_string = cfg_get(attention_cfg, 'mlp_activation', required=True)
+        mlp_bias = cfg_get(attention_cfg, 'mlp_bias', True)
+        mlp_expand_ratio = cfg_get(attention_cfg, 'mlp_ratio', 4)
+        drop_path = cfg_get(attention_cfg, 'drop_path', 0.0)
+        drop_mlp = cfg_get(attention_cfg, 'drop_mlp', 0.0)
+        ls_init_value = cfg_get(attention_cfg, 'ls_init_value', 1e-5)
+        if mlp_act_string != 'gelu':
+            raise NotImplementedError("sast_amd: the fused GLU epilogue implements mlp_activation='gelu' (erf form) only")
+        if isinstance(partition_size, int):
+            partition_size = (partition_size, partition_size)
+        else:
+            partition_size = tuple(partition_size)
+            assert len(partition_size) == 2
+        self.partition_size = partition_size
+        if partition_size[0] * partition_size[1] > 128:
+            raise NotImplementedError("sast_amd: partitions of more than 128 tokens are not supported by the selection kernels")
+        sub_layer_params = (ls_init_value, drop_path, mlp_expand_ratio, None, mlp_bias, drop_mlp)
+        self.enable_CB = cfg_get(attention_cfg, 'enable_CB', False)
+        mk_norm = lambda: LayerNorm(dim, eps=norm_eps)
+        self.win_attn = MS_WSA(dim, dim_head=dim_head, bias=attention_bias, sub_layer_params=sub_layer_params,
+                               norms=[mk_norm(), mk_norm()])
+        self.grid_attn = MS_WSA(dim, dim_head=dim_head, bias=attention_bias, sub_layer_params=sub_layer_params,
+                                norms=[mk_norm(), mk_norm()])
+        if first_block:
+            self.to_scores = nn.Linear(dim, dim)
+            self.to_controls = PositiveLinear(20, dim, bias=False)
+            torch.nn.init.constant_(self.to_controls.weight, 1)
+            self.act = nn.ReLU()
+        self.amp_value = cfg_get(attention_cfg, 'AMP', 2e-4)
+        self.bounce_value = cfg_get(attention_cfg, 'BOUNCE', 1e-3)
+        self.first_block = first_block
+        self.sync_index_count = sync_index_count
+        self.B, self.N, self.dim = None, None, dim
+
+    # -- fused entry used by the backbone: `xp` already holds x + pos_emb (added by the LayerNorm kernel)
+    def forward_posadded(self, xp: torch.Tensor, r: torch.Tensor, index_list):
+        if self.enable_CB:
+            raise NotImplementedError("sast_amd: Context Broadcasting (enable_CB=True, SAST.py:240-246) is not implemented yet")
+        B, H, W, C = xp.shape
+        ph, pw = self.partition_size
+        self.B, self.N = B, H * W // (ph * pw)
+        if self.first_block:
+            xw, tok = SF.score_stp(xp, r, self.to_scores.weight, self.to_scores.bias, self.to_controls.weight, self.amp_value)
+            sel1 = SF.select(tok, B, H, W, ph, pw, 0, self.bounce_value)
+            sel2 = SF.select(tok, B, H, W, ph, pw, 1, self.bounce_value)
+        else:
+            xw = xp
+            sel1, sel2 = index_list
+            if not isinstance(sel1, SF.Selection):
+                raise TypeError("sast_amd: index_list must be the [Selection, Selection] pair returned by the first block")
+        x = self.win_attn.forward_image(xw, sel1)
+        x = self.grid_attn.forward_image(x, sel2)
+        count = sel1.counts[2] + sel2.counts[2]          # SAST.py:136,159 (floor per layer), device scalar
+        if self.sync_index_count:
+            count = int(count.item())
+        return x, count, [sel1, sel2]
+
+    def forward(self, x: torch.Tensor, pos_emb, r: torch.Tensor, index_list) -> Tuple[torch.Tensor, object, List]:
+        """x (B,H,W,C) NHWC, pos_emb: module returning the (B,H,W,C) table (sast_rnn.py:215-219) or a tensor,
+        r (B,20).  -> (x, index_count, [list1, list2])"""
+        table = pos_emb.table_for(x) if hasattr(pos_emb, "table_for") else pos_emb(x)[0]
+        xp = SF.add_pos_embedding(x, table.contiguous())
+        return self.forward_posadded(xp, r, index_list)

@@ -1,0 +1,252 @@
+"""GPU parity: the HIP path (through the C ABI of libsast_hip.so) against the oracle and the
+golden fixtures captured from the reference.
+
+Bars (BASELINE.json north_star): token/window index masks bit-exact; floating point within
+FWD_ATOL = 3e-5 absolute on O(1) activations (fp32 everywhere, only the summation order differs
+from the CPU path), gradients within 2e-3 relative to the tensor's max-norm.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sast_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD_ATOL = 3e-5
+GRAD_RTOL = 2e-3
+LIST_NAMES = ("index_window", "index_token", "padding_index", "asy_index", "K")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def load_params(module, params, prefix=""):
+    """oracle/reference-named param dict -> sast_amd module (state_dict names are the reference's)."""
+    sd = module.state_dict()
+    new = {}
+    for k in sd:
+        kk = k
+        for a, b in (("sub_layers.0.", "ls1."), ("sub_layers.2.", "norm2."), ("sub_layers.3.", "mlp."), ("sub_layers.4.", "ls2.")):
+            kk = kk.replace(a, b)
+        new[k] = sd[k] if kk.endswith("num_batches_tracked") else params[prefix + kk]
+    module.load_state_dict(new, strict=True)
+
+
+def maxnorm_close(a, b, rtol, what=""):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    scale = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max())
+    assert err <= rtol * scale + 1e-9, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+def attn_cfg(part, amp, ls=0.5, cb=False):
+    return dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True, mlp_ratio=4,
+                drop_mlp=0, drop_path=0, ls_init_value=ls, enable_CB=cb, AMP=amp, BOUNCE=1e-3)
+
+
+def block_params(C, seed, nblocks=1):
+    cfg = O.BackboneCfg(in_res_hw=(64, 80), partition_size=(4, 5), embed_dim=C, num_blocks=(nblocks, 1, 1, 1))
+    p = O.init_backbone_params(cfg, seed=seed, ls_init=0.5)
+    return {k[len("stages.0."):]: v for k, v in p.items() if k.startswith("stages.0.att_blocks.")}
+
+
+# ------------------------------------------------------------------------------------------------
+def test_library_loaded():
+    from sast_amd import _lib
+    assert _lib.lib().sast_version() >= 100
+
+
+def test_non_zero_ratio(golden_dir, dev):
+    from sast_amd import functional as SF
+    g = _load(golden_dir, "nzr")
+    for xk, rk in (("x", "r"), ("xb", "rb")):
+        x = torch.from_numpy(g[xk])
+        r = SF.non_zero_ratio(x.to(dev)).cpu()
+        assert torch.equal(r, torch.from_numpy(g[rk])), xk
+    # 1Mpx size, all three dtypes, against the oracle
+    x = O.count_events(2, (384, 640), seed=5, density=0.01)
+    ref = O.non_zero_ratio(x)
+    for xx in (x, x.int(), x.float()):
+        assert torch.equal(SF.non_zero_ratio(xx.to(dev)).cpu(), ref)
+
+
+@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1"])
+def test_sast_block_vs_golden(golden_dir, dev, name):
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    g = _load(golden_dir, name)
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    B, H, W, C = x.shape
+    params = block_params(C, int(g["seed"]))
+    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"])), first_block=True).to(dev)
+    load_params(blk, params, "att_blocks.0.att.")
+    pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    xd = x.to(dev).requires_grad_(True)
+    out, cnt, lists = blk(xd, pe, r.to(dev), None)
+    assert int(cnt) == int(g["count"])
+    for li, sel in enumerate(lists):
+        got = sel.to_index_list()
+        for nm in ("index_window", "asy_index", "K"):            # order-defined lists: exact
+            assert np.array_equal(got[LIST_NAMES.index(nm)].cpu().numpy(), g[f"l{li}_{nm}"]), (li, nm)
+        for nm in ("index_token", "padding_index"):              # top-k fillers: as sets (order unspecified upstream)
+            assert set(got[LIST_NAMES.index(nm)].cpu().tolist()) == set(g[f"l{li}_{nm}"].tolist()), (li, nm)
+    assert float((out.detach().cpu() - torch.from_numpy(g["out"])).abs().max()) <= FWD_ATOL
+    (out ** 2).mean().backward()
+    maxnorm_close(xd.grad, torch.from_numpy(g["dx"]), GRAD_RTOL, "dx")
+    for k, v in blk.named_parameters():
+        if "sub_layers" in k:
+            continue
+        maxnorm_close(v.grad, torch.from_numpy(g["g_" + k]), GRAD_RTOL, k)
+
+
+def test_ms_wsa_reference_signature(golden_dir, dev):
+    """drop-in MS_WSA.forward(x_partitioned, index lists...) against the oracle's ms_wsa."""
+    from sast_amd.layers import MS_WSA
+    from sast_amd.layers.ops import LayerNorm
+    g = _load(golden_dir, "block_amp2e-2")
+    params = block_params(64, int(g["seed"]))
+    pre = "att_blocks.0.att.win_attn."
+    lists = [torch.from_numpy(g[f"l0_{nm}"]) for nm in LIST_NAMES]
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(2 * 16, 20, 64, generator=gen)
+    ref = O.ms_wsa(x.clone(), lists, 2, params, pre, O.AttnCfg(partition_size=(4, 5)))
+    m = MS_WSA(64, 32, True, (0.5, 0.0, 4, None, True, 0.0), [LayerNorm(64, eps=1e-5), LayerNorm(64, eps=1e-5)]).to(dev)
+    load_params(m, {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
+    out = m(x.to(dev), *[l.to(dev) for l in lists[:4]], len(lists[0]), 2, False)
+    assert float((out.cpu() - ref).abs().max()) <= FWD_ATOL
+
+
+def test_cb_and_masking_fail_loudly(dev):
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    blk = SAST_block(64, attn_cfg((4, 5), 2e-2, cb=True), first_block=True).to(dev)
+    pe = PositionEmbeddingSine(32, normalize=True, input_size=(1, 16, 20))
+    with pytest.raises(NotImplementedError):
+        blk(torch.randn(1, 16, 20, 64, device=dev), pe, torch.rand(1, 20, device=dev), None)
+
+
+def _rcfg(hw, part, E, amp, ls):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from _ref_import import backbone_cfg
+    return backbone_cfg(hw, part, embed_dim=E, amp=amp, ls_init=ls)
+
+
+@pytest.mark.parametrize("tag", ["dense", "sparse"])
+def test_backbone_tiny_vs_golden(golden_dir, dev, tag):
+    from sast_amd.detection import RNNDetector
+    g = _load(golden_dir, f"backbone_tiny_{tag}")
+    hw, part, E = (128, 160), (4, 5), 32
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=float(g["amp"]))
+    params = O.init_backbone_params(ocfg, seed=int(g["seed"]), ls_init=0.5)
+    net = RNNDetector(_rcfg(hw, part, E, float(g["amp"]), 0.5)).to(dev)
+    load_params(net, params)
+    x0, x1 = torch.from_numpy(g["x0"]).to(dev), torch.from_numpy(g["x1"]).to(dev)
+    out0, st0, P0 = net(x0)
+    out1, st1, P1 = net(x1, [(h.detach(), c.detach()) for h, c in st0])
+    assert [int(p) for p in P0] == list(g["P0"]) and [int(p) for p in P1] == list(g["P1"])
+    for k in (1, 2, 3, 4):
+        assert out1[k].shape == g[f"h1_{k}"].shape
+        assert float((out0[k].detach().cpu() - torch.from_numpy(g[f"h0_{k}"])).abs().max()) <= FWD_ATOL, ("h0", k)
+        assert float((out1[k].detach().cpu() - torch.from_numpy(g[f"h1_{k}"])).abs().max()) <= FWD_ATOL, ("h1", k)
+        assert float((st1[k - 1][1].detach().cpu() - torch.from_numpy(g[f"c1_{k}"])).abs().max()) <= FWD_ATOL, ("c1", k)
+    loss = sum((out1[k] ** 2).mean() for k in (1, 2, 3, 4))
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    # full oracle gradients on the host for every parameter
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    o0, s0, _ = O.backbone(x0.cpu(), None, po, ocfg)
+    o1, _, _ = O.backbone(x1.cpu(), [(h.detach(), c.detach()) for h, c in s0], po, ocfg)
+    sum((o1[k] ** 2).mean() for k in (1, 2, 3, 4)).backward()
+    for k, v in net.named_parameters():
+        if "sub_layers" in k:
+            continue
+        maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+
+
+def test_pafpn_vs_golden(golden_dir, dev):
+    from sast_amd.detection import YOLOPAFPN
+    g = _load(golden_dir, "pafpn")
+    chans = (64, 128, 256)
+    params = O.init_pafpn_params(chans, seed=int(g["seed"]))
+    net = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev)
+    load_params(net, params)
+    feats = {k: torch.from_numpy(g[f"in{k}"]).to(dev).requires_grad_(True) for k in (2, 3, 4)}
+    net.train()
+    outs = net(feats)
+    for i, o in enumerate(outs):
+        assert float((o.detach().cpu() - torch.from_numpy(g[f"train_out{i}"])).abs().max()) <= FWD_ATOL, i
+    maxnorm_close(net.lateral_conv0.bn.running_mean, torch.from_numpy(g["rm_lateral"]), 1e-5, "running_mean")
+    maxnorm_close(net.lateral_conv0.bn.running_var, torch.from_numpy(g["rv_lateral"]), 1e-5, "running_var")
+    sum((o ** 2).mean() for o in outs).backward()
+    for k in (2, 3, 4):
+        maxnorm_close(feats[k].grad, torch.from_numpy(g[f"din{k}"]), GRAD_RTOL, f"din{k}")
+    stats = json.loads(str(g["grad_stats_json"]))
+    named = dict(net.named_parameters())
+    for k, (nrm, _s) in stats.items():
+        got = float(named[k].grad.double().norm())
+        assert abs(got - nrm) <= GRAD_RTOL * nrm + 1e-9, k
+    maxnorm_close(named["C3_p3.conv3.conv.weight"].grad, torch.from_numpy(g["g_C3_p3.conv3.conv.weight"]), GRAD_RTOL, "dW")
+    net.eval()
+    with torch.no_grad():
+        ev = net({k: v.detach() for k, v in feats.items()})
+    for i, o in enumerate(ev):
+        assert float((o.cpu() - torch.from_numpy(g[f"eval_out{i}"])).abs().max()) <= 1e-4, i
+
+
+@pytest.mark.parametrize("tag,hw,part", [("G1", (256, 320), (8, 10)), ("M1", (384, 640), (6, 10))])
+def test_full_size_backbone(golden_dir, dev, tag, hw, part):
+    """BASELINE configs at full size: kept-token counts and P identical to the reference run
+    (tests/golden/full_stats.json), activations statistics within tolerance."""
+    from sast_amd.detection import RNNDetector
+    with open(os.path.join(golden_dir, "full_stats.json")) as f:
+        ref = json.load(f)[tag]
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part)
+    params = O.init_backbone_params(ocfg, seed=0)
+    net = RNNDetector(_rcfg(hw, part, 64, 2e-4, 1e-5)).to(dev)
+    load_params(net, params)
+    x = O.synthetic_events(4, hw, seed=0, sparsity=0.9).to(dev)
+    with torch.no_grad():
+        out, st, P = net(x)
+    assert [int(p) for p in P] == ref["P"]
+    for k in (1, 2, 3, 4):
+        t = out[k].double()
+        assert abs(float(t.abs().mean()) - ref[f"h{k}"]["absmean"]) <= 1e-5
+        assert abs(float(t.abs().max()) - ref[f"h{k}"]["maxabs"]) <= 1e-4
+
+
+def test_selection_properties_full_size(dev):
+    """size-independent properties of the selection at 1Mpx stage-1 size: compaction is a bijection
+    between kept tokens and compact rows, counts agree, rows are window-major / token-ascending."""
+    from sast_amd import functional as SF
+    B, H, W, ph, pw = 4, 96, 160, 6, 10
+    g = torch.Generator().manual_seed(0)
+    tok = (torch.rand(B, H * W, generator=g) ** 4).to(dev)
+    for mode in (0, 1):
+        sel = SF.select(tok, B, H, W, ph, pw, mode, 1e-3)
+        total, M = int(sel.counts[0]), int(sel.counts[1])
+        assert int(sel.win_keep.sum()) == M and int(sel.K.sum()) == total
+        slot = sel.tok_slot.long()
+        kept = torch.nonzero(slot >= 0).view(-1)
+        assert kept.numel() == total
+        assert torch.equal(torch.sort(slot[kept])[0], torch.arange(total, device=dev))
+        assert torch.equal(sel.row_tok[:total].long()[slot[kept]], kept)
+        # oracle on the same scalars: identical kept sets
+        gid = sel.group_token_ids()
+        sc = tok.cpu().view(B, H * W)[:, gid].reshape(B, sel.N, sel.T, 1)
+        iw = O.select_windows(sc, B, sel.N, sel.T, 1e-3)
+        _it, asy, K = O.select_tokens(sc, iw, B, sel.N, sel.T, 1e-3)
+        assert torch.equal(sel.index_window().cpu(), iw)
+        assert torch.equal(sel.asy_index().cpu(), asy)
+        assert torch.equal(sel.K_list().cpu(), K)
