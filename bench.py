@@ -1,0 +1,213 @@
+"""bench.py -- frames/sec of the SAST hot path on MI355X.
+
+Workload (BASELINE.json configs[2] / SURVEY §8d C3): 1Mpx 640x360 padded to 384x640, B=4 per GPU, full
+SAST backbone (4 stages: conv-downsample+LN, STP scoring/selection, 2x MS-WSA, ConvLSTM) + YOLOX PAFPN,
+forward + backward of the proxy loss sum_k mean(out_k^2) + gradient all-reduce (N>1) + AdamW update.
+One "step" = one such pass over one synthetic batch (benchmark.py:52-64 input protocol).
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HW, PART, BATCH = (384, 640), (6, 10), 4
+SPARSITY = 0.5
+
+
+def ref_cfg(hw, part, amp=2e-4, ls=1e-5):
+    from sast_amd.config import backbone_config
+    return backbone_config(hw, part, embed_dim=64, AMP=amp, ls_init_value=ls)
+
+
+def synthetic_events(B, hw, seed):
+    """benchmark.py:58-60 protocol: (rand > sparsity).int() at the already-padded size."""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(B, 20, hw[0], hw[1], generator=g) > SPARSITY).int()
+
+
+class Trainer:
+    """minimal training step of the hot path (the reference's is Lightning's, modules/detection.py:113-221)."""
+
+    def __init__(self, dev, amp, world, use_graph):
+        from sast_amd.detection import RNNDetector, YOLOPAFPN
+        from sast_amd.dist import FlatParams, FusedAdamW
+        torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
+        self.net = RNNDetector(ref_cfg(HW, PART, amp))
+        self.fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(128, 256, 512))
+        # host copy of the initial weights under the reference's state_dict names: the CPU baseline leg runs on them
+        self.init_state = {"net": {k: v.clone() for k, v in self.net.state_dict().items() if "sub_layers" not in k},
+                           "fpn": {k: v.clone() for k, v in self.fpn.state_dict().items()}}
+        self.net.to(dev)
+        self.fpn.to(dev)
+        self.flat = FlatParams([self.net, self.fpn])
+        self.opt = FusedAdamW(self.flat, lr=2e-4, weight_decay=0.0, clip_value=1.0)
+        self.world = world
+        rank = dist.get_rank() if world > 1 else 0
+        self.x = synthetic_events(BATCH, HW, seed=rank).to(dev)
+        self.loss = None
+        self.P = None
+        self.graph = None
+        self.use_graph = use_graph
+
+    def fwd_bwd(self):
+        self.flat.zero_grad()
+        feats, _states, P = self.net.forward_nhwc(self.x)
+        outs = self.fpn.forward_nhwc(feats)
+        loss = sum((o * o).mean() for o in outs)
+        loss.backward()
+        self.loss, self.P = loss.detach(), P
+
+    def update(self):
+        self.flat.all_reduce()
+        self.opt.step(grad_scale=1.0 / self.world)
+
+    def capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self.fwd_bwd()
+                self.update()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if not self.use_graph:
+            return False
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.fwd_bwd()
+                if self.world == 1:
+                    self.update()
+            self.graph = g
+            return True
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            self.graph = None
+            torch.cuda.synchronize()
+            return False
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+            if self.world > 1:
+                self.update()
+        else:
+            self.fwd_bwd()
+            self.update()
+
+
+def cpu_baseline(amp, init_state, seconds_budget=25.0):
+    """the oracle (torch-CPU port of the reference path) timed on this box's host cores on a bounded sample,
+    on the same initial weights and the same input as rank 0's GPU leg."""
+    from oracle import sast_oracle as O
+    ocfg = O.BackboneCfg(in_res_hw=HW, partition_size=PART, amp=amp)
+    p = {k: v.clone().float().requires_grad_(True) for k, v in init_state["net"].items()}
+    f = {k: (v.clone().float().requires_grad_(True) if ("running" not in k and "num_batches" not in k) else v.clone())
+         for k, v in init_state["fpn"].items()}
+    x = synthetic_events(BATCH, HW, seed=0)
+    cores = torch.get_num_threads()
+
+    def one():
+        for t in list(p.values()) + list(f.values()):
+            t.grad = None
+        out, _s, _P = O.backbone(x, None, p, ocfg)
+        outs = O.pafpn(out, f, training=True)
+        O.proxy_loss(outs).backward()
+
+    one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > seconds_budget or n >= 8:
+            break
+    return {"value": BATCH * n / el, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of the same workload (B={BATCH}, 384x640, backbone+PAFPN, proxy loss), "
+                      f"oracle/sast_oracle.py, torch {torch.__version__} CPU, {cores} threads, no optimizer step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--amp", type=float, default=2e-4, help="attention_cfg.AMP (controls the kept-token fraction)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph)
+    graphed = tr.capture()
+    for _ in range(args.warmup):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        kept = [int(p) for p in tr.P]
+        L = [(HW[0] // s) * (HW[1] // s) for s in (4, 8, 16, 32)]
+        res = {
+            "metric": "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360",
+            "value": BATCH * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1Mpx 640x360 (padded 384x640) full SAST backbone + PAFPN, fwd+bwd + AdamW, "
+                                   f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
+                       "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
+                       "loss": float(tr.loss)},
+        }
+        if not args.no_roofline:
+            from sast_amd.profiling import dominant_kernel_roofline
+            res["roofline"] = dominant_kernel_roofline(tr)
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -166,6 +166,12 @@ int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,
                float beta1, float beta2, float eps, float weight_decay, float grad_scale,
                float clip_value /* <=0: off; reference clips by value 1.0, train.py:156-157 */, sast_stream_t stream);
 
+/* measurement aid (bench.py roofline leg): HIP-event timing of every launch of the GEMM-template kernels, recorded on
+ * the launch stream; the report lists per kernel instantiation: calls, total ms, total algorithmic FLOPs (2*M*N*K with
+ * the device-side row counts read back).  Enabling it adds host syncs -- never enable inside a timed region. */
+int sast_prof_enable(int on);
+size_t sast_prof_report(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

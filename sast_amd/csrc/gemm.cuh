@@ -198,12 +198,21 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     }
 }
 
+// ---- optional per-launch HIP-event timing of the GEMM family (bench.py roofline leg; off by default).
+// When enabled, every launch is bracketed by events on the launch stream and device-side row counts
+// are read back, so the report carries measured time AND algorithmic FLOPs (2*M*N*R with the real M/R).
+void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin);
+bool prof_enabled();
+
 template <class T, class LA, class LB, class EP>
 inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM,
                        const int* dR, hipStream_t st) {
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
+  const bool prof = prof_enabled();
+  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, true);
   hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR);
+  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, false);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -215,8 +224,11 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
   if (splits < 1) splits = 1;
+  const bool prof = prof_enabled();
+  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, true);
   hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
                      nullptr, dR);
+  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, false);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

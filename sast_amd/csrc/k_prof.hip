@@ -1,0 +1,71 @@
+// Optional HIP-event timing of the GEMM-family launches (used by bench.py's roofline leg only).
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+#include "../../include/sast_hip.h"
+
+namespace sast {
+
+struct ProfLaunch { hipEvent_t e0, e1; double flops; std::string tag; };
+static bool g_on = false;
+static std::vector<ProfLaunch> g_launches;
+static hipEvent_t g_pending;
+
+bool prof_enabled() { return g_on; }
+
+void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin) {
+  if (begin) {
+    hipEventCreate(&g_pending);
+    hipEventRecord(g_pending, st);
+    return;
+  }
+  ProfLaunch l;
+  l.e0 = g_pending;
+  hipEventCreate(&l.e1);
+  hipEventRecord(l.e1, st);
+  int m = M, r = R;
+  if (dM) { int v; hipMemcpyAsync(&v, dM, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < m) m = v; }
+  if (dR) { int v; hipMemcpyAsync(&v, dR, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < r) r = v; }
+  l.flops = 2.0 * (double)m * (double)NJ * (double)G * (double)r;
+  l.tag = tag;
+  g_launches.push_back(l);
+}
+
+}  // namespace sast
+
+extern "C" {
+
+int sast_prof_enable(int on) {
+  sast::g_on = on != 0;
+  if (on) {
+    for (auto& l : sast::g_launches) { hipEventDestroy(l.e0); hipEventDestroy(l.e1); }
+    sast::g_launches.clear();
+  }
+  return 0;
+}
+
+// writes "tag\tcalls\ttotal_ms\ttotal_flops\n" lines (sorted by time) into buf; returns bytes needed
+size_t sast_prof_report(char* buf, size_t cap) {
+  hipDeviceSynchronize();
+  struct Acc { int n = 0; double ms = 0, fl = 0; };
+  std::map<std::string, Acc> acc;
+  for (auto& l : sast::g_launches) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, l.e0, l.e1) != hipSuccess) continue;
+    Acc& a = acc[l.tag];
+    a.n++; a.ms += ms; a.fl += l.flops;
+  }
+  std::string out;
+  for (auto& kv : acc) {
+    char line[64];
+    snprintf(line, sizeof line, "\t%d\t%.6f\t%.6e\n", kv.second.n, kv.second.ms, kv.second.fl);
+    out += kv.first + line;
+  }
+  if (buf && cap) { const size_t n = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), n); buf[n] = 0; }
+  return out.size() + 1;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""Roofline leg of bench.py: HIP-event timing (on the launch stream, inside libsast_hip.so) of every launch of the
+GEMM-template kernels during a few extra, un-timed eager steps; reports the dominant instantiation.
+
+Peak: 157.3 TFLOP/s fp32 matrix (v_mfma_f32_32x32x2_f32, /opt/skills/guides/MI355X_MICROARCH.md) -- all GEMM-shaped work
+of this path is exact fp32 because index-exact token selection forbids reduced precision upstream of a selection."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+
+import torch
+
+from . import _lib as L
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def _short(tag: str) -> str:
+    m = re.search(r"launch_gemm(_split)?\b.*\[T = (.*?), LA = (.*?), LB = (.*?), EP = (.*?)\]", tag)
+    if not m:
+        return tag[:120]
+    t = re.sub(r"sast::|\(anonymous namespace\)::", "", m.group(2))
+    names = [re.sub(r"sast::|\(anonymous namespace\)::", "", m.group(i)) for i in (3, 4, 5)]
+    return f"gemm_kernel<{t}, {names[0]}, {names[1]}, {names[2]}{', split' if m.group(1) else ''}>"
+
+
+def gemm_report(run_steps, n_steps: int = 3):
+    """run_steps(n): executes n eager steps.  Returns [(name, calls, total_ms, total_flops)] sorted by time."""
+    lib = L.lib()
+    torch.cuda.synchronize()
+    lib.sast_prof_enable(1)
+    try:
+        run_steps(n_steps)
+        torch.cuda.synchronize()
+        need = lib.sast_prof_report(None, 0)
+        buf = C.create_string_buffer(int(need) + 16)
+        lib.sast_prof_report(buf, len(buf))
+    finally:
+        lib.sast_prof_enable(0)
+    rows = []
+    for line in buf.value.decode().splitlines():
+        tag, n, ms, fl = line.rsplit("\t", 3)
+        rows.append((_short(tag), int(n), float(ms), float(fl)))
+    rows.sort(key=lambda r: -r[2])
+    return rows
+
+
+def dominant_kernel_roofline(trainer, n_steps: int = 3):
+    def run(n):
+        for _ in range(n):
+            trainer.fwd_bwd()
+            trainer.update()
+
+    rows = gemm_report(run, n_steps)
+    name, calls, ms, flops = rows[0]
+    achieved = flops / (ms * 1e-3) / 1e12
+    total_ms = sum(r[2] for r in rows)
+    total_fl = sum(r[3] for r in rows)
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": name,
+            "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
+            "algorithmic_gflop_per_launch": flops / calls / 1e9,
+            "all_gemm_kernels": {"ms_per_step": total_ms / n_steps, "gflop_per_step": total_fl / n_steps / 1e9,
+                                 "achieved_tflops": total_fl / (total_ms * 1e-3) / 1e12},
+            "method": "hipEvent pairs on the launch stream around each launch (libsast_hip sast_prof_*), eager, un-timed extra steps"}

@@ -137,10 +137,8 @@ def test_cb_and_masking_fail_loudly(dev):
 
 
 def _rcfg(hw, part, E, amp, ls):
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
-    from _ref_import import backbone_cfg
-    return backbone_cfg(hw, part, embed_dim=E, amp=amp, ls_init=ls)
+    from sast_amd.config import backbone_config
+    return backbone_config(hw, part, embed_dim=E, AMP=amp, ls_init_value=ls)
 
 
 @pytest.mark.parametrize("tag", ["dense", "sparse"])
