@@ -139,6 +139,7 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);
 typedef struct SastConvBnArgs {
   int32_t B, H, W, Cin, Cout, ksize, stride, training;
   int32_t ldx, ldy, lddy, lddx;   /* channel strides of x, y, dy, dx rows (slices of concat buffers) */
+  int32_t bn_ws_zeroed;           /* 1: caller guarantees bn_ws is zero-filled (one memset for the whole FPN) */
   float momentum, eps;
   const float* x; const float* w; const float* bn_w; const float* bn_b;
   float* run_mean; float* run_var;  /* updated in training mode */
@@ -147,7 +148,8 @@ typedef struct SastConvBnArgs {
   float* y;
   /* backward */
   const float* dy; float* dx; float* dw; float* d_bn_w; float* d_bn_b;
-  float* ws;             /* fp32[M*Cout + 4*Cout] (fwd uses the first 4*Cout as fp64[2*Cout]) */
+  float* bn_ws;          /* fp32[8*Cout] reduction scratch: fwd uses [0,4C) as fp64 sums, bwd uses [4C,6C) */
+  float* ws;             /* bwd only: fp32[M*Cout] (dconv) */
 } SastConvBnArgs;
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);

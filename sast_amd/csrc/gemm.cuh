@@ -9,7 +9,9 @@
 //   of the compacted token list, dual-source rows ([x|h] of the ConvLSTM) and the
 //   transposed "TN" form used for weight gradients.  A loader declares its
 //   orientation: RC (reduce-contiguous: returns 4 values along r) or IC
-//   (index-contiguous: 4 values along m / j).
+//   (index-contiguous: 4 values along m / j).  The index-dependent part of an address
+//   (row pointer, pixel decomposition of an im2col row, ...) is hoisted out of the
+//   reduction loop: `prep(index)` once per thread, `load(ctx, r)` per k-tile.
 // * G "column groups" put G weight rows that belong to the same output channel into
 //   the same lane (GLU value|gate: G=2, LSTM f|i|o|g: G=4) so the epilogue can fuse
 //   the gate arithmetic.
@@ -19,7 +21,11 @@
 // * LDS: A and B tiles are stored reduce-major ([r][m]) so a lane's MFMA operand is a
 //   conflict-free ds_read_b32; RC tiles are transposed on the way in with a row pad
 //   chosen so the 4 scalar ds_writes of a float4 hit 32 distinct banks.
+// * split-R form (weight gradients): gridDim.y partitions the reduction, the epilogue
+//   accumulates atomically; optionally the column sums of the A operand (bias gradient)
+//   are produced by the same pass (COLSUM) so dY is read once.
 #pragma once
+#include <type_traits>
 #include "common.cuh"
 
 namespace sast {
@@ -43,9 +49,15 @@ struct LdsLd {
   static constexpr int value = RC ? (R + 8 / (T::BK / 4)) : (R + 4);
 };
 
+// epilogues may ask for per-column sum / sum-of-squares of the stored values (BatchNorm batch statistics fused
+// into the producing conv): EP::COLSTATS = true, EP::sums -> double[2*EP::C]
+template <class EP, class = void> struct EpHasStats : std::false_type {};
+template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
+
 template <class T, class LA, class LB, class EP, bool SPLIT>
 __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M, int NJ, int R,
-                                                     const int* __restrict__ dM, const int* __restrict__ dR) {
+                                                     const int* __restrict__ dM, const int* __restrict__ dR,
+                                                     float* __restrict__ colsum) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT, G = T::G, BJ = T::BJ;
   constexpr int LDA = LdsLd<T, LA::RC, BM>::value;
   constexpr int LDB = LdsLd<T, LB::RC, BN>::value;
@@ -80,35 +92,51 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     return (jb / T::TJ) * T::WTN + ((jb % T::TJ) * G + g) * 32 + (jl & 31);
   };
 
+  // ---- per-thread slot geometry, fixed for the whole reduction loop
+  typename LA::Ctx ca[A_PER];
+  typename LB::Ctx cb[B_PER];
+  int ra_off[A_PER], rb_off[B_PER];      // r offset inside a k-tile
+  int la_off[A_PER], lb_off[B_PER];      // LDS store offset
+#pragma unroll
+  for (int it = 0; it < A_PER; ++it) {
+    const int s = tid + it * NT;
+    if constexpr (LA::RC) {
+      const int row = s / (BK / 4), kq = s % (BK / 4);
+      ca[it] = la.prep(m0 + row, Meff);
+      ra_off[it] = kq * 4;
+      la_off[it] = (kq * 4) * LDA + row;
+    } else {
+      const int iq = s % (BM / 4), kk = s / (BM / 4);
+      ca[it] = la.prep(m0 + iq * 4, Meff);
+      ra_off[it] = kk;
+      la_off[it] = kk * LDA + iq * 4;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < B_PER; ++it) {
+    const int s = tid + it * NT;
+    if constexpr (LB::RC) {
+      const int rr = s / (BK / 4), kq = s % (BK / 4);
+      const int g = (rr / BJ) % G, jl = rr % BJ;
+      cb[it] = lb.prep(j0 + jl, g, NJ);
+      rb_off[it] = kq * 4;
+      lb_off[it] = (kq * 4) * LDB + nnmap(jl, g);
+    } else {
+      const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
+      cb[it] = lb.prep(j0 + jq * 4, g, NJ);
+      rb_off[it] = kk;
+      lb_off[it] = kk * LDB + nnmap(jq * 4, g);
+    }
+  }
+
   auto gload = [&](int kt) {
     const int r0 = kt * BK;
 #pragma unroll
-    for (int it = 0; it < A_PER; ++it) {
-      const int s = tid + it * NT;
-      if (A_SLOTS % NT == 0 || s < A_SLOTS) {
-        if constexpr (LA::RC) {
-          const int row = s / (BK / 4), kq = s % (BK / 4);
-          ra[it] = la.load(m0 + row, r0 + kq * 4, Meff, Reff);
-        } else {
-          const int iq = s % (BM / 4), kk = s / (BM / 4);
-          ra[it] = la.load(m0 + iq * 4, r0 + kk, Meff, Reff);
-        }
-      }
-    }
+    for (int it = 0; it < A_PER; ++it)
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) ra[it] = la.load(ca[it], r0 + ra_off[it], Reff);
 #pragma unroll
-    for (int it = 0; it < B_PER; ++it) {
-      const int s = tid + it * NT;
-      if (B_SLOTS % NT == 0 || s < B_SLOTS) {
-        if constexpr (LB::RC) {
-          const int rr = s / (BK / 4), kq = s % (BK / 4);
-          const int g = rr / BJ, jl = rr % BJ;
-          rb[it] = lb.load(j0 + jl, g, r0 + kq * 4, NJ, Reff);
-        } else {
-          const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
-          rb[it] = lb.load(j0 + jq * 4, g, r0 + kk, NJ, Reff);
-        }
-      }
-    }
+    for (int it = 0; it < B_PER; ++it)
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) rb[it] = lb.load(cb[it], r0 + rb_off[it], Reff);
   };
 
   auto lstore = [&](int buf) {
@@ -116,31 +144,18 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     float* bs = Bs + buf * B_STAGE;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it) {
-      const int s = tid + it * NT;
-      if (A_SLOTS % NT == 0 || s < A_SLOTS) {
-        if constexpr (LA::RC) {
-          const int row = s / (BK / 4), kq = s % (BK / 4);
-          float* d = as + (kq * 4) * LDA + row;
-          d[0] = ra[it].x; d[LDA] = ra[it].y; d[2 * LDA] = ra[it].z; d[3 * LDA] = ra[it].w;
-        } else {
-          const int iq = s % (BM / 4), kk = s / (BM / 4);
-          st4(as + kk * LDA + iq * 4, ra[it]);
-        }
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
+        float* d = as + la_off[it];
+        if constexpr (LA::RC) { d[0] = ra[it].x; d[LDA] = ra[it].y; d[2 * LDA] = ra[it].z; d[3 * LDA] = ra[it].w; }
+        else st4(d, ra[it]);
       }
     }
 #pragma unroll
     for (int it = 0; it < B_PER; ++it) {
-      const int s = tid + it * NT;
-      if (B_SLOTS % NT == 0 || s < B_SLOTS) {
-        if constexpr (LB::RC) {
-          const int rr = s / (BK / 4), kq = s % (BK / 4);
-          const int g = rr / BJ, jl = rr % BJ;
-          float* d = bs + (kq * 4) * LDB + nnmap(jl, g);
-          d[0] = rb[it].x; d[LDB] = rb[it].y; d[2 * LDB] = rb[it].z; d[3 * LDB] = rb[it].w;
-        } else {
-          const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
-          st4(bs + kk * LDB + nnmap(jq * 4, g), rb[it]);
-        }
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
+        float* d = bs + lb_off[it];
+        if constexpr (LB::RC) { d[0] = rb[it].x; d[LDB] = rb[it].y; d[2 * LDB] = rb[it].z; d[3 * LDB] = rb[it].w; }
+        else st4(d, rb[it]);
       }
     }
   };
@@ -152,6 +167,10 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     for (int b = 0; b < T::TN; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  float csum[T::TM];
+#pragma unroll
+  for (int a = 0; a < T::TM; ++a) csum[a] = 0.f;
+  const bool do_colsum = SPLIT && colsum != nullptr && bj == 0 && wn == 0;
 
   gload(kt0);
   lstore(0);
@@ -169,6 +188,10 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
       for (int t = 0; t < T::TM; ++t) a[t] = as[kk * LDA + t * 32];
 #pragma unroll
       for (int t = 0; t < T::TN; ++t) b[t] = bs[kk * LDB + t * 32];
+      if (SPLIT && do_colsum) {
+#pragma unroll
+        for (int t = 0; t < T::TM; ++t) csum[t] += a[t];
+      }
 #pragma unroll
       for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
@@ -179,7 +202,20 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     __syncthreads();
   }
 
+  if (SPLIT && do_colsum) {
+#pragma unroll
+    for (int t = 0; t < T::TM; ++t) {
+      const float s = csum[t] + __shfl_xor(csum[t], 32, 64);   // the two k-parities of the 32x32x2 A operand
+      const int m = m0 + wm * T::WTM + t * 32 + (lane & 31);
+      if (lane < 32 && m < Meff) atomicAdd(colsum + m, s);
+    }
+  }
+
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  constexpr bool STATS = EpHasStats<EP>::value;
+  float cs[T::TJ], cq[T::TJ];
+#pragma unroll
+  for (int tj = 0; tj < T::TJ; ++tj) { cs[tj] = 0.f; cq[tj] = 0.f; }
 #pragma unroll
   for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
@@ -193,9 +229,18 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 #pragma unroll
           for (int g = 0; g < G; ++g) v[g] = acc[ta][tj * G + g][reg];
           ep(m, j, v);
+          if constexpr (STATS) { cs[tj] += v[0]; cq[tj] += v[0] * v[0]; }
         }
       }
     }
+  if constexpr (STATS) {
+#pragma unroll
+    for (int tj = 0; tj < T::TJ; ++tj) {
+      const float s = cs[tj] + __shfl_xor(cs[tj], 32, 64), q = cq[tj] + __shfl_xor(cq[tj], 32, 64);
+      const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
+      if (lane < 32 && j < NJ) { atomicAdd(ep.sums + j, (double)s); atomicAdd(ep.sums + NJ + j, (double)q); }
+    }
+  }
 }
 
 // ---- optional per-launch HIP-event timing of the GEMM family (bench.py roofline leg; off by default).
@@ -203,6 +248,12 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 // are read back, so the report carries measured time AND algorithmic FLOPs (2*M*N*R with the real M/R).
 void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin);
 bool prof_enabled();
+void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin);
+struct ProfScope {
+  const char* n; int c, m; hipStream_t st; bool on;
+  ProfScope(const char* n_, int c_, int m_, hipStream_t s_) : n(n_), c(c_), m(m_), st(s_), on(prof_enabled()) { if (on) prof_scope(n, c, m, st, true); }
+  ~ProfScope() { if (on) prof_scope(n, c, m, st, false); }
+};
 
 template <class T, class LA, class LB, class EP>
 inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM,
@@ -211,23 +262,25 @@ inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, 
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
   const bool prof = prof_enabled();
   if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, true);
-  hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR);
+  hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
+                     (float*)nullptr);
   if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, false);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 
-// split-R form (weight gradients: R = number of rows, possibly device-side); EP must accumulate atomically
+// split-R form (weight gradients: R = number of rows, possibly device-side); EP must accumulate atomically.
+// colsum (optional): colsum[m] += sum_r A(m, r)
 template <class T, class LA, class LB, class EP>
 inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dR,
-                             int splits, hipStream_t st) {
+                             int splits, float* colsum, hipStream_t st) {
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
   if (splits < 1) splits = 1;
   const bool prof = prof_enabled();
   if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, true);
   hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
-                     nullptr, dR);
+                     (const int*)nullptr, dR, colsum);
   if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, false);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -237,71 +290,96 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
 using TileBig   = Tile<128, 128, 2, 2, 1>;  // wave tile 64x64
 using TileMid   = Tile<64, 128, 2, 2, 1>;   // wave tile 32x64
 using TileSmall = Tile<64, 64, 2, 2, 1>;    // wave tile 32x32
+using TileTiny  = Tile<32, 32, 1, 1, 1>;    // one wave per block: fills the chip when M*N is small (stage 3/4, PAFPN)
 using TileN64   = Tile<128, 64, 4, 1, 1>;   // N = 64 layers (stage 1): wave tile 32x64
 using TileG2    = Tile<64, 128, 2, 2, 2>;   // GLU: 64 rows x (64 ch x 2 groups), wave tile 32x(32x2)
 using TileG2Big = Tile<128, 128, 2, 2, 2>;  // wave tile 64 x (32 ch x 2 groups)
+using TileG2Tiny = Tile<32, 64, 1, 1, 2>;   // one wave: 32 rows x (32 ch x 2 groups)
 using TileG4    = Tile<64, 128, 2, 1, 4>;   // LSTM: 64 rows x (32 ch x 4 gates); 2 waves
 using TileG4Big = Tile<128, 128, 4, 1, 4>;  // 128 rows x (32 ch x 4 gates)
+using TileG4Tiny = Tile<32, 128, 1, 1, 4>;  // one wave: 32 rows x (32 ch x 4 gates)
+
+// fast exact division by a small runtime constant d (d <= 64, n < 4096): n / d == (n * mul) >> 16
+__host__ __device__ inline int small_div_mul(int d) { return 65536 / d + 1; }
 
 // ------------------------------------------------------------------ loaders
-// A-side loaders: load(i, r, Ieff, Reff);  B-side: load(j, g, r, NJ, Reff)
+// concept:  struct Ctx;  A side: Ctx prep(int i, int Ieff);  B side: Ctx prep(int j, int g, int NJ);
+//           float4 load(const Ctx&, int r, int Reff)     (out-of-range -> zeros)
 
 // RC rows: X[i][r] = p[row(i)*ld + r]
 struct LdRows {
   static constexpr bool RC = true;
   const float* p; int ld; const int* idx;
-  __device__ __forceinline__ float4 load(int i, int r, int Ieff, int Reff) const {
-    if (i >= Ieff || r >= Reff) return zero4();
-    const int row = idx ? idx[i] : i;
-    return ld4(p + (size_t)row * ld + r);
+  struct Ctx { const float* row; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    if (i >= Ieff) return Ctx{nullptr};
+    return Ctx{p + (size_t)(idx ? idx[i] : i) * ld};
+  }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    return (c.row && r < Reff) ? ld4(c.row + r) : zero4();
   }
 };
 // RC rows from two sources split along r (cat along channels without materialising it)
 struct LdRows2 {
   static constexpr bool RC = true;
   const float* p1; int ld1; int R1; const float* p2; int ld2;
-  __device__ __forceinline__ float4 load(int i, int r, int Ieff, int Reff) const {
-    if (i >= Ieff || r >= Reff) return zero4();
-    if (r < R1) return ld4(p1 + (size_t)i * ld1 + r);
-    return p2 ? ld4(p2 + (size_t)i * ld2 + (r - R1)) : zero4();
+  struct Ctx { const float* a; const float* b; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    if (i >= Ieff) return Ctx{nullptr, nullptr};
+    return Ctx{p1 + (size_t)i * ld1, p2 ? p2 + (size_t)i * ld2 - R1 : nullptr};
+  }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (!c.a || r >= Reff) return zero4();
+    if (r < R1) return ld4(c.a + r);
+    return c.b ? ld4(c.b + r) : zero4();
   }
 };
 // IC rows (transposed use): X(t)[r][i] = p[row(r)*ld + i]
 struct LdRowsT {
   static constexpr bool RC = false;
   const float* p; int ld; const int* idx;
-  __device__ __forceinline__ float4 load(int i, int r, int Ieff, int Reff) const {
-    if (i >= Ieff || r >= Reff) return zero4();
-    const int row = idx ? idx[r] : r;
-    return ld4(p + (size_t)row * ld + i);
+  struct Ctx { int i; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return Ctx{i < Ieff ? i : -1}; }
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : -1}; }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (c.i < 0 || r >= Reff) return zero4();
+    return ld4(p + (size_t)(idx ? idx[r] : r) * ld + c.i);
   }
-  __device__ __forceinline__ float4 load(int j, int, int r, int NJ, int Reff) const { return load(j, r, NJ, Reff); }
 };
-struct LdRowsT2 {  // dual source along i (for d[W_x | W_h])
+struct LdRowsT2 {  // dual source along j (for d[W_x | W_h])
   static constexpr bool RC = false;
   const float* p1; int ld1; int I1; const float* p2; int ld2;
-  __device__ __forceinline__ float4 load(int j, int, int r, int NJ, int Reff) const {
-    if (j >= NJ || r >= Reff) return zero4();
-    if (j < I1) return ld4(p1 + (size_t)r * ld1 + j);
-    return p2 ? ld4(p2 + (size_t)r * ld2 + (j - I1)) : zero4();
+  struct Ctx { const float* base; int ld; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
+    if (j >= NJ) return Ctx{nullptr, 0};
+    if (j < I1) return Ctx{p1 + j, ld1};
+    return Ctx{p2 ? p2 + (j - I1) : nullptr, ld2};
+  }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    return (c.base && r < Reff) ? ld4(c.base + (size_t)r * c.ld) : zero4();
   }
 };
 // weights [G*gs rows][ldw], reduce-contiguous (y = x W^T)
 struct LdWeightNT {
   static constexpr bool RC = true;
   const float* w; int ldw; int gs;
-  __device__ __forceinline__ float4 load(int j, int g, int r, int NJ, int Reff) const {
-    if (j >= NJ || r >= Reff) return zero4();
-    return ld4(w + (size_t)(g * gs + j) * ldw + r);
+  struct Ctx { const float* row; };
+  __device__ __forceinline__ Ctx prep(int j, int g, int NJ) const {
+    return Ctx{j < NJ ? w + (size_t)(g * gs + j) * ldw : nullptr};
+  }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    return (c.row && r < Reff) ? ld4(c.row + r) : zero4();
   }
 };
 // weights used as B[r][j] = w[r*ldw + j]  (dx = dy W), optional per-row scale (LayerScale folded in)
 struct LdWeightNN {
   static constexpr bool RC = false;
   const float* w; int ldw; const float* rscale;
-  __device__ __forceinline__ float4 load(int j, int, int r, int NJ, int Reff) const {
-    if (j >= NJ || r >= Reff) return zero4();
-    float4 v = ld4(w + (size_t)r * ldw + j);
+  struct Ctx { const float* col; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? w + j : nullptr}; }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (!c.col || r >= Reff) return zero4();
+    float4 v = ld4(c.col + (size_t)r * ldw);
     if (rscale) { const float s = rscale[r]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
     return v;
   }
@@ -310,68 +388,102 @@ struct LdWeightNN {
 // implicit-GEMM geometry of a 2D convolution on NHWC activations
 struct ConvGeom {
   int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad, replicate, ldx;  // ldx: channel stride of the input rows
+  int cin_shift, kw_mul;                                           // Cin == 1 << cin_shift (or -1); kw_mul = small_div_mul(KW)
 };
+__device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, int shift, int r, int& kh, int& kw, int& c) {
+  const int tap = shift >= 0 ? (r >> shift) : (r / chans);
+  c = r - tap * chans;
+  kh = (tap * g.kw_mul) >> 16;
+  kw = tap - kh * g.KW;
+}
 // RC: A[m = (b,oy,ox)][r = (kh,kw,c)]
 struct LdIm2col {
   static constexpr bool RC = true;
   const float* x; ConvGeom g;
-  __device__ __forceinline__ float4 load(int i, int r, int Ieff, int Reff) const {
-    if (i >= Ieff || r >= Reff) return zero4();
+  struct Ctx { const float* img; int iy0, ix0; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    if (i >= Ieff) return Ctx{nullptr, 0, 0};
     const int ox = i % g.Wo, t = i / g.Wo, oy = t % g.Ho, b = t / g.Ho;
-    const int tap = r / g.Cin, c = r - tap * g.Cin;
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
-    int iy = oy * g.stride - g.pad + kh, ix = ox * g.stride - g.pad + kw;
+    return Ctx{x + (size_t)b * g.H * g.W * g.ldx, oy * g.stride - g.pad, ox * g.stride - g.pad};
+  }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (!c.img || r >= Reff) return zero4();
+    int kh, kw, ch;
+    split_tap(g, g.Cin, g.cin_shift, r, kh, kw, ch);
+    int iy = c.iy0 + kh, ix = c.ix0 + kw;
     if (g.replicate) { iy = min(max(iy, 0), g.H - 1); ix = min(max(ix, 0), g.W - 1); }
-    else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return zero4();
-    return ld4(x + ((size_t)(b * g.H + iy) * g.W + ix) * g.ldx + c);
+    else if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return zero4();
+    return ld4(c.img + ((size_t)iy * g.W + ix) * g.ldx + ch);
   }
 };
 // IC: B(t)[r = (b,oy,ox)][j = (kh,kw,c)]   (weight gradient)
 struct LdIm2colT {
   static constexpr bool RC = false;
   const float* x; ConvGeom g;
-  __device__ __forceinline__ float4 load(int j, int, int r, int NJ, int Reff) const {
-    if (j >= NJ || r >= Reff) return zero4();
+  struct Ctx { int kh, kw, c; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
+    if (j >= NJ) return Ctx{-1, 0, 0};
+    Ctx c;
+    split_tap(g, g.Cin, g.cin_shift, j, c.kh, c.kw, c.c);
+    return c;
+  }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (c.kh < 0 || r >= Reff) return zero4();
     const int ox = r % g.Wo, t = r / g.Wo, oy = t % g.Ho, b = t / g.Ho;
-    const int tap = j / g.Cin, c = j - tap * g.Cin;
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
-    int iy = oy * g.stride - g.pad + kh, ix = ox * g.stride - g.pad + kw;
+    int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
     if (g.replicate) { iy = min(max(iy, 0), g.H - 1); ix = min(max(ix, 0), g.W - 1); }
-    else if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return zero4();
-    return ld4(x + ((size_t)(b * g.H + iy) * g.W + ix) * g.ldx + c);
+    else if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return zero4();
+    return ld4(x + ((size_t)(b * g.H + iy) * g.W + ix) * g.ldx + c.c);
   }
 };
 // RC: backward-data gather  A[m = (b,iy,ix)][r = (kh,kw,co)] = dY[b,(iy+p-kh)/s,(ix+p-kw)/s,co]
 // replicate padding: the clamped taps (kh < pad at iy == 0, same for x) fold onto output row/col 0.
 struct LdConvDx {
   static constexpr bool RC = true;
-  const float* dy; ConvGeom g; int Cout; int lddy;
+  const float* dy; ConvGeom g; int Cout; int lddy; int cout_shift;
+  struct Ctx { const float* img; int iy, ix; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    if (i >= Ieff) return Ctx{nullptr, 0, 0};
+    const int ix = i % g.W, t = i / g.W, iy = t % g.H, b = t / g.H;
+    return Ctx{dy + (size_t)b * g.Ho * g.Wo * lddy, iy, ix};
+  }
   __device__ __forceinline__ bool src(int i, int k, int n_out, int& o) const {
     const int t = i + g.pad - k;
-    if (t >= 0 && t % g.stride == 0 && t / g.stride < n_out) { o = t / g.stride; return true; }
+    if (g.stride == 1) { o = t; return (unsigned)t < (unsigned)n_out; }
+    if (t >= 0) {
+      const int q = g.stride == 2 ? (t >> 1) : (t / g.stride);
+      if (q * g.stride == t && q < n_out) { o = q; return true; }
+    }
     if (g.replicate && i == 0 && k < g.pad) { o = 0; return true; }
     return false;
   }
-  __device__ __forceinline__ float4 load(int i, int r, int Ieff, int Reff) const {
-    if (i >= Ieff || r >= Reff) return zero4();
-    const int ix = i % g.W, t = i / g.W, iy = t % g.H, b = t / g.H;
-    const int tap = r / Cout, co = r - tap * Cout;
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (!c.img || r >= Reff) return zero4();
+    int kh, kw, co;
+    split_tap(g, Cout, cout_shift, r, kh, kw, co);
     int oy, ox;
-    if (!src(iy, kh, g.Ho, oy) || !src(ix, kw, g.Wo, ox)) return zero4();
-    return ld4(dy + ((size_t)(b * g.Ho + oy) * g.Wo + ox) * lddy + co);
+    if (!src(c.iy, kh, g.Ho, oy) || !src(c.ix, kw, g.Wo, ox)) return zero4();
+    return ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co);
   }
 };
 // IC: B[r = (tap,co)][j = ci] = w[co][tap][ci]   (weights stored channels-last: [Cout][KH][KW][Cin])
 struct LdWeightConvDx {
   static constexpr bool RC = false;
-  const float* w; int Cout, taps, Cin;
-  __device__ __forceinline__ float4 load(int j, int, int r, int NJ, int Reff) const {
-    if (j >= NJ || r >= Reff) return zero4();
-    const int tap = r / Cout, co = r - tap * Cout;
-    return ld4(w + ((size_t)co * taps + tap) * Cin + j);
+  const float* w; int Cout, taps, Cin, cout_shift;
+  struct Ctx { const float* col; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? w + j : nullptr}; }
+  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
+    if (!c.col || r >= Reff) return zero4();
+    const int tap = cout_shift >= 0 ? (r >> cout_shift) : (r / Cout), co = r - tap * Cout;
+    return ld4(c.col + ((size_t)co * taps + tap) * Cin);
   }
 };
+
+inline int pow2_shift(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return (1 << s) == v ? s : -1;
+}
 
 // ------------------------------------------------------------------ generic epilogues
 struct EpStore {  // C[m*ldc + j] = v (+bias)
@@ -379,6 +491,11 @@ struct EpStore {  // C[m*ldc + j] = v (+bias)
   __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
     c[(size_t)m * ldc + j] = v[0] + (bias ? bias[j] : 0.f);
   }
+};
+struct EpStoreStats {  // C[m*ldc + j] = v ; sums[j] += v ; sums[NJ + j] += v*v   (conv -> BatchNorm batch statistics)
+  static constexpr bool COLSTATS = true;
+  float* c; int ldc; double* sums;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const { c[(size_t)m * ldc + j] = v[0]; }
 };
 struct EpStoreAdd {  // C[m*ldc+j] = v + add[m*ldadd + j]
   float* c; int ldc; const float* add; int ldadd;

@@ -10,21 +10,20 @@ namespace {
 
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
-  if (NJ <= 64) return launch_gemm<TileN64>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-  const long nb_big = (long)((M + 127) / 128) * ((NJ + 127) / 128);
-  if (nb_big >= 512) return launch_gemm<TileBig>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
+  // when that grid cannot fill the 256 CUs, one-wave 32x32 blocks quadruple the block count.
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
 }
 
 // weight-gradient form: out[Mo, NJ] += A^T B over R (device-side count dR) rows
 template <class LA, class LB>
-int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, hipStream_t st) {
+int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (1024 + nb - 1) / nb;
-  const int max_splits = (R + 127) / 128;
+  int splits = (768 + nb - 1) / nb;
+  const int max_splits = (R + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, st);
+  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
 }
 
 // ---------------------------------------------------------------- epilogues
@@ -149,6 +148,7 @@ int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode,
 // ------------------------------------------------------------------ scoring + STP
 int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("score_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
   if (!a || a->C % 32) return SAST_EINVAL;
   const int M = a->B * a->L, C = a->C;
   int rc = controls_fwd_launch(a->wc, a->r, a->r_stride, a->scale, a->B, C, 20, st);
@@ -160,6 +160,7 @@ int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
 
 int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("score_bwd", a->C, a->B * a->L, st);
   const int M = a->B * a->L, C = a->C;
   float* dz = a->ws;
   float* dscale = a->ws + (size_t)M * C;
@@ -167,13 +168,13 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   int rc = stp_bwd_launch(a->xp, a->s, a->scale, a->dxw, a->dxp, dz, dscale, a->B, a->L, C, st);
   if (rc) return rc;
   // dxp = direct + dz Ws
-  rc = gemm_auto(LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C, nullptr}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
+  Side sd(st);
+  sd.after_main();
+  rc = gemm_tn(LdRowsT{dz, C, nullptr}, LdRowsT{a->xp, C, nullptr}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b, sd.side);
   if (rc) return rc;
-  rc = gemm_tn(LdRowsT{dz, C, nullptr}, LdRowsT{a->xp, C, nullptr}, a->d_ws_w, C, C, C, M, nullptr, st);
+  rc = controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, sd.side);
   if (rc) return rc;
-  rc = colsum_launch(dz, C, nullptr, M, nullptr, C, a->d_ws_b, st);
-  if (rc) return rc;
-  return controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, st);
+  return gemm_auto(LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C, nullptr}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
 }
 
 // ------------------------------------------------------------------ MS-WSA
@@ -183,6 +184,7 @@ size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
 
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("mswsa_fwd", a ? a->C : 0, a ? (a->mode ? -1 : 1) * a->B * a->H * a->W : 0, st);
   if (!a || a->C % 32 || a->inner % 32) return SAST_EINVAL;
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
@@ -200,9 +202,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
     const LdRows la{a->Y, C, nullptr};
     const LdWeightNT lb{a->fc1_w, C, inner};
     const EpGlu ep{a->UG, a->Hh, a->fc1_b, inner};
-    const long nb_big = (long)((R + 127) / 128) * ((inner + 63) / 64);
-    rc = nb_big >= 512 ? launch_gemm<TileG2Big>(la, lb, ep, R, inner, C, dR, nullptr, st)
-                       : launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     if (rc) return rc;
   }
   return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
@@ -211,6 +211,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
 
 int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("mswsa_bwd", a->C, (a->mode ? -1 : 1) * a->B * a->H * a->W, st);
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   const int* dR = a->sel.counts;
@@ -226,42 +227,39 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   float* s1 = s2 + C;
   hipMemsetAsync(raw2, 0, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
   int rc;
+  Side sd(st);   // weight-gradient GEMMs run beside the activation-gradient chain
+  // fc2 grads (raw, LayerScale applied in the finish kernel): need only dZ (= dout rows) and H
+  sd.after_main();
+  rc = gemm_tn(LdRowsT{a->dout, C, row_tok}, LdRowsT{a->Hh, inner, nullptr}, raw2, inner, C, inner, R, dR, s2, sd.side);
+  if (rc) return rc;
+  rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, sd.side);
+  if (rc) return rc;
   // dH = (gamma2 * dZ) W2 ; fused: dUG from the saved pre-activations
   rc = gemm_auto(LdRows{a->dout, C, row_tok}, LdWeightNN{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
   if (rc) return rc;
-  // fc2 grads (raw, LayerScale applied in the finish kernel)
-  rc = gemm_tn(LdRowsT{a->dout, C, row_tok}, LdRowsT{a->Hh, inner, nullptr}, raw2, inner, C, inner, R, dR, st);
-  if (rc) return rc;
-  rc = colsum_launch(a->dout, C, row_tok, R, dR, C, s2, st);
-  if (rc) return rc;
-  rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, st);
+  sd.after_main();
+  rc = gemm_tn(LdRowsT{dUG, 2 * inner, nullptr}, LdRowsT{a->Y, C, nullptr}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b, sd.side);
   if (rc) return rc;
   // dY = dZ + dUG W1
   rc = gemm_auto(LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C, nullptr}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C,
                  2 * inner, dR, st);
   if (rc) return rc;
-  rc = gemm_tn(LdRowsT{dUG, 2 * inner, nullptr}, LdRowsT{a->Y, C, nullptr}, a->d_fc1_w, C, 2 * inner, C, R, dR, st);
+  sd.after_main();
+  rc = gemm_tn(LdRowsT{dY, C, nullptr}, LdRowsT{a->O, C, nullptr}, raw1, C, C, C, R, dR, s1, sd.side);
   if (rc) return rc;
-  rc = colsum_launch(dUG, 2 * inner, nullptr, R, dR, 2 * inner, a->d_fc1_b, st);
+  rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, sd.side);
   if (rc) return rc;
-  // dO = (gamma1 * dY) Wp ; proj grads
+  // dO = (gamma1 * dY) Wp
   rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
-  if (rc) return rc;
-  rc = gemm_tn(LdRowsT{dY, C, nullptr}, LdRowsT{a->O, C, nullptr}, raw1, C, C, C, R, dR, st);
-  if (rc) return rc;
-  rc = colsum_launch(dY, C, nullptr, R, dR, C, s1, st);
-  if (rc) return rc;
-  rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
   if (rc) return rc;
   // attention backward
   rc = attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, st);
   if (rc) return rc;
-  // dS = dY + dQKV Wqkv ; qkv grads
+  sd.after_main();
+  rc = gemm_tn(LdRowsT{dQKV, 3 * C, nullptr}, LdRowsT{a->S, C, nullptr}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);
+  if (rc) return rc;
+  // dS = dY + dQKV Wqkv
   rc = gemm_auto(LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C, nullptr}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
-  if (rc) return rc;
-  rc = gemm_tn(LdRowsT{dQKV, 3 * C, nullptr}, LdRowsT{a->S, C, nullptr}, a->d_qkv_w, C, 3 * C, C, R, dR, st);
-  if (rc) return rc;
-  rc = colsum_launch(dQKV, 3 * C, nullptr, R, dR, 3 * C, a->d_qkv_b, st);
   if (rc) return rc;
   // LN2 (kept rows) + LN1 (all tokens) backward
   return ln1_gather_bwd_launch(a->xin, a->dout, dS, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->mean1, a->rstd1, a->mean2,
@@ -271,31 +269,31 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
 // ------------------------------------------------------------------ ConvLSTM (1x1 conv on [x|h])
 int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("lstm_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
   if (!a || a->C % 32) return SAST_EINVAL;
   const int M = a->B * a->L, C = a->C;
   const int Kred = a->h0 ? 2 * C : C;   // zero hidden state: skip the h half of the reduction
   const LdRows2 la{a->x, C, C, a->h0, C};
   const LdWeightNT lb{a->w, 2 * C, C};
   const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C};
-  const long nb_big = (long)((M + 127) / 128) * ((C + 31) / 32);
-  return nb_big >= 512 ? launch_gemm<TileG4Big>(la, lb, ep, M, C, Kred, nullptr, nullptr, st)
-                       : launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
+  return launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
 }
 
 int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("lstm_bwd", a->C, a->B * a->L, st);
   const int M = a->B * a->L, C = a->C;
   float* dmix = a->ws;
   const size_t n = (size_t)M * C;
   hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
                      a->dc1, dmix, a->dc0, n, C);
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
-  int rc = gemm_auto(LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C, nullptr}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C,
-                     nullptr, st);
+  Side sd(st);
+  sd.after_main();
+  int rc = gemm_tn(LdRowsT{dmix, 4 * C, nullptr}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
+                   sd.side);
   if (rc) return rc;
-  rc = gemm_tn(LdRowsT{dmix, 4 * C, nullptr}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, st);
-  if (rc) return rc;
-  return colsum_launch(dmix, 4 * C, nullptr, M, nullptr, 4 * C, a->db, st);
+  return gemm_auto(LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C, nullptr}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
 }
 
 }  // extern "C"

@@ -12,82 +12,54 @@ namespace {
 
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
-  if (NJ <= 64) return launch_gemm<TileN64>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
-  const long nb_big = (long)((M + 127) / 128) * ((NJ + 127) / 128);
-  if (nb_big >= 512) return launch_gemm<TileBig>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
 }
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (1024 + nb - 1) / nb;
-  const int max_splits = (R + 127) / 128;
+  int splits = (768 + nb - 1) / nb;
+  const int max_splits = (R + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, st);
+  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
 }
 
 // ---------------------------------------------------------------- BatchNorm pieces
-// per-channel sum / sum of squares of x[M, C] in fp64
-__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
-                                                       int rows_per_block) {
-  const int c4 = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-  if (c4 * 4 < C)
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const float4 v = ld4(x + (size_t)r * C + c4 * 4);
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
-    }
-  __shared__ double red[4][64][8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { red[rl][threadIdx.x & 63][e] = s[e]; red[rl][threadIdx.x & 63][4 + e] = q[e]; }
-  __syncthreads();
-  if (rl == 0 && c4 * 4 < C) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      double a = 0, b = 0;
-      for (int k = 0; k < 4; ++k) { a += red[k][threadIdx.x][e]; b += red[k][threadIdx.x][4 + e]; }
-      atomicAdd(sums + c4 * 4 + e, a);
-      atomicAdd(sums + C + c4 * 4 + e, b);
-    }
-  }
-}
-// batch statistics -> (mean, rstd) + running-stat update (momentum, unbiased variance), torch BatchNorm2d semantics
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int M, int C, float eps, float momentum,
-                                   float* __restrict__ run_mean, float* __restrict__ run_var, float* __restrict__ stats) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = sums[c] / M;
-  double var = sums[C + c] / M - mean * mean;
-  if (var < 0) var = 0;
-  stats[c] = (float)mean;
-  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (run_mean) {
-    const double unb = M > 1 ? var * M / (M - 1) : var;
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
-  }
-}
-__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float eps,
-                                     float* __restrict__ stats) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  stats[c] = run_mean[c];
-  stats[C + c] = 1.0f / sqrtf(run_var[c] + eps);
-}
-// y = silu((x - mean) * rstd * gamma + beta)
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ y, int ldy, size_t n4, int C) {
+// y = silu(BN(x)); training: batch statistics from the fp64 column sums the conv epilogue accumulated; the threads that
+// own row 0 also publish (mean, rstd) for the backward and update the running statistics (torch BatchNorm2d semantics:
+// momentum, unbiased variance).  eval: running statistics.
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restrict__ x, const double* __restrict__ sums, int M, float eps,
+                                                            float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                            float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y, int ldy, size_t n4, int C,
+                                                            int training) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n4) return;
   const int c4 = C / 4;
   const size_t m = e / c4; const int c = (int)(e % c4) * 4;
-  const float4 v = ld4(x + m * C + c), mu = ld4(stats + c), rs = ld4(stats + C + c), g = ld4(gamma + c), b = ld4(beta + c);
-  float4 z = make_float4((v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z,
-                         (v.w - mu.w) * rs.w * g.w + b.w);
+  float mu[4], rs[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (training) {
+      const double mean = sums[c + k] / M;
+      double var = sums[C + c + k] / M - mean * mean;
+      if (var < 0) var = 0;
+      mu[k] = (float)mean;
+      rs[k] = (float)(1.0 / sqrt(var + (double)eps));
+      if (m == 0 && run_mean) {
+        const double unb = M > 1 ? var * M / (M - 1) : var;
+        run_mean[c + k] = (1.f - momentum) * run_mean[c + k] + momentum * (float)mean;
+        run_var[c + k] = (1.f - momentum) * run_var[c + k] + momentum * (float)unb;
+      }
+    } else {
+      mu[k] = run_mean[c + k];
+      rs[k] = 1.0f / sqrtf(run_var[c + k] + eps);
+    }
+    if (m == 0) { stats[c + k] = mu[k]; stats[C + c + k] = rs[k]; }
+  }
+  const float4 v = ld4(x + m * C + c), g = ld4(gamma + c), b = ld4(beta + c);
+  float4 z = make_float4((v.x - mu[0]) * rs[0] * g.x + b.x, (v.y - mu[1]) * rs[1] * g.y + b.y, (v.z - mu[2]) * rs[2] * g.z + b.z,
+                         (v.w - mu[3]) * rs[3] * g.w + b.w);
   z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
   st4(y + m * ldy + c, z);
 }
@@ -132,11 +104,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dy, int lddy, const float* __restrict__ sums,
-                                                           float* __restrict__ dconv, size_t n4, int C, float invM, int training) {
+                                                           float* __restrict__ dconv, size_t n4, int C, float invM, int training,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e4 >= n4) return;
   const int c4 = C / 4;
   const size_t m = e4 / c4; const int c = (int)(e4 % c4) * 4;
+  if (m == 0) {   // the row-0 threads also publish the affine gradients (sums are complete: previous kernel)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dbeta[c + e] += sums[c + e]; dgamma[c + e] += sums[C + c + e]; }
+  }
   const float4 v = ld4(x + m * C + c), d = ld4(dy + m * lddy + c);
   float out[4];
 #pragma unroll
@@ -149,13 +126,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
   st4(dconv + m * C + c, make_float4(out[0], out[1], out[2], out[3]));
 }
-__global__ void bn_bwd_finish_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  dbeta[c] += sums[c];
-  dgamma[c] += sums[C + c];
-}
-
 // ---------------------------------------------------------------- upsample / concat
 __global__ __launch_bounds__(256) void upsample_cat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                float* __restrict__ out, int H, int W, int C1, int C2, size_t n4) {
@@ -230,6 +200,8 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad; g.replicate = replicate; g.ldx = ldx;
   g.Ho = (H + 2 * pad - k) / stride + 1;
   g.Wo = (W + 2 * pad - k) / stride + 1;
+  g.cin_shift = pow2_shift(Cin);
+  g.kw_mul = small_div_mul(k);
   return g;
 }
 
@@ -240,6 +212,7 @@ extern "C" {
 // ------------------------------------------------------------------ downsample conv + LayerNorm
 int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("down_fwd", a ? a->Cout : 0, a ? a->B * a->H * a->W : 0, st);
   if (!a || a->Cin % 4 || a->Cout % 32) return SAST_EINVAL;
   const int k = 2 * a->factor - 1;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
@@ -251,17 +224,20 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
 
 int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("down_bwd", a->Cout, a->B * a->H * a->W, st);
   const int k = 2 * a->factor - 1;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
   float* dconv = a->ws;
   int rc = ln_bwd_launch(a->conv_out, a->dy, a->ln_w, a->mean, a->rstd, dconv, a->d_ln_w, a->d_ln_b, M, a->Cout, st);
   if (rc) return rc;
-  rc = gemm_tn(LdRowsT{dconv, a->Cout, nullptr}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, st);
+  Side sd(st);
+  sd.after_main();
+  rc = gemm_tn(LdRowsT{dconv, a->Cout, nullptr}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, sd.side);
   if (rc) return rc;
   if (a->dx) {
     const int Min = a->B * a->H * a->W;
-    rc = gemm_auto(LdConvDx{dconv, g, a->Cout, a->Cout}, LdWeightConvDx{a->w, a->Cout, k * k, a->Cin}, EpStore{a->dx, a->Cin, nullptr},
+    rc = gemm_auto(LdConvDx{dconv, g, a->Cout, a->Cout, pow2_shift(a->Cout)}, LdWeightConvDx{a->w, a->Cout, k * k, a->Cin, pow2_shift(a->Cout)}, EpStore{a->dx, a->Cin, nullptr},
                    Min, a->Cin, k * k * a->Cout, st);
   }
   return rc;
@@ -270,59 +246,60 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
 // ------------------------------------------------------------------ conv + BN + SiLU
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("convbn_fwd", a ? a->Cout * 10 + a->ksize : 0, a ? a->B * a->H * a->W : 0, st);
   if (!a || a->Cin % 4 || a->Cout % 4 || (a->ksize != 1 && a->ksize != 3)) return SAST_EINVAL;
   const int k = a->ksize, pad = (k - 1) / 2;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
+  double* sums = (double*)a->bn_ws;
+  if (a->training && !a->bn_ws_zeroed) hipMemsetAsync(a->bn_ws, 0, sizeof(float) * 8 * C, st);
   int rc;
-  if (k == 1 && a->stride == 1)
-    rc = gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, C, nullptr}, M, C, K, st);
-  else
-    rc = gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, C, nullptr}, M, C, K, st);
-  if (rc) return rc;
-  if (a->training) {
-    double* sums = (double*)a->ws;
-    hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
-    const int rpb = 128;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((C / 4 + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, a->conv_out, M, C, sums, rpb);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, M, C, a->eps, a->momentum, a->run_mean,
-                       a->run_var, a->stats);
+  if (a->training) {   // conv + per-channel sum / sum-of-squares in one pass
+    const EpStoreStats ep{a->conv_out, C, sums};
+    rc = (k == 1 && a->stride == 1) ? gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                                    : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   } else {
-    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a->run_mean, a->run_var, C, a->eps, a->stats);
+    const EpStore ep{a->conv_out, C, nullptr};
+    rc = (k == 1 && a->stride == 1) ? gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                                    : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
+  if (rc) return rc;
   const size_t n4 = (size_t)M * (C / 4);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
-                     a->y, a->ldy, n4, C);
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, sums, M, a->eps, a->momentum,
+                     a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, n4, C, a->training);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
+  ProfScope ps_("convbn_bwd", a->Cout * 10 + a->ksize, a->B * a->H * a->W, st);
   const int k = a->ksize, pad = (k - 1) / 2;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
-  float* sums = a->ws;                 // [2C]
-  float* dconv = a->ws + 4 * C;        // [M, C]
-  hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
-  const int rpb = 128;
+  float* sums = a->bn_ws + 4 * C;      // [2C]
+  float* dconv = a->ws;                // [M, C]
+  if (!a->bn_ws_zeroed) hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
+  int rpb = (int)(((long)M * ((C / 4 + 63) / 64) + 511) / 512);   // aim at >= 512 blocks
+  rpb = rpb < 8 ? 8 : (rpb > 128 ? 128 : rpb);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C / 4 + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w,
                      a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
   const size_t n4 = (size_t)M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
-                     a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training);
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, a->d_bn_w, a->d_bn_b, C);
+                     a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w, a->d_bn_b);
   SAST_CHECK_LAUNCH();
   int rc;
+  Side sd(st);
+  sd.after_main();
   if (k == 1 && a->stride == 1) {
-    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdRowsT{a->x, a->ldx, nullptr}, a->dw, K, C, K, M, st);
+    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdRowsT{a->x, a->ldx, nullptr}, a->dw, K, C, K, M, sd.side);
     if (rc) return rc;
     if (a->dx) rc = gemm_auto(LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K, nullptr}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, st);
   } else {
-    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, st);
+    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, sd.side);
     if (rc) return rc;
     if (a->dx)
-      rc = gemm_auto(LdConvDx{dconv, g, C, C}, LdWeightConvDx{a->w, C, k * k, a->Cin}, EpStore{a->dx, a->lddx, nullptr},
+      rc = gemm_auto(LdConvDx{dconv, g, C, C, pow2_shift(C)}, LdWeightConvDx{a->w, C, k * k, a->Cin, pow2_shift(C)}, EpStore{a->dx, a->lddx, nullptr},
                      a->B * a->H * a->W, a->Cin, k * k * C, st);
   }
   return rc;

@@ -12,18 +12,21 @@ namespace sast {
 struct ProfLaunch { hipEvent_t e0, e1; double flops; std::string tag; };
 static bool g_on = false;
 static std::vector<ProfLaunch> g_launches;
-static hipEvent_t g_pending;
+static std::vector<hipEvent_t> g_pending;
 
 bool prof_enabled() { return g_on; }
 
 void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin) {
   if (begin) {
-    hipEventCreate(&g_pending);
-    hipEventRecord(g_pending, st);
+    hipEvent_t e;
+    hipEventCreate(&e);
+    hipEventRecord(e, st);
+    g_pending.push_back(e);
     return;
   }
   ProfLaunch l;
-  l.e0 = g_pending;
+  l.e0 = g_pending.back();
+  g_pending.pop_back();
   hipEventCreate(&l.e1);
   hipEventRecord(l.e1, st);
   int m = M, r = R;
@@ -32,6 +35,14 @@ void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, co
   l.flops = 2.0 * (double)m * (double)NJ * (double)G * (double)r;
   l.tag = tag;
   g_launches.push_back(l);
+}
+
+
+// op-level scopes (C-ABI entry points): tag = "op:<name> C=<c> M=<m>"
+void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin) {
+  char tag[96];
+  snprintf(tag, sizeof tag, "op:%s C=%d M=%d", name, c, m);
+  prof_record(tag, 0, 0, 0, 0, nullptr, nullptr, st, begin);
 }
 
 }  // namespace sast

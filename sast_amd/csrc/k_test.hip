@@ -1,0 +1,28 @@
+// micro-benchmark / unit-test entry points for the GEMM template (not used by the product path)
+#include "gemm.cuh"
+#include "kernels.h"
+using namespace sast;
+
+extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int tile,
+                                 sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const LdRows la{a, K, nullptr};
+  const LdWeightNT lb{w, K, 0};
+  const EpStore ep{c, N, bias};
+  switch (tile) {
+    case 0: return launch_gemm<TileSmall>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 1: return launch_gemm<TileMid>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 2: return launch_gemm<TileBig>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 3: return launch_gemm<TileN64>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 4: return launch_gemm<Tile<64, 64, 2, 2, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 5: return launch_gemm<Tile<64, 128, 2, 2, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 6: return launch_gemm<Tile<128, 128, 2, 2, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 7: return launch_gemm<Tile<128, 64, 2, 2, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 8: return launch_gemm<Tile<128, 64, 2, 2, 1, 16>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 9: return launch_gemm<TileTiny>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 10: return launch_gemm<Tile<32, 64, 1, 2, 1, 16>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 11: return launch_gemm<Tile<64, 32, 2, 1, 1, 16>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    default: return SAST_EINVAL;
+  }
+}

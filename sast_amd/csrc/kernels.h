@@ -32,6 +32,15 @@ int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* d
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st);
 
+// k_side.hip
+struct Side {
+  hipStream_t main, side; bool used;
+  Side(hipStream_t m, int which = 0);
+  void after_main();
+  void join();
+  ~Side() { join(); }
+};
+
 // k_select.hip
 int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mode, float thr_win, float thr_tok,
                   int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,

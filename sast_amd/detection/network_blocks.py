@@ -20,16 +20,43 @@ class BaseConv(nn.Module):
         self.conv.weight = channels_last_conv_weight(out_channels, in_channels, ksize)
         self.bn = nn.BatchNorm2d(out_channels)
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, arena=None):
+        """arena: optional `BnArena` handing out zero-filled reduction scratch (one memset per FPN forward) and
+        batching the num_batches_tracked increments."""
         bn = self.bn
+        ws = arena.take(8 * bn.num_features) if arena is not None else None
         y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
-                            self.training, bn.momentum, bn.eps)
+                            self.training, bn.momentum, bn.eps, ws)
         if self.training and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+            if arena is not None:
+                arena.counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
         return y
 
     def forward(self, x):
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
+
+
+class BnArena:
+    """zero-filled scratch for the BatchNorm reductions of a whole FPN pass: ONE memset instead of one per conv."""
+
+    def __init__(self, n_floats, device):
+        self.buf = torch.zeros(n_floats, device=device)
+        self.off = 0
+        self.counters = []
+
+    def take(self, n):
+        if self.off + n > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n
+        return t
+
+    def finish(self):
+        if self.counters:
+            torch._foreach_add_(self.counters, 1)
+            self.counters = []
 
 
 class Bottleneck(nn.Module):
@@ -44,8 +71,8 @@ class Bottleneck(nn.Module):
         self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
-    def forward_nhwc(self, x):
-        y = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x))
+    def forward_nhwc(self, x, arena=None):
+        y = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x, arena), arena)
         return y + x if self.use_add else y
 
     def forward(self, x):
@@ -63,12 +90,12 @@ class CSPLayer(nn.Module):
         self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
-    def forward_nhwc(self, x):
-        x1 = self.conv1.forward_nhwc(x)
-        x2 = self.conv2.forward_nhwc(x)
+    def forward_nhwc(self, x, arena=None):
+        x1 = self.conv1.forward_nhwc(x, arena)
+        x2 = self.conv2.forward_nhwc(x, arena)
         for b in self.m:
-            x1 = b.forward_nhwc(x1)
-        return self.conv3.forward_nhwc(SF.cat2(x1, x2))
+            x1 = b.forward_nhwc(x1, arena)
+        return self.conv3.forward_nhwc(SF.cat2(x1, x2), arena)
 
     def forward(self, x):
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))

@@ -6,7 +6,7 @@ from typing import Dict, Optional, Tuple
 import torch.nn as nn
 
 from .. import functional as SF
-from .network_blocks import BaseConv, CSPLayer
+from .network_blocks import BaseConv, BnArena, CSPLayer
 
 
 class YOLOPAFPN(nn.Module):
@@ -34,14 +34,18 @@ class YOLOPAFPN(nn.Module):
 
     def forward_nhwc(self, feats: Dict[int, object]):
         x2, x1, x0 = (feats[f] for f in self.in_features)
-        fpn_out0 = self.lateral_conv0.forward_nhwc(x0)
-        f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1))     # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
-        fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0)
-        pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2))
-        p_out1 = SF.cat2(self.bu_conv2.forward_nhwc(pan_out2), fpn_out1)
-        pan_out1 = self.C3_n3.forward_nhwc(p_out1)
-        p_out0 = SF.cat2(self.bu_conv1.forward_nhwc(pan_out1), fpn_out0)
-        pan_out0 = self.C3_n4.forward_nhwc(p_out0)
+        if not hasattr(self, "_bn_floats"):
+            self._bn_floats = sum(8 * m.num_features for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        ar = BnArena(self._bn_floats, x0.device)                            # one memset for all 32 BatchNorm reductions
+        fpn_out0 = self.lateral_conv0.forward_nhwc(x0, ar)
+        f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1), ar)  # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
+        fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0, ar)
+        pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2), ar)
+        p_out1 = SF.cat2(self.bu_conv2.forward_nhwc(pan_out2, ar), fpn_out1)
+        pan_out1 = self.C3_n3.forward_nhwc(p_out1, ar)
+        p_out0 = SF.cat2(self.bu_conv1.forward_nhwc(pan_out1, ar), fpn_out0)
+        pan_out0 = self.C3_n4.forward_nhwc(p_out0, ar)
+        ar.finish()
         return pan_out2, pan_out1, pan_out0
 
     def forward(self, input):

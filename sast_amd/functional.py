@@ -468,7 +468,7 @@ def conv_lstm(x_nhwc, h0, c0, w, b):
 # ---------------------------------------------------------------------------------------------- a13
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps):
+    def forward(ctx, x, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws):
         _need_gpu(x, w)
         x = x.contiguous()
         if not is_channels_last_weight(w):
@@ -482,33 +482,35 @@ class _ConvBnSilu(torch.autograd.Function):
         conv_out = torch.empty(M, Cout, device=dev)
         stats = torch.empty(2 * Cout, device=dev)
         y = torch.empty(B, Ho, Wo, Cout, device=dev)
-        ws = torch.empty(4 * Cout, device=dev)
+        if bn_ws is None:  # zero-filled reduction scratch (a whole FPN passes slices of one arena: one memset per step)
+            bn_ws = torch.zeros(8 * Cout, device=dev)
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin,
-                  ldy=Cout, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean), run_var=_ptr(run_var),
-                  conv_out=conv_out, stats=stats, y=y, ws=ws)
+                  ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
+                  run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws)
         L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
-        ctx.save_for_backward(x, conv_out, stats)
+        ctx.save_for_backward(x, conv_out, stats, bn_ws)
         ctx.params = (w, bn_w, bn_b)
         ctx.meta = (B, H, W, Cin, Cout, ksize, stride, int(training), momentum, eps, M)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, conv_out, stats = ctx.saved_tensors
+        x, conv_out, stats, bn_ws = ctx.saved_tensors
         w, bn_w, bn_b = ctx.params
         B, H, W, Cin, Cout, ksize, stride, training, momentum, eps, M = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        ws = torch.empty(M * Cout + 4 * Cout, device=x.device)
+        ws = torch.empty(M * Cout, device=x.device)
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin,
-                  ldy=Cout, lddy=Cout, lddx=Cin, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out,
-                  stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w), d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), ws=ws)
+                  ldy=Cout, lddy=Cout, lddx=Cin, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b,
+                  conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w), d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws)
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
 
 
-def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5):
-    return _ConvBnSilu.apply(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps))
+def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None):
+    """bn_ws: optional zero-filled fp32[8*Cout] scratch (consumed: do not reuse within a step)."""
+    return _ConvBnSilu.apply(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws)
 
 
 class _UpsampleCat(torch.autograd.Function):

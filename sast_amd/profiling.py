@@ -51,7 +51,7 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
             trainer.fwd_bwd()
             trainer.update()
 
-    rows = gemm_report(run, n_steps)
+    rows = [r for r in gemm_report(run, n_steps) if not r[0].startswith("op:")]
     name, calls, ms, flops = rows[0]
     achieved = flops / (ms * 1e-3) / 1e12
     total_ms = sum(r[2] for r in rows)
