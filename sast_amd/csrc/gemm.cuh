@@ -32,10 +32,13 @@ namespace sast {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16>
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16, int KS_ = 1>
 struct Tile {
-  static constexpr int BM = BM_, BN = BN_, BK = BK_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, G = G_;
-  static constexpr int NT = 64 * WAVES_M * WAVES_N;
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, G = G_, KS = KS_;
+  // KS > 1: intra-block split of the reduction over KS wave groups (each with private LDS stages).  When M*N yields too
+  // few tiles to give every SIMD two waves, this puts KS waves on each SIMD so MFMA overlaps the other group's LDS traffic.
+  static constexpr int NTG = 64 * WAVES_M * WAVES_N;   // threads per k-group
+  static constexpr int NT = NTG * KS;
   static constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   static constexpr int TM = WTM / 32, TN = WTN / 32, TJ = TN / G;
   static constexpr int BJ = BN / G;  // output channels (j) per block
@@ -58,15 +61,18 @@ template <class T, class LA, class LB, class EP, bool SPLIT>
 __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M, int NJ, int R,
                                                      const int* __restrict__ dM, const int* __restrict__ dR,
                                                      float* __restrict__ colsum) {
-  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NT, G = T::G, BJ = T::BJ;
+  constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NTG, G = T::G, BJ = T::BJ, KS = T::KS;
   constexpr int LDA = LdsLd<T, LA::RC, BM>::value;
   constexpr int LDB = LdsLd<T, LB::RC, BN>::value;
   constexpr int A_STAGE = BK * LDA, B_STAGE = BK * LDB;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_STAGE + B_STAGE)];
-  float* As = smem;
-  float* Bs = smem + 2 * A_STAGE;
+  constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
+  static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
+  __shared__ __attribute__((aligned(16))) float smem[KS * GROUP_FLOATS];
+  const int kg = threadIdx.x / NT;          // k-group of this wave (wave-uniform)
+  float* As = smem + kg * GROUP_FLOATS;
+  float* Bs = As + 2 * A_STAGE;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
   const int nbj = (NJ + BJ - 1) / BJ;
   const int bj = blockIdx.x % nbj, bm = blockIdx.x / nbj;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 
   constexpr int A_SLOTS = BM * BK / 4, B_SLOTS = BN * BK / 4;
   constexpr int A_PER = (A_SLOTS + NT - 1) / NT, B_PER = (B_SLOTS + NT - 1) / NT;
-  float4 ra[A_PER], rb[B_PER];
+  float4 ra[2][A_PER], rb[2][B_PER];   // two k-tiles in flight (global-load latency ~ 2 compute phases)
 
   auto nnmap = [&](int jl, int g) -> int {  // (local channel, group) -> column inside the block tile
     const int jb = jl >> 5;
@@ -129,33 +135,33 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     }
   }
 
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt, float4 (&xa)[A_PER], float4 (&xb)[B_PER]) {
     const int r0 = kt * BK;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) ra[it] = la.load(ca[it], r0 + ra_off[it], Reff);
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) xa[it] = la.load(ca[it], r0 + ra_off[it], Reff);
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
-      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) rb[it] = lb.load(cb[it], r0 + rb_off[it], Reff);
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) xb[it] = lb.load(cb[it], r0 + rb_off[it], Reff);
   };
 
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const float4 (&xa)[A_PER], const float4 (&xb)[B_PER]) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it) {
       if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
         float* d = as + la_off[it];
-        if constexpr (LA::RC) { d[0] = ra[it].x; d[LDA] = ra[it].y; d[2 * LDA] = ra[it].z; d[3 * LDA] = ra[it].w; }
-        else st4(d, ra[it]);
+        if constexpr (LA::RC) { d[0] = xa[it].x; d[LDA] = xa[it].y; d[2 * LDA] = xa[it].z; d[3 * LDA] = xa[it].w; }
+        else st4(d, xa[it]);
       }
     }
 #pragma unroll
     for (int it = 0; it < B_PER; ++it) {
       if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
         float* d = bs + lb_off[it];
-        if constexpr (LB::RC) { d[0] = rb[it].x; d[LDB] = rb[it].y; d[2 * LDB] = rb[it].z; d[3 * LDB] = rb[it].w; }
-        else st4(d, rb[it]);
+        if constexpr (LB::RC) { d[0] = xb[it].x; d[LDB] = xb[it].y; d[2 * LDB] = xb[it].z; d[3 * LDB] = xb[it].w; }
+        else st4(d, xb[it]);
       }
     }
   };
@@ -172,12 +178,7 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
   for (int a = 0; a < T::TM; ++a) csum[a] = 0.f;
   const bool do_colsum = SPLIT && colsum != nullptr && bj == 0 && wn == 0;
 
-  gload(kt0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) gload(kt + 1);
+  auto compute = [&](int buf) {
     const float* as = As + buf * A_STAGE + wm * T::WTM + (lane & 31);
     const float* bs = Bs + buf * B_STAGE + wn * T::WTN + (lane & 31);
 #pragma unroll
@@ -198,8 +199,63 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
         for (int tb = 0; tb < T::TN; ++tb)
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
     }
-    if (kt + 1 < kt1) lstore(buf ^ 1);
+  };
+
+  // software pipeline: this k-group owns tiles kt0 + kg + KS*i; tiles i+1 and i+2 are in flight (registers) while tile i
+  // is multiplied out of LDS.  n_it is block-uniform so every wave meets every barrier.
+  const int n_it = (kt1 - kt0 + KS - 1) / KS;
+  auto tile_of = [&](int i) { return kt0 + kg + KS * i; };
+  auto valid = [&](int i) { return tile_of(i) < kt1; };
+  if (valid(0)) gload(tile_of(0), ra[0], rb[0]);
+  if (valid(1)) gload(tile_of(1), ra[1], rb[1]);
+  if (valid(0)) lstore(0, ra[0], rb[0]);
+  __syncthreads();
+  for (int i = 0; i < n_it; i += 2) {
+    // even phase: LDS buffer 0 holds tile i; register set 1 holds tile i+1; refill set 0 with tile i+2
+    if (valid(i + 2)) gload(tile_of(i + 2), ra[0], rb[0]);
+    if (valid(i)) compute(0);
+    if (valid(i + 1)) lstore(1, ra[1], rb[1]);
     __syncthreads();
+    if (i + 1 >= n_it) break;
+    // odd phase
+    if (valid(i + 3)) gload(tile_of(i + 3), ra[1], rb[1]);
+    if (valid(i + 1)) compute(1);
+    if (valid(i + 2)) lstore(0, ra[0], rb[0]);
+    __syncthreads();
+  }
+
+  if constexpr (KS > 1) {   // fold the k-groups' partial accumulators into group 0 through LDS
+    float* red = smem + kg * GROUP_FLOATS + (wave * T::TM * T::TN) * 16 * 64 + lane;
+    if (kg > 0) {
+#pragma unroll
+      for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) red[((a * T::TN + b) * 16 + e) * 64] = acc[a][b][e];
+    }
+    __syncthreads();
+    if (kg > 0) {
+      if (SPLIT && do_colsum) {
+#pragma unroll
+        for (int t = 0; t < T::TM; ++t) {
+          const float sv = csum[t] + __shfl_xor(csum[t], 32, 64);
+          const int m = m0 + wm * T::WTM + t * 32 + (lane & 31);
+          if (lane < 32 && m < Meff) atomicAdd(colsum + m, sv);
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float* src = smem + g * GROUP_FLOATS + (wave * T::TM * T::TN) * 16 * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < T::TM; ++a)
+#pragma unroll
+        for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[a][b][e] += src[((a * T::TN + b) * 16 + e) * 64];
+    }
   }
 
   if (SPLIT && do_colsum) {
@@ -290,6 +346,8 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
 using TileBig   = Tile<128, 128, 2, 2, 1>;  // wave tile 64x64
 using TileMid   = Tile<64, 128, 2, 2, 1>;   // wave tile 32x64
 using TileSmall = Tile<64, 64, 2, 2, 1>;    // wave tile 32x32
+using TileSmallK2 = Tile<64, 64, 2, 2, 1, 16, 2>;   // + 2-way intra-block k split (8 waves)
+using TileSmallK4 = Tile<64, 64, 2, 2, 1, 16, 4>;   // + 4-way intra-block k split (16 waves)
 using TileTiny  = Tile<32, 32, 1, 1, 1>;    // one wave per block: fills the chip when M*N is small (stage 3/4, PAFPN)
 using TileN64   = Tile<128, 64, 4, 1, 1>;   // N = 64 layers (stage 1): wave tile 32x64
 using TileG2    = Tile<64, 128, 2, 2, 2>;   // GLU: 64 rows x (64 ch x 2 groups), wave tile 32x(32x2)

@@ -12,18 +12,24 @@ template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
   // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
   // when that grid cannot fill the 256 CUs, one-wave 32x32 blocks quadruple the block count.
+  // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
+  // when the grid gives < 2 blocks per CU and the reduction is long, split k over two wave groups inside the block
+  const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
+  if (nb <= 480 && R >= 256) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
 }
 
 // weight-gradient form: out[Mo, NJ] += A^T B over R (device-side count dR) rows
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
+  // ~256-384 blocks of 16 waves (4-way intra-block k split): few enough blocks that the atomic epilogue does not
+  // dominate (each block adds its whole 64x64 tile), enough waves per SIMD to overlap MFMA with LDS traffic
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (768 + nb - 1) / nb;
+  int splits = (320 + nb - 1) / nb;
   const int max_splits = (R + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
+  return launch_gemm_split<TileSmallK4>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
 }
 
 // ---------------------------------------------------------------- epilogues

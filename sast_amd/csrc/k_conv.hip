@@ -12,16 +12,18 @@ namespace {
 
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
+  const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
+  if (nb <= 480 && R >= 256) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
 }
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (768 + nb - 1) / nb;
+  int splits = (320 + nb - 1) / nb;
   const int max_splits = (R + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
+  return launch_gemm_split<TileSmallK4>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
 }
 
 // ---------------------------------------------------------------- BatchNorm pieces

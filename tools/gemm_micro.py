@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 shapes = [(61440, 192, 64), (61440, 64, 64), (61440, 320, 64), (61440, 64, 160), (15360, 384, 128), (15360, 128, 128), (15360, 640, 128),
           (15360, 128, 320), (3840, 768, 256), (3840, 256, 256), (3840, 1344, 256), (3840, 256, 672), (960, 1536, 512), (960, 512, 512),
           (960, 2688, 512), (960, 512, 1344), (61440, 256, 128), (15360, 512, 256), (3840, 1024, 512), (960, 2048, 1024)]
-tiles = {0: "64x64k16", 4: "64x64k32", 9: "32x32k16", 12: "32x32k32", 10: "32x64k16", 11: "64x32k16", 1: "64x128k16"}
+tiles = {0: "64x64k16", 13: "64x64 KS2", 14: "64x64 KS4", 4: "64x64k32"}
 st = torch.cuda.current_stream().cuda_stream
 print("shape".ljust(22) + " ".join(f"{v:>15}" for v in tiles.values()))
 for (M, N, K) in shapes:
