@@ -65,41 +65,47 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restr
   z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
   st4(y + m * ldy + c, z);
 }
-// backward pass 1: sums[c] += dz, sums[C+c] += dz * xhat, with dz = dy * silu'(z)
+// backward pass 1: sums[c] += dz, sums[C+c] += dz * xhat, with dz = dy * silu'(z).
+// One block owns a strip of rows and ALL channels (fully coalesced float4 rows), reduces over its rows in LDS and
+// issues one atomic per channel -> (M / rows_per_block) * 2C atomics in total.
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ dy, int lddy, int M, int C,
                                                             float* __restrict__ sums, int rows_per_block) {
-  const int c4 = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  float4 a = zero4(), b = zero4();
-  if (c4 * 4 < C) {
-    const int c = c4 * 4;
-    const float4 mu = ld4(stats + c), rs = ld4(stats + C + c), g = ld4(gamma + c), bt = ld4(beta + c);
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const float4 v = ld4(x + (size_t)r * C + c), d = ld4(dy + (size_t)r * lddy + c);
-      const float xh[4] = {(v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w};
-      const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w}, dd[4] = {d.x, d.y, d.z, d.w};
-      float* ap = &a.x; float* bp = &b.x;
+  extern __shared__ float4 red[];                 // [RP][C/4][2]
+  const int c4n = C / 4;
+  const int RP = 256 / c4n > 0 ? 256 / c4n : 1;   // rows processed in parallel by the block
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int cq = threadIdx.x % min(c4n, 256); cq < c4n; cq += 256) {
+    const int rl = threadIdx.x / c4n;
+    const int c = cq * 4;
+    float4 a = zero4(), b = zero4();
+    if (rl < RP) {
+      const float4 mu = ld4(stats + c), rs = ld4(stats + C + c), g = ld4(gamma + c), bt = ld4(beta + c);
+      for (int r = r0 + rl; r < r1; r += RP) {
+        const float4 v = ld4(x + (size_t)r * C + c), d = ld4(dy + (size_t)r * lddy + c);
+        const float xh[4] = {(v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w};
+        const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w}, dd[4] = {d.x, d.y, d.z, d.w};
+        float* ap = &a.x; float* bp = &b.x;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float z = xh[e] * gg[e] + bb[e], sg = sigmoid_exact(z);
-        const float dz = dd[e] * sg * (1.f + z * (1.f - sg));
-        ap[e] += dz; bp[e] += dz * xh[e];
+        for (int e = 0; e < 4; ++e) {
+          const float z = xh[e] * gg[e] + bb[e], sg = sigmoid_exact(z);
+          const float dz = dd[e] * sg * (1.f + z * (1.f - sg));
+          ap[e] += dz; bp[e] += dz * xh[e];
+        }
       }
+      red[(rl * c4n + cq) * 2] = a; red[(rl * c4n + cq) * 2 + 1] = b;
     }
-  }
-  __shared__ float4 red[4][64][2];
-  red[rl][threadIdx.x & 63][0] = a; red[rl][threadIdx.x & 63][1] = b;
-  __syncthreads();
-  if (rl == 0 && c4 * 4 < C) {
-    for (int k = 1; k < 4; ++k) {
-      const float4 t = red[k][threadIdx.x][0], u = red[k][threadIdx.x][1];
-      a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; b.x += u.x; b.y += u.y; b.z += u.z; b.w += u.w;
+    __syncthreads();
+    if (rl == 0) {
+      for (int k = 1; k < RP; ++k) {
+        const float4 t = red[(k * c4n + cq) * 2], u = red[(k * c4n + cq) * 2 + 1];
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; b.x += u.x; b.y += u.y; b.z += u.z; b.w += u.w;
+      }
+      atomicAdd(sums + c, a.x); atomicAdd(sums + c + 1, a.y); atomicAdd(sums + c + 2, a.z); atomicAdd(sums + c + 3, a.w);
+      atomicAdd(sums + C + c, b.x); atomicAdd(sums + C + c + 1, b.y); atomicAdd(sums + C + c + 2, b.z); atomicAdd(sums + C + c + 3, b.w);
     }
-    const int c = c4 * 4;
-    atomicAdd(sums + c, a.x); atomicAdd(sums + c + 1, a.y); atomicAdd(sums + c + 2, a.z); atomicAdd(sums + c + 3, a.w);
-    atomicAdd(sums + C + c, b.x); atomicAdd(sums + C + c + 1, b.y); atomicAdd(sums + C + c + 2, b.z); atomicAdd(sums + C + c + 3, b.w);
+    __syncthreads();
   }
 }
 // backward pass 2: dconv = gamma * rstd * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]
@@ -282,10 +288,13 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   float* sums = a->bn_ws + 4 * C;      // [2C]
   float* dconv = a->ws;                // [M, C]
   if (!a->bn_ws_zeroed) hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
-  int rpb = (int)(((long)M * ((C / 4 + 63) / 64) + 511) / 512);   // aim at >= 512 blocks
-  rpb = rpb < 8 ? 8 : (rpb > 128 ? 128 : rpb);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C / 4 + 63) / 64, (M + rpb - 1) / rpb), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w,
-                     a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
+  int rpb = (M + 383) / 384;   // ~384 blocks
+  rpb = rpb < 16 ? 16 : (rpb > 128 ? 128 : rpb);
+  {
+    const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(float4) * 2 * RP * c4n, st, a->conv_out, a->stats,
+                       a->bn_w, a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
+  }
   const size_t n4 = (size_t)M * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
                      a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w, a->d_bn_b);
