@@ -200,7 +200,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
-  rc = attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, st);
+  rc = T <= 64 ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, C, st)
+               : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
   if (rc) return rc;
@@ -259,7 +260,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   if (rc) return rc;
   // attention backward
-  rc = attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, st);
+  rc = T <= 64 ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, C, st)
+               : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, st);
   if (rc) return rc;
   sd.after_main();
   rc = gemm_tn(LdRowsT{dQKV, 3 * C, nullptr}, LdRowsT{a->S, C, nullptr}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);

@@ -52,4 +52,9 @@ int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, 
 int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
                     const int* Kw, int W, int T, int C, hipStream_t st);
 
+// k_attn_mfma.hip (T <= 64)
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, hipStream_t st);
+int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
+                         int C, hipStream_t st);
+
 }  // namespace sast

@@ -248,3 +248,45 @@ def test_selection_properties_full_size(dev):
         assert torch.equal(sel.index_window().cpu(), iw)
         assert torch.equal(sel.asy_index().cpu(), asy)
         assert torch.equal(sel.K_list().cpu(), K)
+
+
+def test_ms_wsa_varlen_T60_fwd_bwd(dev):
+    """1Mpx-sized groups (T = 60 -> two 32-token MFMA tiles) with ragged K_m in {60, 33, 32, 1, 17, dropped}:
+    forward and every gradient of the MFMA attention path against the oracle's padded / masked formulation."""
+    from sast_amd.layers import MS_WSA
+    from sast_amd.layers.ops import LayerNorm
+    C, T, NW = 64, 60, 6
+    Ks = [60, 33, 32, 1, 17]                      # window 5 is dropped
+    g = torch.Generator().manual_seed(11)
+    kept = [torch.sort(torch.randperm(T, generator=g)[:k])[0] for k in Ks]
+    index_window = torch.arange(len(Ks))
+    asy = torch.cat([m * T + kt for m, kt in enumerate(kept)])
+    Kmax = max(Ks)
+    tok_rows = []
+    for m, kt in enumerate(kept):
+        rest = torch.tensor([t for t in range(T) if t not in set(kt.tolist())], dtype=torch.long)
+        tok_rows.append(m * T + torch.cat([kt, rest])[:Kmax])
+    index_token = torch.cat(tok_rows)
+    padding_index = index_token[torch.isin(index_token, asy, invert=True)]
+    lists = [index_window, index_token, padding_index, asy, torch.tensor(Ks)]
+    cfg = O.BackboneCfg(in_res_hw=(64, 80), partition_size=(4, 5), embed_dim=C)
+    full = O.init_backbone_params(cfg, seed=7, ls_init=0.5)
+    pre = "stages.0.att_blocks.0.att.win_attn."
+    params = {k[len(pre):]: v for k, v in full.items() if k.startswith(pre)}
+    x = torch.randn(NW, T, C, generator=g)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    ref = O.ms_wsa(xo, lists, 1, po, "", O.AttnCfg(partition_size=(6, 10)))
+    wgt = torch.randn(NW, T, C, generator=g)
+    (ref * wgt).sum().backward()
+    m = MS_WSA(C, 32, True, (0.5, 0.0, 4, None, True, 0.0), [LayerNorm(C, eps=1e-5), LayerNorm(C, eps=1e-5)]).to(dev)
+    load_params(m, params)
+    xd = x.to(dev).requires_grad_(True)
+    out = m(xd, *[l.to(dev) for l in lists[:4]], len(Ks), 1, False)
+    assert float((out.detach().cpu() - ref.detach()).abs().max()) <= FWD_ATOL
+    (out * wgt.to(dev)).sum().backward()
+    maxnorm_close(xd.grad, xo.grad, GRAD_RTOL, "dx")
+    for k, v in m.named_parameters():
+        if "sub_layers" in k:
+            continue
+        maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
