@@ -1,12 +1,30 @@
 // C-ABI entry points of the SAST block: STP scoring, MS-WSA (fwd/bwd) and the ConvLSTM.
 // Each entry point enqueues a short chain of kernels on the caller's stream; the GEMMs are
 // the fp32-MFMA template of gemm.cuh with op-specific loaders / fused epilogues.
+#include <cstdlib>
 #include "gemm.cuh"
 #include "kernels.h"
 
 using namespace sast;
 
 namespace {
+
+inline int tn_total_blocks() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_TN_BLOCKS"); v = e ? atoi(e) : 384; }
+  return v;
+}
+
+inline int ks_min_r() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
+  return v;
+}
+inline int ks_nb_limit() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_KS_NB"); v = e ? atoi(e) : 1000000; }
+  return v;
+}
 
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
@@ -15,21 +33,21 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, co
   // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
   // when the grid gives < 2 blocks per CU and the reduction is long, split k over two wave groups inside the block
   const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
-  if (nb <= 480 && R >= 256) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  if (nb <= ks_nb_limit() && R >= ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
 }
 
 // weight-gradient form: out[Mo, NJ] += A^T B over R (device-side count dR) rows
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
-  // ~256-384 blocks of 16 waves (4-way intra-block k split): few enough blocks that the atomic epilogue does not
-  // dominate (each block adds its whole 64x64 tile), enough waves per SIMD to overlap MFMA with LDS traffic
+  // measured (tools/gemm_tn_micro.py): the split-R kernel is latency-bound per block, so many short blocks win;
+  // 2-way intra-block k split with ~384+ blocks was the best point (the atomic epilogue costs ~25 %).
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (320 + nb - 1) / nb;
-  const int max_splits = (R + 255) / 256;
+  int splits = (tn_total_blocks() + nb - 1) / nb;
+  const int max_splits = (R + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmallK4>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
+  return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
 }
 
 // ---------------------------------------------------------------- epilogues

@@ -3,6 +3,7 @@
 //   - BaseConv = conv + BatchNorm2d + SiLU                network_blocks.py:29-54
 //   - nearest x2 upsample + concat, concat                yolo_pafpn.py:117-137
 //   - fused AdamW on the flat parameter buffer
+#include <cstdlib>
 #include "gemm.cuh"
 #include "kernels.h"
 
@@ -10,20 +11,33 @@ using namespace sast;
 
 namespace {
 
+inline int ks_min_r() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
+  return v;
+}
+inline int ks_nb_limit() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_KS_NB"); v = e ? atoi(e) : 1000000; }
+  return v;
+}
+
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
   const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
-  if (nb <= 480 && R >= 256) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
+  if (nb <= ks_nb_limit() && R >= ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
 }
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (320 + nb - 1) / nb;
-  const int max_splits = (R + 255) / 256;
+  static int total = -1;
+  if (total < 0) { const char* e = getenv("SAST_TN_BLOCKS"); total = e ? atoi(e) : 384; }
+  int splits = (total + nb - 1) / nb;
+  const int max_splits = (R + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmallK4>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
+  return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
 }
 
 // ---------------------------------------------------------------- BatchNorm pieces

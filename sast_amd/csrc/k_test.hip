@@ -28,3 +28,32 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     default: return SAST_EINVAL;
   }
 }
+
+struct EpNull {  // discards the result (measures the kernel without the atomic epilogue)
+  float* c;
+  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+    if (v[0] == 123456.789f) c[0] = v[0];
+  }
+};
+
+extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, float* colsum, int Mo, int NJ, int R, int tile, int splits,
+                                 int null_ep, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const LdRowsT la{dy, Mo, nullptr};
+  const LdRowsT lb{x, NJ, nullptr};
+  if (null_ep) {
+    const EpNull ep{out};
+    switch (tile) {
+      case 0: return launch_gemm_split<TileSmall>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+      case 1: return launch_gemm_split<TileSmallK2>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+      case 2: return launch_gemm_split<TileSmallK4>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    }
+  }
+  const EpAtomic ep{out, NJ};
+  switch (tile) {
+    case 0: return launch_gemm_split<TileSmall>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 1: return launch_gemm_split<TileSmallK2>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 2: return launch_gemm_split<TileSmallK4>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    default: return SAST_EINVAL;
+  }
+}
