@@ -79,6 +79,40 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restr
   z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
   st4(y + m * ldy + c, z);
 }
+// forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
+// fp64 per-channel sum / sum of squares, one atomic pair per channel per block.
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
+                                                       int rows_per_block) {
+  extern __shared__ double redd[];                // [RP][C][2]
+  const int c4n = C / 4;
+  const int RP = 256 / c4n > 0 ? 256 / c4n : 1;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  for (int cq = threadIdx.x % min(c4n, 256); cq < c4n; cq += 256) {
+    const int rl = threadIdx.x / c4n, c = cq * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rl < RP) {
+      for (int r = r0 + rl; r < r1; r += RP) {
+        const float4 v = ld4(x + (size_t)r * C + c);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { redd[((rl * C) + c + e) * 2] = s[e]; redd[((rl * C) + c + e) * 2 + 1] = q[e]; }
+    }
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double a = s[e], b = q[e];
+        for (int k = 1; k < RP; ++k) { a += redd[((k * C) + c + e) * 2]; b += redd[((k * C) + c + e) * 2 + 1]; }
+        atomicAdd(sums + c + e, a);
+        atomicAdd(sums + C + c + e, b);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // backward pass 1: sums[c] += dz, sums[C+c] += dz * xhat, with dz = dy * silu'(z).
 // One block owns a strip of rows and ALL channels (fully coalesced float4 rows), reduces over its rows in LDS and
 // issues one atomic per channel -> (M / rows_per_block) * 2C atomics in total.
@@ -276,7 +310,9 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   double* sums = (double*)a->bn_ws;
   if (a->training && !a->bn_ws_zeroed) hipMemsetAsync(a->bn_ws, 0, sizeof(float) * 8 * C, st);
   int rc;
-  if (a->training) {   // conv + per-channel sum / sum-of-squares in one pass
+  static int sep = -1;
+  if (sep < 0) { const char* e = getenv("SAST_BN_STATS_SEPARATE"); sep = e ? atoi(e) : 0; }
+  if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
     rc = (k == 1 && a->stride == 1) ? gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
                                     : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
@@ -286,6 +322,12 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
                                     : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (rc) return rc;
+  if (a->training && sep) {
+    int rpb = (M + sep - 1) / sep;
+    rpb = rpb < 8 ? 8 : rpb;
+    const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(double) * 2 * RP * C, st, a->conv_out, M, C, sums, rpb);
+  }
   const size_t n4 = (size_t)M * (C / 4);
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, sums, M, a->eps, a->momentum,
                      a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, n4, C, a->training);
@@ -302,8 +344,10 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   float* sums = a->bn_ws + 4 * C;      // [2C]
   float* dconv = a->ws;                // [M, C]
   if (!a->bn_ws_zeroed) hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
-  int rpb = (M + 383) / 384;   // ~384 blocks
-  rpb = rpb < 16 ? 16 : (rpb > 128 ? 128 : rpb);
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
+  int rpb = (M + target - 1) / target;
+  rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
   {
     const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(float4) * 2 * RP * c4n, st, a->conv_out, a->stats,
