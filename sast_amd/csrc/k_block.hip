@@ -20,6 +20,11 @@ inline int ks_min_r() {
   if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
   return v;
 }
+inline int thin_nb_limit() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_THIN_NB"); v = e ? atoi(e) : 384; }
+  return v;
+}
 inline int ks_nb_limit() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("SAST_KS_NB"); v = e ? atoi(e) : 1000000; }
@@ -33,6 +38,7 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, co
   // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
   // when the grid gives < 2 blocks per CU and the reduction is long, split k over two wave groups inside the block
   const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
+  if (nb <= thin_nb_limit() && R >= ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   if (nb <= ks_nb_limit() && R >= ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
 }

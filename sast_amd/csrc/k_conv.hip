@@ -16,6 +16,11 @@ inline int ks_min_r() {
   if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
   return v;
 }
+inline int thin_nb_limit() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_THIN_NB"); v = e ? atoi(e) : 384; }
+  return v;
+}
 inline int ks_nb_limit() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("SAST_KS_NB"); v = e ? atoi(e) : 1000000; }
@@ -25,6 +30,7 @@ inline int ks_nb_limit() {
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
   const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
+  if (nb <= thin_nb_limit() && R >= ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
   if (nb <= ks_nb_limit() && R >= ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
 }

@@ -24,6 +24,11 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     case 11: return launch_gemm<Tile<64, 32, 2, 1, 1, 16>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 13: return launch_gemm<TileSmallK2>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 14: return launch_gemm<TileSmallK4>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 15: return launch_gemm<Tile<64, 64, 2, 2, 1, 32, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 16: return launch_gemm<Tile<64, 64, 2, 2, 1, 32, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 17: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 18: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 19: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     default: return SAST_EINVAL;
   }
