@@ -354,6 +354,9 @@ using TileN64   = Tile<128, 64, 4, 1, 1>;   // N = 64 layers (stage 1): wave til
 using TileG2    = Tile<64, 128, 2, 2, 2>;   // GLU: 64 rows x (64 ch x 2 groups), wave tile 32x(32x2)
 using TileG2Big = Tile<128, 128, 2, 2, 2>;  // wave tile 64 x (32 ch x 2 groups)
 using TileG2Tiny = Tile<32, 64, 1, 1, 2>;   // one wave: 32 rows x (32 ch x 2 groups)
+using TileG2K2  = Tile<64, 64, 2, 1, 2, 16, 2>;   // GLU with 2-way k split: 64 rows x (32 ch x 2 groups)
+using TileG2K4  = Tile<32, 64, 1, 1, 2, 16, 4>;   // GLU, 4 single-wave k-groups: 32 rows x (32 ch x 2 groups)
+using TileG4K4  = Tile<32, 128, 1, 1, 4, 16, 4>;  // LSTM, 4 single-wave k-groups: 32 rows x (32 ch x 4 gates)
 using TileG4    = Tile<64, 128, 2, 1, 4>;   // LSTM: 64 rows x (32 ch x 4 gates); 2 waves
 using TileG4Big = Tile<128, 128, 4, 1, 4>;  // 128 rows x (32 ch x 4 gates)
 using TileG4Tiny = Tile<32, 128, 1, 1, 4>;  // one wave: 32 rows x (32 ch x 4 gates)

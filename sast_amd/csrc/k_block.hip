@@ -233,7 +233,12 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
     const LdRows la{a->Y, C, nullptr};
     const LdWeightNT lb{a->fc1_w, C, inner};
     const EpGlu ep{a->UG, a->Hh, a->fc1_b, inner};
-    rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    const long nb = (long)((R + 63) / 64) * ((inner + 63) / 64);
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SAST_GLU_TILE"); mode = e ? atoi(e) : 0; }
+    if (mode && C >= 256 && nb <= 2 * thin_nb_limit()) rc = launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    else if (mode && C >= 256) rc = launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    else rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     if (rc) return rc;
   }
   return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
@@ -308,6 +313,10 @@ int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
   const LdRows2 la{a->x, C, C, a->h0, C};
   const LdWeightNT lb{a->w, 2 * C, C};
   const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C};
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("SAST_LSTM_TILE"); mode = e ? atoi(e) : 0; }
+  if (mode && Kred >= 256 && (long)((M + 63) / 64) * ((C + 31) / 32) <= 2 * thin_nb_limit())
+    return launch_gemm<TileG4K4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
   return launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
 }
 
