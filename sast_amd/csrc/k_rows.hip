@@ -19,10 +19,13 @@ __global__ __launch_bounds__(256) void nzr_count_kernel(const T* __restrict__ x,
   bool valid = (y0 < H) && (x0 < W);
   if (valid) {
     const T* p = x + ((size_t)plane * H + y0) * W + x0;
+    struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };            // one 4-pixel cell row per load (16 B for int32/fp32, 4 B for uint8)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      const Vec4 q4 = *reinterpret_cast<const Vec4*>(p + (size_t)r * W);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, (float)p[(size_t)r * W + q]);
+      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, (float)q4.v[q]);
+    }
   }
   cell[cy][cx] = mx;
   const int b = plane / C, c = plane % C;
@@ -550,7 +553,7 @@ int stp_fwd_launch(const float* xp, const float* s, const float* scale, float am
 int stp_bwd_launch(const float* xp, const float* s, const float* scale, const float* g, float* direct, float* dz,
                    float* dscale, int B, int L, int C, hipStream_t st) {
   // dscale must be zeroed by the caller
-  const int rpb = 512;
+  const int rpb = L >= 8192 ? 128 : (L >= 1024 ? 64 : 32);   // >= ~120 blocks per sample at every stage
   SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_bwd_kernel<GL, VPL>), dim3((L + rpb - 1) / rpb, B), dim3(256),
                                         sizeof(float) * (256 / GL) * C, st, xp, s, scale, g, direct, dz, dscale, L, rpb));
   SAST_CHECK_LAUNCH();
