@@ -172,6 +172,7 @@ int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,
  * the launch stream; the report lists per kernel instantiation: calls, total ms, total algorithmic FLOPs (2*M*N*K with
  * the device-side row counts read back).  Enabling it adds host syncs -- never enable inside a timed region. */
 int sast_prof_enable(int on);
+float sast_prof_calibrate(sast_stream_t stream, int n);  /* ms a hipEvent pair reports around an empty kernel */
 size_t sast_prof_report(char* buf, size_t cap);
 
 #ifdef __cplusplus

@@ -76,6 +76,7 @@ _SIGNATURES = {
     "sast_cat2_fwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_cat2_bwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_prof_enable": (C.c_int, [C.c_int]),
+    "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "sast_adamw": (C.c_int, [P, P, P, P, C.c_size_t, P, F32, F32, F32, F32, F32, F32, P]),
 }

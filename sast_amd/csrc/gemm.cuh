@@ -26,6 +26,7 @@
 //   are produced by the same pass (COLSUM) so dY is read once.
 #pragma once
 #include <type_traits>
+#include <hip/hip_ext.h>
 #include "common.cuh"
 
 namespace sast {
@@ -303,6 +304,9 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 // When enabled, every launch is bracketed by events on the launch stream and device-side row counts
 // are read back, so the report carries measured time AND algorithmic FLOPs (2*M*N*R with the real M/R).
 void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin);
+// kernel-exact timing: events handed to hipExtLaunchKernelGGL are stamped at the kernel's own begin / end
+void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st,
+                        hipEvent_t* e0, hipEvent_t* e1);
 bool prof_enabled();
 void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin);
 struct ProfScope {
@@ -316,11 +320,15 @@ inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, 
                        const int* dR, hipStream_t st) {
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
-  const bool prof = prof_enabled();
-  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, true);
-  hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
-                     (float*)nullptr);
-  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, false);
+  if (prof_enabled()) {
+    hipEvent_t e0, e1;
+    prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, &e0, &e1);
+    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R, dM, dR,
+                          (float*)nullptr);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
+                       (float*)nullptr);
+  }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -333,11 +341,15 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
   if (splits < 1) splits = 1;
-  const bool prof = prof_enabled();
-  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, true);
-  hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
-                     (const int*)nullptr, dR, colsum);
-  if (prof) prof_record(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, false);
+  if (prof_enabled()) {
+    hipEvent_t e0, e1;
+    prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, &e0, &e1);
+    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R,
+                          (const int*)nullptr, dR, colsum);
+  } else {
+    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
+                       (const int*)nullptr, dR, colsum);
+  }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

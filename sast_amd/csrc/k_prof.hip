@@ -38,6 +38,21 @@ void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, co
 }
 
 
+void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st,
+                        hipEvent_t* e0, hipEvent_t* e1) {
+  ProfLaunch l;
+  hipEventCreate(&l.e0);
+  hipEventCreate(&l.e1);
+  int m = M, r = R;
+  if (dM) { int v; hipMemcpyAsync(&v, dM, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < m) m = v; }
+  if (dR) { int v; hipMemcpyAsync(&v, dR, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < r) r = v; }
+  l.flops = 2.0 * (double)m * (double)NJ * (double)G * (double)r;
+  l.tag = tag;
+  g_launches.push_back(l);
+  *e0 = l.e0;
+  *e1 = l.e1;
+}
+
 // op-level scopes (C-ABI entry points): tag = "op:<name> C=<c> M=<m>"
 void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin) {
   char tag[96];
@@ -47,7 +62,26 @@ void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin) {
 
 }  // namespace sast
 
+namespace sast { __global__ void prof_empty_kernel() {} }
+
 extern "C" {
+
+// average elapsed time (ms) that a hipEvent pair reports around an EMPTY kernel launch on `stream`: the bracket's own
+// overhead (launch latency + event timestamps), subtracted from every bracketed launch by the Python side.
+float sast_prof_calibrate(sast_stream_t stream, int n) {
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<hipEvent_t> e0(n), e1(n);
+  for (int i = 0; i < n; ++i) { hipEventCreate(&e0[i]); hipEventCreate(&e1[i]); }
+  for (int i = 0; i < n; ++i) {
+    hipEventRecord(e0[i], st);
+    hipLaunchKernelGGL(sast::prof_empty_kernel, dim3(1), dim3(64), 0, st);
+    hipEventRecord(e1[i], st);
+  }
+  hipStreamSynchronize(st);
+  double tot = 0;
+  for (int i = 0; i < n; ++i) { float ms = 0.f; hipEventElapsedTime(&ms, e0[i], e1[i]); tot += ms; hipEventDestroy(e0[i]); hipEventDestroy(e1[i]); }
+  return (float)(tot / n);
+}
 
 int sast_prof_enable(int on) {
   sast::g_on = on != 0;

@@ -52,6 +52,10 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
             trainer.update()
 
     rows = [r for r in gemm_report(run, n_steps) if not r[0].startswith("op:")]
+    # GEMM launches are timed with hipExtLaunchKernelGGL start/stop events (stamped at the kernel's own begin / end, the
+    # same quantity rocprofv3 reports); a plain record-launch-record bracket would add ~8 us (reported for reference)
+    calib_ms = float(L.lib().sast_prof_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 200))
+    rows.sort(key=lambda r: -r[2])
     name, calls, ms, flops = rows[0]
     achieved = flops / (ms * 1e-3) / 1e12
     total_ms = sum(r[2] for r in rows)
@@ -62,4 +66,6 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
             "algorithmic_gflop_per_launch": flops / calls / 1e9,
             "all_gemm_kernels": {"ms_per_step": total_ms / n_steps, "gflop_per_step": total_fl / n_steps / 1e9,
                                  "achieved_tflops": total_fl / (total_ms * 1e-3) / 1e12},
-            "method": "hipEvent pairs on the launch stream around each launch (libsast_hip sast_prof_*), eager, un-timed extra steps"}
+            "plain_event_bracket_overhead_us": 1e3 * calib_ms,
+            "method": "hipExtLaunchKernelGGL start/stop events on the launch stream for every launch of the GEMM-template kernels "
+                      "(libsast_hip sast_prof_*); eager, un-timed extra steps"}
