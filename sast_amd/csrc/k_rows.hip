@@ -1,6 +1,7 @@
 // Row-wise (per token) HBM-bound kernels: event-tensor statistics, layout change,
 // LayerNorm family, STP weighting, column reductions.  One sub-group of GL lanes owns
 // one token row of C channels (C = 4*GL*VPL), float4 accesses, wave shuffles only.
+#include <cstdlib>
 #include "common.cuh"
 #include "kernels.h"
 
@@ -305,8 +306,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
   }
 
 static inline int bwd_grid(int rows, int rpb) {
+  // every block ends with one atomicAdd per channel per parameter-gradient vector: same-address float atomics serialise
+  // at the memory side on MI355X, so the block count (not the row count) sets the tail -> keep it small
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("SAST_LN_BLOCKS"); cap = e ? atoi(e) : 256; }
   int g = (rows + rpb - 1) / rpb;
-  return g < 1 ? 1 : (g > 1024 ? 1024 : g);
+  return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
 int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* beta, const float* add, int add_rows,

@@ -59,6 +59,12 @@ extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, fl
     case 0: return launch_gemm_split<TileSmall>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 1: return launch_gemm_split<TileSmallK2>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 2: return launch_gemm_split<TileSmallK4>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 3: return launch_gemm_split<Tile<128, 128, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 4: return launch_gemm_split<Tile<192, 64, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 5: return launch_gemm_split<Tile<320, 64, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 6: return launch_gemm_split<Tile<64, 192, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 7: return launch_gemm_split<Tile<192, 128, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 8: return launch_gemm_split<Tile<128, 64, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     default: return SAST_EINVAL;
   }
 }
