@@ -250,13 +250,14 @@ def test_selection_properties_full_size(dev):
         assert torch.equal(sel.K_list().cpu(), K)
 
 
-def test_ms_wsa_varlen_T60_fwd_bwd(dev):
-    """1Mpx-sized groups (T = 60 -> two 32-token MFMA tiles) with ragged K_m in {60, 33, 32, 1, 17, dropped}:
-    forward and every gradient of the MFMA attention path against the oracle's padded / masked formulation."""
+@pytest.mark.parametrize("T,Ks", [(60, [60, 33, 32, 1, 17]), (80, [80, 65, 64, 3, 40])])
+def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
+    """1Mpx-sized groups (T = 60 -> two 32-token MFMA tiles) and Gen1-sized groups (T = 80 -> VALU attention kernels)
+    with ragged K_m (full, tile boundary +-1, tiny, dropped window): forward and every gradient against the oracle's
+    padded / masked formulation."""
     from sast_amd.layers import MS_WSA
     from sast_amd.layers.ops import LayerNorm
-    C, T, NW = 64, 60, 6
-    Ks = [60, 33, 32, 1, 17]                      # window 5 is dropped
+    C, NW = 64, 6                                 # window 5 is dropped
     g = torch.Generator().manual_seed(11)
     kept = [torch.sort(torch.randperm(T, generator=g)[:k])[0] for k in Ks]
     index_window = torch.arange(len(Ks))
@@ -276,7 +277,7 @@ def test_ms_wsa_varlen_T60_fwd_bwd(dev):
     x = torch.randn(NW, T, C, generator=g)
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     xo = x.clone().requires_grad_(True)
-    ref = O.ms_wsa(xo, lists, 1, po, "", O.AttnCfg(partition_size=(6, 10)))
+    ref = O.ms_wsa(xo, lists, 1, po, "", O.AttnCfg(partition_size=(T // 10, 10)))
     wgt = torch.randn(NW, T, C, generator=g)
     (ref * wgt).sum().backward()
     m = MS_WSA(C, 32, True, (0.5, 0.0, 4, None, True, 0.0), [LayerNorm(C, eps=1e-5), LayerNorm(C, eps=1e-5)]).to(dev)
