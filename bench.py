@@ -156,26 +156,35 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0):
 
 
 def main():
+    global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--amp", type=float, default=2e-4, help="attention_cfg.AMP (controls the kept-token fraction)")
+    ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (BASELINE config: 4; sparsity sweep C5: 8)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    BATCH = args.batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    ndev = torch.cuda.device_count()
+    local = local % max(ndev, 1)          # (test rigs with fewer GPUs than ranks share a device; the driver gives one GPU per rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SAST_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for plumbing tests
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph)
     graphed = tr.capture()

@@ -194,7 +194,7 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   const int M = a->B * a->L, C = a->C;
   float* dz = a->ws;
   float* dscale = a->ws + (size_t)M * C;
-  hipMemsetAsync(dscale, 0, sizeof(float) * a->B * C, st);
+  zero_fill(dscale, sizeof(float) * a->B * C, st);
   int rc = stp_bwd_launch(a->xp, a->s, a->scale, a->dxw, a->dxp, dz, dscale, a->B, a->L, C, st);
   if (rc) return rc;
   // dxp = direct + dz Ws
@@ -261,7 +261,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   float* raw1 = raw2 + (size_t)C * inner;
   float* s2 = raw1 + (size_t)C * C;
   float* s1 = s2 + C;
-  hipMemsetAsync(raw2, 0, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
+  zero_fill(raw2, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
   int rc;
   Side sd(st);   // weight-gradient GEMMs run beside the activation-gradient chain
   // fc2 grads (raw, LayerScale applied in the finish kernel): need only dZ (= dout rows) and H

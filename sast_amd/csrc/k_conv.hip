@@ -314,7 +314,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
   double* sums = (double*)a->bn_ws;
-  if (a->training && !a->bn_ws_zeroed) hipMemsetAsync(a->bn_ws, 0, sizeof(float) * 8 * C, st);
+  if (a->training && !a->bn_ws_zeroed) zero_fill(a->bn_ws, sizeof(float) * 8 * C, st);
   int rc;
   static int sep = -1;
   if (sep < 0) { const char* e = getenv("SAST_BN_STATS_SEPARATE"); sep = e ? atoi(e) : 0; }
@@ -349,7 +349,7 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
   float* sums = a->bn_ws + 4 * C;      // [2C]
   float* dconv = a->ws;                // [M, C]
-  if (!a->bn_ws_zeroed) hipMemsetAsync(sums, 0, sizeof(float) * 2 * C, st);
+  if (!a->bn_ws_zeroed) zero_fill(sums, sizeof(float) * 2 * C, st);
   static int target = -1;
   if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
   int rpb = (M + target - 1) / target;

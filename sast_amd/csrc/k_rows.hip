@@ -7,6 +7,22 @@
 
 namespace sast {
 
+// ============================================================ zero fill
+// hipMemsetAsync nodes captured into a hipGraph were observed NOT to re-zero these scratch buffers on replay
+// (ROCm 7.2, MI355X: gradients of the LayerScale'd linears picked up stale partial sums from the 2nd replay on),
+// so every scratch clear in this library is an ordinary kernel.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+int zero_fill(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = (bytes + 3) / 4;
+  if (!n) return SAST_OK;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float*)p, n);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
 // ============================================================ non_zero_ratio (a1)
 // reference: sast_rnn.py:45-60.  One block = 32 rows x 128 cols of one (b, c) plane:
 // thread -> one 4x4 cell max, then the 2x2 max cascade through LDS (8x8, 16x16, 32x32).
@@ -82,7 +98,7 @@ __global__ void nzr_finish_kernel(const int* __restrict__ cnt, float* __restrict
 
 template <typename T>
 int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, hipStream_t st) {
-  hipMemsetAsync(cnt, 0, sizeof(int) * B * 4 * C, st);
+  zero_fill(cnt, sizeof(int) * B * 4 * C, st);
   dim3 grid((W + 127) / 128, (H + 31) / 32, B * C);
   hipLaunchKernelGGL((nzr_count_kernel<T>), grid, dim3(256), 0, st, (const T*)x, cnt, C, H, W);
   float s[4];
