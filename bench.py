@@ -85,6 +85,7 @@ class Trainer:
                 self.update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        self.loss_first = float(self.loss)
         if not self.use_graph:
             return False
         try:
@@ -186,8 +187,16 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # Everything below runs on an explicit (non-default) HIP stream.  Measured on ROCm 7.2 / MI355X: a hipGraph launched on
+    # the legacy NULL stream is NOT ordered after kernels enqueued on the NULL stream just before it, so with the optimizer
+    # step outside the graph (N > 1) the next replay's gradient clear raced the AdamW kernel.  On a created stream the
+    # replays and the eager all-reduce / AdamW are strictly ordered.
+    run_stream = torch.cuda.Stream()
+    run_stream.wait_stream(torch.cuda.current_stream())
+    torch.cuda.set_stream(run_stream)
     tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph)
     graphed = tr.capture()
+    loss_first = tr.loss_first
     for _ in range(args.warmup):
         tr.step()
     torch.cuda.synchronize()
@@ -219,7 +228,8 @@ def main():
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
-                       "loss": float(tr.loss)},
+                       "loss_first_step": loss_first, "loss": float(tr.loss),
+                       "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},
         }
         if not args.no_roofline:
             from sast_amd.profiling import dominant_kernel_roofline

@@ -59,7 +59,12 @@ class FlatParams:
     def all_reduce(self, group=None):
         """sum over ranks (the 1/world factor is applied by the optimizer's grad_scale)."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            host_side = self.grad.is_cuda and dist.get_backend(group) != "nccl"
+            if host_side:
+                torch.cuda.synchronize()   # gloo stages device tensors through the host: not stream-ordered like RCCL
             dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
+            if host_side:
+                torch.cuda.synchronize()
 
 
 class FusedAdamW:
