@@ -157,18 +157,21 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0):
 
 
 def main():
-    global BATCH
+    global BATCH, HW, PART
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--amp", type=float, default=2e-4, help="attention_cfg.AMP (controls the kept-token fraction)")
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (BASELINE config: 4; sparsity sweep C5: 8)")
+    ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     BATCH = args.batch
+    if args.res == "gen1":
+        HW, PART = (256, 320), (8, 10)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -219,12 +222,15 @@ def main():
     if rank == 0:
         kept = [int(p) for p in tr.P]
         L = [(HW[0] // s) * (HW[1] // s) for s in (4, 8, 16, 32)]
+        if args.res != "1mpx" or BATCH != 4:
+            pass  # (metric string stays BASELINE's; `config.workload` names what was actually run)
         res = {
             "metric": "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360",
             "value": BATCH * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "1Mpx 640x360 (padded 384x640) full SAST backbone + PAFPN, fwd+bwd + AdamW, "
+            "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
+                                   " full SAST backbone + PAFPN, fwd+bwd + AdamW, "
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
