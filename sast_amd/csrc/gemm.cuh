@@ -55,6 +55,11 @@ struct LdsLd {
 
 // epilogues may ask for per-column sum / sum-of-squares of the stored values (BatchNorm batch statistics fused
 // into the producing conv): EP::COLSTATS = true, EP::sums -> double[2*EP::C]
+template <class EP, class = void> struct EpHasVec : std::false_type {};
+#ifndef SAST_VEC_EPI_MASK
+#define SAST_VEC_EPI_MASK 0x0   /* measured round 1: +10-15 % in tools/gemm_micro.py, but -1..3 % on the whole step -> off */
+#endif
+template <class EP> struct EpHasVec<EP, std::void_t<decltype(EP::VEC4)>> : std::bool_constant<EP::VEC4 && ((SAST_VEC_EPI_MASK >> EP::VEC_ID) & 1)> {};
 template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
@@ -268,6 +273,64 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     }
   }
 
+  // vectorised epilogue (EP::VEC4): each wave transposes its 32x32 accumulator tiles through LDS and hands the functor
+  // float4 row segments -> 16-byte global stores (1 KiB per wave instruction) instead of 4-byte ones
+  if constexpr (EpHasVec<EP>::value) {
+    static_assert(GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * 32 * 33, "epilogue transpose scratch");
+    float* scr = smem + wave * (32 * 33);
+    constexpr bool VSTATS = EpHasStats<EP>::value;
+    float4 vs[T::TJ], vq[T::TJ];
+#pragma unroll
+    for (int tj = 0; tj < T::TJ; ++tj) { vs[tj] = zero4(); vq[tj] = zero4(); }
+#pragma unroll
+    for (int ta = 0; ta < T::TM; ++ta)
+#pragma unroll
+      for (int tj = 0; tj < T::TJ; ++tj) {
+        float4 vv[4][G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          __syncthreads();
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg)
+            scr[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[ta][tj * G + g][reg];
+          __syncthreads();
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const float* q = scr + (it * 8 + (lane >> 3)) * 33 + (lane & 7) * 4;
+            vv[it][g] = make_float4(q[0], q[1], q[2], q[3]);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + wm * T::WTM + ta * 32 + it * 8 + (lane >> 3), j = j0 + (wn * T::TJ + tj) * 32 + (lane & 7) * 4;
+          if (m < Meff && j < NJ) {
+            ep.vec(m, j, vv[it]);
+            if constexpr (VSTATS) {
+              const float4 v = vv[it][0];
+              vs[tj].x += v.x; vs[tj].y += v.y; vs[tj].z += v.z; vs[tj].w += v.w;
+              vq[tj].x += v.x * v.x; vq[tj].y += v.y * v.y; vq[tj].z += v.z * v.z; vq[tj].w += v.w * v.w;
+            }
+          }
+        }
+      }
+    if constexpr (VSTATS) {   // lanes sharing (lane & 7) own the same 4 columns: fold over the other lane bits, 8 lanes publish
+#pragma unroll
+      for (int tj = 0; tj < T::TJ; ++tj) {
+        float* a = &vs[tj].x; float* b = &vq[tj].x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int o = 8; o < 64; o <<= 1) { a[e] += __shfl_xor(a[e], o, 64); b[e] += __shfl_xor(b[e], o, 64); }
+        }
+        const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 7) * 4;
+        if (lane < 8 && j < NJ) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { atomicAdd(ep.sums + j + e, (double)a[e]); atomicAdd(ep.sums + NJ + j + e, (double)b[e]); }
+        }
+      }
+    }
+    return;
+  }
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   constexpr bool STATS = EpHasStats<EP>::value;
   float cs[T::TJ], cq[T::TJ];
@@ -560,21 +623,38 @@ inline int pow2_shift(int v) {
 }
 
 // ------------------------------------------------------------------ generic epilogues
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float4 g, float4 a, float4 r) {   // r + g * a
+  return make_float4(fmaf(g.x, a.x, r.x), fmaf(g.y, a.y, r.y), fmaf(g.z, a.z, r.z), fmaf(g.w, a.w, r.w));
+}
 struct EpStore {  // C[m*ldc + j] = v (+bias)
+  static constexpr bool VEC4 = true;
+  static constexpr int VEC_ID = 1;
   float* c; int ldc; const float* bias;
   __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
     c[(size_t)m * ldc + j] = v[0] + (bias ? bias[j] : 0.f);
   }
+  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
+    st4(c + (size_t)m * ldc + j, bias ? add4(v[0], ld4(bias + j)) : v[0]);
+  }
 };
 struct EpStoreStats {  // C[m*ldc + j] = v ; sums[j] += v ; sums[NJ + j] += v*v   (conv -> BatchNorm batch statistics)
   static constexpr bool COLSTATS = true;
+  static constexpr bool VEC4 = true;
+  static constexpr int VEC_ID = 0;
   float* c; int ldc; double* sums;
   __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const { c[(size_t)m * ldc + j] = v[0]; }
+  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const { st4(c + (size_t)m * ldc + j, v[0]); }
 };
 struct EpStoreAdd {  // C[m*ldc+j] = v + add[m*ldadd + j]
+  static constexpr bool VEC4 = true;
+  static constexpr int VEC_ID = 2;
   float* c; int ldc; const float* add; int ldadd;
   __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
     c[(size_t)m * ldc + j] = v[0] + add[(size_t)m * ldadd + j];
+  }
+  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
+    st4(c + (size_t)m * ldc + j, add4(v[0], ld4(add + (size_t)m * ldadd + j)));
   }
 };
 struct EpAtomic {  // C[m*ldc + j] += v   (split-R weight gradients)

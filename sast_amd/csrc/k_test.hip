@@ -29,6 +29,8 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     case 17: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 18: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 19: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 20: return launch_gemm<TileSmall>(la, lb, EpStore{c, N, bias}, M, N, K, nullptr, nullptr, st);
+    case 21: return launch_gemm<TileSmallK2>(la, lb, EpStore{c, N, bias}, M, N, K, nullptr, nullptr, st);
     case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     default: return SAST_EINVAL;
   }
