@@ -10,9 +10,28 @@ import re
 
 import torch
 
+import json
+import os
+
 from . import _lib as L
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+_PMC_SUMMARY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_hbm_traffic_latest.json")
+
+
+def pmc_traffic_bytes(kernel_name: str):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary (tools/rocpd_pmc.py: two separate
+    passes FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); None when not profiled."""
+    try:
+        with open(_PMC_SUMMARY) as f:
+            ks = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    key = kernel_name.replace(", split>", ", true>")
+    if not key.endswith(", true>"):
+        key = key[:-1] + ", false>"
+    ent = ks.get(key)
+    return None if ent is None else float(ent["hbm_bytes_per_launch"])
 
 
 def _short(tag: str) -> str:
@@ -61,7 +80,8 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
     total_ms = sum(r[2] for r in rows)
     total_fl = sum(r[3] for r in rows)
     return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": name,
+            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
+            "profiles/pmc_hbm_traffic_latest.json)", "kernel": name,
             "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
             "algorithmic_gflop_per_launch": flops / calls / 1e9,
             "all_gemm_kernels": {"ms_per_step": total_ms / n_steps, "gflop_per_step": total_fl / n_steps / 1e9,
