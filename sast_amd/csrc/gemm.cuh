@@ -68,9 +68,13 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
                                                      const int* __restrict__ dM, const int* __restrict__ dR,
                                                      float* __restrict__ colsum) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NTG, G = T::G, BJ = T::BJ, KS = T::KS;
-  constexpr int LDA = LdsLd<T, LA::RC, BM>::value;
-  constexpr int LDB = LdsLd<T, LB::RC, BN>::value;
-  constexpr int A_STAGE = BK * LDA, B_STAGE = BK * LDB;
+  // LDS tile layouts: a reduce-contiguous (RC) operand keeps its natural [row][k] order (row stride LDK = BK + 4 floats):
+  // one ds_write_b128 per global float4 and BK/8 ds_read_b128 per lane per k-tile, both conflict-free; an index-contiguous
+  // (IC) operand is stored [k][row] (row stride R + 4) and read with ds_read_b32.  MFMA step ks pairs k = half*BK/2 + ks.
+  constexpr int LDK = BK + 4, HK = BK / 2;
+  constexpr int LDA = LA::RC ? LDK : BM + 4;
+  constexpr int LDB = LB::RC ? LDK : BN + 4;
+  constexpr int A_STAGE = LA::RC ? BM * LDK : BK * LDA, B_STAGE = LB::RC ? BN * LDK : BK * LDB;
   constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
   static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
   __shared__ __attribute__((aligned(16))) float smem[KS * GROUP_FLOATS];
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
       const int row = s / (BK / 4), kq = s % (BK / 4);
       ca[it] = la.prep(m0 + row, Meff);
       ra_off[it] = kq * 4;
-      la_off[it] = (kq * 4) * LDA + row;
+      la_off[it] = row * LDK + kq * 4;
     } else {
       const int iq = s % (BM / 4), kk = s / (BM / 4);
       ca[it] = la.prep(m0 + iq * 4, Meff);
@@ -132,7 +136,7 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
       const int g = (rr / BJ) % G, jl = rr % BJ;
       cb[it] = lb.prep(j0 + jl, g, NJ);
       rb_off[it] = kq * 4;
-      lb_off[it] = (kq * 4) * LDB + nnmap(jl, g);
+      lb_off[it] = nnmap(jl, g) * LDK + kq * 4;
     } else {
       const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
       cb[it] = lb.prep(j0 + jq * 4, g, NJ);
@@ -157,17 +161,13 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 #pragma unroll
     for (int it = 0; it < A_PER; ++it) {
       if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
-        float* d = as + la_off[it];
-        if constexpr (LA::RC) { d[0] = xa[it].x; d[LDA] = xa[it].y; d[2 * LDA] = xa[it].z; d[3 * LDA] = xa[it].w; }
-        else st4(d, xa[it]);
+        st4(as + la_off[it], xa[it]);
       }
     }
 #pragma unroll
     for (int it = 0; it < B_PER; ++it) {
       if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
-        float* d = bs + lb_off[it];
-        if constexpr (LB::RC) { d[0] = xb[it].x; d[LDB] = xb[it].y; d[2 * LDB] = xb[it].z; d[3 * LDB] = xb[it].w; }
-        else st4(d, xb[it]);
+        st4(bs + lb_off[it], xb[it]);
       }
     }
   };
@@ -185,26 +185,45 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
   const bool do_colsum = SPLIT && colsum != nullptr && bj == 0 && wn == 0;
 
   auto compute = [&](int buf) {
-    const float* as = As + buf * A_STAGE + wm * T::WTM + (lane & 31);
-    const float* bs = Bs + buf * B_STAGE + wn * T::WTN + (lane & 31);
+    const float* as = As + buf * A_STAGE;
+    const float* bs = Bs + buf * B_STAGE;
+    const int l31 = lane & 31, hf = lane >> 5;
+    float a[T::TM][HK], b[T::TN][HK];
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      float a[T::TM], b[T::TN];
+    for (int t = 0; t < T::TM; ++t) {
+      if constexpr (LA::RC) {
+        const float* p = as + (wm * T::WTM + t * 32 + l31) * LDK + hf * HK;
 #pragma unroll
-      for (int t = 0; t < T::TM; ++t) a[t] = as[kk * LDA + t * 32];
+        for (int q = 0; q < HK / 4; ++q) { const float4 v = ld4(p + 4 * q); a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w; }
+      } else {
 #pragma unroll
-      for (int t = 0; t < T::TN; ++t) b[t] = bs[kk * LDB + t * 32];
-      if (SPLIT && do_colsum) {
-#pragma unroll
-        for (int t = 0; t < T::TM; ++t) csum[t] += a[t];
+        for (int ks = 0; ks < HK; ++ks) a[t][ks] = as[(hf * HK + ks) * LDA + wm * T::WTM + t * 32 + l31];
       }
+    }
+#pragma unroll
+    for (int t = 0; t < T::TN; ++t) {
+      if constexpr (LB::RC) {
+        const float* p = bs + (wn * T::WTN + t * 32 + l31) * LDK + hf * HK;
+#pragma unroll
+        for (int q = 0; q < HK / 4; ++q) { const float4 v = ld4(p + 4 * q); b[t][4 * q] = v.x; b[t][4 * q + 1] = v.y; b[t][4 * q + 2] = v.z; b[t][4 * q + 3] = v.w; }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < HK; ++ks) b[t][ks] = bs[(hf * HK + ks) * LDB + wn * T::WTN + t * 32 + l31];
+      }
+    }
+    if (SPLIT && do_colsum) {
+#pragma unroll
+      for (int t = 0; t < T::TM; ++t)
+#pragma unroll
+        for (int ks = 0; ks < HK; ++ks) csum[t] += a[t][ks];
+    }
+#pragma unroll
+    for (int ks = 0; ks < HK; ++ks)
 #pragma unroll
       for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
         for (int tb = 0; tb < T::TN; ++tb)
-          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
-    }
+          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][ks], b[tb][ks], acc[ta][tb], 0, 0, 0);
   };
 
   // software pipeline: this k-group owns tiles kt0 + kg + KS*i; tiles i+1 and i+2 are in flight (registers) while tile i
