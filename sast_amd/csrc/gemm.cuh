@@ -101,7 +101,12 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 
   constexpr int A_SLOTS = BM * BK / 4, B_SLOTS = BN * BK / 4;
   constexpr int A_PER = (A_SLOTS + NT - 1) / NT, B_PER = (B_SLOTS + NT - 1) / NT;
-  float4 ra[2][A_PER], rb[2][B_PER];   // two k-tiles in flight (global-load latency ~ 2 compute phases)
+  // two k-tiles in flight (global-load latency ~ 2 compute phases).  Loaded registers are NOT touched until the LDS store
+  // one or two phases later (validity select / LayerScale multiply are deferred to `finish`), so hipcc can keep the loads
+  // outstanding behind counted s_waitcnt vmcnt(N) instead of draining them right after issue.
+  float4 ra[2][A_PER], rb[2][B_PER];
+  float aa[2][A_PER], ab[2][B_PER];
+  bool oa[2][A_PER], ob[2][B_PER];
 
   auto nnmap = [&](int jl, int g) -> int {  // (local channel, group) -> column inside the block tile
     const int jb = jl >> 5;
@@ -145,31 +150,25 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     }
   }
 
-  auto gload = [&](int kt, float4 (&xa)[A_PER], float4 (&xb)[B_PER]) {
+  auto gload = [&](int kt, int set) {
     const int r0 = kt * BK;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) xa[it] = la.load(ca[it], r0 + ra_off[it], Reff);
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) la.load(ca[it], r0 + ra_off[it], Reff, ra[set][it], aa[set][it], oa[set][it]);
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
-      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) xb[it] = lb.load(cb[it], r0 + rb_off[it], Reff);
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) lb.load(cb[it], r0 + rb_off[it], Reff, rb[set][it], ab[set][it], ob[set][it]);
   };
 
-  auto lstore = [&](int buf, const float4 (&xa)[A_PER], const float4 (&xb)[B_PER]) {
+  auto lstore = [&](int buf, int set) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
 #pragma unroll
-    for (int it = 0; it < A_PER; ++it) {
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
-        st4(as + la_off[it], xa[it]);
-      }
-    }
+    for (int it = 0; it < A_PER; ++it)
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) st4(as + la_off[it], la.finish(ra[set][it], aa[set][it], oa[set][it]));
 #pragma unroll
-    for (int it = 0; it < B_PER; ++it) {
-      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
-        st4(bs + lb_off[it], xb[it]);
-      }
-    }
+    for (int it = 0; it < B_PER; ++it)
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
   };
 
   f32x16 acc[T::TM][T::TN];
@@ -231,21 +230,36 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
   const int n_it = (kt1 - kt0 + KS - 1) / KS;
   auto tile_of = [&](int i) { return kt0 + kg + KS * i; };
   auto valid = [&](int i) { return tile_of(i) < kt1; };
-  if (valid(0)) gload(tile_of(0), ra[0], rb[0]);
-  if (valid(1)) gload(tile_of(1), ra[1], rb[1]);
-  if (valid(0)) lstore(0, ra[0], rb[0]);
+  if (valid(0)) gload(tile_of(0), 0);
+  if (valid(1)) gload(tile_of(1), 1);
+  if (valid(0)) lstore(0, 0);
   __syncthreads();
-  for (int i = 0; i < n_it; i += 2) {
+  // Steady state (every k-group still has tiles i+2 and i+3): loads are issued UNCONDITIONALLY, so the compiler's
+  // s_waitcnt vmcnt(N) before each LDS store counts exactly the two loads of the younger tile and leaves them in flight.
+  // (With the loads under a branch it has to assume the not-taken path and drains everything: no prefetch.)
+  const int n_all = (kt1 - kt0) / KS;     // iterations in which every k-group owns a valid tile (block-uniform)
+  int i = 0;
+  for (; i + 3 < n_all; i += 2) {
+    gload(tile_of(i + 2), 0);
+    compute(0);
+    lstore(1, 1);
+    __syncthreads();
+    gload(tile_of(i + 3), 1);
+    compute(1);
+    lstore(0, 0);
+    __syncthreads();
+  }
+  for (; i < n_it; i += 2) {   // tail: per-group validity checks
     // even phase: LDS buffer 0 holds tile i; register set 1 holds tile i+1; refill set 0 with tile i+2
-    if (valid(i + 2)) gload(tile_of(i + 2), ra[0], rb[0]);
+    if (valid(i + 2)) gload(tile_of(i + 2), 0);
     if (valid(i)) compute(0);
-    if (valid(i + 1)) lstore(1, ra[1], rb[1]);
+    if (valid(i + 1)) lstore(1, 1);
     __syncthreads();
     if (i + 1 >= n_it) break;
     // odd phase
-    if (valid(i + 3)) gload(tile_of(i + 3), ra[1], rb[1]);
+    if (valid(i + 3)) gload(tile_of(i + 3), 1);
     if (valid(i + 1)) compute(1);
-    if (valid(i + 2)) lstore(0, ra[0], rb[0]);
+    if (valid(i + 2)) lstore(0, 0);
     __syncthreads();
   }
 
@@ -460,84 +474,114 @@ __host__ __device__ inline int small_div_mul(int d) { return 65536 / d + 1; }
 
 // ------------------------------------------------------------------ loaders
 // concept:  struct Ctx;  A side: Ctx prep(int i, int Ieff);  B side: Ctx prep(int j, int g, int NJ);
-//           float4 load(const Ctx&, int r, int Reff)     (out-of-range -> zeros)
+//           void load(const Ctx&, int r, int Reff, float4& raw, float& aux, bool& ok)   (raw registers untouched until ...)
+//           float4 finish(float4 raw, float aux, bool ok)                              (... the LDS store: zeros if !ok)
+
+// All loads are BRANCH-FREE: an out-of-range slot reads a safe in-bounds address and the result is replaced by zeros
+// with a select.  (A predicated `cond ? ld4(p) : 0` becomes an exec-masked branch around the global_load; hipcc then
+// cannot count outstanding loads across the join and emits s_waitcnt vmcnt(0) at the top of every k-loop phase, which
+// serialised the two-tile prefetch -- seen in the ISA of the first version of this kernel.)
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return ok ? v : zero4(); }
+#define SAST_DEFAULT_FINISH \
+  __device__ __forceinline__ float4 finish(float4 v, float, bool ok) const { return sel4(ok, v); }
 
 // RC rows: X[i][r] = p[row(i)*ld + r]
 struct LdRows {
   static constexpr bool RC = true;
   const float* p; int ld; const int* idx;
-  struct Ctx { const float* row; };
+  struct Ctx { const float* row; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
-    if (i >= Ieff) return Ctx{nullptr};
-    return Ctx{p + (size_t)(idx ? idx[i] : i) * ld};
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    return Ctx{p + (size_t)(idx ? idx[ii] : ii) * ld, ok};
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    return (c.row && r < Reff) ? ld4(c.row + r) : zero4();
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = ld4(c.row + (ok ? r : 0));
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // RC rows from two sources split along r (cat along channels without materialising it)
 struct LdRows2 {
   static constexpr bool RC = true;
   const float* p1; int ld1; int R1; const float* p2; int ld2;
-  struct Ctx { const float* a; const float* b; };
+  struct Ctx { const float* a; const float* b; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
-    if (i >= Ieff) return Ctx{nullptr, nullptr};
-    return Ctx{p1 + (size_t)i * ld1, p2 ? p2 + (size_t)i * ld2 - R1 : nullptr};
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    return Ctx{p1 + (size_t)ii * ld1, p2 ? p2 + (size_t)ii * ld2 - R1 : p1 + (size_t)ii * ld1, ok};
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (!c.a || r >= Reff) return zero4();
-    if (r < R1) return ld4(c.a + r);
-    return c.b ? ld4(c.b + r) : zero4();
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const bool second = r >= R1;
+    ok = c.ok && r < Reff && (!second || p2 != nullptr);
+    const float* q = second ? c.b : c.a;
+    v = ld4(ok ? q + r : c.a);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // IC rows (transposed use): X(t)[r][i] = p[row(r)*ld + i]
 struct LdRowsT {
   static constexpr bool RC = false;
   const float* p; int ld; const int* idx;
-  struct Ctx { int i; };
-  __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return Ctx{i < Ieff ? i : -1}; }
-  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : -1}; }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (c.i < 0 || r >= Reff) return zero4();
-    return ld4(p + (size_t)(idx ? idx[r] : r) * ld + c.i);
+  struct Ctx { int i; bool ok; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return Ctx{i < Ieff ? i : 0, i < Ieff}; }
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    const int rr = min(r, Reff - 1);
+    v = ld4(p + (size_t)(idx ? idx[rr] : rr) * ld + c.i);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 struct LdRowsT2 {  // dual source along j (for d[W_x | W_h])
   static constexpr bool RC = false;
   const float* p1; int ld1; int I1; const float* p2; int ld2;
-  struct Ctx { const float* base; int ld; };
+  struct Ctx { const float* base; int ld; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
-    if (j >= NJ) return Ctx{nullptr, 0};
-    if (j < I1) return Ctx{p1 + j, ld1};
-    return Ctx{p2 ? p2 + (j - I1) : nullptr, ld2};
+    if (j >= NJ) return Ctx{p1, 0, false};
+    if (j < I1) return Ctx{p1 + j, ld1, true};
+    return p2 ? Ctx{p2 + (j - I1), ld2, true} : Ctx{p1, 0, false};
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    return (c.base && r < Reff) ? ld4(c.base + (size_t)r * c.ld) : zero4();
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = ld4(c.base + (size_t)min(r, Reff - 1) * c.ld);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // weights [G*gs rows][ldw], reduce-contiguous (y = x W^T)
 struct LdWeightNT {
   static constexpr bool RC = true;
   const float* w; int ldw; int gs;
-  struct Ctx { const float* row; };
+  struct Ctx { const float* row; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int g, int NJ) const {
-    return Ctx{j < NJ ? w + (size_t)(g * gs + j) * ldw : nullptr};
+    const bool ok = j < NJ;
+    return Ctx{w + (size_t)(g * gs + (ok ? j : 0)) * ldw, ok};
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    return (c.row && r < Reff) ? ld4(c.row + r) : zero4();
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = ld4(c.row + (ok ? r : 0));
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // weights used as B[r][j] = w[r*ldw + j]  (dx = dy W), optional per-row scale (LayerScale folded in)
 struct LdWeightNN {
   static constexpr bool RC = false;
   const float* w; int ldw; const float* rscale;
-  struct Ctx { const float* col; };
-  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? w + j : nullptr}; }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (!c.col || r >= Reff) return zero4();
-    float4 v = ld4(c.col + (size_t)r * ldw);
-    if (rscale) { const float s = rscale[r]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
-    return v;
+  struct Ctx { const float* col; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{w + (j < NJ ? j : 0), j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 1);
+    ok = c.ok && r < Reff;
+    v = ld4(c.col + (size_t)rr * ldw);
+    aux = rscale ? rscale[rr] : 1.f;
+  }
+  __device__ __forceinline__ float4 finish(float4 v, float aux, bool ok) const {
+    return ok ? make_float4(v.x * aux, v.y * aux, v.z * aux, v.w * aux) : zero4();
   }
 };
 
@@ -556,83 +600,92 @@ __device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, int shif
 struct LdIm2col {
   static constexpr bool RC = true;
   const float* x; ConvGeom g;
-  struct Ctx { const float* img; int iy0, ix0; };
+  struct Ctx { const float* img; int iy0, ix0; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
-    if (i >= Ieff) return Ctx{nullptr, 0, 0};
-    const int ox = i % g.Wo, t = i / g.Wo, oy = t % g.Ho, b = t / g.Ho;
-    return Ctx{x + (size_t)b * g.H * g.W * g.ldx, oy * g.stride - g.pad, ox * g.stride - g.pad};
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    const int ox = ii % g.Wo, t = ii / g.Wo, oy = t % g.Ho, b = t / g.Ho;
+    return Ctx{x + (size_t)b * g.H * g.W * g.ldx, oy * g.stride - g.pad, ox * g.stride - g.pad, ok};
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (!c.img || r >= Reff) return zero4();
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     int kh, kw, ch;
-    split_tap(g, g.Cin, g.cin_shift, r, kh, kw, ch);
-    int iy = c.iy0 + kh, ix = c.ix0 + kw;
-    if (g.replicate) { iy = min(max(iy, 0), g.H - 1); ix = min(max(ix, 0), g.W - 1); }
-    else if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return zero4();
-    return ld4(c.img + ((size_t)iy * g.W + ix) * g.ldx + ch);
+    split_tap(g, g.Cin, g.cin_shift, min(r, Reff - 1), kh, kw, ch);
+    const int iy = c.iy0 + kh, ix = c.ix0 + kw;
+    const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+    ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
+    v = ld4(c.img + ((size_t)cy * g.W + cx) * g.ldx + ch);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // IC: B(t)[r = (b,oy,ox)][j = (kh,kw,c)]   (weight gradient)
 struct LdIm2colT {
   static constexpr bool RC = false;
   const float* x; ConvGeom g;
-  struct Ctx { int kh, kw, c; };
+  struct Ctx { int kh, kw, c; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
-    if (j >= NJ) return Ctx{-1, 0, 0};
     Ctx c;
-    split_tap(g, g.Cin, g.cin_shift, j, c.kh, c.kw, c.c);
+    c.ok = j < NJ;
+    split_tap(g, g.Cin, g.cin_shift, c.ok ? j : 0, c.kh, c.kw, c.c);
     return c;
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (c.kh < 0 || r >= Reff) return zero4();
-    const int ox = r % g.Wo, t = r / g.Wo, oy = t % g.Ho, b = t / g.Ho;
-    int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
-    if (g.replicate) { iy = min(max(iy, 0), g.H - 1); ix = min(max(ix, 0), g.W - 1); }
-    else if ((unsigned)iy >= (unsigned)g.H || (unsigned)ix >= (unsigned)g.W) return zero4();
-    return ld4(x + ((size_t)(b * g.H + iy) * g.W + ix) * g.ldx + c.c);
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 1);
+    const int ox = rr % g.Wo, t = rr / g.Wo, oy = t % g.Ho, b = t / g.Ho;
+    const int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
+    const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+    ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
+    v = ld4(x + ((size_t)(b * g.H + cy) * g.W + cx) * g.ldx + c.c);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // RC: backward-data gather  A[m = (b,iy,ix)][r = (kh,kw,co)] = dY[b,(iy+p-kh)/s,(ix+p-kw)/s,co]
 // replicate padding: the clamped taps (kh < pad at iy == 0, same for x) fold onto output row/col 0.
 struct LdConvDx {
   static constexpr bool RC = true;
   const float* dy; ConvGeom g; int Cout; int lddy; int cout_shift;
-  struct Ctx { const float* img; int iy, ix; };
+  struct Ctx { const float* img; int iy, ix; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
-    if (i >= Ieff) return Ctx{nullptr, 0, 0};
-    const int ix = i % g.W, t = i / g.W, iy = t % g.H, b = t / g.H;
-    return Ctx{dy + (size_t)b * g.Ho * g.Wo * lddy, iy, ix};
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    const int ix = ii % g.W, t = ii / g.W, iy = t % g.H, b = t / g.H;
+    return Ctx{dy + (size_t)b * g.Ho * g.Wo * lddy, iy, ix, ok};
   }
+  // source output coordinate of input coordinate i under tap k (returns validity; o is always in range)
   __device__ __forceinline__ bool src(int i, int k, int n_out, int& o) const {
     const int t = i + g.pad - k;
-    if (g.stride == 1) { o = t; return (unsigned)t < (unsigned)n_out; }
-    if (t >= 0) {
-      const int q = g.stride == 2 ? (t >> 1) : (t / g.stride);
-      if (q * g.stride == t && q < n_out) { o = q; return true; }
-    }
-    if (g.replicate && i == 0 && k < g.pad) { o = 0; return true; }
-    return false;
+    const int q = g.stride == 1 ? t : (g.stride == 2 ? (t >> 1) : (t / g.stride));
+    const bool hit = t >= 0 && q * g.stride == t && q < n_out;
+    const bool rep = g.replicate && i == 0 && k < g.pad;
+    o = hit ? q : 0;
+    return hit || rep;
   }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (!c.img || r >= Reff) return zero4();
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     int kh, kw, co;
-    split_tap(g, Cout, cout_shift, r, kh, kw, co);
+    split_tap(g, Cout, cout_shift, min(r, Reff - 1), kh, kw, co);
     int oy, ox;
-    if (!src(c.iy, kh, g.Ho, oy) || !src(c.ix, kw, g.Wo, ox)) return zero4();
-    return ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co);
+    const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
+    ok = c.ok && r < Reff && vy && vx;
+    v = ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 // IC: B[r = (tap,co)][j = ci] = w[co][tap][ci]   (weights stored channels-last: [Cout][KH][KW][Cin])
 struct LdWeightConvDx {
   static constexpr bool RC = false;
   const float* w; int Cout, taps, Cin, cout_shift;
-  struct Ctx { const float* col; };
-  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? w + j : nullptr}; }
-  __device__ __forceinline__ float4 load(const Ctx& c, int r, int Reff) const {
-    if (!c.col || r >= Reff) return zero4();
-    const int tap = cout_shift >= 0 ? (r >> cout_shift) : (r / Cout), co = r - tap * Cout;
-    return ld4(c.col + ((size_t)co * taps + tap) * Cin);
+  struct Ctx { const float* col; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{w + (j < NJ ? j : 0), j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 1);
+    const int tap = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - tap * Cout;
+    ok = c.ok && r < Reff;
+    v = ld4(c.col + ((size_t)co * taps + tap) * Cin);
+    aux = 0.f;
   }
+  SAST_DEFAULT_FINISH
 };
 
 inline int pow2_shift(int v) {
