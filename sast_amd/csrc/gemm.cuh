@@ -55,11 +55,6 @@ struct LdsLd {
 
 // epilogues may ask for per-column sum / sum-of-squares of the stored values (BatchNorm batch statistics fused
 // into the producing conv): EP::COLSTATS = true, EP::sums -> double[2*EP::C]
-template <class EP, class = void> struct EpHasVec : std::false_type {};
-#ifndef SAST_VEC_EPI_MASK
-#define SAST_VEC_EPI_MASK 0x0   /* measured round 1: +10-15 % in tools/gemm_micro.py, but -1..3 % on the whole step -> off */
-#endif
-template <class EP> struct EpHasVec<EP, std::void_t<decltype(EP::VEC4)>> : std::bool_constant<EP::VEC4 && ((SAST_VEC_EPI_MASK >> EP::VEC_ID) & 1)> {};
 template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
@@ -306,65 +301,12 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     }
   }
 
-  // vectorised epilogue (EP::VEC4): each wave transposes its 32x32 accumulator tiles through LDS and hands the functor
-  // float4 row segments -> 16-byte global stores (1 KiB per wave instruction) instead of 4-byte ones
-  if constexpr (EpHasVec<EP>::value) {
-    static_assert(GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * 32 * 33, "epilogue transpose scratch");
-    float* scr = smem + wave * (32 * 33);
-    constexpr bool VSTATS = EpHasStats<EP>::value;
-    float4 vs[T::TJ], vq[T::TJ];
-#pragma unroll
-    for (int tj = 0; tj < T::TJ; ++tj) { vs[tj] = zero4(); vq[tj] = zero4(); }
-#pragma unroll
-    for (int ta = 0; ta < T::TM; ++ta)
-#pragma unroll
-      for (int tj = 0; tj < T::TJ; ++tj) {
-        float4 vv[4][G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          __syncthreads();
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg)
-            scr[((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) * 33 + (lane & 31)] = acc[ta][tj * G + g][reg];
-          __syncthreads();
-#pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            const float* q = scr + (it * 8 + (lane >> 3)) * 33 + (lane & 7) * 4;
-            vv[it][g] = make_float4(q[0], q[1], q[2], q[3]);
-          }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          const int m = m0 + wm * T::WTM + ta * 32 + it * 8 + (lane >> 3), j = j0 + (wn * T::TJ + tj) * 32 + (lane & 7) * 4;
-          if (m < Meff && j < NJ) {
-            ep.vec(m, j, vv[it]);
-            if constexpr (VSTATS) {
-              const float4 v = vv[it][0];
-              vs[tj].x += v.x; vs[tj].y += v.y; vs[tj].z += v.z; vs[tj].w += v.w;
-              vq[tj].x += v.x * v.x; vq[tj].y += v.y * v.y; vq[tj].z += v.z * v.z; vq[tj].w += v.w * v.w;
-            }
-          }
-        }
-      }
-    if constexpr (VSTATS) {   // lanes sharing (lane & 7) own the same 4 columns: fold over the other lane bits, 8 lanes publish
-#pragma unroll
-      for (int tj = 0; tj < T::TJ; ++tj) {
-        float* a = &vs[tj].x; float* b = &vq[tj].x;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int o = 8; o < 64; o <<= 1) { a[e] += __shfl_xor(a[e], o, 64); b[e] += __shfl_xor(b[e], o, 64); }
-        }
-        const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 7) * 4;
-        if (lane < 8 && j < NJ) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { atomicAdd(ep.sums + j + e, (double)a[e]); atomicAdd(ep.sums + NJ + j + e, (double)b[e]); }
-        }
-      }
-    }
-    return;
-  }
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Epilogue protocol (keeps every global LOAD of the epilogue out of divergent control flow, so all of them are issued
+  // back to back and waited for once -- the first version re-loaded the bias under a branch and drained vmcnt per element):
+  //   Col col(j)              per-column constants (bias, LayerScale gamma ...), once per lane and column tile
+  //   Aux pre(m, j)           per-element loads only (residual, gathered row ...), indices already clamped in range
+  //   post(m, j, v, col, aux) arithmetic + stores, executed under the bounds predicate
   constexpr bool STATS = EpHasStats<EP>::value;
   float cs[T::TJ], cq[T::TJ];
 #pragma unroll
@@ -374,14 +316,20 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
 #pragma unroll
     for (int tj = 0; tj < T::TJ; ++tj) {
       const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
+      const int jc = min(j, NJ - 1);
+      const int mb = m0 + wm * T::WTM + ta * 32 + 4 * (lane >> 5);
+      const typename EP::Col col = ep.col(jc);
+      typename EP::Aux aux[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) aux[reg] = ep.pre(min(mb + (reg & 3) + 8 * (reg >> 2), Meff - 1), jc);
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int m = m0 + wm * T::WTM + ta * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        const int m = mb + (reg & 3) + 8 * (reg >> 2);
         if (m < Meff && j < NJ) {
           float v[G];
 #pragma unroll
           for (int g = 0; g < G; ++g) v[g] = acc[ta][tj * G + g][reg];
-          ep(m, j, v);
+          ep.post(m, j, v, col, aux[reg]);
           if constexpr (STATS) { cs[tj] += v[0]; cq[tj] += v[0] * v[0]; }
         }
       }
@@ -694,44 +642,42 @@ inline int pow2_shift(int v) {
   return (1 << s) == v ? s : -1;
 }
 
-// ------------------------------------------------------------------ generic epilogues
-__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-__device__ __forceinline__ float4 fma4(float4 g, float4 a, float4 r) {   // r + g * a
-  return make_float4(fmaf(g.x, a.x, r.x), fmaf(g.y, a.y, r.y), fmaf(g.z, a.z, r.z), fmaf(g.w, a.w, r.w));
-}
+// ------------------------------------------------------------------ generic epilogues (protocol: see gemm_kernel)
+struct EpNone {};   // empty Col / Aux
 struct EpStore {  // C[m*ldc + j] = v (+bias)
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 1;
   float* c; int ldc; const float* bias;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    c[(size_t)m * ldc + j] = v[0] + (bias ? bias[j] : 0.f);
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    st4(c + (size_t)m * ldc + j, bias ? add4(v[0], ld4(bias + j)) : v[0]);
+  struct Col { float b; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const { return Col{bias ? bias[j] : 0.f}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
+    c[(size_t)m * ldc + j] = v[0] + k.b;
   }
 };
 struct EpStoreStats {  // C[m*ldc + j] = v ; sums[j] += v ; sums[NJ + j] += v*v   (conv -> BatchNorm batch statistics)
   static constexpr bool COLSTATS = true;
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 0;
   float* c; int ldc; double* sums;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const { c[(size_t)m * ldc + j] = v[0]; }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const { st4(c + (size_t)m * ldc + j, v[0]); }
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const { c[(size_t)m * ldc + j] = v[0]; }
 };
 struct EpStoreAdd {  // C[m*ldc+j] = v + add[m*ldadd + j]
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 2;
   float* c; int ldc; const float* add; int ldadd;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    c[(size_t)m * ldc + j] = v[0] + add[(size_t)m * ldadd + j];
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    st4(c + (size_t)m * ldc + j, add4(v[0], ld4(add + (size_t)m * ldadd + j)));
+  using Col = EpNone;
+  struct Aux { float a; };
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{add[(size_t)m * ldadd + j]}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
+    c[(size_t)m * ldc + j] = v[0] + x.a;
   }
 };
 struct EpAtomic {  // C[m*ldc + j] += v   (split-R weight gradients)
   float* c; int ldc;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
     atomicAdd(c + (size_t)m * ldc + j, v[0]);
   }
 };

@@ -56,113 +56,81 @@ int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int
   return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
 }
 
-// ---------------------------------------------------------------- epilogues
+// ---------------------------------------------------------------- epilogues (protocol: col / pre / post, see gemm.cuh)
 struct EpBiasRelu {
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 3;
   float* c; int ldc; const float* bias;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    c[(size_t)m * ldc + j] = fmaxf(v[0] + bias[j], 0.f);
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    const float4 t = add4(v[0], ld4(bias + j));
-    st4(c + (size_t)m * ldc + j, make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f)));
+  struct Col { float b; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const { return Col{bias[j]}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
+    c[(size_t)m * ldc + j] = fmaxf(v[0] + k.b, 0.f);
   }
 };
 struct EpResidualLS {  // y = res + gamma * (v + bias)
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 4;
   float* y; const float* res; const float* bias; const float* gamma; int C;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    const float z = v[0] + bias[j];
-    y[(size_t)m * C + j] = res[(size_t)m * C + j] + (gamma ? gamma[j] * z : z);
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    const float4 z = add4(v[0], ld4(bias + j)), r = ld4(res + (size_t)m * C + j);
-    st4(y + (size_t)m * C + j, gamma ? fma4(ld4(gamma + j), z, r) : add4(r, z));
+  struct Col { float b, g; };
+  struct Aux { float r; };
+  __device__ __forceinline__ Col col(int j) const { return Col{bias[j], gamma ? gamma[j] : 1.f}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{res[(size_t)m * C + j]}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux& x) const {
+    y[(size_t)m * C + j] = x.r + k.g * (v[0] + k.b);
   }
 };
 struct EpResidualLSScatter {  // out[row_tok[m]] = res + gamma * (v + bias)
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 5;
   float* out; const float* res; const float* bias; const float* gamma; const int* row_tok; int C;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    const float z = v[0] + bias[j];
-    out[(size_t)row_tok[m] * C + j] = res[(size_t)m * C + j] + (gamma ? gamma[j] * z : z);
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    const float4 z = add4(v[0], ld4(bias + j)), r = ld4(res + (size_t)m * C + j);
-    st4(out + (size_t)row_tok[m] * C + j, gamma ? fma4(ld4(gamma + j), z, r) : add4(r, z));
+  struct Col { float b, g; };
+  struct Aux { float r; int row; };
+  __device__ __forceinline__ Col col(int j) const { return Col{bias[j], gamma ? gamma[j] : 1.f}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{res[(size_t)m * C + j], row_tok[m]}; }
+  __device__ __forceinline__ void post(int, int j, const float (&v)[1], const Col& k, const Aux& x) const {
+    out[(size_t)x.row * C + j] = x.r + k.g * (v[0] + k.b);
   }
 };
 struct EpGlu {  // ops.py:136-137: value = first half, gate = second half, exact-erf GELU
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 6;
   float* ug; float* h; const float* bias; int inner;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[2]) const {
-    const float u = v[0] + bias[j], g = v[1] + bias[inner + j];
+  struct Col { float bu, bg; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[inner + j]}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[2], const Col& k, const Aux&) const {
+    const float u = v[0] + k.bu, g = v[1] + k.bg;
     ug[(size_t)m * 2 * inner + j] = u;
     ug[(size_t)m * 2 * inner + inner + j] = g;
     h[(size_t)m * inner + j] = u * gelu_erf(g);
   }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[2]) const {
-    const float4 u = add4(v[0], ld4(bias + j)), g = add4(v[1], ld4(bias + inner + j));
-    st4(ug + (size_t)m * 2 * inner + j, u);
-    st4(ug + (size_t)m * 2 * inner + inner + j, g);
-    st4(h + (size_t)m * inner + j, make_float4(u.x * gelu_erf(g.x), u.y * gelu_erf(g.y), u.z * gelu_erf(g.z), u.w * gelu_erf(g.w)));
-  }
 };
 struct EpDGlu {  // v = dH -> d(value), d(gate)
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 7;
   const float* ug; float* dug; int inner;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    const float u = ug[(size_t)m * 2 * inner + j], g = ug[(size_t)m * 2 * inner + inner + j];
-    dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(g);
-    dug[(size_t)m * 2 * inner + inner + j] = v[0] * u * gelu_erf_grad(g);
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    const float4 u = ld4(ug + (size_t)m * 2 * inner + j), g = ld4(ug + (size_t)m * 2 * inner + inner + j), d = v[0];
-    st4(dug + (size_t)m * 2 * inner + j, make_float4(d.x * gelu_erf(g.x), d.y * gelu_erf(g.y), d.z * gelu_erf(g.z), d.w * gelu_erf(g.w)));
-    st4(dug + (size_t)m * 2 * inner + inner + j, make_float4(d.x * u.x * gelu_erf_grad(g.x), d.y * u.y * gelu_erf_grad(g.y),
-                                                             d.z * u.z * gelu_erf_grad(g.z), d.w * u.w * gelu_erf_grad(g.w)));
+  using Col = EpNone;
+  struct Aux { float u, g; };
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{ug[(size_t)m * 2 * inner + j], ug[(size_t)m * 2 * inner + inner + j]}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
+    dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(x.g);
+    dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * gelu_erf_grad(x.g);
   }
 };
 struct EpAddGather {  // c[m,j] = v + src[idx[m], j]
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 8;
   float* c; int ldc; const float* src; const int* idx; int lds;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
-    c[(size_t)m * ldc + j] = v[0] + src[(size_t)idx[m] * lds + j];
-  }
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    st4(c + (size_t)m * ldc + j, add4(v[0], ld4(src + (size_t)idx[m] * lds + j)));
+  using Col = EpNone;
+  struct Aux { float a; };
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{src[(size_t)idx[m] * lds + j]}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
+    c[(size_t)m * ldc + j] = v[0] + x.a;
   }
 };
 struct EpLstm {  // rnn.py:57-67
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 9;
   const float* bias; const float* c0; float* h1; float* c1; float* gates; int C;
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[4]) const {
-    const float4 bf = ld4(bias + j), bi = ld4(bias + C + j), bo = ld4(bias + 2 * C + j), bg = ld4(bias + 3 * C + j);
-    const float4 cp = c0 ? ld4(c0 + (size_t)m * C + j) : zero4();
-    float4 f, i, o, g, c, h;
-    const float* vf = &v[0].x; const float* vi = &v[1].x; const float* vo = &v[2].x; const float* vg = &v[3].x;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      (&f.x)[e] = sigmoid_exact(vf[e] + (&bf.x)[e]); (&i.x)[e] = sigmoid_exact(vi[e] + (&bi.x)[e]);
-      (&o.x)[e] = sigmoid_exact(vo[e] + (&bo.x)[e]); (&g.x)[e] = tanhf(vg[e] + (&bg.x)[e]);
-      (&c.x)[e] = (&f.x)[e] * (&cp.x)[e] + (&i.x)[e] * (&g.x)[e];
-      (&h.x)[e] = (&o.x)[e] * tanhf((&c.x)[e]);
-    }
-    st4(c1 + (size_t)m * C + j, c); st4(h1 + (size_t)m * C + j, h);
-    float* gp = gates + (size_t)m * 4 * C + j;
-    st4(gp, f); st4(gp + C, i); st4(gp + 2 * C, o); st4(gp + 3 * C, g);
-  }
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[4]) const {
-    const float f = sigmoid_exact(v[0] + bias[j]), i = sigmoid_exact(v[1] + bias[C + j]);
-    const float o = sigmoid_exact(v[2] + bias[2 * C + j]), g = tanhf(v[3] + bias[3 * C + j]);
-    const float c = f * (c0 ? c0[(size_t)m * C + j] : 0.f) + i * g;
+  struct Col { float bf, bi, bo, bg; };
+  struct Aux { float c; };
+  __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[C + j], bias[2 * C + j], bias[3 * C + j]}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{c0 ? c0[(size_t)m * C + j] : 0.f}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[4], const Col& k, const Aux& x) const {
+    const float f = sigmoid_exact(v[0] + k.bf), i = sigmoid_exact(v[1] + k.bi);
+    const float o = sigmoid_exact(v[2] + k.bo), g = tanhf(v[3] + k.bg);
+    const float c = f * x.c + i * g;
     c1[(size_t)m * C + j] = c;
     h1[(size_t)m * C + j] = o * tanhf(c);
     float* gp = gates + (size_t)m * 4 * C + j;
@@ -170,14 +138,11 @@ struct EpLstm {  // rnn.py:57-67
   }
 };
 struct EpSplit2 {  // j < C1 -> a, else b
-  static constexpr bool VEC4 = true;
-  static constexpr int VEC_ID = 10;
   float* a; float* b; int C1, C2;
-  __device__ __forceinline__ void vec(int m, int j, const float4 (&v)[1]) const {
-    if (j < C1) st4(a + (size_t)m * C1 + j, v[0]);
-    else if (b) st4(b + (size_t)m * C2 + (j - C1), v[0]);
-  }
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
     if (j < C1) a[(size_t)m * C1 + j] = v[0];
     else if (b) b[(size_t)m * C2 + (j - C1)] = v[0];
   }

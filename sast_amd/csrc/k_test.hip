@@ -29,8 +29,6 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     case 17: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 18: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 19: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
-    case 20: return launch_gemm<TileSmall>(la, lb, EpStore{c, N, bias}, M, N, K, nullptr, nullptr, st);
-    case 21: return launch_gemm<TileSmallK2>(la, lb, EpStore{c, N, bias}, M, N, K, nullptr, nullptr, st);
     case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     default: return SAST_EINVAL;
   }
@@ -38,7 +36,10 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
 
 struct EpNull {  // discards the result (measures the kernel without the atomic epilogue)
   float* c;
-  __device__ __forceinline__ void operator()(int m, int j, const float (&v)[1]) const {
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int, int, const float (&v)[1], const Col&, const Aux&) const {
     if (v[0] == 123456.789f) c[0] = v[0];
   }
 };

@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 shapes = [(61440, 192, 64), (61440, 64, 64), (61440, 320, 64), (61440, 64, 160), (15360, 384, 128), (15360, 128, 128), (15360, 640, 128),
           (15360, 128, 320), (3840, 768, 256), (3840, 256, 256), (3840, 1344, 256), (3840, 256, 672), (960, 1536, 512), (960, 512, 512),
           (960, 2688, 512), (960, 512, 1344), (61440, 256, 128), (15360, 512, 256), (3840, 1024, 512), (960, 2048, 1024), (3840, 128, 1152), (15360, 64, 576), (960, 256, 2304), (15360, 128, 1152), (3840, 256, 2304)]
-tiles = {0: "64x64k16", 20: "64x64 vec-epi", 13: "64x64 KS2", 21: "KS2 vec-epi"}
+tiles = {0: "64x64k16", 13: "64x64 KS2", 19: "32x64 KS4"}
 st = torch.cuda.current_stream().cuda_stream
 print("shape".ljust(22) + " ".join(f"{v:>15}" for v in tiles.values()))
 for (M, N, K) in shapes:
