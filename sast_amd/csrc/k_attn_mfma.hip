@@ -28,15 +28,28 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 __device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// stage rows [r0, r0+K) x 32 channels of `src` (row stride ld, channel offset coff) transposed into dst[d][tok]
-__device__ __forceinline__ void stage_t(float* dst, const float* __restrict__ src, int ld, int coff, int r0, int K, int KT,
-                                        float mul) {
-  for (int s = threadIdx.x; s < KT * 8; s += 128) {
-    const int row = s >> 3, dq = (s & 7) * 4;
-    float4 v = zero4();
-    if (row < K) v = ld4(src + (size_t)(r0 + row) * ld + coff + dq);
-    float* d = dst + dq * LDT + row;
-    d[0] = v.x * mul; d[LDT] = v.y * mul; d[2 * LDT] = v.z * mul; d[3 * LDT] = v.w * mul;
+// stage rows [r0, r0+K) x 32 channels of `src` (row stride ld, channel offset coff) transposed into dst[d][tok].
+// Two steps so that the loads of ALL staged matrices are in flight together (branch-free: clamped row + select at
+// commit time; a predicated load would make hipcc drain vmcnt after every single one).
+struct Staged { float4 v[4]; };
+__device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K) {
+  Staged st;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = threadIdx.x + it * 128, row = s >> 3, dq = (s & 7) * 4;
+    st.v[it] = ld4(src + (size_t)(r0 + min(row, K - 1)) * ld + coff + dq);
+  }
+  return st;
+}
+__device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K, int KT, float mul) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int s = threadIdx.x + it * 128, row = s >> 3, dq = (s & 7) * 4;
+    if (s < KT * 8) {
+      const float m = row < K ? mul : 0.f;
+      float* d = dst + dq * LDT + row;
+      d[0] = st.v[it].x * m; d[LDT] = st.v[it].y * m; d[2 * LDT] = st.v[it].z * m; d[3 * LDT] = st.v[it].w * m;
+    }
   }
 }
 
@@ -55,9 +68,12 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restr
   const int NTL = (K + 31) >> 5, KT = NTL * 32;          // 1 or 2 token tiles
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
   const int C3 = 3 * C, coff = h * 96;
-  stage_t(Qt, qkv, C3, coff, r0, K, KT, scale);
-  stage_t(Kt, qkv, C3, coff + 32, r0, K, KT, 1.f);
-  stage_t(Vt, qkv, C3, coff + 64, r0, K, KT, 1.f);
+  {
+    const Staged sq = stage_issue(qkv, C3, coff, r0, K), sk = stage_issue(qkv, C3, coff + 32, r0, K), sv = stage_issue(qkv, C3, coff + 64, r0, K);
+    stage_commit(Qt, sq, K, KT, scale);
+    stage_commit(Kt, sk, K, KT, 1.f);
+    stage_commit(Vt, sv, K, KT, 1.f);
+  }
   __syncthreads();
   const bool active = w < NTL;
   f32x16 s[2];
@@ -65,12 +81,20 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restr
 #pragma unroll
   for (int e = 0; e < 16; ++e) { s[0][e] = 0.f; s[1][e] = 0.f; inv[e] = 0.f; }
   if (active) {
+    if (NTL > 1) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      const float a = Qt[kk * LDT + w * 32 + l31];
-      s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + l31], s[0], 0, 0, 0);
-      if (NTL > 1) s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + 32 + l31], s[1], 0, 0, 0);
+      for (int ks = 0; ks < 16; ++ks) {
+        const int kk = ks * 2 + (lane >> 5);
+        const float a = Qt[kk * LDT + w * 32 + l31];
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + l31], s[0], 0, 0, 0);
+        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + 32 + l31], s[1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int kk = ks * 2 + (lane >> 5);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[kk * LDT + w * 32 + l31], Kt[kk * LDT + l31], s[0], 0, 0, 0);
+      }
     }
     const bool c0 = l31 < K, c1 = (NTL > 1) && (32 + l31 < K);
 #pragma unroll
@@ -129,25 +153,36 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
   const int NTL = (K + 31) >> 5, KT = NTL * 32;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
   const int C3 = 3 * C, coff = h * 96;
-  stage_t(Qt, qkv, C3, coff, r0, K, KT, scale);
-  stage_t(Kt, qkv, C3, coff + 32, r0, K, KT, 1.f);
-  stage_t(Vt, qkv, C3, coff + 64, r0, K, KT, 1.f);
-  stage_t(Gt, dout, C, h * ADH, r0, K, KT, 1.f);
+  {
+    const Staged sq = stage_issue(qkv, C3, coff, r0, K), sk = stage_issue(qkv, C3, coff + 32, r0, K);
+    const Staged sv = stage_issue(qkv, C3, coff + 64, r0, K), sg = stage_issue(dout, C, h * ADH, r0, K);
+    stage_commit(Qt, sq, K, KT, scale);
+    stage_commit(Kt, sk, K, KT, 1.f);
+    stage_commit(Vt, sv, K, KT, 1.f);
+    stage_commit(Gt, sg, K, KT, 1.f);
+  }
   __syncthreads();
   const bool active = w < NTL;
   f32x16 s[2], dp[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) { s[0][e] = 0.f; s[1][e] = 0.f; dp[0][e] = 0.f; dp[1][e] = 0.f; }
   if (active) {
+    if (NTL > 1) {
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      const float a = Qt[kk * LDT + w * 32 + l31], ga = Gt[kk * LDT + w * 32 + l31];
-      s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + l31], s[0], 0, 0, 0);
-      dp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + l31], dp[0], 0, 0, 0);
-      if (NTL > 1) {
+      for (int ks = 0; ks < 16; ++ks) {
+        const int kk = ks * 2 + (lane >> 5);
+        const float a = Qt[kk * LDT + w * 32 + l31], ga = Gt[kk * LDT + w * 32 + l31];
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + l31], s[0], 0, 0, 0);
+        dp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + l31], dp[0], 0, 0, 0);
         s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + 32 + l31], s[1], 0, 0, 0);
         dp[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + 32 + l31], dp[1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const int kk = ks * 2 + (lane >> 5);
+        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[kk * LDT + w * 32 + l31], Kt[kk * LDT + l31], s[0], 0, 0, 0);
+        dp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[kk * LDT + w * 32 + l31], Vt[kk * LDT + l31], dp[0], 0, 0, 0);
       }
     }
     const bool c0 = l31 < K, c1 = (NTL > 1) && (32 + l31 < K);
