@@ -100,6 +100,7 @@ int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode,
 typedef struct SastMswsaArgs {
   int32_t B, H, W, C, ph, pw, mode, inner;
   float eps;
+  int32_t cb_tps;        /* Context Broadcasting (enable_CB, SAST.py:240-246): tokens per sample, 0 = off */
   const float* xin;      /* [B*L, C] image layout */
   float* out;            /* [B*L, C] */
   SastSel sel;
@@ -114,6 +115,7 @@ typedef struct SastMswsaArgs {
   float *d_ln1_w, *d_ln1_b, *d_ln2_w, *d_ln2_b, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_ls1;
   float *d_fc1_w, *d_fc1_b, *d_fc2_w, *d_fc2_b, *d_ls2;
   float* ws;             /* sast_mswsa_bwd_ws_floats() */
+  float *cb_m, *cb_sum;  /* cb_tps > 0 only: scratch [R,C] and [B*L/cb_tps, C] (fwd and bwd) */
 } SastMswsaArgs;
 size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner);
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream);

@@ -36,13 +36,13 @@ SastScoreArgs = _struct("SastScoreArgs", [
 ])
 SastSel = _struct("SastSel", [(P, "win_keep mask K row_off win_rank counts tok_slot row_tok")])
 SastMswsaArgs = _struct("SastMswsaArgs", [
-    (I32, "B H W C ph pw mode inner"), (F32, "eps"),
+    (I32, "B H W C ph pw mode inner"), (F32, "eps"), (I32, "cb_tps"),
     (P, "xin out"), (SastSel, "sel"),
     (P, "ln1_w ln1_b ln2_w ln2_b qkv_w qkv_b proj_w proj_b ls1 fc1_w fc1_b fc2_w fc2_b ls2"),
     (P, "mean1 rstd1 mean2 rstd2 S QKV O lse Y UG Hh"),
     (P, "dout dxin"),
     (P, "d_ln1_w d_ln1_b d_ln2_w d_ln2_b d_qkv_w d_qkv_b d_proj_w d_proj_b d_ls1 d_fc1_w d_fc1_b d_fc2_w d_fc2_b d_ls2"),
-    (P, "ws"),
+    (P, "ws cb_m cb_sum"),
 ])
 SastLstmArgs = _struct("SastLstmArgs", [
     (I32, "B L C"),

@@ -269,8 +269,16 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
     else rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     if (rc) return rc;
   }
-  return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
-                   EpResidualLSScatter{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C}, R, C, inner, dR, st);
+  if (a->cb_tps <= 0)
+    return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
+                     EpResidualLSScatter{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C}, R, C, inner, dR, st);
+  // Context Broadcasting (SAST.py:240-246): the MLP output is mixed with its per-sample mean over ALL L tokens before LayerScale
+  if (!a->cb_m || !a->cb_sum || R % a->cb_tps) return SAST_EINVAL;
+  rc = gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0}, EpStore{a->cb_m, C, a->fc2_b}, R, C, inner, dR, st);
+  if (rc) return rc;
+  rc = cb_sample_sum_launch(a->cb_m, C, false, a->sel.row_tok, dR, R, a->cb_tps, R / a->cb_tps, C, a->cb_sum, st);
+  if (rc) return rc;
+  return cb_apply_fwd_launch(a->cb_m, a->Y, a->ls2, a->cb_sum, a->sel.row_tok, dR, R, a->cb_tps, C, a->out, st);
 }
 
 int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
@@ -292,14 +300,27 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   zero_fill(raw2, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
   int rc;
   Side sd(st);   // weight-gradient GEMMs run beside the activation-gradient chain
+  // Context Broadcasting: the gradient reaching the MLP output is dZ'[r] = 0.5 dZ[r] + (0.5/L) sum_{r' in sample} dZ[r']
+  // (gamma2 factored out exactly as without CB); everything downstream of the MLP output consumes dZ' in compact form.
+  const float* dz = a->dout;
+  const int* dz_tok = row_tok;
+  if (a->cb_tps > 0) {
+    if (!a->cb_m || !a->cb_sum || R % a->cb_tps) return SAST_EINVAL;
+    rc = cb_sample_sum_launch(a->dout, C, true, row_tok, dR, R, a->cb_tps, R / a->cb_tps, C, a->cb_sum, st);
+    if (rc) return rc;
+    rc = cb_apply_bwd_launch(a->dout, a->cb_sum, row_tok, dR, R, a->cb_tps, C, a->cb_m, st);
+    if (rc) return rc;
+    dz = a->cb_m;
+    dz_tok = nullptr;
+  }
   // fc2 grads (raw, LayerScale applied in the finish kernel): need only dZ (= dout rows) and H
   sd.after_main();
-  rc = gemm_tn(LdRowsT{a->dout, C, row_tok}, LdRowsT{a->Hh, inner, nullptr}, raw2, inner, C, inner, R, dR, s2, sd.side);
+  rc = gemm_tn(LdRowsT{dz, C, dz_tok}, LdRowsT{a->Hh, inner, nullptr}, raw2, inner, C, inner, R, dR, s2, sd.side);
   if (rc) return rc;
   rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, sd.side);
   if (rc) return rc;
   // dH = (gamma2 * dZ) W2 ; fused: dUG from the saved pre-activations
-  rc = gemm_auto(LdRows{a->dout, C, row_tok}, LdWeightNN{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+  rc = gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
   if (rc) return rc;
   sd.after_main();
   rc = gemm_tn(LdRowsT{dUG, 2 * inner, nullptr}, LdRowsT{a->Y, C, nullptr}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b, sd.side);

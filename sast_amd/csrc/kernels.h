@@ -32,6 +32,13 @@ int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, i
 int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* drows, int C, float* out, hipStream_t st);
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st);
+// Context Broadcasting (SAST.py:240-246): per-sample column sums of the kept rows, and the two pointwise halves
+int cb_sample_sum_launch(const float* src, int ld, bool gather, const int* row_tok, const int* nrows_dev, int rows_max, int tps,
+                         int n_samples, int C, float* out, hipStream_t st);
+int cb_apply_fwd_launch(const float* m, const float* y, const float* gamma, const float* sum, const int* row_tok,
+                        const int* nrows_dev, int rows_max, int tps, int C, float* out, hipStream_t st);
+int cb_apply_bwd_launch(const float* dout, const float* gsum, const int* row_tok, const int* nrows_dev, int rows_max, int tps, int C,
+                        float* dz, hipStream_t st);
 
 // k_side.hip
 struct Side {

@@ -349,7 +349,7 @@ _MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w",
 
 class _MSWSA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xin, sel: Selection, eps, *params):
+    def forward(ctx, xin, sel: Selection, eps, cb_tps, *params):
         _need_gpu(xin)
         xin = xin.contiguous()
         p = dict(zip(_MSWSA_PARAMS, params))
@@ -375,11 +375,16 @@ class _MSWSA(torch.autograd.Function):
         a = L.SastMswsaArgs()
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, xin=xin, out=out,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
+        if cb_tps:
+            if R % cb_tps:
+                raise RuntimeError(f"sast_amd: Context Broadcasting needs rows ({R}) divisible by tokens per sample ({cb_tps})")
+            cb_m, cb_sum = torch.empty(R, Cc, device=dev), torch.empty(R // cb_tps, Cc, device=dev)
+            _fill(a, cb_tps=cb_tps, cb_m=cb_m, cb_sum=cb_sum)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
         ctx.save_for_backward(xin, stats, big)
-        ctx.sel, ctx.params, ctx.eps, ctx.inner = sel, params, eps, inner
+        ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps = sel, params, eps, inner, cb_tps
         return out
 
     @staticmethod
@@ -407,16 +412,20 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, xin=xin,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh,
               dout=dout, dxin=dxin, ws=ws)
+        if ctx.cb_tps:
+            cb_m, cb_sum = torch.empty(R, Cc, device=xin.device), torch.empty(R // ctx.cb_tps, Cc, device=xin.device)
+            _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         _fill(a, **{"d_" + k: _ptr(_g(v)) for k, v in p.items()})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
-        return (dxin, None, None) + (None,) * len(params)
+        return (dxin, None, None, None) + (None,) * len(params)
 
 
-def mswsa(xin, sel: Selection, eps: float, params: dict) -> torch.Tensor:
-    """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled)."""
-    return _MSWSA.apply(xin, sel, float(eps), *[params[k] for k in _MSWSA_PARAMS])
+def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0) -> torch.Tensor:
+    """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled).
+    cb_tokens_per_sample > 0 enables Context Broadcasting (SAST.py:240-246) with that many tokens per sample."""
+    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), *[params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12

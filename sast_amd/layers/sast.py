@@ -103,16 +103,14 @@ class MS_WSA(nn.Module):
                     ls1=getattr(self.ls1, "gamma", None), fc1_w=self.mlp.net[0].proj.weight, fc1_b=self.mlp.net[0].proj.bias,
                     fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias, ls2=getattr(self.ls2, "gamma", None))
 
-    def forward_image(self, x: torch.Tensor, sel: SF.Selection) -> torch.Tensor:
+    def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False) -> torch.Tensor:
         """fused path: x (B,H,W,C) in IMAGE layout + device-side selection."""
-        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params())
+        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0)
 
     def forward(self, x: torch.Tensor, index_window: torch.Tensor, index_token: torch.Tensor, padding_index: torch.Tensor,
                 asy_index: torch.Tensor, M: int, B, enable_CB: bool) -> torch.Tensor:
         """reference signature (SAST.py:199-201): x (B*N, T, C) already partitioned, reference index lists.
         The top-k fillers (index_token / padding_index) are semantically inert and ignored."""
-        if enable_CB:
-            raise NotImplementedError("sast_amd: Context Broadcasting (enable_CB=True, SAST.py:240-246) is not implemented yet")
         shape = x.shape
         N, C = x.shape[0], x.shape[-1]
         x3 = x.reshape(N, -1, C)
@@ -120,7 +118,8 @@ class MS_WSA(nn.Module):
         K = torch.bincount(torch.div(asy_index, T, rounding_mode='floor'), minlength=len(index_window)) if len(index_window) \
             else torch.zeros(0, dtype=torch.long, device=x.device)
         sel = SF.selection_from_index_lists(index_window, asy_index, K, N, T, x.device)
-        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params())
+        # Context Broadcasting averages over the tokens of one sample = N*T/B consecutive partitioned tokens (SAST.py:244-245)
+        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0)
         return out.view(*shape)
 
 
@@ -169,8 +168,6 @@ class SAST_block(nn.Module):
 
     # -- fused entry used by the backbone: `xp` already holds x + pos_emb (added by the LayerNorm kernel)
     def forward_posadded(self, xp: torch.Tensor, r: torch.Tensor, index_list):
-        if self.enable_CB:
-            raise NotImplementedError("sast_amd: Context Broadcasting (enable_CB=True, SAST.py:240-246) is not implemented yet")
         B, H, W, C = xp.shape
         ph, pw = self.partition_size
         self.B, self.N = B, H * W // (ph * pw)
@@ -183,8 +180,8 @@ class SAST_block(nn.Module):
             sel1, sel2 = index_list
             if not isinstance(sel1, SF.Selection):
                 raise TypeError("sast_amd: index_list must be the [Selection, Selection] pair returned by the first block")
-        x = self.win_attn.forward_image(xw, sel1)
-        x = self.grid_attn.forward_image(x, sel2)
+        x = self.win_attn.forward_image(xw, sel1, self.enable_CB)
+        x = self.grid_attn.forward_image(x, sel2, self.enable_CB)
         count = sel1.counts[2] + sel2.counts[2]          # SAST.py:136,159 (floor per layer), device scalar
         if self.sync_index_count:
             count = int(count.item())

@@ -81,7 +81,7 @@ def test_non_zero_ratio(golden_dir, dev):
         assert torch.equal(SF.non_zero_ratio(xx.to(dev)).cpu(), ref)
 
 
-@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1"])
+@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
@@ -89,7 +89,8 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
     B, H, W, C = x.shape
     params = block_params(C, int(g["seed"]))
-    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"])), first_block=True).to(dev)
+    cb = bool(g["enable_cb"]) if "enable_cb" in g else False     # Context Broadcasting fixture (SAST.py:240-246)
+    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"]), cb=cb), first_block=True).to(dev)
     load_params(blk, params, "att_blocks.0.att.")
     pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     xd = x.to(dev).requires_grad_(True)
@@ -125,15 +126,20 @@ def test_ms_wsa_reference_signature(golden_dir, dev):
     load_params(m, {k[len(pre):]: v for k, v in params.items() if k.startswith(pre)})
     out = m(x.to(dev), *[l.to(dev) for l in lists[:4]], len(lists[0]), 2, False)
     assert float((out.cpu() - ref).abs().max()) <= FWD_ATOL
+    # same call with Context Broadcasting (per-sample mean over the N*T/B partitioned tokens of each of the B=2 samples)
+    ref_cb = O.ms_wsa(x.clone(), lists, 2, params, pre, O.AttnCfg(partition_size=(4, 5), enable_cb=True))
+    out_cb = m(x.to(dev), *[l.to(dev) for l in lists[:4]], len(lists[0]), 2, True)
+    assert float((ref_cb - ref).abs().max()) > 1e-3
+    assert float((out_cb.cpu() - ref_cb).abs().max()) <= FWD_ATOL
 
 
-def test_cb_and_masking_fail_loudly(dev):
-    from sast_amd.layers import SAST_block
-    from sast_amd.detection import PositionEmbeddingSine
-    blk = SAST_block(64, attn_cfg((4, 5), 2e-2, cb=True), first_block=True).to(dev)
-    pe = PositionEmbeddingSine(32, normalize=True, input_size=(1, 16, 20))
+def test_token_masking_fails_loudly(dev):
+    """enable_masking (mask_token write, sast_rnn.py:271-273; off in every shipped config) is not implemented: no silent fallback."""
+    from sast_amd.detection import RNNDetector
+    cfg = _rcfg((128, 160), (4, 5), 32, 2e-4, 0.5)
+    cfg["enable_masking"] = True
     with pytest.raises(NotImplementedError):
-        blk(torch.randn(1, 16, 20, 64, device=dev), pe, torch.rand(1, 20, device=dev), None)
+        RNNDetector(cfg)
 
 
 def _rcfg(hw, part, E, amp, ls):
