@@ -43,7 +43,7 @@ def synthetic_events(B, hw, seed):
 class Trainer:
     """minimal training step of the hot path (the reference's is Lightning's, modules/detection.py:113-221)."""
 
-    def __init__(self, dev, amp, world, use_graph):
+    def __init__(self, dev, amp, world, use_graph, seq_len=1):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.dist import FlatParams, FusedAdamW
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -58,7 +58,10 @@ class Trainer:
         self.opt = FusedAdamW(self.flat, lr=2e-4, weight_decay=0.0, clip_value=1.0)
         self.world = world
         rank = dist.get_rank() if world > 1 else 0
-        self.x = synthetic_events(BATCH, HW, seed=rank).to(dev)
+        # seq_len > 1 (opt-in, --seq-len): the reference's BPTT step shape (modules/detection.py:141-177): L timesteps with the
+        # recurrent states carried, PAFPN + loss on the last one, one backward through time.  Default 1 = BASELINE's metric.
+        self.xs = [synthetic_events(BATCH, HW, seed=rank + 1000 * t).to(dev) for t in range(seq_len)]
+        self.x = self.xs[0]
         self.loss = None
         self.P = None
         self.graph = None
@@ -66,7 +69,9 @@ class Trainer:
 
     def fwd_bwd(self):
         self.flat.zero_grad()
-        feats, _states, P = self.net.forward_nhwc(self.x)
+        states = None
+        for x in self.xs:
+            feats, states, P = self.net.forward_nhwc(x, states)
         outs = self.fpn.forward_nhwc(feats)
         loss = sum((o * o).mean() for o in outs)
         loss.backward()
@@ -165,6 +170,7 @@ def main():
     ap.add_argument("--amp", type=float, default=2e-4, help="attention_cfg.AMP (controls the kept-token fraction)")
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (BASELINE config: 4; sparsity sweep C5: 8)")
     ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
+    ap.add_argument("--seq-len", type=int, default=1, help="timesteps per step with recurrent state + BPTT (1 = BASELINE metric)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -197,7 +203,7 @@ def main():
     run_stream = torch.cuda.Stream()
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
-    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph)
+    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len)
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -226,13 +232,13 @@ def main():
             pass  # (metric string stays BASELINE's; `config.workload` names what was actually run)
         res = {
             "metric": "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360",
-            "value": BATCH * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": BATCH * args.seq_len * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
                                    " full SAST backbone + PAFPN, fwd+bwd + AdamW, "
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
+                       "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
                        "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},
@@ -240,7 +246,7 @@ def main():
         if not args.no_roofline:
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1:
             res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state)
         print(json.dumps(res))
     if world > 1:

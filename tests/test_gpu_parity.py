@@ -179,6 +179,44 @@ def test_backbone_tiny_vs_golden(golden_dir, dev, tag):
         maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
 
 
+def test_backbone_sequence_bptt(dev):
+    """the training loop shape of modules/detection.py:141-177: L timesteps with the recurrent (h, c) states carried WITHOUT
+    detaching, PAFPN on the last timestep's features, one backward through time; gradients against the oracle run the same way."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    hw, part, E, L, B = (128, 160), (4, 5), 32, 3, 2
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=11, ls_init=0.5)
+    fparams = O.init_pafpn_params((64, 128, 256), seed=12)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev)
+    load_params(net, params)
+    load_params(fpn, fparams)
+    xs = [O.count_events(B, hw, seed=20 + t, density=0.05) for t in range(L)]
+
+    def run(backbone, pafpn, to):
+        states, loss, Ps = None, 0.0, []
+        for t in range(L):
+            out, states, P = backbone(to(xs[t]), states)
+            Ps.append([int(p) for p in P])
+            loss = loss + 0.1 * sum((out[k] ** 2).mean() for k in (1, 2, 3, 4))
+        return loss + sum((o ** 2).mean() for o in pafpn({k: out[k] for k in (2, 3, 4)})), Ps
+
+    fpn.train()
+    loss, Ps = run(net, fpn, lambda x: x.to(dev))
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
+    loss_o, Ps_o = run(lambda x, st: O.backbone(x, st, po, ocfg), lambda f: O.pafpn(f, pf, training=True), lambda x: x)
+    loss_o.backward()
+    assert Ps == Ps_o
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
+    for k, v in net.named_parameters():
+        if "sub_layers" not in k:
+            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+    for k, v in fpn.named_parameters():
+        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
+
+
 def test_pafpn_vs_golden(golden_dir, dev):
     from sast_amd.detection import YOLOPAFPN
     g = _load(golden_dir, "pafpn")
