@@ -21,7 +21,7 @@
 // * LDS: A and B tiles are stored reduce-major ([r][m]) so a lane's MFMA operand is a
 //   conflict-free ds_read_b32; RC tiles are transposed on the way in with a row pad
 //   chosen so the 4 scalar ds_writes of a float4 hit 32 distinct banks.
-// * split-R form (weight gradients): gridDim.y partitions the reduction, the epilogue
+// * split-R form (weight gradients): `nsplit` work items per output tile partition the reduction, the epilogue
 //   accumulates atomically; optionally the column sums of the A operand (bias gradient)
 //   are produced by the same pass (COLSUM) so dY is read once.
 #pragma once
@@ -29,13 +29,27 @@
 #include <hip/hip_ext.h>
 #include "common.cuh"
 
+// per-block phase timestamps for the micro-benchmarks (k_test.hip defines SAST_TL before including this header; the
+// product translation units compile it away)
+#ifndef SAST_TL
+#define SAST_TL(k)
+#endif
+
 namespace sast {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16, int KS_ = 1>
+// PF: k-tiles kept in flight in registers per k-group (global-load latency under load is ~2-3 us on MI355X, one k-tile of
+// MFMA work is ~0.2-0.4 us: see tools/gemm_timeline.py).  Must be even (LDS is double-buffered).
+#ifndef SAST_PF_DEFAULT
+#define SAST_PF_DEFAULT 2
+#endif
+// OCC: blocks per CU the register allocation must leave room for (0 = no constraint beyond the block size).
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16, int KS_ = 1, int PF_ = SAST_PF_DEFAULT, int OCC_ = 0>
 struct Tile {
-  static constexpr int BM = BM_, BN = BN_, BK = BK_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, G = G_, KS = KS_;
+  static constexpr int BM = BM_, BN = BN_, BK = BK_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, G = G_, KS = KS_, PF = PF_;
+  static constexpr int MINW = OCC_ > 0 ? OCC_ * ((WAVES_M_ * WAVES_N_ * KS_ + 3) / 4) : 1;   // min waves per SIMD (launch bounds)
+  static_assert(PF >= 2 && PF % 2 == 0, "PF");
   // KS > 1: intra-block split of the reduction over KS wave groups (each with private LDS stages).  When M*N yields too
   // few tiles to give every SIMD two waves, this puts KS waves on each SIMD so MFMA overlaps the other group's LDS traffic.
   static constexpr int NTG = 64 * WAVES_M * WAVES_N;   // threads per k-group
@@ -59,9 +73,9 @@ template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
 template <class T, class LA, class LB, class EP, bool SPLIT>
-__global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M, int NJ, int R,
-                                                     const int* __restrict__ dM, const int* __restrict__ dR,
-                                                     float* __restrict__ colsum) {
+__global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP ep, int M, int NJ, int R,
+                                                              const int* __restrict__ dM, const int* __restrict__ dR,
+                                                              float* __restrict__ colsum, int nsplit, int xcd_remap) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NTG, G = T::G, BJ = T::BJ, KS = T::KS;
   // LDS tile layouts: a reduce-contiguous (RC) operand keeps its natural [row][k] order (row stride LDK = BK + 4 floats):
   // one ds_write_b128 per global float4 and BK/8 ds_read_b128 per lane per k-tile, both conflict-free; an index-contiguous
@@ -80,28 +94,43 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
   const int tid = threadIdx.x % NT, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / T::WAVES_N, wn = wave % T::WAVES_N;
   const int nbj = (NJ + BJ - 1) / BJ;
-  const int bj = blockIdx.x % nbj, bm = blockIdx.x / nbj;
+  // 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (each with a private L2); with xcd_remap the launch order is
+  // re-read so that consecutive work items -- the column tiles that share the same A rows, and all tiles of one reduction
+  // split -- run on the SAME XCD at about the same time and share its L2 instead of fetching the rows once per XCD.
+  int work = blockIdx.x;
+  if (xcd_remap) {
+    work = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  }
+  const int ntile = nbj * ((M + BM - 1) / BM);
+  if (work >= ntile * nsplit) return;
+  const int tile_id = SPLIT ? work % ntile : work, split_id = SPLIT ? work / ntile : 0;
+  const int bj = tile_id % nbj, bm = tile_id / nbj;
   const int m0 = bm * BM, j0 = bj * BJ;
   const int Meff = dM ? min(M, *dM) : M;
   const int Reff = dR ? min(R, *dR) : R;
+  SAST_TL(0);
   if (m0 >= Meff) return;
   const int nkt = (Reff + BK - 1) / BK;
   int kt0 = 0, kt1 = nkt;
   if (SPLIT) {
-    const int per = (nkt + gridDim.y - 1) / gridDim.y;
-    kt0 = blockIdx.y * per;
+    const int per = (nkt + nsplit - 1) / nsplit;
+    kt0 = split_id * per;
     kt1 = min(nkt, kt0 + per);
   }
   if (kt0 >= kt1) return;
 
   constexpr int A_SLOTS = BM * BK / 4, B_SLOTS = BN * BK / 4;
   constexpr int A_PER = (A_SLOTS + NT - 1) / NT, B_PER = (B_SLOTS + NT - 1) / NT;
-  // two k-tiles in flight (global-load latency ~ 2 compute phases).  Loaded registers are NOT touched until the LDS store
-  // one or two phases later (validity select / LayerScale multiply are deferred to `finish`), so hipcc can keep the loads
-  // outstanding behind counted s_waitcnt vmcnt(N) instead of draining them right after issue.
-  float4 ra[2][A_PER], rb[2][B_PER];
-  float aa[2][A_PER], ab[2][B_PER];
-  bool oa[2][A_PER], ob[2][B_PER];
+  // PF k-tiles in flight.  Loaded registers are NOT touched until the LDS store PF-1 phases later (validity select /
+  // LayerScale multiply are deferred to `finish`), so hipcc keeps the loads outstanding behind counted s_waitcnt vmcnt(N)
+  // instead of draining them right after issue.
+  constexpr int PF = T::PF;
+  float4 ra[PF][A_PER], rb[PF][B_PER];
+  float aa[PF][A_PER], ab[PF][B_PER];
+  bool oa[PF][A_PER], ob[PF][B_PER];
+  // rows at or beyond the end of this block's reduction range read as zeros: the pipeline below never branches on tile
+  // validity (a k-group that owns one tile fewer than its siblings multiplies a zero tile instead)
+  const int Rl = min(Reff, kt1 * BK);
 
   auto nnmap = [&](int jl, int g) -> int {  // (local channel, group) -> column inside the block tile
     const int jb = jl >> 5;
@@ -149,10 +178,10 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     const int r0 = kt * BK;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) la.load(ca[it], r0 + ra_off[it], Reff, ra[set][it], aa[set][it], oa[set][it]);
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) la.load(ca[it], r0 + ra_off[it], Rl, ra[set][it], aa[set][it], oa[set][it]);
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
-      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) lb.load(cb[it], r0 + rb_off[it], Reff, rb[set][it], ab[set][it], ob[set][it]);
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) lb.load(cb[it], r0 + rb_off[it], Rl, rb[set][it], ab[set][it], ob[set][it]);
   };
 
   auto lstore = [&](int buf, int set) {
@@ -165,6 +194,15 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
     for (int it = 0; it < B_PER; ++it)
       if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
   };
+
+  // epilogue operands are requested EARLY: the per-column constants (bias, LayerScale gamma ...) before the reduction loop,
+  // the per-element ones (residual / gathered rows) right after it when the tile is a single MFMA block -- otherwise the
+  // epilogue starts with a full global-load latency (~2 us of the ~6 us a K=64 block lives; tools/gemm_timeline.py)
+  typename EP::Col ecol[T::TJ];
+#pragma unroll
+  for (int tj = 0; tj < T::TJ; ++tj) ecol[tj] = ep.col(min(j0 + (wn * T::TJ + tj) * 32 + (lane & 31), NJ - 1));
+  constexpr bool EARLY_AUX = T::TM * T::TJ == 1;
+  typename EP::Aux eaux[EARLY_AUX ? 16 : 1];
 
   f32x16 acc[T::TM][T::TN];
 #pragma unroll
@@ -220,44 +258,46 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
           acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][ks], b[tb][ks], acc[ta][tb], 0, 0, 0);
   };
 
-  // software pipeline: this k-group owns tiles kt0 + kg + KS*i; tiles i+1 and i+2 are in flight (registers) while tile i
-  // is multiplied out of LDS.  n_it is block-uniform so every wave meets every barrier.
+  // software pipeline: this k-group owns tiles kt0 + kg + KS*i.  At phase p the LDS buffer p%2 holds tile p, register set
+  // (p+1)%PF .. (p+PF-1)%PF hold tiles p+1 .. p+PF-1 and set p%PF (stored to LDS one phase ago) is refilled with tile p+PF.
+  // All loads are issued UNCONDITIONALLY (tiles past the end read clamped addresses and become zeros), so the compiler's
+  // s_waitcnt vmcnt(N) before each LDS store counts exactly the PF-1 younger tiles and leaves them in flight; with loads
+  // under a validity branch it has to assume the not-taken path and drains everything.  n_it is block-uniform.
   const int n_it = (kt1 - kt0 + KS - 1) / KS;
   auto tile_of = [&](int i) { return kt0 + kg + KS * i; };
-  auto valid = [&](int i) { return tile_of(i) < kt1; };
-  if (valid(0)) gload(tile_of(0), 0);
-  if (valid(1)) gload(tile_of(1), 1);
-  if (valid(0)) lstore(0, 0);
+#pragma unroll
+  for (int u = 0; u < PF; ++u) gload(tile_of(u), u);
+  lstore(0, 0);
   __syncthreads();
-  // Steady state (every k-group still has tiles i+2 and i+3): loads are issued UNCONDITIONALLY, so the compiler's
-  // s_waitcnt vmcnt(N) before each LDS store counts exactly the two loads of the younger tile and leaves them in flight.
-  // (With the loads under a branch it has to assume the not-taken path and drains everything: no prefetch.)
-  const int n_all = (kt1 - kt0) / KS;     // iterations in which every k-group owns a valid tile (block-uniform)
+  SAST_TL(1);
   int i = 0;
-  for (; i + 3 < n_all; i += 2) {
-    gload(tile_of(i + 2), 0);
-    compute(0);
-    lstore(1, 1);
-    __syncthreads();
-    gload(tile_of(i + 3), 1);
-    compute(1);
-    lstore(0, 0);
-    __syncthreads();
+  for (; i + PF <= n_it; i += PF) {   // no exits inside the unrolled body: one straight-line block per PF phases
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      gload(tile_of(i + u + PF), u);
+      compute(u & 1);
+      lstore((u + 1) & 1, (u + 1) % PF);
+      __syncthreads();
+    }
   }
-  for (; i < n_it; i += 2) {   // tail: per-group validity checks
-    // even phase: LDS buffer 0 holds tile i; register set 1 holds tile i+1; refill set 0 with tile i+2
-    if (valid(i + 2)) gload(tile_of(i + 2), 0);
-    if (valid(i)) compute(0);
-    if (valid(i + 1)) lstore(1, 1);
-    __syncthreads();
-    if (i + 1 >= n_it) break;
-    // odd phase
-    if (valid(i + 3)) gload(tile_of(i + 3), 1);
-    if (valid(i + 1)) compute(1);
-    if (valid(i + 2)) lstore(0, 0);
-    __syncthreads();
+  if constexpr (EARLY_AUX) {
+    const int jc = min(j0 + wn * 32 + (lane & 31), NJ - 1), mb = m0 + wm * T::WTM + 4 * (lane >> 5);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) eaux[reg] = ep.pre(min(mb + (reg & 3) + 8 * (reg >> 2), Meff - 1), jc);
+  }
+  {   // remainder (< PF phases): everything it needs is already in registers
+    const int rem = n_it - i;
+#pragma unroll
+    for (int u = 0; u < PF - 1; ++u) {
+      if (u < rem) {
+        compute(u & 1);
+        lstore((u + 1) & 1, (u + 1) % PF);
+        __syncthreads();
+      }
+    }
   }
 
+  SAST_TL(2);
   if constexpr (KS > 1) {   // fold the k-groups' partial accumulators into group 0 through LDS
     float* red = smem + kg * GROUP_FLOATS + (wave * T::TM * T::TN) * 16 * 64 + lane;
     if (kg > 0) {
@@ -307,6 +347,7 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
   //   Col col(j)              per-column constants (bias, LayerScale gamma ...), once per lane and column tile
   //   Aux pre(m, j)           per-element loads only (residual, gathered row ...), indices already clamped in range
   //   post(m, j, v, col, aux) arithmetic + stores, executed under the bounds predicate
+  SAST_TL(3);
   constexpr bool STATS = EpHasStats<EP>::value;
   float cs[T::TJ], cq[T::TJ];
 #pragma unroll
@@ -318,10 +359,13 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
       const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
       const int jc = min(j, NJ - 1);
       const int mb = m0 + wm * T::WTM + ta * 32 + 4 * (lane >> 5);
-      const typename EP::Col col = ep.col(jc);
+      const typename EP::Col col = ecol[tj];
       typename EP::Aux aux[16];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) aux[reg] = ep.pre(min(mb + (reg & 3) + 8 * (reg >> 2), Meff - 1), jc);
+      for (int reg = 0; reg < 16; ++reg) {
+        if constexpr (EARLY_AUX) aux[reg] = eaux[reg];
+        else aux[reg] = ep.pre(min(mb + (reg & 3) + 8 * (reg >> 2), Meff - 1), jc);
+      }
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int m = mb + (reg & 3) + 8 * (reg >> 2);
@@ -342,6 +386,7 @@ __global__ __launch_bounds__(T::NT) void gemm_kernel(LA la, LB lb, EP ep, int M,
       if (lane < 32 && j < NJ) { atomicAdd(ep.sums + j, (double)s); atomicAdd(ep.sums + NJ + j, (double)q); }
     }
   }
+  SAST_TL(4);
 }
 
 // ---- optional per-launch HIP-event timing of the GEMM family (bench.py roofline leg; off by default).
@@ -352,6 +397,7 @@ void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, co
 void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st,
                         hipEvent_t* e0, hipEvent_t* e1);
 bool prof_enabled();
+bool xcd_remap_enabled();   // SAST_XCD_REMAP (default on)
 void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin);
 struct ProfScope {
   const char* n; int c, m; hipStream_t st; bool on;
@@ -364,14 +410,16 @@ inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, 
                        const int* dR, hipStream_t st) {
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
+  const int remap = xcd_remap_enabled() && nb >= 16;
+  const int grid = remap ? (nb + 7) / 8 * 8 : nb;
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R, dM, dR,
-                          (float*)nullptr);
+    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R, dM, dR,
+                          (float*)nullptr, 1, remap);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(nb), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
-                       (float*)nullptr);
+    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
+                       (float*)nullptr, 1, remap);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -385,14 +433,16 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
   if (splits < 1) splits = 1;
+  const int remap = xcd_remap_enabled() && nb * splits >= 16;
+  const int grid = remap ? (nb * splits + 7) / 8 * 8 : nb * splits;
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R,
-                          (const int*)nullptr, dR, colsum);
+    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R,
+                          (const int*)nullptr, dR, colsum, splits, remap);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(nb, splits), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
-                       (const int*)nullptr, dR, colsum);
+    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
+                       (const int*)nullptr, dR, colsum, splits, remap);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -469,8 +519,23 @@ struct LdRows2 {
   }
   SAST_DEFAULT_FINISH
 };
-// IC rows (transposed use): X(t)[r][i] = p[row(r)*ld + i]
+// IC rows (transposed use): X(t)[r][i] = p[row(r)*ld + i].  The gathered form (row(r) = idx[r]) is a separate type: a
+// `idx ? idx[r] : r` inside load() is a branch around a global load, after which hipcc drains vmcnt(0) before EVERY load of
+// the k-loop (seen in the ISA: no two loads of a wave were ever in flight together in the weight-gradient kernels).
 struct LdRowsT {
+  static constexpr bool RC = false;
+  const float* p; int ld;
+  struct Ctx { int i; bool ok; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return Ctx{i < Ieff ? i : 0, i < Ieff}; }
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = ld4(p + (size_t)min(r, Reff - 1) * ld + c.i);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+struct LdRowsTG {  // gathered rows: row(r) = idx[r] (a dependent load per k-tile)
   static constexpr bool RC = false;
   const float* p; int ld; const int* idx;
   struct Ctx { int i; bool ok; };
@@ -478,8 +543,7 @@ struct LdRowsT {
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    const int rr = min(r, Reff - 1);
-    v = ld4(p + (size_t)(idx ? idx[rr] : rr) * ld + c.i);
+    v = ld4(p + (size_t)idx[min(r, Reff - 1)] * ld + c.i);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -516,8 +580,21 @@ struct LdWeightNT {
   }
   SAST_DEFAULT_FINISH
 };
-// weights used as B[r][j] = w[r*ldw + j]  (dx = dy W), optional per-row scale (LayerScale folded in)
+// weights used as B[r][j] = w[r*ldw + j]  (dx = dy W)
 struct LdWeightNN {
+  static constexpr bool RC = false;
+  const float* w; int ldw;
+  struct Ctx { const float* col; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{w + (j < NJ ? j : 0), j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = ld4(c.col + (size_t)min(r, Reff - 1) * ldw);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+// same with a per-row scale (LayerScale gamma folded into the weight rows); separate type, see LdRowsT
+struct LdWeightNNS {
   static constexpr bool RC = false;
   const float* w; int ldw; const float* rscale;
   struct Ctx { const float* col; bool ok; };
@@ -526,7 +603,7 @@ struct LdWeightNN {
     const int rr = min(r, Reff - 1);
     ok = c.ok && r < Reff;
     v = ld4(c.col + (size_t)rr * ldw);
-    aux = rscale ? rscale[rr] : 1.f;
+    aux = rscale[rr];
   }
   __device__ __forceinline__ float4 finish(float4 v, float aux, bool ok) const {
     return ok ? make_float4(v.x * aux, v.y * aux, v.z * aux, v.w * aux) : zero4();

@@ -53,7 +53,10 @@ int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int
   const int max_splits = (R + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
+  static int k2 = -1;
+  if (k2 < 0) { const char* e = getenv("SAST_TN_K2"); k2 = e ? atoi(e) : 1; }
+  if (k2) return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
+  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
 }
 
 // ---------------------------------------------------------------- epilogues (protocol: col / pre / post, see gemm.cuh)
@@ -228,11 +231,11 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   // dxp = direct + dz Ws
   Side sd(st);
   sd.after_main();
-  rc = gemm_tn(LdRowsT{dz, C, nullptr}, LdRowsT{a->xp, C, nullptr}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b, sd.side);
+  rc = gemm_tn(LdRowsT{dz, C}, LdRowsT{a->xp, C}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b, sd.side);
   if (rc) return rc;
   rc = controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, sd.side);
   if (rc) return rc;
-  return gemm_auto(LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C, nullptr}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
+  return gemm_auto(LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
 }
 
 // ------------------------------------------------------------------ MS-WSA
@@ -315,37 +318,40 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   }
   // fc2 grads (raw, LayerScale applied in the finish kernel): need only dZ (= dout rows) and H
   sd.after_main();
-  rc = gemm_tn(LdRowsT{dz, C, dz_tok}, LdRowsT{a->Hh, inner, nullptr}, raw2, inner, C, inner, R, dR, s2, sd.side);
+  rc = dz_tok ? gemm_tn(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, sd.side)
+              : gemm_tn(LdRowsT{dz, C}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, sd.side);
   if (rc) return rc;
   rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, sd.side);
   if (rc) return rc;
   // dH = (gamma2 * dZ) W2 ; fused: dUG from the saved pre-activations
-  rc = gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+  rc = a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st)
+              : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
   if (rc) return rc;
   sd.after_main();
-  rc = gemm_tn(LdRowsT{dUG, 2 * inner, nullptr}, LdRowsT{a->Y, C, nullptr}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b, sd.side);
+  rc = gemm_tn(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b, sd.side);
   if (rc) return rc;
   // dY = dZ + dUG W1
-  rc = gemm_auto(LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C, nullptr}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C,
+  rc = gemm_auto(LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C,
                  2 * inner, dR, st);
   if (rc) return rc;
   sd.after_main();
-  rc = gemm_tn(LdRowsT{dY, C, nullptr}, LdRowsT{a->O, C, nullptr}, raw1, C, C, C, R, dR, s1, sd.side);
+  rc = gemm_tn(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, sd.side);
   if (rc) return rc;
   rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, sd.side);
   if (rc) return rc;
   // dO = (gamma1 * dY) Wp
-  rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+  rc = a->ls1 ? gemm_auto(LdRows{dY, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st)
+              : gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   if (rc) return rc;
   // attention backward
   rc = T <= 64 ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, C, st)
                : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, st);
   if (rc) return rc;
   sd.after_main();
-  rc = gemm_tn(LdRowsT{dQKV, 3 * C, nullptr}, LdRowsT{a->S, C, nullptr}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);
+  rc = gemm_tn(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);
   if (rc) return rc;
   // dS = dY + dQKV Wqkv
-  rc = gemm_auto(LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C, nullptr}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
+  rc = gemm_auto(LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
   if (rc) return rc;
   // LN2 (kept rows) + LN1 (all tokens) backward
   return ln1_gather_bwd_launch(a->xin, a->dout, dS, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->mean1, a->rstd1, a->mean2,
@@ -380,10 +386,10 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
   Side sd(st);
   sd.after_main();
-  int rc = gemm_tn(LdRowsT{dmix, 4 * C, nullptr}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
+  int rc = gemm_tn(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
                    sd.side);
   if (rc) return rc;
-  return gemm_auto(LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C, nullptr}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
+  return gemm_auto(LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
 }
 
 }  // extern "C"

@@ -43,7 +43,10 @@ int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int
   const int max_splits = (R + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
-  return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
+  static int k2 = -1;
+  if (k2 < 0) { const char* e = getenv("SAST_TN_K2"); k2 = e ? atoi(e) : 1; }
+  if (k2) return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
+  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
 }
 
 // ---------------------------------------------------------------- BatchNorm pieces
@@ -295,7 +298,7 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
   if (rc) return rc;
   Side sd(st);
   sd.after_main();
-  rc = gemm_tn(LdRowsT{dconv, a->Cout, nullptr}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, sd.side);
+  rc = gemm_tn(LdRowsT{dconv, a->Cout}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, sd.side);
   if (rc) return rc;
   if (a->dx) {
     const int Min = a->B * a->H * a->W;
@@ -367,11 +370,11 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   Side sd(st);
   sd.after_main();
   if (k == 1 && a->stride == 1) {
-    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdRowsT{a->x, a->ldx, nullptr}, a->dw, K, C, K, M, sd.side);
+    rc = gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, sd.side);
     if (rc) return rc;
-    if (a->dx) rc = gemm_auto(LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K, nullptr}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, st);
+    if (a->dx) rc = gemm_auto(LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, st);
   } else {
-    rc = gemm_tn(LdRowsT{dconv, C, nullptr}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, sd.side);
+    rc = gemm_tn(LdRowsT{dconv, C}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, sd.side);
     if (rc) return rc;
     if (a->dx)
       rc = gemm_auto(LdConvDx{dconv, g, C, C, pow2_shift(C)}, LdWeightConvDx{a->w, C, k * k, a->Cin, pow2_shift(C)}, EpStore{a->dx, a->lddx, nullptr},

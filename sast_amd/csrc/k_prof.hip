@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "../../include/sast_hip.h"
 
@@ -15,6 +16,12 @@ static std::vector<ProfLaunch> g_launches;
 static std::vector<hipEvent_t> g_pending;
 
 bool prof_enabled() { return g_on; }
+
+bool xcd_remap_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_XCD_REMAP"); v = e ? (atoi(e) != 0) : 1; }
+  return v != 0;
+}
 
 void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin) {
   if (begin) {

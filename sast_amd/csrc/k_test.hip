@@ -1,14 +1,37 @@
 // micro-benchmark / unit-test entry points for the GEMM template (not used by the product path)
+#include <hip/hip_runtime.h>
+// phase timestamps (100 MHz wall clock) of every block of the LAST instrumented launch: only the kernel instantiations of
+// this translation unit carry them (they use the test-only epilogues below, so no product kernel is affected)
+__device__ unsigned long long sast_tl_buf[8 * 8192];
+#define SAST_TL(k)                                                                                          \
+  do {                                                                                                      \
+    const unsigned bid_ = blockIdx.y * gridDim.x + blockIdx.x;                                              \
+    if (threadIdx.x == 0 && bid_ < 8192) sast_tl_buf[bid_ * 8 + (k)] = wall_clock64();                      \
+    if (threadIdx.x == 0 && bid_ < 8192 && (k) == 0) sast_tl_buf[bid_ * 8 + 7] = __smid();                 \
+  } while (0)
 #include "gemm.cuh"
 #include "kernels.h"
 using namespace sast;
+
+extern "C" int sast_test_timeline_reset(void) {
+  static unsigned long long zeros[8 * 8192];
+  return hipMemcpyToSymbol(HIP_SYMBOL(sast_tl_buf), zeros, sizeof(zeros)) == hipSuccess ? 0 : -5;
+}
+extern "C" int sast_test_timeline(unsigned long long* host_out, int nblocks) {
+  if (nblocks > 8192) nblocks = 8192;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sast_tl_buf), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -5;
+}
+
+struct EpStoreT : EpStore {  // distinct type: keeps the instrumented instantiations apart from the product's
+  EpStoreT(float* c_, int ld_, const float* b_) : EpStore{c_, ld_, b_} {}
+};
 
 extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int tile,
                                  sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const LdRows la{a, K, nullptr};
   const LdWeightNT lb{w, K, 0};
-  const EpStore ep{c, N, bias};
+  const EpStoreT ep(c, N, bias);
   switch (tile) {
     case 0: return launch_gemm<TileSmall>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 1: return launch_gemm<TileMid>(la, lb, ep, M, N, K, nullptr, nullptr, st);
@@ -44,11 +67,21 @@ struct EpNull {  // discards the result (measures the kernel without the atomic 
   }
 };
 
+struct EpAtomicT {  // same as EpAtomic, distinct type (instrumented instantiation)
+  float* c; int ldc;
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
+    atomicAdd(c + (size_t)m * ldc + j, v[0]);
+  }
+};
+
 extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, float* colsum, int Mo, int NJ, int R, int tile, int splits,
                                  int null_ep, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  const LdRowsT la{dy, Mo, nullptr};
-  const LdRowsT lb{x, NJ, nullptr};
+  const LdRowsT la{dy, Mo};
+  const LdRowsT lb{x, NJ};
   if (null_ep) {
     const EpNull ep{out};
     switch (tile) {
@@ -57,11 +90,26 @@ extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, fl
       case 2: return launch_gemm_split<TileSmallK4>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     }
   }
-  const EpAtomic ep{out, NJ};
+  const EpAtomicT ep{out, NJ};
   switch (tile) {
     case 0: return launch_gemm_split<TileSmall>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 1: return launch_gemm_split<TileSmallK2>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 2: return launch_gemm_split<TileSmallK4>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 20: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 2, 4, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 21: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 2, 4, 3>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 22: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 2, 6, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 23: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 2, 8, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 24: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 1, 4, 4>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 25: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 1, 8, 3>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 26: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 4, 4, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 27: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 2, 2, 4>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 28: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 1, 2, 8>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 30: return launch_gemm_split<Tile<128, 64, 2, 2, 1, 16, 1, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 32: return launch_gemm_split<Tile<64, 128, 2, 2, 1, 16, 1, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 33: return launch_gemm_split<Tile<128, 128, 2, 2, 1, 16, 1, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 34: return launch_gemm_split<Tile<192, 64, 2, 2, 1, 16, 1, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 35: return launch_gemm_split<Tile<128, 64, 4, 1, 1, 16, 1, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+    case 36: return launch_gemm_split<Tile<128, 64, 4, 2, 1, 16, 1, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 3: return launch_gemm_split<Tile<128, 128, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 4: return launch_gemm_split<Tile<192, 64, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 5: return launch_gemm_split<Tile<320, 64, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
