@@ -43,7 +43,7 @@ def synthetic_events(B, hw, seed):
 class Trainer:
     """minimal training step of the hot path (the reference's is Lightning's, modules/detection.py:113-221)."""
 
-    def __init__(self, dev, amp, world, use_graph, seq_len=1):
+    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.dist import FlatParams, FusedAdamW
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -62,12 +62,18 @@ class Trainer:
         # recurrent states carried, PAFPN + loss on the last one, one backward through time.  Default 1 = BASELINE's metric.
         self.xs = [synthetic_events(BATCH, HW, seed=rank + 1000 * t).to(dev) for t in range(seq_len)]
         self.x = self.xs[0]
+        self.fwd_only = fwd_only     # --fwd-only: backbone forward, the reference's own benchmark.py protocol (BASELINE config C2)
         self.loss = None
         self.P = None
         self.graph = None
         self.use_graph = use_graph
 
     def fwd_bwd(self):
+        if self.fwd_only:
+            with torch.no_grad():
+                feats, _states, P = self.net.forward_nhwc(self.x)
+            self.loss, self.P, self.feats = feats[4].sum(), P, feats
+            return
         self.flat.zero_grad()
         states = None
         for x in self.xs:
@@ -78,6 +84,8 @@ class Trainer:
         self.loss, self.P = loss.detach(), P
 
     def update(self):
+        if self.fwd_only:
+            return
         self.flat.all_reduce()
         self.opt.step(grad_scale=1.0 / self.world)
 
@@ -117,7 +125,7 @@ class Trainer:
             self.update()
 
 
-def cpu_baseline(amp, init_state, seconds_budget=25.0):
+def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False):
     """the oracle (torch-CPU port of the reference path) timed on this box's host cores on a bounded sample,
     on the same initial weights and the same input as rank 0's GPU leg."""
     from oracle import sast_oracle as O
@@ -128,6 +136,10 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0):
     x = synthetic_events(BATCH, HW, seed=0)
 
     def one():
+        if fwd_only:
+            with torch.no_grad():
+                O.backbone(x, None, p, ocfg)
+            return
         for t in list(p.values()) + list(f.values()):
             t.grad = None
         out, _s, _P = O.backbone(x, None, p, ocfg)
@@ -154,10 +166,11 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0):
         one()
         n += 1
         el = time.perf_counter() - t0
-        if el > seconds_budget or n >= 8:
+        if el > seconds_budget or n >= (32 if fwd_only else 8):
             break
     return {"value": BATCH * n / el, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fwd+bwd steps of the same workload (B={BATCH}, 384x640, backbone+PAFPN, proxy loss), "
+            "sample": (f"{n} backbone forward passes of the same workload (B={BATCH}, {HW[0]}x{HW[1]}), " if fwd_only else
+                       f"{n} fwd+bwd steps of the same workload (B={BATCH}, {HW[0]}x{HW[1]}, backbone+PAFPN, proxy loss), ") +
                       f"oracle/sast_oracle.py, torch {torch.__version__} CPU, {cores} threads, no optimizer step"}
 
 
@@ -171,6 +184,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (BASELINE config: 4; sparsity sweep C5: 8)")
     ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
     ap.add_argument("--seq-len", type=int, default=1, help="timesteps per step with recurrent state + BPTT (1 = BASELINE metric)")
+    ap.add_argument("--fwd-only", action="store_true", help="backbone forward only (reference benchmark.py protocol; BASELINE config C2 with --res gen1)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -203,7 +217,7 @@ def main():
     run_stream = torch.cuda.Stream()
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
-    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len)
+    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only)
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -236,7 +250,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
-                                   " full SAST backbone + PAFPN, fwd+bwd + AdamW, "
+                                   (" full SAST backbone, forward only (benchmark.py protocol), " if args.fwd_only else
+                                    " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
@@ -247,7 +262,7 @@ def main():
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr)
         if not args.no_cpu_baseline and world == 1 and args.seq_len == 1:
-            res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state)
+            res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

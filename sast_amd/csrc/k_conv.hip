@@ -4,6 +4,9 @@
 //   - nearest x2 upsample + concat, concat                yolo_pafpn.py:117-137
 //   - fused AdamW on the flat parameter buffer
 #include <cstdlib>
+#ifdef SAST_CONV_PF
+#define SAST_PF_DEFAULT SAST_CONV_PF
+#endif
 #include "gemm.cuh"
 #include "kernels.h"
 

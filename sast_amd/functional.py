@@ -172,6 +172,7 @@ class _ScoreSTP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, r, ws_w, ws_b, wc, amp):
         _need_gpu(xp, r, ws_w)
+        ctx.set_materialize_grads(False)   # no zero-filled gradient for the non-differentiable token scores
         xp = xp.contiguous()
         B = xp.shape[0]
         Cc = xp.shape[-1]
@@ -196,6 +197,8 @@ class _ScoreSTP(torch.autograd.Function):
         xp, r, scale, s = ctx.saved_tensors
         ws_w, ws_b, wc = ctx.params
         B, Lt, Cc, amp = ctx.meta
+        if dxw is None:
+            return None, None, None, None, None, None
         dxw = dxw.contiguous()
         dxp = torch.empty_like(xp)
         ws = torch.empty(B * Lt * Cc + B * Cc, device=xp.device)
@@ -340,6 +343,38 @@ def selection_from_index_lists(index_window, asy_index, K, n_groups: int, T: int
     sel.mask = torch.zeros(n_groups, 2, device=device, dtype=torch.int64)
     sel.tok = None
     return sel
+
+
+class DeviceCount:
+    """sum of 0-dim device integers that is only evaluated when somebody looks at it (int(), .item(), .tensor()).
+    The reference returns python ints for the kept-token count P (SAST.py:136,159; >= 8 host syncs per block); on the
+    device-resident path even a 2-element integer add is a ~5 us kernel launch per block, so the additions are deferred."""
+    __slots__ = ("terms",)
+
+    def __init__(self, terms=()):
+        self.terms = tuple(terms)
+
+    def __add__(self, other):
+        if isinstance(other, DeviceCount):
+            return DeviceCount(self.terms + other.terms)
+        if isinstance(other, int) and other == 0:
+            return self
+        return DeviceCount(self.terms + (other,))
+
+    __radd__ = __add__
+
+    def tensor(self) -> torch.Tensor:
+        ts = [t if isinstance(t, torch.Tensor) else torch.as_tensor(t) for t in self.terms]
+        return torch.stack([t.to(ts[0].device).long() for t in ts]).sum() if ts else torch.zeros((), dtype=torch.long)
+
+    def item(self) -> int:
+        return int(self.tensor().item())
+
+    __int__ = item
+    __index__ = item
+
+    def __repr__(self):
+        return f"DeviceCount({len(self.terms)} terms)"
 
 
 # ---------------------------------------------------------------------------------------------- a9

@@ -182,9 +182,9 @@ class SAST_block(nn.Module):
                 raise TypeError("sast_amd: index_list must be the [Selection, Selection] pair returned by the first block")
         x = self.win_attn.forward_image(xw, sel1, self.enable_CB)
         x = self.grid_attn.forward_image(x, sel2, self.enable_CB)
-        count = sel1.counts[2] + sel2.counts[2]          # SAST.py:136,159 (floor per layer), device scalar
+        count = SF.DeviceCount((sel1.counts[2], sel2.counts[2]))   # SAST.py:136,159 (floor per layer), summed lazily on the device
         if self.sync_index_count:
-            count = int(count.item())
+            count = count.item()
         return x, count, [sel1, sel2]
 
     def forward(self, x: torch.Tensor, pos_emb, r: torch.Tensor, index_list) -> Tuple[torch.Tensor, object, List]:
