@@ -101,6 +101,7 @@ typedef struct SastMswsaArgs {
   int32_t B, H, W, C, ph, pw, mode, inner;
   float eps;
   int32_t cb_tps;        /* Context Broadcasting (enable_CB, SAST.py:240-246): tokens per sample, 0 = off */
+  int32_t dim_head;      /* attention head width (SAST.py:171-181): 32 (default when 0) or 24; heads = C / dim_head */
   const float* xin;      /* [B*L, C] image layout */
   float* out;            /* [B*L, C] */
   SastSel sel;
@@ -109,7 +110,7 @@ typedef struct SastMswsaArgs {
   /* saved for backward; R = B*L rows upper bound */
   float *mean1, *rstd1;  /* [B*L] */
   float *mean2, *rstd2;  /* [R] */
-  float *S, *QKV, *O, *lse, *Y, *UG, *Hh; /* [R,C] [R,3C] [R,C] [R,C/32] [R,C] [R,2*inner] [R,inner] */
+  float *S, *QKV, *O, *lse, *Y, *UG, *Hh; /* [R,C] [R,3C] [R,C] [R,heads] [R,C] [R,2*inner] [R,inner] */
   /* backward */
   const float* dout; float* dxin;
   float *d_ln1_w, *d_ln1_b, *d_ln2_w, *d_ln2_b, *d_qkv_w, *d_qkv_b, *d_proj_w, *d_proj_b, *d_ls1;

@@ -57,10 +57,11 @@ class BackboneCfg:
     amp: float = 2e-4
     bounce: float = 1e-3
     enable_cb: bool = False
+    dim_head: int = 32     # 24 in the reference's "small" size (config/experiment/gen1/small.yaml)
 
     def __post_init__(self):
         self.attn = AttnCfg(partition_size=tuple(self.partition_size), amp=self.amp,
-                            bounce=self.bounce, enable_cb=self.enable_cb)
+                            bounce=self.bounce, enable_cb=self.enable_cb, dim_head=self.dim_head)
 
     @property
     def stage_dims(self):

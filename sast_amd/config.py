@@ -34,14 +34,14 @@ def modified_hw(dataset_hw, partition_split_32=2):
 
 
 def backbone_config(in_res_hw, partition_size, embed_dim=64, num_blocks=(1, 1, 1, 1), AMP=2e-4, BOUNCE=1e-3,
-                    ls_init_value=1e-5, enable_CB=False, input_channels=20):
+                    ls_init_value=1e-5, enable_CB=False, input_channels=20, dim_head=32):
     return to_attr({
         "name": "SASTRNN", "compile": None, "input_channels": input_channels, "enable_masking": False,
         "partition_split_32": 2, "embed_dim": embed_dim, "dim_multiplier": [1, 2, 4, 8], "num_blocks": list(num_blocks),
         "T_max_chrono_init": [4, 8, 16, 32], "stem": {"patch_size": 4}, "in_res_hw": tuple(in_res_hw),
         "stage": {
             "downsample": {"type": "patch", "overlap": True, "norm_affine": True},
-            "attention": {"use_torch_mha": False, "partition_size": tuple(partition_size), "dim_head": 32,
+            "attention": {"use_torch_mha": False, "partition_size": tuple(partition_size), "dim_head": dim_head,
                           "attention_bias": True, "mlp_activation": "gelu", "mlp_gated": False, "mlp_bias": True,
                           "mlp_ratio": 4, "drop_mlp": 0, "drop_path": 0, "ls_init_value": ls_init_value,
                           "enable_CB": enable_CB, "AMP": AMP, "BOUNCE": BOUNCE},

@@ -16,8 +16,7 @@
 
 namespace sast {
 
-constexpr int DH = 32;
-
+template <int DH>
 __device__ __forceinline__ float dot32(const float (&q)[DH], const float* __restrict__ k) {
   float s = 0.f;
 #pragma unroll
@@ -28,7 +27,7 @@ __device__ __forceinline__ float dot32(const float (&q)[DH], const float* __rest
   return s;
 }
 
-template <int NT>
+template <int NT, int DH>
 __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                       float* __restrict__ lse, const int* __restrict__ row_off,
                                                       const int* __restrict__ Kw, int C, int heads, float scale, int T) {
@@ -40,28 +39,28 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
   float* ks = sm;              // [T][32]
   float* vs = sm + T * DH;     // [T][32]
   const int C3 = 3 * C;
-  for (int e = threadIdx.x; e < K * 8; e += NT) {
-    const int j = e >> 3, d4 = (e & 7) * 4;
-    const float* src = qkv + (size_t)(r0 + j) * C3 + h * 96;
-    st4(ks + j * DH + d4, ld4(src + 32 + d4));
-    st4(vs + j * DH + d4, ld4(src + 64 + d4));
+  for (int e = threadIdx.x; e < K * (DH / 4); e += NT) {
+    const int j = e / (DH / 4), d4 = (e % (DH / 4)) * 4;
+    const float* src = qkv + (size_t)(r0 + j) * C3 + h * 3 * DH;
+    st4(ks + j * DH + d4, ld4(src + DH + d4));
+    st4(vs + j * DH + d4, ld4(src + 2 * DH + d4));
   }
   __syncthreads();
   const int i = threadIdx.x;
   if (i >= K) return;
   float q[DH];
   {
-    const float* src = qkv + (size_t)(r0 + i) * C3 + h * 96;
+    const float* src = qkv + (size_t)(r0 + i) * C3 + h * 3 * DH;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) { const float4 t = ld4(src + d); q[d] = t.x * scale; q[d + 1] = t.y * scale; q[d + 2] = t.z * scale; q[d + 3] = t.w * scale; }
   }
   float mx = -INFINITY;
-  for (int j = 0; j < K; ++j) mx = fmaxf(mx, dot32(q, ks + j * DH));
+  for (int j = 0; j < K; ++j) mx = fmaxf(mx, dot32<DH>(q, ks + j * DH));
   float l = 0.f, acc[DH];
 #pragma unroll
   for (int d = 0; d < DH; ++d) acc[d] = 0.f;
   for (int j = 0; j < K; ++j) {
-    const float p = expf(dot32(q, ks + j * DH) - mx);
+    const float p = expf(dot32<DH>(q, ks + j * DH) - mx);
     l += p;
     const float* vj = vs + j * DH;
 #pragma unroll
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_kernel(const float* __restrict__ 
 }
 
 // backward: recompute P from (q,k,lse); phase 1 lane = query (dQ), phase 2 lane = key (dK, dV)
-template <int NT>
+template <int NT, int DH>
 __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                       const float* __restrict__ dout, const float* __restrict__ lse,
                                                       float* __restrict__ dqkv, const int* __restrict__ row_off,
@@ -96,14 +95,14 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
   float* ls = gs + T * DH;        // lse [T]
   float* Ds = ls + T;             // D   [T]
   const int C3 = 3 * C;
-  for (int e = threadIdx.x; e < K * 8; e += NT) {
-    const int j = e >> 3, d4 = (e & 7) * 4;
-    const float* src = qkv + (size_t)(r0 + j) * C3 + h * 96;
+  for (int e = threadIdx.x; e < K * (DH / 4); e += NT) {
+    const int j = e / (DH / 4), d4 = (e % (DH / 4)) * 4;
+    const float* src = qkv + (size_t)(r0 + j) * C3 + h * 3 * DH;
     float4 qv = ld4(src + d4);
     qv.x *= scale; qv.y *= scale; qv.z *= scale; qv.w *= scale;
     st4(qs + j * DH + d4, qv);
-    st4(ks + j * DH + d4, ld4(src + 32 + d4));
-    st4(vs + j * DH + d4, ld4(src + 64 + d4));
+    st4(ks + j * DH + d4, ld4(src + DH + d4));
+    st4(vs + j * DH + d4, ld4(src + 2 * DH + d4));
     st4(gs + j * DH + d4, ld4(dout + (size_t)(r0 + j) * C + h * DH + d4));
   }
   const int i = threadIdx.x;
@@ -128,8 +127,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
   {
     const float li = ls[i], Di = Ds[i];
     for (int j = 0; j < K; ++j) {
-      const float p = expf(dot32(a, ks + j * DH) - li);
-      const float dS = p * (dot32(b, vs + j * DH) - Di);
+      const float p = expf(dot32<DH>(a, ks + j * DH) - li);
+      const float dS = p * (dot32<DH>(b, vs + j * DH) - Di);
       const float* kj = ks + j * DH;
 #pragma unroll
       for (int d = 0; d < DH; d += 4) {
@@ -138,7 +137,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
         acc[d + 2] = fmaf(dS, kv.z, acc[d + 2]); acc[d + 3] = fmaf(dS, kv.w, acc[d + 3]);
       }
     }
-    float* dq = dqkv + (size_t)(r0 + i) * C3 + h * 96;
+    float* dq = dqkv + (size_t)(r0 + i) * C3 + h * 3 * DH;
 #pragma unroll
     for (int d = 0; d < DH; d += 4) st4(dq + d, make_float4(acc[d] * scale, acc[d + 1] * scale, acc[d + 2] * scale, acc[d + 3] * scale));
   }
@@ -147,8 +146,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
 #pragma unroll
   for (int d = 0; d < DH; ++d) { a[d] = ks[i * DH + d]; b[d] = vs[i * DH + d]; acc[d] = 0.f; dv[d] = 0.f; }
   for (int q = 0; q < K; ++q) {
-    const float p = expf(dot32(a, qs + q * DH) - ls[q]);     // qs is pre-scaled
-    const float dS = p * (dot32(b, gs + q * DH) - Ds[q]);
+    const float p = expf(dot32<DH>(a, qs + q * DH) - ls[q]);     // qs is pre-scaled
+    const float dS = p * (dot32<DH>(b, gs + q * DH) - Ds[q]);
     const float* qq = qs + q * DH;
     const float* gq = gs + q * DH;
 #pragma unroll
@@ -160,34 +159,50 @@ __global__ __launch_bounds__(NT) void attn_bwd_kernel(const float* __restrict__ 
       dv[d + 2] = fmaf(p, gv.z, dv[d + 2]); dv[d + 3] = fmaf(p, gv.w, dv[d + 3]);
     }
   }
-  float* dk = dqkv + (size_t)(r0 + i) * C3 + h * 96 + 32;
+  float* dk = dqkv + (size_t)(r0 + i) * C3 + h * 3 * DH + DH;
 #pragma unroll
   for (int d = 0; d < DH; d += 4) {
     st4(dk + d, make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]));   // qs already carries `scale`
-    st4(dk + 32 + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
+    st4(dk + DH + d, make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]));
   }
 }
 
-int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C,
-                    hipStream_t st) {
+template <int DH>
+static int fwd_launch_dh(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, hipStream_t st) {
   const int heads = C / DH;
   const float scale = 1.0f / sqrtf((float)DH);
-  if (T <= 64) hipLaunchKernelGGL((attn_fwd_kernel<64>), dim3(W, heads), dim3(64), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
-  else if (T <= 128) hipLaunchKernelGGL((attn_fwd_kernel<128>), dim3(W, heads), dim3(128), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
+  if (T <= 64) hipLaunchKernelGGL((attn_fwd_kernel<64, DH>), dim3(W, heads), dim3(64), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
+  else if (T <= 128) hipLaunchKernelGGL((attn_fwd_kernel<128, DH>), dim3(W, heads), dim3(128), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
+  else return SAST_EINVAL;
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+template <int DH>
+static int bwd_launch_dh(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
+                         const int* Kw, int W, int T, int C, hipStream_t st) {
+  const int heads = C / DH;
+  const float scale = 1.0f / sqrtf((float)DH);
+  if (T <= 64) hipLaunchKernelGGL((attn_bwd_kernel<64, DH>), dim3(W, heads), dim3(64), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
+  else if (T <= 128) hipLaunchKernelGGL((attn_bwd_kernel<128, DH>), dim3(W, heads), dim3(128), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
   else return SAST_EINVAL;
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 
+// dim_head 32 (default) and 24 (the reference's "small" model, config/experiment/*/small.yaml)
+int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
+                    hipStream_t st) {
+  if (C % dh) return SAST_EINVAL;
+  if (dh == 32) return fwd_launch_dh<32>(qkv, o, lse, row_off, Kw, W, T, C, st);
+  if (dh == 24) return fwd_launch_dh<24>(qkv, o, lse, row_off, Kw, W, T, C, st);
+  return SAST_EINVAL;
+}
 int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
-                    const int* Kw, int W, int T, int C, hipStream_t st) {
-  const int heads = C / DH;
-  const float scale = 1.0f / sqrtf((float)DH);
-  if (T <= 64) hipLaunchKernelGGL((attn_bwd_kernel<64>), dim3(W, heads), dim3(64), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
-  else if (T <= 128) hipLaunchKernelGGL((attn_bwd_kernel<128>), dim3(W, heads), dim3(128), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
-  else return SAST_EINVAL;
-  SAST_CHECK_LAUNCH();
-  return SAST_OK;
+                    const int* Kw, int W, int T, int C, int dh, hipStream_t st) {
+  if (C % dh) return SAST_EINVAL;
+  if (dh == 32) return bwd_launch_dh<32>(qkv, o, dout, lse, dqkv, row_off, Kw, W, T, C, st);
+  if (dh == 24) return bwd_launch_dh<24>(qkv, o, dout, lse, dqkv, row_off, Kw, W, T, C, st);
+  return SAST_EINVAL;
 }
 
 }  // namespace sast

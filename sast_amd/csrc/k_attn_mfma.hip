@@ -1,4 +1,5 @@
-// MFMA version of the variable-length per-window attention (T <= 64 tokens per group, dim_head 32).
+// MFMA version of the variable-length per-window attention (T <= 64 tokens per group, dim_head <= 32, multiple of 4;
+// the reference ships dim_head 32 and 24 (config/experiment/*/small.yaml); head dims below 32 are zero-padded in LDS).
 //
 // One workgroup (2 waves) per (group, head).  The K_m surviving tokens of the group are compact rows
 // [row_off, row_off + K_m); they are staged TRANSPOSED in LDS ([d][token], odd leading dimension 65) so that
@@ -13,7 +14,7 @@
 
 namespace sast {
 
-constexpr int ADH = 32;    // dim_head
+constexpr int ADH = 32;    // LDS tile height = maximum dim_head
 constexpr int LDT = 65;    // leading dimension of the [32][64] transposed tiles and of the [64][64] P tile
 
 __device__ __forceinline__ float half_max(float v) {
@@ -32,21 +33,21 @@ __device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * 
 // Two steps so that the loads of ALL staged matrices are in flight together (branch-free: clamped row + select at
 // commit time; a predicated load would make hipcc drain vmcnt after every single one).
 struct Staged { float4 v[4]; };
-__device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K) {
+__device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K, int dh) {
   Staged st;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int s = threadIdx.x + it * 128, row = s >> 3, dq = (s & 7) * 4;
-    st.v[it] = ld4(src + (size_t)(r0 + min(row, K - 1)) * ld + coff + dq);
+    st.v[it] = ld4(src + (size_t)(r0 + min(row, K - 1)) * ld + coff + min(dq, dh - 4));
   }
   return st;
 }
-__device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K, int KT, float mul) {
+__device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K, int KT, float mul, int dh) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int s = threadIdx.x + it * 128, row = s >> 3, dq = (s & 7) * 4;
     if (s < KT * 8) {
-      const float m = row < K ? mul : 0.f;
+      const float m = (row < K && dq < dh) ? mul : 0.f;   // channels dh..31 of the tile are zero
       float* d = dst + dq * LDT + row;
       d[0] = st.v[it].x * m; d[LDT] = st.v[it].y * m; d[2 * LDT] = st.v[it].z * m; d[3 * LDT] = st.v[it].w * m;
     }
@@ -55,7 +56,7 @@ __device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K
 
 __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                             float* __restrict__ lse, const int* __restrict__ row_off,
-                                                            const int* __restrict__ Kw, int C, int heads, float scale) {
+                                                            const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
   __shared__ float sm[3 * 32 * LDT];
   float* Qt = sm;                 // [32][65]  (pre-scaled)
   float* Kt = sm + 32 * LDT;
@@ -67,12 +68,12 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restr
   const int r0 = row_off[g];
   const int NTL = (K + 31) >> 5, KT = NTL * 32;          // 1 or 2 token tiles
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
-  const int C3 = 3 * C, coff = h * 96;
+  const int C3 = 3 * C, coff = h * 3 * dh;
   {
-    const Staged sq = stage_issue(qkv, C3, coff, r0, K), sk = stage_issue(qkv, C3, coff + 32, r0, K), sv = stage_issue(qkv, C3, coff + 64, r0, K);
-    stage_commit(Qt, sq, K, KT, scale);
-    stage_commit(Kt, sk, K, KT, 1.f);
-    stage_commit(Vt, sv, K, KT, 1.f);
+    const Staged sq = stage_issue(qkv, C3, coff, r0, K, dh), sk = stage_issue(qkv, C3, coff + dh, r0, K, dh), sv = stage_issue(qkv, C3, coff + 2 * dh, r0, K, dh);
+    stage_commit(Qt, sq, K, KT, scale, dh);
+    stage_commit(Kt, sk, K, KT, 1.f, dh);
+    stage_commit(Vt, sv, K, KT, 1.f, dh);
   }
   __syncthreads();
   const bool active = w < NTL;
@@ -132,14 +133,14 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restr
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int i = w * 32 + crow(e, lane);
-    if (i < K) o[(size_t)(r0 + i) * C + h * ADH + l31] = acc[e] * inv[e];
+    if (i < K && l31 < dh) o[(size_t)(r0 + i) * C + h * dh + l31] = acc[e] * inv[e];
   }
 }
 
 __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                             const float* __restrict__ lse, float* __restrict__ dqkv,
                                                             const int* __restrict__ row_off, const int* __restrict__ Kw, int C,
-                                                            int heads, float scale) {
+                                                            int heads, float scale, int dh) {
   __shared__ float sm[4 * 32 * LDT + 64 * LDT];
   float* Qt = sm;                 // pre-scaled q
   float* Kt = Qt + 32 * LDT;
@@ -152,14 +153,14 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
   const int r0 = row_off[g];
   const int NTL = (K + 31) >> 5, KT = NTL * 32;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
-  const int C3 = 3 * C, coff = h * 96;
+  const int C3 = 3 * C, coff = h * 3 * dh;
   {
-    const Staged sq = stage_issue(qkv, C3, coff, r0, K), sk = stage_issue(qkv, C3, coff + 32, r0, K);
-    const Staged sv = stage_issue(qkv, C3, coff + 64, r0, K), sg = stage_issue(dout, C, h * ADH, r0, K);
-    stage_commit(Qt, sq, K, KT, scale);
-    stage_commit(Kt, sk, K, KT, 1.f);
-    stage_commit(Vt, sv, K, KT, 1.f);
-    stage_commit(Gt, sg, K, KT, 1.f);
+    const Staged sq = stage_issue(qkv, C3, coff, r0, K, dh), sk = stage_issue(qkv, C3, coff + dh, r0, K, dh);
+    const Staged sv = stage_issue(qkv, C3, coff + 2 * dh, r0, K, dh), sg = stage_issue(dout, C, h * dh, r0, K, dh);
+    stage_commit(Qt, sq, K, KT, scale, dh);
+    stage_commit(Kt, sk, K, KT, 1.f, dh);
+    stage_commit(Vt, sv, K, KT, 1.f, dh);
+    stage_commit(Gt, sg, K, KT, 1.f, dh);
   }
   __syncthreads();
   const bool active = w < NTL;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int j = w * 32 + crow(e, lane);
-      if (j < K) dqkv[(size_t)(r0 + j) * C3 + coff + 64 + l31] = acc[e];
+      if (j < K && l31 < dh) dqkv[(size_t)(r0 + j) * C3 + coff + 2 * dh + l31] = acc[e];
     }
   }
   __syncthreads();   // P fully consumed -> overwrite with dS
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int j = w * 32 + crow(e, lane);
-    if (j < K) dqkv[(size_t)(r0 + j) * C3 + coff + 32 + l31] = acc[e];
+    if (j < K && l31 < dh) dqkv[(size_t)(r0 + j) * C3 + coff + dh + l31] = acc[e];
   }
   // ---- dQ tile (queries 32w..): scale * sum_j dS[i][j] K[j][d]
 #pragma unroll
@@ -257,21 +258,23 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int i = w * 32 + crow(e, lane);
-    if (i < K) dqkv[(size_t)(r0 + i) * C3 + coff + l31] = acc[e] * scale;
+    if (i < K && l31 < dh) dqkv[(size_t)(r0 + i) * C3 + coff + l31] = acc[e] * scale;
   }
 }
 
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, hipStream_t st) {
-  const int heads = C / ADH;
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, 1.0f / sqrtf((float)ADH));
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, int dh, hipStream_t st) {
+  if (dh < 4 || dh > ADH || dh % 4 || C % dh) return SAST_EINVAL;
+  const int heads = C / dh;
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, 1.0f / sqrtf((float)dh), dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int C, hipStream_t st) {
-  const int heads = C / ADH;
+                         int C, int dh, hipStream_t st) {
+  if (dh < 4 || dh > ADH || dh % 4 || C % dh) return SAST_EINVAL;
+  const int heads = C / dh;
   hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads,
-                     1.0f / sqrtf((float)ADH));
+                     1.0f / sqrtf((float)dh), dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -210,7 +210,7 @@ int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode,
 int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("score_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
-  if (!a || a->C % 32) return SAST_EINVAL;
+  if (!a || a->C % 4) return SAST_EINVAL;
   const int M = a->B * a->L, C = a->C;
   int rc = controls_fwd_launch(a->wc, a->r, a->r_stride, a->scale, a->B, C, 20, st);
   if (rc) return rc;
@@ -246,7 +246,9 @@ size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("mswsa_fwd", a ? a->C : 0, a ? (a->mode ? -1 : 1) * a->B * a->H * a->W : 0, st);
-  if (!a || a->C % 32 || a->inner % 32) return SAST_EINVAL;
+  if (!a || a->C % 4 || a->inner % 32) return SAST_EINVAL;
+  const int dh = a->dim_head > 0 ? a->dim_head : 32;
+  if (a->C % dh) return SAST_EINVAL;
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   const int* dR = a->sel.counts;  // device-side number of kept tokens
@@ -255,8 +257,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
-  rc = T <= 64 ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, C, st)
-               : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, st);
+  rc = T <= 64 ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, C, dh, st)
+               : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
   if (rc) return rc;
@@ -289,6 +291,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   ProfScope ps_("mswsa_bwd", a->C, (a->mode ? -1 : 1) * a->B * a->H * a->W, st);
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
+  const int dh = a->dim_head > 0 ? a->dim_head : 32;
   const int* dR = a->sel.counts;
   const int* row_tok = a->sel.row_tok;
   float* dUG = a->ws;
@@ -344,8 +347,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
               : gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   if (rc) return rc;
   // attention backward
-  rc = T <= 64 ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, C, st)
-               : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, st);
+  rc = T <= 64 ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, C, dh, st)
+               : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
   sd.after_main();
   rc = gemm_tn(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);
@@ -362,7 +365,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
 int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("lstm_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
-  if (!a || a->C % 32) return SAST_EINVAL;
+  if (!a || a->C % 4) return SAST_EINVAL;
   const int M = a->B * a->L, C = a->C;
   const int Kred = a->h0 ? 2 * C : C;   // zero hidden state: skip the h half of the reduction
   const LdRows2 la{a->x, C, C, a->h0, C};

@@ -281,7 +281,7 @@ extern "C" {
 int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("down_fwd", a ? a->Cout : 0, a ? a->B * a->H * a->W : 0, st);
-  if (!a || a->Cin % 4 || a->Cout % 32) return SAST_EINVAL;
+  if (!a || a->Cin % 4 || a->Cout % 4) return SAST_EINVAL;
   const int k = 2 * a->factor - 1;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;

@@ -313,6 +313,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #define SAST_DISPATCH_C(C, CALL)                      \
   switch (C) {                                        \
     case 32:  { constexpr int GL = 8,  VPL = 1; CALL; } break;  \
+    case 48:  { constexpr int GL = 4,  VPL = 3; CALL; } break;  \
+    case 96:  { constexpr int GL = 8,  VPL = 3; CALL; } break;  \
+    case 192: { constexpr int GL = 16, VPL = 3; CALL; } break;  \
+    case 384: { constexpr int GL = 32, VPL = 3; CALL; } break;  \
+    case 768: { constexpr int GL = 64, VPL = 3; CALL; } break;  \
     case 64:  { constexpr int GL = 16, VPL = 1; CALL; } break;  \
     case 128: { constexpr int GL = 32, VPL = 1; CALL; } break;  \
     case 256: { constexpr int GL = 64, VPL = 1; CALL; } break;  \

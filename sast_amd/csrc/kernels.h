@@ -55,14 +55,14 @@ int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mod
                   int* row_tok, hipStream_t st);
 
 // k_attn.hip
-int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C,
+int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
                     hipStream_t st);
 int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
-                    const int* Kw, int W, int T, int C, hipStream_t st);
+                    const int* Kw, int W, int T, int C, int dh, hipStream_t st);
 
 // k_attn_mfma.hip (T <= 64)
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, hipStream_t st);
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, int dh, hipStream_t st);
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int C, hipStream_t st);
+                         int C, int dh, hipStream_t st);
 
 }  // namespace sast

@@ -384,14 +384,16 @@ _MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w",
 
 class _MSWSA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xin, sel: Selection, eps, cb_tps, *params):
+    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, *params):
         _need_gpu(xin)
         xin = xin.contiguous()
         p = dict(zip(_MSWSA_PARAMS, params))
         Cc = xin.shape[-1]
         R = xin.numel() // Cc
         inner = p["fc2_w"].shape[1]
-        heads = Cc // 32
+        if Cc % dim_head:
+            raise RuntimeError(f"sast_amd: dim ({Cc}) must be a multiple of dim_head ({dim_head})")
+        heads = Cc // dim_head
         dev = xin.device
         out = torch.empty_like(xin)
         stats = torch.empty(4, R, device=dev)
@@ -408,7 +410,7 @@ class _MSWSA(torch.autograd.Function):
 
         S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
         a = L.SastMswsaArgs()
-        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, xin=xin, out=out,
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, xin=xin, out=out,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
         if cb_tps:
             if R % cb_tps:
@@ -419,7 +421,7 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
         ctx.save_for_backward(xin, stats, big)
-        ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps = sel, params, eps, inner, cb_tps
+        ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
         return out
 
     @staticmethod
@@ -429,7 +431,7 @@ class _MSWSA(torch.autograd.Function):
         p = dict(zip(_MSWSA_PARAMS, params))
         Cc = xin.shape[-1]
         R = xin.numel() // Cc
-        heads = Cc // 32
+        heads = Cc // ctx.dim_head
         dout = dout.contiguous()
         dxin = torch.empty_like(xin)
         flat = big.view(-1)
@@ -444,7 +446,7 @@ class _MSWSA(torch.autograd.Function):
         S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
         ws = torch.empty(L.lib().sast_mswsa_bwd_ws_floats(R, Cc, inner), device=xin.device)
         a = L.SastMswsaArgs()
-        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, xin=xin,
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, dim_head=ctx.dim_head, xin=xin,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh,
               dout=dout, dxin=dxin, ws=ws)
         if ctx.cb_tps:
@@ -454,13 +456,14 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         _fill(a, **{"d_" + k: _ptr(_g(v)) for k, v in p.items()})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
-        return (dxin, None, None, None) + (None,) * len(params)
+        return (dxin, None, None, None, None) + (None,) * len(params)
 
 
-def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0) -> torch.Tensor:
+def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32) -> torch.Tensor:
     """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled).
-    cb_tokens_per_sample > 0 enables Context Broadcasting (SAST.py:240-246) with that many tokens per sample."""
-    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), *[params[k] for k in _MSWSA_PARAMS])
+    cb_tokens_per_sample > 0 enables Context Broadcasting (SAST.py:240-246) with that many tokens per sample.
+    dim_head: 32 or 24 (the widths the reference ships)."""
+    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), *[params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12

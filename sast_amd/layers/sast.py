@@ -71,8 +71,8 @@ class MS_WSA(nn.Module):
 
     def __init__(self, dim: int, dim_head: int = 32, bias: bool = True, sub_layer_params=None, norms=None):
         super().__init__()
-        if dim_head != 32:
-            raise NotImplementedError("sast_amd: the attention kernels are built for dim_head = 32 (every shipped config)")
+        if dim_head not in (24, 32):
+            raise NotImplementedError("sast_amd: the attention kernels are built for dim_head 32 and 24 (the widths the reference ships)")
         if not bias:
             raise NotImplementedError("sast_amd: attention_bias=False is not implemented")
         self.num_heads = dim // dim_head
@@ -105,7 +105,7 @@ class MS_WSA(nn.Module):
 
     def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False) -> torch.Tensor:
         """fused path: x (B,H,W,C) in IMAGE layout + device-side selection."""
-        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0)
+        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0, self.dim_head)
 
     def forward(self, x: torch.Tensor, index_window: torch.Tensor, index_token: torch.Tensor, padding_index: torch.Tensor,
                 asy_index: torch.Tensor, M: int, B, enable_CB: bool) -> torch.Tensor:
@@ -119,7 +119,7 @@ class MS_WSA(nn.Module):
             else torch.zeros(0, dtype=torch.long, device=x.device)
         sel = SF.selection_from_index_lists(index_window, asy_index, K, N, T, x.device)
         # Context Broadcasting averages over the tokens of one sample = N*T/B consecutive partitioned tokens (SAST.py:244-245)
-        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0)
+        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0, self.dim_head)
         return out.view(*shape)
 
 

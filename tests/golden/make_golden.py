@@ -84,11 +84,11 @@ def run_ref_block(ref, params, x, r, pe_mod, acfg, first=True, index_list=None, 
     return blk, xx, out, cnt, lists
 
 
-def gen_block(ref, name, B, amp, enable_cb=False, seed0=0):
-    C, H, W, part = 64, 16, 20, (4, 5)
-    acfg = dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
+def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32):
+    H, W, part = 16, 20, (4, 5)
+    acfg = dict(partition_size=part, dim_head=dim_head, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
                 mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=0.5, enable_CB=enable_cb, AMP=amp, BOUNCE=1e-3)
-    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb)
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb, dim_head=dim_head)
     pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     pe = O.position_embedding_sine(H, W, C)
     assert torch.equal(pe, pe_mod.pos_embedding)
@@ -125,7 +125,7 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0):
     assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
     d = dict(x=np_(x), r=np_(r), out=np_(out), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)),
-             enable_cb=np.int64(enable_cb))
+             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head))
     d.update(lists_to_np(lists, ""))
     named = dict(blk.named_parameters())
     for k, v in named.items():
@@ -277,12 +277,18 @@ def gen_full_stats(ref):
 
 def main():
     ref = RI.import_reference()
+    if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
+        gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
+        gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
+        return
     gen_nzr(ref)
     gen_block(ref, "block_amp2e-4", 2, 2e-4)
     gen_block(ref, "block_amp2e-2", 2, 2e-2)
     gen_block(ref, "block_amp1", 2, 1.0)
     gen_block(ref, "block_b1", 1, 2e-2)
     gen_block(ref, "block_cb", 2, 2e-2, enable_cb=True)
+    gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
+    gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)

@@ -50,8 +50,8 @@ def maxnorm_close(a, b, rtol, what=""):
     assert err <= rtol * scale + 1e-9, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
-def attn_cfg(part, amp, ls=0.5, cb=False):
-    return dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True, mlp_ratio=4,
+def attn_cfg(part, amp, ls=0.5, cb=False, dim_head=32):
+    return dict(partition_size=part, dim_head=dim_head, attention_bias=True, mlp_activation="gelu", mlp_bias=True, mlp_ratio=4,
                 drop_mlp=0, drop_path=0, ls_init_value=ls, enable_CB=cb, AMP=amp, BOUNCE=1e-3)
 
 
@@ -81,7 +81,8 @@ def test_non_zero_ratio(golden_dir, dev):
         assert torch.equal(SF.non_zero_ratio(xx.to(dev)).cpu(), ref)
 
 
-@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb"])
+@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
+                                  "block_large_c96"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
@@ -90,7 +91,8 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     B, H, W, C = x.shape
     params = block_params(C, int(g["seed"]))
     cb = bool(g["enable_cb"]) if "enable_cb" in g else False     # Context Broadcasting fixture (SAST.py:240-246)
-    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"]), cb=cb), first_block=True).to(dev)
+    dh = int(g["dim_head"]) if "dim_head" in g else 32      # 24: the reference's "small" size
+    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"]), cb=cb, dim_head=dh), first_block=True).to(dev)
     load_params(blk, params, "att_blocks.0.att.")
     pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     xd = x.to(dev).requires_grad_(True)
@@ -142,9 +144,9 @@ def test_token_masking_fails_loudly(dev):
         RNNDetector(cfg)
 
 
-def _rcfg(hw, part, E, amp, ls):
+def _rcfg(hw, part, E, amp, ls, dim_head=32):
     from sast_amd.config import backbone_config
-    return backbone_config(hw, part, embed_dim=E, AMP=amp, ls_init_value=ls)
+    return backbone_config(hw, part, embed_dim=E, AMP=amp, ls_init_value=ls, dim_head=dim_head)
 
 
 @pytest.mark.parametrize("tag", ["dense", "sparse"])
@@ -177,6 +179,46 @@ def test_backbone_tiny_vs_golden(golden_dir, dev, tag):
         if "sub_layers" in k:
             continue
         maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+
+
+@pytest.mark.parametrize("size,E,dh,depth,hw,part", [("large", 96, 32, 0.67, (128, 160), (4, 5)), ("small", 48, 24, 0.33, (128, 160), (4, 5)),
+                                                    ("small_T80", 48, 24, 0.33, (256, 320), (8, 10))])
+def test_backbone_other_sizes(dev, size, E, dh, depth, hw, part):
+    """the reference's other model sizes (config/experiment/gen1/{large,small}.yaml): embed_dim 96 -> C = 96..768 with
+    3..24 heads; embed_dim 48 with dim_head 24 and PAFPN depth 0.33 -- channel counts that are not powers of two and the
+    24-wide heads, backbone + PAFPN forward and backward against the oracle (T=20: MFMA attention; T=80: the >64-token kernel)."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    B = 2
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2, dim_head=dh)
+    params = O.init_backbone_params(ocfg, seed=21, ls_init=0.5)
+    chans = (2 * E, 4 * E, 8 * E)
+    fparams = O.init_pafpn_params(chans, depth=depth, seed=22)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5, dim_head=dh)).to(dev)
+    fpn = YOLOPAFPN(depth=depth, in_stages=(2, 3, 4), in_channels=chans).to(dev)
+    load_params(net, params)
+    load_params(fpn, fparams)
+    fpn.train()
+    x = O.count_events(B, hw, seed=23, density=0.05)
+    out, _st, P = net(x.to(dev))
+    outs = fpn({k: out[k] for k in (2, 3, 4)})
+    loss = sum((out[k] ** 2).mean() for k in (1, 2, 3, 4)) + sum((o ** 2).mean() for o in outs)
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
+    oo, _s, Po, lists = O.backbone(x, None, po, ocfg, return_lists=True)
+    oouts = O.pafpn({k: oo[k] for k in (2, 3, 4)}, pf, depth=depth, training=True)
+    loss_o = sum((oo[k] ** 2).mean() for k in (1, 2, 3, 4)) + sum((o ** 2).mean() for o in oouts)
+    loss_o.backward()
+    assert [int(p) for p in P] == [int(p) for p in Po]
+    for k in (1, 2, 3, 4):
+        assert float((out[k].detach().cpu() - oo[k].detach()).abs().max()) <= FWD_ATOL, k
+    for i, (a, b) in enumerate(zip(outs, oouts)):   # reductions of up to 9*768 terms after batch-stat BN: relative tolerance
+        maxnorm_close(a, b, 1e-4, f"pafpn out {i}")
+    for k, v in net.named_parameters():
+        if "sub_layers" not in k:
+            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+    for k, v in fpn.named_parameters():
+        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
 
 
 def test_backbone_sequence_bptt(dev):

@@ -41,13 +41,15 @@ def test_non_zero_ratio(golden_dir):
     assert torch.equal(O.non_zero_ratio(torch.from_numpy(g["xb"])), torch.from_numpy(g["rb"]))
 
 
-@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb"])
+@pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
+                                  "block_large_c96"])
 def test_sast_block(golden_dir, name):
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
-    params = _block_params(64, int(g["seed"]))
+    params = _block_params(x.shape[-1], int(g["seed"]))
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
-    cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]))
+    cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]),
+                    dim_head=int(g["dim_head"]) if "dim_head" in g else 32)
     pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])
     xo = x.clone().requires_grad_(True)
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
