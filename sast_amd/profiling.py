@@ -19,6 +19,24 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 _PMC_SUMMARY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_hbm_traffic_latest.json")
 
 
+_TILE_DEFAULTS = (None, None, None, None, None, "16", "1", "2", "0")   # Tile<BM, BN, WM, WN, G, BK=16, KS=1, PF=2, OCC=0>
+
+
+def _norm_kernel(name: str) -> str:
+    """canonical spelling of a gemm_kernel instantiation: rocprofv3 prints every Tile<> argument, __PRETTY_FUNCTION__
+    (the roofline leg) omits defaulted ones; the split flag is `true`/`false` in one and `split`/absent in the other."""
+    m = re.search(r"Tile<([^>]*)>", name)
+    if m:
+        args = [a.strip() for a in m.group(1).split(",")]
+        args += [d for d in _TILE_DEFAULTS[len(args):]]
+        name = name[:m.start()] + "Tile<" + ", ".join(args) + ">" + name[m.end():]
+    name = re.sub(r"\(.*$", "", name)                       # drop the argument list rocprof appends
+    name = name.replace(", split>", ", true>")
+    if name.startswith("gemm_kernel<") and not re.search(r", (true|false)>$", name):
+        name = name[:-1] + ", false>"
+    return name
+
+
 def pmc_traffic_bytes(kernel_name: str):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary (tools/rocpd_pmc.py: two separate
     passes FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); None when not profiled."""
@@ -27,11 +45,11 @@ def pmc_traffic_bytes(kernel_name: str):
             ks = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
-    key = kernel_name.replace(", split>", ", true>")
-    if not key.endswith(", true>"):
-        key = key[:-1] + ", false>"
-    ent = ks.get(key)
-    return None if ent is None else float(ent["hbm_bytes_per_launch"])
+    want = _norm_kernel(kernel_name)
+    for k, ent in ks.items():
+        if _norm_kernel(k) == want:
+            return float(ent["hbm_bytes_per_launch"])
+    return None
 
 
 def _short(tag: str) -> str:
