@@ -634,7 +634,7 @@ struct LdIm2col {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     int kh, kw, ch;
-    split_tap(g, g.Cin, g.cin_shift, min(r, Reff - 1), kh, kw, ch);
+    split_tap(g, g.Cin, g.cin_shift, min(r, Reff - 4), kh, kw, ch);   // r and Reff are multiples of 4: the clamped float4 stays inside one pixel
     const int iy = c.iy0 + kh, ix = c.ix0 + kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
@@ -688,7 +688,7 @@ struct LdConvDx {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     int kh, kw, co;
-    split_tap(g, Cout, cout_shift, min(r, Reff - 1), kh, kw, co);
+    split_tap(g, Cout, cout_shift, min(r, Reff - 4), kh, kw, co);
     int oy, ox;
     const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
     ok = c.ok && r < Reff && vy && vx;

@@ -426,3 +426,36 @@ def test_graph_replay_matches_eager(dev):
         err = float((gr[2].grad - ref).abs().max())
         assert torch.isfinite(gr[2].grad).all()
         assert err <= 1e-2 * float(ref.abs().max()) + 1e-7, (k, err)      # atomics order + 3 optimizer steps of drift
+
+
+# kept last: if this ever regresses the symptom is a GPU memory fault that aborts the process
+def test_conv_reads_stay_inside_the_input_buffer(dev):
+    """the implicit-GEMM loaders prefetch k-tiles past the end of the reduction with clamped addresses; a clamp that is not
+    float4-aligned read 12 bytes past the last pixel (a GPU memory fault whenever the input ends at an allocation boundary,
+    as the Gen1 B=4 input does).  Here the input is the tail of an exactly 2 MiB-multiple allocation."""
+    import ctypes
+    from sast_amd import functional as SF
+    B, H, W, Cin, Cout, f = 1, 64, 64, 20, 64, 4
+    n = B * H * W * Cin
+    seg = 2 * 1024 * 1024 // 4
+    total = ((n + seg - 1) // seg) * seg              # floats: a whole number of 2 MiB pages, from hipMalloc directly (not cached)
+    hip = ctypes.CDLL("libamdhip64.so")
+    ptr = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(4 * total)) == 0
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (total,), "typestr": "<f4", "data": (ptr.value, False), "version": 2}
+
+    store = torch.as_tensor(_Raw(), device=dev)
+    x = store[-n:].view(B, H, W, Cin)
+    x.copy_(torch.randn(B, H, W, Cin, generator=torch.Generator().manual_seed(0)))
+    g = torch.Generator().manual_seed(1)
+    w = (torch.randn(Cout, Cin, 7, 7, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    lw, lb = torch.ones(Cout, device=dev), torch.zeros(Cout, device=dev)
+    y = SF.downsample_ln(x, w, lw, lb, None, f)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.pad(x.permute(0, 3, 1, 2).cpu(), (3, 3, 3, 3), mode="replicate"), w.cpu(), stride=f)
+    ref = torch.nn.functional.layer_norm(ref.permute(0, 2, 3, 1), (Cout,))
+    assert float((y.cpu() - ref).abs().max()) <= 2e-4
+    torch.cuda.synchronize()
+    del x, store
+    hip.hipFree(ptr)
