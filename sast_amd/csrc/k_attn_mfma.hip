@@ -1,21 +1,23 @@
-// MFMA version of the variable-length per-window attention (T <= 64 tokens per group, dim_head <= 32, multiple of 4;
-// the reference ships dim_head 32 and 24 (config/experiment/*/small.yaml); head dims below 32 are zero-padded in LDS).
+// MFMA version of the variable-length per-window attention (dim_head <= 32, multiple of 4; the reference ships dim_head
+// 32 and 24 (config/experiment/*/small.yaml); head dims below 32 are zero-padded in LDS).
 //
-// One workgroup (2 waves) per (group, head).  The K_m surviving tokens of the group are compact rows
-// [row_off, row_off + K_m); they are staged TRANSPOSED in LDS ([d][token], odd leading dimension 65) so that
+// One workgroup per (group, head): NTMAX waves, NTMAX = 2 for partitions of up to 64 tokens (1Mpx: T = 60) and 4 for up to
+// 128 tokens (Gen1: T = 80).  The K_m surviving tokens of the group are compact rows [row_off, row_off + K_m); they are
+// staged TRANSPOSED in LDS ([d][token], odd leading dimension 32*NTMAX+1) so that
 //   * operands whose reduce index is d   (S = Q K^T, dP = dO V^T)            are contiguous ds_read_b32, and
-//   * operands whose reduce index is a token (P V, P^T dO, dS^T Q, dS K)     are stride-65 reads,
+//   * operands whose reduce index is a token (P V, P^T dO, dS^T Q, dS K)     are odd-stride reads,
 // both bank-conflict free.  QK^T / PV / all five backward products run on v_mfma_f32_32x32x2_f32 (exact fp32);
 // the softmax lives in the MFMA C layout (row = f(reg, lane>>5), col = lane&31) with half-wave shuffles.
 // Wave w owns query rows [32w, 32w+32) (forward; S, dP, dS, dQ in backward) and key rows [32w, 32w+32) for dK/dV.
-// No padding work beyond rounding K_m up to 32; padded keys are masked to -inf, padded queries are never stored.
+// The number of 32-token tiles NT = ceil(K_m / 32) is a template parameter of the body (block-uniform switch), so the
+// product loops carry no branches.  No padding work beyond rounding K_m up to 32; padded keys are masked to -inf,
+// padded queries are never stored.
 #include "gemm.cuh"
 #include "kernels.h"
 
 namespace sast {
 
 constexpr int ADH = 32;    // LDS tile height = maximum dim_head
-constexpr int LDT = 65;    // leading dimension of the [32][64] transposed tiles and of the [64][64] P tile
 
 __device__ __forceinline__ float half_max(float v) {
 #pragma unroll
@@ -29,23 +31,27 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 __device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// stage rows [r0, r0+K) x 32 channels of `src` (row stride ld, channel offset coff) transposed into dst[d][tok].
+// stage rows [r0, r0+K) x dh channels of `src` (row stride ld, channel offset coff) transposed into dst[d][tok].
 // Two steps so that the loads of ALL staged matrices are in flight together (branch-free: clamped row + select at
-// commit time; a predicated load would make hipcc drain vmcnt after every single one).
+// commit time; a predicated load would make hipcc drain vmcnt after every single one).  64*NTMAX threads cover the
+// 32*NTMAX x 8 float4 slots in 4 rounds.
 struct Staged { float4 v[4]; };
+template <int NTMAX>
 __device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K, int dh) {
   Staged st;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int s = threadIdx.x + it * 128, row = s >> 3, dq = (s & 7) * 4;
+    const int s = threadIdx.x + it * 64 * NTMAX, row = s >> 3, dq = (s & 7) * 4;
     st.v[it] = ld4(src + (size_t)(r0 + min(row, K - 1)) * ld + coff + min(dq, dh - 4));
   }
   return st;
 }
+template <int NTMAX>
 __device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K, int KT, float mul, int dh) {
+  constexpr int LDT = 32 * NTMAX + 1;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int s = threadIdx.x + it * 128, row = s >> 3, dq = (s & 7) * 4;
+    const int s = threadIdx.x + it * 64 * NTMAX, row = s >> 3, dq = (s & 7) * 4;
     if (s < KT * 8) {
       const float m = (row < K && dq < dh) ? mul : 0.f;   // channels dh..31 of the tile are zero
       float* d = dst + dq * LDT + row;
@@ -54,69 +60,68 @@ __device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K
   }
 }
 
-__global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
-                                                            float* __restrict__ lse, const int* __restrict__ row_off,
-                                                            const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
-  __shared__ float sm[3 * 32 * LDT];
-  float* Qt = sm;                 // [32][65]  (pre-scaled)
+// ------------------------------------------------------------------ forward
+template <int NTMAX, int NT>
+__device__ __forceinline__ void attn_fwd_body(float* sm, const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
+                                              int r0, int K, int C, int heads, int h, float scale, int dh) {
+  constexpr int LDT = 32 * NTMAX + 1, KT = NT * 32;
+  float* Qt = sm;                 // [32][LDT]  (pre-scaled)
   float* Kt = sm + 32 * LDT;
   float* Vt = sm + 2 * 32 * LDT;
-  float* P = sm;                  // [64][65] aliases Qt|Kt once S is in registers
-  const int g = blockIdx.x, h = blockIdx.y;
-  const int K = Kw[g];
-  if (K == 0) return;
-  const int r0 = row_off[g];
-  const int NTL = (K + 31) >> 5, KT = NTL * 32;          // 1 or 2 token tiles
+  // P [32*NTMAX][LDT]: for NTMAX = 2 it aliases Qt|Kt once S is in registers; for NTMAX = 4 it has its own storage
+  float* P = NTMAX == 2 ? sm : sm + 3 * 32 * LDT;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
   const int C3 = 3 * C, coff = h * 3 * dh;
   {
-    const Staged sq = stage_issue(qkv, C3, coff, r0, K, dh), sk = stage_issue(qkv, C3, coff + dh, r0, K, dh), sv = stage_issue(qkv, C3, coff + 2 * dh, r0, K, dh);
-    stage_commit(Qt, sq, K, KT, scale, dh);
-    stage_commit(Kt, sk, K, KT, 1.f, dh);
-    stage_commit(Vt, sv, K, KT, 1.f, dh);
+    const Staged sq = stage_issue<NTMAX>(qkv, C3, coff, r0, K, dh), sk = stage_issue<NTMAX>(qkv, C3, coff + dh, r0, K, dh),
+                 sv = stage_issue<NTMAX>(qkv, C3, coff + 2 * dh, r0, K, dh);
+    stage_commit<NTMAX>(Qt, sq, K, KT, scale, dh);
+    stage_commit<NTMAX>(Kt, sk, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Vt, sv, K, KT, 1.f, dh);
   }
   __syncthreads();
-  const bool active = w < NTL;
-  f32x16 s[2];
+  const bool active = w < NT;
+  f32x16 s[NT];
   float inv[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { s[0][e] = 0.f; s[1][e] = 0.f; inv[e] = 0.f; }
+  for (int e = 0; e < 16; ++e) {
+    inv[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s[t][e] = 0.f;
+  }
   if (active) {
-    if (NTL > 1) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int kk = ks * 2 + (lane >> 5);
-        const float a = Qt[kk * LDT + w * 32 + l31];
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + l31], s[0], 0, 0, 0);
-        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + 32 + l31], s[1], 0, 0, 0);
-      }
-    } else {
+    for (int ks = 0; ks < 16; ++ks) {
+      const int kk = ks * 2 + (lane >> 5);
+      const float a = Qt[kk * LDT + w * 32 + l31];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int kk = ks * 2 + (lane >> 5);
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[kk * LDT + w * 32 + l31], Kt[kk * LDT + l31], s[0], 0, 0, 0);
-      }
+      for (int t = 0; t < NT; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + t * 32 + l31], s[t], 0, 0, 0);
     }
-    const bool c0 = l31 < K, c1 = (NTL > 1) && (32 + l31 < K);
+    bool cv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cv[t] = t * 32 + l31 < K;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const float v0 = c0 ? s[0][e] : -INFINITY, v1 = c1 ? s[1][e] : -INFINITY;
-      const float m = half_max(fmaxf(v0, v1));
-      const float p0 = c0 ? __expf(v0 - m) : 0.f, p1 = c1 ? __expf(v1 - m) : 0.f;
-      const float sum = half_sum(p0 + p1);
-      s[0][e] = p0; s[1][e] = p1;
+      float v[NT], mloc = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { v[t] = cv[t] ? s[t][e] : -INFINITY; mloc = fmaxf(mloc, v[t]); }
+      const float m = half_max(mloc);
+      float ploc = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { const float pt = cv[t] ? __expf(v[t] - m) : 0.f; s[t][e] = pt; ploc += pt; }
+      const float sum = half_sum(ploc);
       inv[e] = 1.0f / sum;
       const int i = w * 32 + crow(e, lane);
       if (l31 == 0 && i < K) lse[(size_t)(r0 + i) * heads + h] = m + logf(sum);
     }
   }
-  __syncthreads();   // everyone is done with Qt / Kt -> reuse as P
+  if (NTMAX == 2) __syncthreads();   // everyone is done with Qt / Kt -> reuse as P
   if (active) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float* pr = P + (w * 32 + crow(e, lane)) * LDT + l31;
-      pr[0] = s[0][e];
-      if (NTL > 1) pr[32] = s[1][e];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) pr[t * 32] = s[t][e];
     }
   }
   __syncthreads();
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restr
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   const float* pa = P + (w * 32 + l31) * LDT;
   const float* vb = Vt + l31 * LDT;
+#pragma unroll 8
   for (int ks = 0; ks < KT / 2; ++ks) {
     const int kk = ks * 2 + (lane >> 5);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], vb[kk], acc, 0, 0, 0);
@@ -137,68 +143,85 @@ __global__ __launch_bounds__(128) void attn_fwd_mfma_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                            const float* __restrict__ lse, float* __restrict__ dqkv,
-                                                            const int* __restrict__ row_off, const int* __restrict__ Kw, int C,
-                                                            int heads, float scale, int dh) {
-  __shared__ float sm[4 * 32 * LDT + 64 * LDT];
-  float* Qt = sm;                 // pre-scaled q
-  float* Kt = Qt + 32 * LDT;
-  float* Vt = Kt + 32 * LDT;
-  float* Gt = Vt + 32 * LDT;      // dO
-  float* PB = Gt + 32 * LDT;      // [64][65]: P, then dS
+template <int NTMAX>
+__global__ __launch_bounds__(64 * NTMAX) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                   float* __restrict__ lse, const int* __restrict__ row_off,
+                                                                   const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
+  constexpr int LDT = 32 * NTMAX + 1;
+  __shared__ float sm[3 * 32 * LDT + (NTMAX == 2 ? 0 : 32 * NTMAX * LDT)];
   const int g = blockIdx.x, h = blockIdx.y;
   const int K = Kw[g];
   if (K == 0) return;
   const int r0 = row_off[g];
-  const int NTL = (K + 31) >> 5, KT = NTL * 32;
+  switch ((K + 31) >> 5) {   // block-uniform
+    case 1: attn_fwd_body<NTMAX, 1>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+    case 2: attn_fwd_body<NTMAX, 2>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+    case 3: if constexpr (NTMAX >= 4) attn_fwd_body<NTMAX, 3>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+    case 4: if constexpr (NTMAX >= 4) attn_fwd_body<NTMAX, 4>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+  }
+}
+
+// ------------------------------------------------------------------ backward
+template <int NTMAX, int NT>
+__device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                              const float* __restrict__ lse, float* __restrict__ dqkv, int r0, int K, int C, int heads,
+                                              int h, float scale, int dh) {
+  constexpr int LDT = 32 * NTMAX + 1, KT = NT * 32;
+  float* Qt = sm;                 // pre-scaled q
+  float* Kt = Qt + 32 * LDT;
+  float* Vt = Kt + 32 * LDT;
+  float* Gt = Vt + 32 * LDT;      // dO
+  float* PB = Gt + 32 * LDT;      // [32*NTMAX][LDT]: P, then dS
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
   const int C3 = 3 * C, coff = h * 3 * dh;
   {
-    const Staged sq = stage_issue(qkv, C3, coff, r0, K, dh), sk = stage_issue(qkv, C3, coff + dh, r0, K, dh);
-    const Staged sv = stage_issue(qkv, C3, coff + 2 * dh, r0, K, dh), sg = stage_issue(dout, C, h * dh, r0, K, dh);
-    stage_commit(Qt, sq, K, KT, scale, dh);
-    stage_commit(Kt, sk, K, KT, 1.f, dh);
-    stage_commit(Vt, sv, K, KT, 1.f, dh);
-    stage_commit(Gt, sg, K, KT, 1.f, dh);
+    const Staged sq = stage_issue<NTMAX>(qkv, C3, coff, r0, K, dh), sk = stage_issue<NTMAX>(qkv, C3, coff + dh, r0, K, dh);
+    const Staged sv = stage_issue<NTMAX>(qkv, C3, coff + 2 * dh, r0, K, dh), sg = stage_issue<NTMAX>(dout, C, h * dh, r0, K, dh);
+    stage_commit<NTMAX>(Qt, sq, K, KT, scale, dh);
+    stage_commit<NTMAX>(Kt, sk, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Vt, sv, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Gt, sg, K, KT, 1.f, dh);
   }
   __syncthreads();
-  const bool active = w < NTL;
-  f32x16 s[2], dp[2];
+  const bool active = w < NT;
+  f32x16 s[NT], dp[NT];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) { s[0][e] = 0.f; s[1][e] = 0.f; dp[0][e] = 0.f; dp[1][e] = 0.f; }
+  for (int e = 0; e < 16; ++e)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { s[t][e] = 0.f; dp[t][e] = 0.f; }
   if (active) {
-    if (NTL > 1) {
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int kk = ks * 2 + (lane >> 5);
-        const float a = Qt[kk * LDT + w * 32 + l31], ga = Gt[kk * LDT + w * 32 + l31];
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + l31], s[0], 0, 0, 0);
-        dp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + l31], dp[0], 0, 0, 0);
-        s[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + 32 + l31], s[1], 0, 0, 0);
-        dp[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + 32 + l31], dp[1], 0, 0, 0);
-      }
-    } else {
+    for (int ks = 0; ks < 16; ++ks) {
+      const int kk = ks * 2 + (lane >> 5);
+      const float a = Qt[kk * LDT + w * 32 + l31], ga = Gt[kk * LDT + w * 32 + l31];
 #pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        const int kk = ks * 2 + (lane >> 5);
-        s[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qt[kk * LDT + w * 32 + l31], Kt[kk * LDT + l31], s[0], 0, 0, 0);
-        dp[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Gt[kk * LDT + w * 32 + l31], Vt[kk * LDT + l31], dp[0], 0, 0, 0);
+      for (int t = 0; t < NT; ++t) {
+        s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + t * 32 + l31], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + t * 32 + l31], dp[t], 0, 0, 0);
       }
     }
-    const bool c0 = l31 < K, c1 = (NTL > 1) && (32 + l31 < K);
+    bool cv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cv[t] = t * 32 + l31 < K;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int i = w * 32 + crow(e, lane);
       const bool rv = i < K;
       const float li = rv ? lse[(size_t)(r0 + i) * heads + h] : 0.f;
-      const float p0 = (rv && c0) ? __expf(s[0][e] - li) : 0.f, p1 = (rv && c1) ? __expf(s[1][e] - li) : 0.f;
-      const float D = half_sum(p0 * dp[0][e] + p1 * dp[1][e]);
-      s[0][e] = p0; s[1][e] = p1;
-      dp[0][e] = p0 * (dp[0][e] - D); dp[1][e] = p1 * (dp[1][e] - D);     // dS
+      float dloc = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float pt = (rv && cv[t]) ? __expf(s[t][e] - li) : 0.f;
+        s[t][e] = pt;
+        dloc += pt * dp[t][e];
+      }
+      const float D = half_sum(dloc);
       float* pr = PB + i * LDT + l31;
-      pr[0] = p0;
-      if (NTL > 1) pr[32] = p1;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        dp[t][e] = s[t][e] * (dp[t][e] - D);     // dS
+        pr[t * 32] = s[t][e];
+      }
     }
   }
   __syncthreads();
@@ -208,6 +231,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const float* gb = Gt + l31 * LDT;
+#pragma unroll 8
     for (int ks = 0; ks < KT / 2; ++ks) {
       const int kk = ks * 2 + (lane >> 5);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PB[kk * LDT + w * 32 + l31], gb[kk], acc, 0, 0, 0);
@@ -223,8 +247,8 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       float* pr = PB + (w * 32 + crow(e, lane)) * LDT + l31;
-      pr[0] = dp[0][e];
-      if (NTL > 1) pr[32] = dp[1][e];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) pr[t * 32] = dp[t][e];
     }
   }
   __syncthreads();
@@ -234,6 +258,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   {
     const float* qb = Qt + l31 * LDT;
+#pragma unroll 8
     for (int ks = 0; ks < KT / 2; ++ks) {
       const int kk = ks * 2 + (lane >> 5);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PB[kk * LDT + w * 32 + l31], qb[kk], acc, 0, 0, 0);
@@ -250,6 +275,7 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
   {
     const float* da = PB + (w * 32 + l31) * LDT;
     const float* kb = Kt + l31 * LDT;
+#pragma unroll 8
     for (int ks = 0; ks < KT / 2; ++ks) {
       const int kk = ks * 2 + (lane >> 5);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[kk], kb[kk], acc, 0, 0, 0);
@@ -262,19 +288,43 @@ __global__ __launch_bounds__(128) void attn_bwd_mfma_kernel(const float* __restr
   }
 }
 
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, int dh, hipStream_t st) {
-  if (dh < 4 || dh > ADH || dh % 4 || C % dh) return SAST_EINVAL;
+template <int NTMAX>
+__global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                   const int* __restrict__ row_off, const int* __restrict__ Kw, int C,
+                                                                   int heads, float scale, int dh) {
+  constexpr int LDT = 32 * NTMAX + 1;
+  __shared__ float sm[4 * 32 * LDT + 32 * NTMAX * LDT];
+  const int g = blockIdx.x, h = blockIdx.y;
+  const int K = Kw[g];
+  if (K == 0) return;
+  const int r0 = row_off[g];
+  switch ((K + 31) >> 5) {
+    case 1: attn_bwd_body<NTMAX, 1>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 2: attn_bwd_body<NTMAX, 2>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 3: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 3>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+  }
+}
+
+// T: tokens per partition (upper bound of K_m)
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
+                         hipStream_t st) {
+  if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
-  hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, 1.0f / sqrtf((float)dh), dh);
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (T <= 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int C, int dh, hipStream_t st) {
-  if (dh < 4 || dh > ADH || dh % 4 || C % dh) return SAST_EINVAL;
+                         int T, int C, int dh, hipStream_t st) {
+  if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
-  hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads,
-                     1.0f / sqrtf((float)dh), dh);
+  const float scale = 1.0f / sqrtf((float)dh);
+  if (T <= 64) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2>), dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
+  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<4>), dim3(W, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -15,6 +15,14 @@ inline int tn_total_blocks() {
   return v;
 }
 
+// partitions of up to this many tokens use the MFMA attention kernels (k_attn_mfma.hip); SAST_ATTN_MFMA_MAX_T=64 restores the
+// VALU kernel (k_attn.hip) for 64 < T <= 128
+inline int mfma_attn_max_t() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SAST_ATTN_MFMA_MAX_T"); v = e ? atoi(e) : 128; }
+  return v;
+}
+
 inline int ks_min_r() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
@@ -257,8 +265,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
-  rc = T <= 64 ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, C, dh, st)
-               : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
+  rc = T <= mfma_attn_max_t() ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st)
+                              : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
   if (rc) return rc;
@@ -347,8 +355,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
               : gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   if (rc) return rc;
   // attention backward
-  rc = T <= 64 ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, C, dh, st)
-               : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
+  rc = T <= mfma_attn_max_t() ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st)
+                              : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
   sd.after_main();
   rc = gemm_tn(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);

@@ -60,9 +60,10 @@ int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, 
 int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
                     const int* Kw, int W, int T, int C, int dh, hipStream_t st);
 
-// k_attn_mfma.hip (T <= 64)
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int C, int dh, hipStream_t st);
+// k_attn_mfma.hip (T <= 128)
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
+                         hipStream_t st);
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int C, int dh, hipStream_t st);
+                         int T, int C, int dh, hipStream_t st);
 
 }  // namespace sast

@@ -336,11 +336,11 @@ def test_selection_properties_full_size(dev):
         assert torch.equal(sel.K_list().cpu(), K)
 
 
-@pytest.mark.parametrize("T,Ks", [(60, [60, 33, 32, 1, 17]), (80, [80, 65, 64, 3, 40])])
+@pytest.mark.parametrize("T,Ks", [(60, [60, 33, 32, 1, 17]), (80, [80, 65, 64, 3, 40]), (120, [120, 97, 96, 31, 70])])
 def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
-    """1Mpx-sized groups (T = 60 -> two 32-token MFMA tiles) and Gen1-sized groups (T = 80 -> VALU attention kernels)
-    with ragged K_m (full, tile boundary +-1, tiny, dropped window): forward and every gradient against the oracle's
-    padded / masked formulation."""
+    """1Mpx-sized groups (T = 60 -> up to two 32-token MFMA tiles), Gen1-sized groups (T = 80 -> up to three tiles, the
+    4-wave kernel) and near-maximum partitions (T = 120 -> four tiles) with ragged K_m (full, tile boundary +-1, tiny,
+    dropped window): forward and every gradient against the oracle's padded / masked formulation."""
     from sast_amd.layers import MS_WSA
     from sast_amd.layers.ops import LayerNorm
     C, NW = 64, 6                                 # window 5 is dropped
