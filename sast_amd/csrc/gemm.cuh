@@ -69,6 +69,9 @@ struct LdsLd {
 
 // epilogues may ask for per-column sum / sum-of-squares of the stored values (BatchNorm batch statistics fused
 // into the producing conv): EP::COLSTATS = true, EP::sums -> double[2*EP::C]
+// a B-side loader may depend on the block's row tile (LdWeightConvDxP: the parity class of the rows decides the taps)
+template <class L, class = void> struct LoaderWantsM0 : std::false_type {};
+template <class L> struct LoaderWantsM0<L, std::void_t<decltype(L::WANTS_M0)>> : std::bool_constant<L::WANTS_M0> {};
 template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
@@ -163,12 +166,14 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
     if constexpr (LB::RC) {
       const int rr = s / (BK / 4), kq = s % (BK / 4);
       const int g = (rr / BJ) % G, jl = rr % BJ;
-      cb[it] = lb.prep(j0 + jl, g, NJ);
+      if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jl, g, NJ, m0);
+      else cb[it] = lb.prep(j0 + jl, g, NJ);
       rb_off[it] = kq * 4;
       lb_off[it] = nnmap(jl, g) * LDK + kq * 4;
     } else {
       const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
-      cb[it] = lb.prep(j0 + jq * 4, g, NJ);
+      if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jq * 4, g, NJ, m0);
+      else cb[it] = lb.prep(j0 + jq * 4, g, NJ);
       rb_off[it] = kk;
       lb_off[it] = kk * LDB + nnmap(jq * 4, g);
     }
@@ -713,6 +718,77 @@ struct LdWeightConvDx {
   SAST_DEFAULT_FINISH
 };
 
+// ---- stride-2 backward-data by input-pixel parity class.  For stride 2 an input pixel (iy, ix) only receives the taps with
+// kh = (iy + pad) mod 2 (same for x): the generic LdConvDx gather multiplies zeros for the other 3/4 of the k*k taps.  Here
+// the input pixels are re-ordered into the 4 classes (iy & 1, ix & 1) -- row m = class * Mc + (b, yy, xx), pixel
+// (2 yy + py, 2 xx + px) -- and every class reduces over its own list of at most 2 x 2 taps (3x3: 1, 2, 2 and 4 taps; with
+// replicate padding the border-only taps kh < pad join the even classes), padded to 4 slots so that all classes share one
+// launch: 16 tap slots instead of 36.  Mc must be a multiple of the row tile so that a block sees a single class.
+struct ConvDxClasses {
+  int Hc, Wc, Mc;
+  unsigned kh_pack[4], kw_pack[4];   // per class: 4 bits per tap slot, 15 = empty slot
+  __device__ __forceinline__ void packs(int cls, unsigned& kh, unsigned& kw) const {
+    kh = cls == 0 ? kh_pack[0] : cls == 1 ? kh_pack[1] : cls == 2 ? kh_pack[2] : kh_pack[3];
+    kw = cls == 0 ? kw_pack[0] : cls == 1 ? kw_pack[1] : cls == 2 ? kw_pack[2] : kw_pack[3];
+  }
+};
+struct LdConvDxP {
+  static constexpr bool RC = true;
+  const float* dy; ConvGeom g; int Cout; int lddy; int cout_shift; ConvDxClasses k;
+  struct Ctx { const float* img; int iy, ix; unsigned kh, kw; bool ok; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    const int cls = ii / k.Mc, ic = ii - cls * k.Mc;
+    const int xx = ic % k.Wc, t = ic / k.Wc, yy = t % k.Hc, b = t / k.Hc;
+    Ctx c;
+    c.img = dy + (size_t)b * g.Ho * g.Wo * lddy; c.iy = 2 * yy + (cls >> 1); c.ix = 2 * xx + (cls & 1); c.ok = ok;
+    k.packs(cls, c.kh, c.kw);
+    return c;
+  }
+  __device__ __forceinline__ bool src(int i, int kk, int n_out, int& o) const {
+    const int t = i + g.pad - kk;
+    const int q = t >> 1;
+    const bool hit = kk != 15 && t >= 0 && (t & 1) == 0 && q < n_out;
+    const bool rep = g.replicate && i == 0 && kk < g.pad;
+    o = hit ? q : 0;
+    return hit || rep;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 4);
+    const int slot = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - slot * Cout;
+    const int kh = (c.kh >> (4 * slot)) & 15, kw = (c.kw >> (4 * slot)) & 15;
+    int oy, ox;
+    const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
+    ok = c.ok && r < Reff && vy && vx;
+    v = ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+struct LdWeightConvDxP {
+  static constexpr bool RC = false;
+  static constexpr bool WANTS_M0 = true;
+  const float* w; int Cout, taps, Cin, cout_shift, KW; ConvDxClasses k;
+  struct Ctx { const float* col; unsigned kh, kw; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ, int m0) const {
+    Ctx c;
+    c.col = w + (j < NJ ? j : 0); c.ok = j < NJ;
+    k.packs(m0 / k.Mc, c.kh, c.kw);
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 1);
+    const int slot = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - slot * Cout;
+    const int kh = (c.kh >> (4 * slot)) & 15, kw = (c.kw >> (4 * slot)) & 15;
+    const bool empty = kh == 15 || kw == 15;
+    ok = c.ok && r < Reff && !empty;
+    v = ld4(c.col + ((size_t)co * taps + (empty ? 0 : kh * KW + kw)) * Cin);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+
 inline int pow2_shift(int v) {
   int s = 0;
   while ((1 << s) < v) ++s;
@@ -756,6 +832,21 @@ struct EpAtomic {  // C[m*ldc + j] += v   (split-R weight gradients)
   __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
     atomicAdd(c + (size_t)m * ldc + j, v[0]);
+  }
+};
+
+struct EpStoreClass {  // C[pixel(m) * ldc + j] = v, pixel(m) from the parity-class row order of LdConvDxP
+  float* c; int ldc; int H, W; ConvDxClasses k;
+  using Col = EpNone;
+  struct Aux { int p; };
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int m, int) const {
+    const int cls = m / k.Mc, ic = m - cls * k.Mc;
+    const int xx = ic % k.Wc, t = ic / k.Wc, yy = t % k.Hc, b = t / k.Hc;
+    return Aux{(b * H + 2 * yy + (cls >> 1)) * W + 2 * xx + (cls & 1)};
+  }
+  __device__ __forceinline__ void post(int, int j, const float (&v)[1], const Col&, const Aux& a) const {
+    c[(size_t)a.p * ldc + j] = v[0];
   }
 };
 

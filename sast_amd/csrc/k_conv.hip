@@ -273,6 +273,40 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   return g;
 }
 
+// backward-data of a k x k convolution.  Stride 2 with a 3x3 kernel (downsample convs of stages 2-4, the two bottom-up PAFPN
+// convs) goes through the parity-class form (gemm.cuh: LdConvDxP) unless SAST_CONVDX_PARITY=0; everything else through the
+// generic gather.
+int conv_dx(const float* dconv, const ConvGeom& g, int Cout, const float* w, float* dx, int lddx, hipStream_t st) {
+  const int k = g.KH, shift = pow2_shift(Cout);
+  static int parity = -1;
+  if (parity < 0) { const char* e = getenv("SAST_CONVDX_PARITY"); parity = e ? atoi(e) : 1; }
+  const int Mc = g.B * (g.H / 2) * (g.W / 2);
+  if (!(parity && g.stride == 2 && k == 3 && g.pad == 1 && g.H % 2 == 0 && g.W % 2 == 0 && Mc % 64 == 0))
+    return gemm_auto(LdConvDx{dconv, g, Cout, Cout, shift}, LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr},
+                     g.B * g.H * g.W, g.Cin, k * k * Cout, st);
+  ConvDxClasses c;
+  c.Hc = g.H / 2; c.Wc = g.W / 2; c.Mc = Mc;
+  for (int cls = 0; cls < 4; ++cls) {
+    const int py = cls >> 1, px = cls & 1;
+    // taps that can be non-zero for this class: matching parity, plus (replicate padding) the border tap kk < pad that folds
+    // onto output row / column 0 for input row / column 0 (an even one); unused slots are marked 15
+    int ty[2] = {15, 15}, tx[2] = {15, 15}, ny = 0, nx = 0;
+    for (int kk = 0; kk < k; ++kk) {
+      if ((py + g.pad - kk) % 2 == 0 || (g.replicate && py == 0 && kk < g.pad)) ty[ny++] = kk;
+      if ((px + g.pad - kk) % 2 == 0 || (g.replicate && px == 0 && kk < g.pad)) tx[nx++] = kk;
+    }
+    c.kh_pack[cls] = c.kw_pack[cls] = 0;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        const int slot = a * 2 + b;
+        c.kh_pack[cls] |= (unsigned)ty[a] << (4 * slot);
+        c.kw_pack[cls] |= (unsigned)tx[b] << (4 * slot);
+      }
+  }
+  return gemm_auto(LdConvDxP{dconv, g, Cout, Cout, shift, c}, LdWeightConvDxP{w, Cout, k * k, g.Cin, shift, g.KW, c},
+                   EpStoreClass{dx, lddx, g.H, g.W, c}, 4 * Mc, g.Cin, 4 * Cout, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -303,11 +337,7 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
   sd.after_main();
   rc = gemm_tn(LdRowsT{dconv, a->Cout}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, sd.side);
   if (rc) return rc;
-  if (a->dx) {
-    const int Min = a->B * a->H * a->W;
-    rc = gemm_auto(LdConvDx{dconv, g, a->Cout, a->Cout, pow2_shift(a->Cout)}, LdWeightConvDx{a->w, a->Cout, k * k, a->Cin, pow2_shift(a->Cout)}, EpStore{a->dx, a->Cin, nullptr},
-                   Min, a->Cin, k * k * a->Cout, st);
-  }
+  if (a->dx) rc = conv_dx(dconv, g, a->Cout, a->w, a->dx, a->Cin, st);
   return rc;
 }
 
@@ -379,9 +409,7 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   } else {
     rc = gemm_tn(LdRowsT{dconv, C}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, sd.side);
     if (rc) return rc;
-    if (a->dx)
-      rc = gemm_auto(LdConvDx{dconv, g, C, C, pow2_shift(C)}, LdWeightConvDx{a->w, C, k * k, a->Cin, pow2_shift(C)}, EpStore{a->dx, a->lddx, nullptr},
-                     a->B * a->H * a->W, a->Cin, k * k * C, st);
+    if (a->dx) rc = conv_dx(dconv, g, C, a->w, a->dx, a->lddx, st);
   }
   return rc;
 }
