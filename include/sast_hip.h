@@ -95,6 +95,10 @@ typedef struct SastSel {
 /* mode 0: window partition (ops.py:189-195), 1: grid partition (ops.py:206-212) */
 int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode, double bounce, const SastSel* sel,
                 sast_stream_t stream);
+/* both selections of one SAST block (window layer, then grid layer, on the same token scores -- SAST.py:120-123,141-147)
+ * in the same launches; results identical to two sast_select calls with mode 0 and 1. */
+int sast_select_pair(const float* tok, int B, int H, int W, int ph, int pw, double bounce, const SastSel* win, const SastSel* grid,
+                     sast_stream_t stream);
 
 /* a9  MS_WSA -- SAST.py:199-255 with LayerScale (ops.py:178-186) and GLU-MLP (ops.py:111-175). */
 typedef struct SastMswsaArgs {

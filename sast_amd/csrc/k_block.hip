@@ -214,6 +214,15 @@ int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode,
                        s->win_rank, s->counts, s->tok_slot, s->row_tok, (hipStream_t)stream);
 }
 
+int sast_select_pair(const float* tok, int B, int H, int W, int ph, int pw, double bounce, const SastSel* win, const SastSel* grid,
+                     sast_stream_t stream) {
+  if (!tok || !win || !grid) return SAST_EINVAL;
+  const int N = (H / ph) * (W / pw), T = ph * pw;
+  const float thr_w = (float)((1.0 / N) / (1.0 + bounce));
+  const float thr_t = (float)((1.0 / T) / (1.0 + bounce));
+  return select_pair_launch(tok, B, H, W, ph, pw, thr_w, thr_t, win, grid, (hipStream_t)stream);
+}
+
 // ------------------------------------------------------------------ scoring + STP
 int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -13,9 +13,17 @@
 
 namespace sast {
 
+// every kernel below serves up to two partitions of the same token scores in one launch (blockIdx.y = 0: window layer,
+// 1: grid layer -- SAST.py:141-142 regroups the same scores), each with its own output set
+struct SelOut {
+  int* win_keep; unsigned long long* mask; int* K; int* row_off; int* win_rank; int* counts; int* tok_slot; int* row_tok;
+};
+struct SelPair { SelOut o[2]; int mode[2]; };
+
 // one block per sample: L1 norm per window -> softmax over the N windows -> keep flags
-__global__ __launch_bounds__(256) void win_select_kernel(const float* __restrict__ tok, PartMap pm, int L, float thr,
-                                                         int* __restrict__ win_keep) {
+__global__ __launch_bounds__(256) void win_select_kernel(const float* __restrict__ tok, PartMap pm, int L, float thr, SelPair sp) {
+  pm.mode = sp.mode[blockIdx.y];
+  int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
   extern __shared__ float wv[];  // [N]
   __shared__ float redf[4];
   __shared__ double redd[4];
@@ -47,9 +55,11 @@ __global__ __launch_bounds__(256) void win_select_kernel(const float* __restrict
 }
 
 // one wave per window: softmax over its T <= 128 tokens, keep mask by ballot, K by popcount
-__global__ __launch_bounds__(256) void tok_select_kernel(const float* __restrict__ tok, PartMap pm, int L, int W, float thr,
-                                                         const int* __restrict__ win_keep, unsigned long long* __restrict__ mask,
-                                                         int* __restrict__ Kout) {
+__global__ __launch_bounds__(256) void tok_select_kernel(const float* __restrict__ tok, PartMap pm, int L, int W, float thr, SelPair sp) {
+  pm.mode = sp.mode[blockIdx.y];
+  const int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
+  unsigned long long* __restrict__ mask = sp.o[blockIdx.y].mask;
+  int* __restrict__ Kout = sp.o[blockIdx.y].K;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= W) return;
   const int N = pm.N(), T = pm.T();
@@ -71,9 +81,12 @@ __global__ __launch_bounds__(256) void tok_select_kernel(const float* __restrict
 }
 
 // single block: exclusive scan over the W windows (flat b*N+n order == reference's ascending index order)
-__global__ __launch_bounds__(1024) void select_scan_kernel(const int* __restrict__ win_keep, const int* __restrict__ K, int W, int B,
-                                                           int* __restrict__ row_off, int* __restrict__ win_rank,
-                                                           int* __restrict__ counts) {
+__global__ __launch_bounds__(1024) void select_scan_kernel(int W, int B, SelPair sp) {
+  const int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
+  const int* __restrict__ K = sp.o[blockIdx.y].K;
+  int* __restrict__ row_off = sp.o[blockIdx.y].row_off;
+  int* __restrict__ win_rank = sp.o[blockIdx.y].win_rank;
+  int* __restrict__ counts = sp.o[blockIdx.y].counts;
   __shared__ int sk[1024], sw[1024];
   const int per = (W + 1023) / 1024;
   const int w0 = threadIdx.x * per, w1 = min(W, w0 + per);
@@ -103,9 +116,12 @@ __global__ __launch_bounds__(1024) void select_scan_kernel(const int* __restrict
 }
 
 // one wave per window: scatter compact row ids (mbcnt-style rank = popcount of lower mask bits)
-__global__ __launch_bounds__(256) void select_fill_kernel(PartMap pm, int L, int W, const unsigned long long* __restrict__ mask,
-                                                          const int* __restrict__ row_off, int* __restrict__ tok_slot,
-                                                          int* __restrict__ row_tok) {
+__global__ __launch_bounds__(256) void select_fill_kernel(PartMap pm, int L, int W, SelPair sp) {
+  pm.mode = sp.mode[blockIdx.y];
+  const unsigned long long* __restrict__ mask = sp.o[blockIdx.y].mask;
+  const int* __restrict__ row_off = sp.o[blockIdx.y].row_off;
+  int* __restrict__ tok_slot = sp.o[blockIdx.y].tok_slot;
+  int* __restrict__ row_tok = sp.o[blockIdx.y].row_tok;
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (w >= W) return;
   const int N = pm.N(), T = pm.T();
@@ -127,18 +143,40 @@ __global__ __launch_bounds__(256) void select_fill_kernel(PartMap pm, int L, int
   }
 }
 
+static int select_launch_n(const float* tok, int B, int H, int W_, int ph, int pw, float thr_win, float thr_tok, const SelPair& sp,
+                           int nsel, hipStream_t st) {
+  PartMap pm{H, W_, ph, pw, 0};
+  if (H % ph || W_ % pw || pm.T() > 128) return SAST_EINVAL;
+  const int L = H * W_, N = pm.N(), W = B * N;
+  hipLaunchKernelGGL(win_select_kernel, dim3(B, nsel), dim3(256), sizeof(float) * N, st, tok, pm, L, thr_win, sp);
+  hipLaunchKernelGGL(tok_select_kernel, dim3((W + 3) / 4, nsel), dim3(256), 0, st, tok, pm, L, W, thr_tok, sp);
+  hipLaunchKernelGGL(select_scan_kernel, dim3(1, nsel), dim3(1024), 0, st, W, B, sp);
+  hipLaunchKernelGGL(select_fill_kernel, dim3((W + 3) / 4, nsel), dim3(256), 0, st, pm, L, W, sp);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
 int select_launch(const float* tok, int B, int H, int W_, int ph, int pw, int mode, float thr_win, float thr_tok,
                   int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,
                   int* row_tok, hipStream_t st) {
-  PartMap pm{H, W_, ph, pw, mode};
-  if (H % ph || W_ % pw || pm.T() > 128) return SAST_EINVAL;
-  const int L = H * W_, N = pm.N(), W = B * N;
-  hipLaunchKernelGGL(win_select_kernel, dim3(B), dim3(256), sizeof(float) * N, st, tok, pm, L, thr_win, win_keep);
-  hipLaunchKernelGGL(tok_select_kernel, dim3((W + 3) / 4), dim3(256), 0, st, tok, pm, L, W, thr_tok, win_keep, mask, K);
-  hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, st, win_keep, K, W, B, row_off, win_rank, counts);
-  hipLaunchKernelGGL(select_fill_kernel, dim3((W + 3) / 4), dim3(256), 0, st, pm, L, W, mask, row_off, tok_slot, row_tok);
-  SAST_CHECK_LAUNCH();
-  return SAST_OK;
+  SelPair sp;
+  sp.o[0] = SelOut{win_keep, mask, K, row_off, win_rank, counts, tok_slot, row_tok};
+  sp.o[1] = sp.o[0];
+  sp.mode[0] = sp.mode[1] = mode;
+  return select_launch_n(tok, B, H, W_, ph, pw, thr_win, thr_tok, sp, 1, st);
+}
+
+// window-layer and grid-layer selection of one SAST block in the same four launches
+int select_pair_launch(const float* tok, int B, int H, int W_, int ph, int pw, float thr_win, float thr_tok, const SastSel* win,
+                       const SastSel* grid, hipStream_t st) {
+  SelPair sp;
+  const SastSel* s2[2] = {win, grid};
+  for (int i = 0; i < 2; ++i) {
+    sp.o[i] = SelOut{s2[i]->win_keep, (unsigned long long*)s2[i]->mask, s2[i]->K, s2[i]->row_off, s2[i]->win_rank, s2[i]->counts,
+                     s2[i]->tok_slot, s2[i]->row_tok};
+    sp.mode[i] = i;
+  }
+  return select_launch_n(tok, B, H, W_, ph, pw, thr_win, thr_tok, sp, 2, st);
 }
 
 }  // namespace sast

@@ -54,6 +54,9 @@ int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mod
                   int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,
                   int* row_tok, hipStream_t st);
 
+int select_pair_launch(const float* tok, int B, int H, int W, int ph, int pw, float thr_win, float thr_tok, const SastSel* win,
+                       const SastSel* grid, hipStream_t st);
+
 // k_attn.hip
 int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
                     hipStream_t st);

@@ -314,6 +314,21 @@ def select(tok: torch.Tensor, B, H, W, ph, pw, mode, bounce) -> Selection:
     return sel
 
 
+@torch.no_grad()
+def select_pair(tok: torch.Tensor, B, H, W, ph, pw, bounce):
+    """window-layer and grid-layer selection of one SAST block (SAST.py:120-123 and :141-147 use the same token scores) in
+    the same four launches -> (Selection mode 0, Selection mode 1), identical to two `select` calls."""
+    _need_gpu(tok)
+    if H % ph or W % pw:
+        raise AssertionError(f"map {H}x{W} must be divisible by partition ({ph},{pw})")  # ops.py:191-192
+    s1, s2 = Selection(B, H, W, ph, pw, 0, tok.device), Selection(B, H, W, ph, pw, 1, tok.device)
+    tok = tok.contiguous()
+    a, b = s1.struct(), s2.struct()
+    L.check(L.lib().sast_select_pair(tok.data_ptr(), B, H, W, ph, pw, float(bounce), C.byref(a), C.byref(b), _stream()), "select_pair")
+    s1.tok = s2.tok = tok
+    return s1, s2
+
+
 def selection_from_index_lists(index_window, asy_index, K, n_groups: int, T: int, device) -> Selection:
     """build the device-side selection from reference-style lists in PARTITIONED layout
     (token id = group*T + slot): used by the stand-alone MS_WSA.forward drop-in."""

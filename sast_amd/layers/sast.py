@@ -173,8 +173,7 @@ class SAST_block(nn.Module):
         self.B, self.N = B, H * W // (ph * pw)
         if self.first_block:
             xw, tok = SF.score_stp(xp, r, self.to_scores.weight, self.to_scores.bias, self.to_controls.weight, self.amp_value)
-            sel1 = SF.select(tok, B, H, W, ph, pw, 0, self.bounce_value)
-            sel2 = SF.select(tok, B, H, W, ph, pw, 1, self.bounce_value)
+            sel1, sel2 = SF.select_pair(tok, B, H, W, ph, pw, self.bounce_value)
         else:
             xw = xp
             sel1, sel2 = index_list
