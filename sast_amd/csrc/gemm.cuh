@@ -75,10 +75,21 @@ template <class L> struct LoaderWantsM0<L, std::void_t<decltype(L::WANTS_M0)>> :
 template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
+// LDS floats one workgroup of an instantiation needs
+template <class T, class LA, class LB>
+struct GemmSmem {
+  static constexpr int LDK = T::BK + 4;
+  static constexpr int A_STAGE = LA::RC ? T::BM * LDK : T::BK * (T::BM + 4), B_STAGE = LB::RC ? T::BN * LDK : T::BK * (T::BN + 4);
+  static constexpr int FLOATS = T::KS * 2 * (A_STAGE + B_STAGE);
+};
+
+// the whole GEMM of one workgroup.  `block` / `nblocks` are the workgroup's index and the grid size of ITS problem (a
+// launch may carry two problems, see gemm_dual_kernel), `smem` its LDS (GemmSmem<...>::FLOATS floats, 16-byte aligned).
 template <class T, class LA, class LB, class EP, bool SPLIT>
-__global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP ep, int M, int NJ, int R,
-                                                              const int* __restrict__ dM, const int* __restrict__ dR,
-                                                              float* __restrict__ colsum, int nsplit, int xcd_remap) {
+__device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R,
+                                          const int* __restrict__ dM, const int* __restrict__ dR,
+                                          float* __restrict__ colsum, int nsplit, int xcd_remap, int block, int nblocks,
+                                          float* __restrict__ smem) {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NTG, G = T::G, BJ = T::BJ, KS = T::KS;
   // LDS tile layouts: a reduce-contiguous (RC) operand keeps its natural [row][k] order (row stride LDK = BK + 4 floats):
   // one ds_write_b128 per global float4 and BK/8 ds_read_b128 per lane per k-tile, both conflict-free; an index-contiguous
@@ -89,7 +100,7 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
   constexpr int A_STAGE = LA::RC ? BM * LDK : BK * LDA, B_STAGE = LB::RC ? BN * LDK : BK * LDB;
   constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
   static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
-  __shared__ __attribute__((aligned(16))) float smem[KS * GROUP_FLOATS];
+  static_assert(KS * GROUP_FLOATS == GemmSmem<T, LA, LB>::FLOATS, "GemmSmem");
   const int kg = threadIdx.x / NT;          // k-group of this wave (wave-uniform)
   float* As = smem + kg * GROUP_FLOATS;
   float* Bs = As + 2 * A_STAGE;
@@ -100,9 +111,9 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
   // 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (each with a private L2); with xcd_remap the launch order is
   // re-read so that consecutive work items -- the column tiles that share the same A rows, and all tiles of one reduction
   // split -- run on the SAME XCD at about the same time and share its L2 instead of fetching the rows once per XCD.
-  int work = blockIdx.x;
+  int work = block;
   if (xcd_remap) {
-    work = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    work = (block & 7) * (nblocks >> 3) + (block >> 3);
   }
   const int ntile = nbj * ((M + BM - 1) / BM);
   if (work >= ntile * nsplit) return;
@@ -394,6 +405,40 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
   SAST_TL(4);
 }
 
+template <class T, class LA, class LB, class EP, bool SPLIT>
+__global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP ep, int M, int NJ, int R,
+                                                              const int* __restrict__ dM, const int* __restrict__ dR,
+                                                              float* __restrict__ colsum, int nsplit, int xcd_remap) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<T, LA, LB>::FLOATS];
+  gemm_body<T, LA, LB, EP, SPLIT>(la, lb, ep, M, NJ, R, dM, dR, colsum, nsplit, xcd_remap, blockIdx.x, gridDim.x, smem);
+}
+
+// ---- two independent GEMMs in ONE launch: workgroups [0, n1) run problem 1, the rest problem 2.  Used for the (dW, dX)
+// pair of a layer's backward -- both consume the same dY and neither depends on the other.  In a captured stream every
+// kernel boundary is a full drain + dispatch ramp (~3-4 us on MI355X, a fifth of this workload's step); pairing removes
+// one boundary per layer and lets the second problem's workgroups fill the tail of the first.
+template <class T_, class LA_, class LB_, class EP_, bool SPLIT_>
+struct GemmJob {
+  using T = T_; using LA = LA_; using LB = LB_; using EP = EP_;
+  static constexpr bool SPLIT = SPLIT_;
+  LA la; LB lb; EP ep; int M, NJ, R; const int* dM; const int* dR; float* colsum; int nsplit, xcd_remap;
+};
+template <class J1, class J2>
+__global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) void gemm_dual_kernel(J1 a, J2 b, int n1) {
+  constexpr int F1 = GemmSmem<typename J1::T, typename J1::LA, typename J1::LB>::FLOATS;
+  constexpr int F2 = GemmSmem<typename J2::T, typename J2::LA, typename J2::LB>::FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
+  if ((int)blockIdx.x < n1) {
+    if (threadIdx.x >= J1::T::NT) return;   // surplus waves of the larger workgroup shape (block-uniform per wave)
+    gemm_body<typename J1::T, typename J1::LA, typename J1::LB, typename J1::EP, J1::SPLIT>(
+        a.la, a.lb, a.ep, a.M, a.NJ, a.R, a.dM, a.dR, a.colsum, a.nsplit, a.xcd_remap, blockIdx.x, n1, smem);
+  } else {
+    if (threadIdx.x >= J2::T::NT) return;
+    gemm_body<typename J2::T, typename J2::LA, typename J2::LB, typename J2::EP, J2::SPLIT>(
+        b.la, b.lb, b.ep, b.M, b.NJ, b.R, b.dM, b.dR, b.colsum, b.nsplit, b.xcd_remap, blockIdx.x - n1, gridDim.x - n1, smem);
+  }
+}
+
 // ---- optional per-launch HIP-event timing of the GEMM family (bench.py roofline leg; off by default).
 // When enabled, every launch is bracketed by events on the launch stream and device-side row counts
 // are read back, so the report carries measured time AND algorithmic FLOPs (2*M*N*R with the real M/R).
@@ -448,6 +493,43 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
   } else {
     hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
                        (const int*)nullptr, dR, colsum, splits, remap);
+  }
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// grid size of one problem inside a (possibly dual) launch: padded to a multiple of 8 when the XCD remap is on
+inline int gemm_grid(int ntile, int nsplit, int& remap) {
+  const int n = ntile * nsplit;
+  remap = xcd_remap_enabled() && n >= 16;
+  return remap ? (n + 7) / 8 * 8 : n;
+}
+void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, int NJ1, int R1, const int* dM1, const int* dR1, int G2,
+                         int M2, int NJ2, int R2, const int* dM2, const int* dR2, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
+
+// job 1: split-R weight gradient (TS tile), job 2: plain GEMM (TP tile), one launch
+template <class TS, class LA1, class LB1, class EP1, class TP, class LA2, class LB2, class EP2>
+inline int launch_gemm_dual(const LA1& la1, const LB1& lb1, const EP1& ep1, int M1, int NJ1, int R1, const int* dR1, int splits,
+                            float* colsum, const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2,
+                            hipStream_t st) {
+  using J1 = GemmJob<TS, LA1, LB1, EP1, true>;
+  using J2 = GemmJob<TP, LA2, LB2, EP2, false>;
+  if (splits < 1) splits = 1;
+  const int nt1 = ((M1 + TS::BM - 1) / TS::BM) * ((NJ1 + TS::BJ - 1) / TS::BJ);
+  const int nt2 = ((M2 + TP::BM - 1) / TP::BM) * ((NJ2 + TP::BJ - 1) / TP::BJ);
+  int r1, r2;
+  int n1 = gemm_grid(nt1, splits, r1);
+  const int n2 = gemm_grid(nt2, 1, r2);
+  if (r2 && (n1 & 7)) n1 = (n1 + 7) / 8 * 8;   // keep problem 2's workgroup -> XCD phase (surplus workgroups of problem 1 exit)
+  const J1 a{la1, lb1, ep1, M1, NJ1, R1, nullptr, dR1, colsum, splits, r1};
+  const J2 b{la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, nullptr, 1, r2};
+  constexpr int NTHREADS = TS::NT > TP::NT ? TS::NT : TP::NT;
+  if (prof_enabled()) {
+    hipEvent_t e0, e1;
+    prof_kernel_events2(__PRETTY_FUNCTION__, 0.0, TS::G, M1, NJ1, R1, nullptr, dR1, TP::G, M2, NJ2, R2, dM2, nullptr, st, &e0, &e1);
+    hipExtLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
+  } else {
+    hipLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2), dim3(NTHREADS), 0, st, a, b, n1);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;

@@ -1,0 +1,53 @@
+// (dW, dX) of one layer's backward in one launch (gemm.cuh: gemm_dual_kernel), with the same tile heuristics as the
+// separate launches.  SAST_GEMM_PAIR=0 restores two launches.
+#pragma once
+#include <cstdlib>
+#include "gemm.cuh"
+
+namespace sast {
+
+inline int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+inline bool gemm_pair_enabled() { static int v = env_int("SAST_GEMM_PAIR", 1); return v != 0; }
+inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 384); return v; }
+inline int pair_ks_min_r() { static int v = env_int("SAST_KS_MINR", 256); return v; }
+inline int pair_thin_nb() { static int v = env_int("SAST_THIN_NB", 384); return v; }
+inline int pair_ks_nb() { static int v = env_int("SAST_KS_NB", 1000000); return v; }
+
+inline int tn_splits(int Mo, int NJ, int R) {
+  const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
+  int splits = (pair_tn_blocks() + nb - 1) / nb;
+  const int max_splits = (R + 127) / 128;
+  if (splits > max_splits) splits = max_splits;
+  return splits < 1 ? 1 : splits;
+}
+
+// job 1: out[Mo, NJ1] += A1^T B1 over R1 rows (dR1: device-side count), optional column sums of A1 (bias gradient)
+// job 2: plain GEMM (M2 rows, device-side count dM2) with epilogue ep2
+template <class LA1, class LB1, class LA2, class LB2, class EP2>
+int gemm_pair(const LA1& la1, const LB1& lb1, float* out, int ldc, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
+              const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st) {
+  const int splits = tn_splits(Mo, NJ1, R1);
+  const EpAtomic ep1{out, ldc};
+  const long nb2 = (long)((M2 + 63) / 64) * ((NJ2 + 63) / 64);
+  const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
+  if (!gemm_pair_enabled() || Mo <= 0 || NJ1 <= 0 || R1 <= 0 || M2 <= 0 || NJ2 <= 0 || R2 <= 0) {
+    int rc = launch_gemm_split<TileSmallK2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);
+    if (rc) return rc;
+    if (thin) return launch_gemm<TileThinK4>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
+    if (k2) return launch_gemm<TileSmallK2>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
+    return launch_gemm<TileSmall>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
+  }
+  if (thin)
+    return launch_gemm_dual<TileSmallK2, LA1, LB1, EpAtomic, TileThinK4, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+                                                                                      ep2, M2, NJ2, R2, dM2, st);
+  if (k2)
+    return launch_gemm_dual<TileSmallK2, LA1, LB1, EpAtomic, TileSmallK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+                                                                                       ep2, M2, NJ2, R2, dM2, st);
+  return launch_gemm_dual<TileSmallK2, LA1, LB1, EpAtomic, TileSmall, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
+                                                                                   M2, NJ2, R2, dM2, st);
+}
+
+}  // namespace sast

@@ -2,7 +2,7 @@
 // Each entry point enqueues a short chain of kernels on the caller's stream; the GEMMs are
 // the fp32-MFMA template of gemm.cuh with op-specific loaders / fused epilogues.
 #include <cstdlib>
-#include "gemm.cuh"
+#include "gemm_pair.cuh"
 #include "kernels.h"
 
 using namespace sast;
@@ -246,13 +246,10 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   int rc = stp_bwd_launch(a->xp, a->s, a->scale, a->dxw, a->dxp, dz, dscale, a->B, a->L, C, st);
   if (rc) return rc;
   // dxp = direct + dz Ws
-  Side sd(st);
-  sd.after_main();
-  rc = gemm_tn(LdRowsT{dz, C}, LdRowsT{a->xp, C}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b, sd.side);
+  rc = controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, st);
   if (rc) return rc;
-  rc = controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, sd.side);
-  if (rc) return rc;
-  return gemm_auto(LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
+  return gemm_pair(LdRowsT{dz, C}, LdRowsT{a->xp, C}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b,
+                   LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
 }
 
 // ------------------------------------------------------------------ MS-WSA
@@ -322,7 +319,6 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   float* s1 = s2 + C;
   zero_fill(raw2, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
   int rc;
-  Side sd(st);   // weight-gradient GEMMs run beside the activation-gradient chain
   // Context Broadcasting: the gradient reaching the MLP output is dZ'[r] = 0.5 dZ[r] + (0.5/L) sum_{r' in sample} dZ[r']
   // (gamma2 factored out exactly as without CB); everything downstream of the MLP output consumes dZ' in compact form.
   const float* dz = a->dout;
@@ -336,42 +332,45 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
     dz = a->cb_m;
     dz_tok = nullptr;
   }
-  // fc2 grads (raw, LayerScale applied in the finish kernel): need only dZ (= dout rows) and H
-  sd.after_main();
-  rc = dz_tok ? gemm_tn(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, sd.side)
-              : gemm_tn(LdRowsT{dz, C}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, sd.side);
+  // Every (weight gradient, activation gradient) pair below consumes the same dY and goes out as ONE launch (gemm_pair).
+  // fc2: raw dW2 / db2 (LayerScale applied in the finish kernel) need dZ (= dout rows) and H;  dH = (gamma2 * dZ) W2 fused
+  // with the GLU backward: dUG from the saved pre-activations
+  if (dz_tok && a->ls2) {
+    rc = gemm_pair(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2,
+                   LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+  } else {   // Context Broadcasting (compact dZ') or LayerScale disabled: the rarely used combinations stay two launches
+    rc = dz_tok ? gemm_tn(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st)
+                : gemm_tn(LdRowsT{dz, C}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st);
+    if (rc) return rc;
+    rc = a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st)
+                : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+  }
   if (rc) return rc;
-  rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, sd.side);
+  rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, st);
   if (rc) return rc;
-  // dH = (gamma2 * dZ) W2 ; fused: dUG from the saved pre-activations
-  rc = a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st)
-              : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+  // fc1: dW1 / db1, and dY = dZ + dUG W1
+  rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
+                 LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
   if (rc) return rc;
-  sd.after_main();
-  rc = gemm_tn(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b, sd.side);
+  // proj: raw dWp / dbp, and dO = (gamma1 * dY) Wp
+  if (a->ls1) {
+    rc = gemm_pair(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1,
+                   LdRows{dY, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+  } else {
+    rc = gemm_tn(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, st);
+    if (rc) return rc;
+    rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+  }
   if (rc) return rc;
-  // dY = dZ + dUG W1
-  rc = gemm_auto(LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C,
-                 2 * inner, dR, st);
-  if (rc) return rc;
-  sd.after_main();
-  rc = gemm_tn(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, sd.side);
-  if (rc) return rc;
-  rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, sd.side);
-  if (rc) return rc;
-  // dO = (gamma1 * dY) Wp
-  rc = a->ls1 ? gemm_auto(LdRows{dY, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st)
-              : gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+  rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
   if (rc) return rc;
   // attention backward
   rc = T <= mfma_attn_max_t() ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st)
                               : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
-  sd.after_main();
-  rc = gemm_tn(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b, sd.side);
-  if (rc) return rc;
-  // dS = dY + dQKV Wqkv
-  rc = gemm_auto(LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
+  // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv
+  rc = gemm_pair(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b,
+                 LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
   if (rc) return rc;
   // LN2 (kept rows) + LN1 (all tokens) backward
   return ln1_gather_bwd_launch(a->xin, a->dout, dS, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->mean1, a->rstd1, a->mean2,
@@ -404,12 +403,8 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
                      a->dc1, dmix, a->dc0, n, C);
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
-  Side sd(st);
-  sd.after_main();
-  int rc = gemm_tn(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
-                   sd.side);
-  if (rc) return rc;
-  return gemm_auto(LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
+  return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
+                   LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
 }
 
 }  // extern "C"

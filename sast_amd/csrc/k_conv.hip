@@ -7,7 +7,7 @@
 #ifdef SAST_CONV_PF
 #define SAST_PF_DEFAULT SAST_CONV_PF
 #endif
-#include "gemm.cuh"
+#include "gemm_pair.cuh"
 #include "kernels.h"
 
 using namespace sast;
@@ -273,17 +273,22 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   return g;
 }
 
-// backward-data of a k x k convolution.  Stride 2 with a 3x3 kernel (downsample convs of stages 2-4, the two bottom-up PAFPN
-// convs) goes through the parity-class form (gemm.cuh: LdConvDxP) unless SAST_CONVDX_PARITY=0; everything else through the
+// backward of a k x k convolution.  Stride 2 with a 3x3 kernel (downsample convs of stages 2-4, the two bottom-up PAFPN convs)
+// computes dX through the parity-class form (gemm.cuh: LdConvDxP) unless SAST_CONVDX_PARITY=0; everything else through the
 // generic gather.
-int conv_dx(const float* dconv, const ConvGeom& g, int Cout, const float* w, float* dx, int lddx, hipStream_t st) {
-  const int k = g.KH, shift = pow2_shift(Cout);
+// dW (TN over the im2col rows) and dX of a k x k convolution in one launch
+int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cout, const float* w, float* dw, float* dx, int lddx,
+                  hipStream_t st) {
+  const int k = g.KH, shift = pow2_shift(Cout), K = k * k * g.Cin, M = g.B * g.Ho * g.Wo;
+  const LdRowsT ta{dconv, Cout};
+  const LdIm2colT tb{x, g};
+  if (!dx) return gemm_tn(ta, tb, dw, K, Cout, K, M, st);
   static int parity = -1;
   if (parity < 0) { const char* e = getenv("SAST_CONVDX_PARITY"); parity = e ? atoi(e) : 1; }
   const int Mc = g.B * (g.H / 2) * (g.W / 2);
   if (!(parity && g.stride == 2 && k == 3 && g.pad == 1 && g.H % 2 == 0 && g.W % 2 == 0 && Mc % 64 == 0))
-    return gemm_auto(LdConvDx{dconv, g, Cout, Cout, shift}, LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr},
-                     g.B * g.H * g.W, g.Cin, k * k * Cout, st);
+    return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
+                     LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st);
   ConvDxClasses c;
   c.Hc = g.H / 2; c.Wc = g.W / 2; c.Mc = Mc;
   for (int cls = 0; cls < 4; ++cls) {
@@ -303,8 +308,9 @@ int conv_dx(const float* dconv, const ConvGeom& g, int Cout, const float* w, flo
         c.kw_pack[cls] |= (unsigned)tx[b] << (4 * slot);
       }
   }
-  return gemm_auto(LdConvDxP{dconv, g, Cout, Cout, shift, c}, LdWeightConvDxP{w, Cout, k * k, g.Cin, shift, g.KW, c},
-                   EpStoreClass{dx, lddx, g.H, g.W, c}, 4 * Mc, g.Cin, 4 * Cout, st);
+  return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDxP{dconv, g, Cout, Cout, shift, c},
+                   LdWeightConvDxP{w, Cout, k * k, g.Cin, shift, g.KW, c}, EpStoreClass{dx, lddx, g.H, g.W, c}, 4 * Mc, g.Cin, 4 * Cout,
+                   nullptr, st);
 }
 
 }  // namespace
@@ -333,12 +339,7 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
   float* dconv = a->ws;
   int rc = ln_bwd_launch(a->conv_out, a->dy, a->ln_w, a->mean, a->rstd, dconv, a->d_ln_w, a->d_ln_b, M, a->Cout, st);
   if (rc) return rc;
-  Side sd(st);
-  sd.after_main();
-  rc = gemm_tn(LdRowsT{dconv, a->Cout}, LdIm2colT{a->x, g}, a->dw, K, a->Cout, K, M, sd.side);
-  if (rc) return rc;
-  if (a->dx) rc = conv_dx(dconv, g, a->Cout, a->w, a->dx, a->Cin, st);
-  return rc;
+  return conv_bwd_pair(dconv, a->x, g, a->Cout, a->w, a->dw, a->dx, a->Cin, st);
 }
 
 // ------------------------------------------------------------------ conv + BN + SiLU
@@ -399,19 +400,12 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
                      a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w, a->d_bn_b);
   SAST_CHECK_LAUNCH();
-  int rc;
-  Side sd(st);
-  sd.after_main();
   if (k == 1 && a->stride == 1) {
-    rc = gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, sd.side);
-    if (rc) return rc;
-    if (a->dx) rc = gemm_auto(LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, st);
-  } else {
-    rc = gemm_tn(LdRowsT{dconv, C}, LdIm2colT{a->x, g}, a->dw, K, C, K, M, sd.side);
-    if (rc) return rc;
-    if (a->dx) rc = conv_dx(dconv, g, C, a->w, a->dx, a->lddx, st);
+    if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, st);
+    return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr,
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st);
   }
-  return rc;
+  return conv_bwd_pair(dconv, a->x, g, C, a->w, a->dw, a->dx, a->lddx, st);
 }
 
 // ------------------------------------------------------------------ upsample / concat

@@ -60,6 +60,27 @@ void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int*
   *e1 = l.e1;
 }
 
+static int dev_min(int v, const int* d, hipStream_t st) {
+  if (!d) return v;
+  int x;
+  hipMemcpyAsync(&x, d, sizeof(int), hipMemcpyDeviceToHost, st);
+  hipStreamSynchronize(st);
+  return x < v ? x : v;
+}
+// one launch carrying two GEMMs (gemm_dual_kernel): the algorithmic FLOPs of both
+void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, int NJ1, int R1, const int* dM1, const int* dR1, int G2,
+                         int M2, int NJ2, int R2, const int* dM2, const int* dR2, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1) {
+  ProfLaunch l;
+  hipEventCreate(&l.e0);
+  hipEventCreate(&l.e1);
+  l.flops = flops_static + 2.0 * (double)dev_min(M1, dM1, st) * NJ1 * G1 * (double)dev_min(R1, dR1, st) +
+            2.0 * (double)dev_min(M2, dM2, st) * NJ2 * G2 * (double)dev_min(R2, dR2, st);
+  l.tag = tag;
+  g_launches.push_back(l);
+  *e0 = l.e0;
+  *e1 = l.e1;
+}
+
 // op-level scopes (C-ABI entry points): tag = "op:<name> C=<c> M=<m>"
 void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin) {
   char tag[96];
