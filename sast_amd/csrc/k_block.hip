@@ -346,8 +346,6 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
                 : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
   }
   if (rc) return rc;
-  rc = ls_linear_finish_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, C, inner, st);
-  if (rc) return rc;
   // fc1: dW1 / db1, and dY = dZ + dUG W1
   rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
                  LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
@@ -362,7 +360,9 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
     rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   }
   if (rc) return rc;
-  rc = ls_linear_finish_launch(a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
+  // raw (gamma-free) fc2 and proj gradients -> parameter gradients incl. the LayerScale gammas, one launch for both
+  rc = ls_linear_finish2_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner,
+                                a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
   if (rc) return rc;
   // attention backward
   rc = T <= mfma_attn_max_t() ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st)

@@ -640,27 +640,39 @@ int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* d
 // ============================================================ LayerScale'd linear: finalize grads from the raw (gamma-free) ones
 //   y = gamma * (x W^T + b):  raw = dy^T x, s = colsum(dy)
 //   dW += gamma[c]*raw[c,:]; db += gamma*s ; dgamma += <W[c,:], raw[c,:]> + b[c]*s[c]
-__global__ __launch_bounds__(64) void ls_linear_finish_kernel(const float* __restrict__ w, const float* __restrict__ b,
-                                                              const float* __restrict__ gamma, const float* __restrict__ raw,
-                                                              const float* __restrict__ s, float* __restrict__ dw,
-                                                              float* __restrict__ db, float* __restrict__ dgamma, int K) {
+struct LsFinish { const float* w; const float* b; const float* gamma; const float* raw; const float* s; float* dw; float* db; float* dgamma; int K; };
+// two LayerScale'd linears (fc2 and proj of one MS-WSA layer) per launch: blockIdx.y selects the problem
+__global__ __launch_bounds__(64) void ls_linear_finish_kernel(LsFinish p0, LsFinish p1, int C0) {
+  const LsFinish& p = blockIdx.y == 0 ? p0 : p1;
   const int c = blockIdx.x;
-  const float g = gamma ? gamma[c] : 1.f;   // gamma == NULL: LayerScale disabled (ls_init_value <= 0, SAST.py:187)
+  if (blockIdx.y == 0 && c >= C0) return;
+  const int K = p.K;
+  const float g = p.gamma ? p.gamma[c] : 1.f;   // gamma == NULL: LayerScale disabled (ls_init_value <= 0, SAST.py:187)
   float dot = 0.f;
   for (int k = threadIdx.x; k < K; k += 64) {
-    const float rv = raw[(size_t)c * K + k];
-    dot += w[(size_t)c * K + k] * rv;
-    dw[(size_t)c * K + k] += g * rv;
+    const float rv = p.raw[(size_t)c * K + k];
+    dot += p.w[(size_t)c * K + k] * rv;
+    p.dw[(size_t)c * K + k] += g * rv;
   }
   dot = wave_sum(dot);
   if (threadIdx.x == 0) {
-    db[c] += g * s[c];
-    if (gamma) dgamma[c] += dot + b[c] * s[c];
+    p.db[c] += g * p.s[c];
+    if (p.gamma) p.dgamma[c] += dot + p.b[c] * p.s[c];
   }
 }
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st) {
-  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3(C), dim3(64), 0, st, w, b, gamma, raw, s, dw, db, dgamma, K);
+  const LsFinish p{w, b, gamma, raw, s, dw, db, dgamma, K};
+  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3(C, 1), dim3(64), 0, st, p, p, C);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+// both finishes of one MS-WSA layer (same number of output channels C) in one launch
+int ls_linear_finish2_launch(const float* w0, const float* b0, const float* g0, const float* raw0, const float* s0, float* dw0, float* db0,
+                             float* dg0, int K0, const float* w1, const float* b1, const float* g1, const float* raw1, const float* s1,
+                             float* dw1, float* db1, float* dg1, int K1, int C, hipStream_t st) {
+  const LsFinish p0{w0, b0, g0, raw0, s0, dw0, db0, dg0, K0}, p1{w1, b1, g1, raw1, s1, dw1, db1, dg1, K1};
+  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3(C, 2), dim3(64), 0, st, p0, p1, C);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

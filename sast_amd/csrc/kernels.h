@@ -32,6 +32,9 @@ int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, i
 int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* drows, int C, float* out, hipStream_t st);
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st);
+int ls_linear_finish2_launch(const float* w0, const float* b0, const float* g0, const float* raw0, const float* s0, float* dw0, float* db0,
+                             float* dg0, int K0, const float* w1, const float* b1, const float* g1, const float* raw1, const float* s1,
+                             float* dw1, float* db1, float* dg1, int K1, int C, hipStream_t st);
 // Context Broadcasting (SAST.py:240-246): per-sample column sums of the kept rows, and the two pointwise halves
 int cb_sample_sum_launch(const float* src, int ld, bool gather, const int* row_tok, const int* nrows_dev, int rows_max, int tps,
                          int n_samples, int C, float* out, hipStream_t st);
