@@ -77,6 +77,8 @@ typedef struct SastScoreArgs {
   const float* dxw; float* dxp;
   float* d_ws_w; float* d_ws_b; float* d_wc;
   float* ws;             /* fp32[B*L*C + B*C] */
+  float* dscale_ws;      /* optional fp32[B*C]: cleared by the forward, accumulated into by the backward of the same call pair;
+                            NULL = the backward clears the tail of ws itself */
 } SastScoreArgs;
 int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream);
 int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream);
@@ -121,7 +123,10 @@ typedef struct SastMswsaArgs {
   float *d_fc1_w, *d_fc1_b, *d_fc2_w, *d_fc2_b, *d_ls2;
   float* ws;             /* sast_mswsa_bwd_ws_floats() */
   float *cb_m, *cb_sum;  /* cb_tps > 0 only: scratch [R,C] and [B*L/cb_tps, C] (fwd and bwd) */
+  float* raw_ws;         /* optional fp32[sast_mswsa_raw_ws_floats()]: cleared by the forward, accumulated into by the backward of the
+                            SAME call pair (saves the backward a clearing launch); NULL = backward clears its own scratch */
 } SastMswsaArgs;
+size_t sast_mswsa_raw_ws_floats(int C, int inner);
 size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner);
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream);
 int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream);

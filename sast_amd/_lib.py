@@ -32,7 +32,7 @@ SastDownArgs = _struct("SastDownArgs", [
 ])
 SastScoreArgs = _struct("SastScoreArgs", [
     (I32, "B L C r_stride"), (F32, "amp"),
-    (P, "xp r ws_w ws_b wc scale s xw tok dxw dxp d_ws_w d_ws_b d_wc ws"),
+    (P, "xp r ws_w ws_b wc scale s xw tok dxw dxp d_ws_w d_ws_b d_wc ws dscale_ws"),
 ])
 SastSel = _struct("SastSel", [(P, "win_keep mask K row_off win_rank counts tok_slot row_tok")])
 SastMswsaArgs = _struct("SastMswsaArgs", [
@@ -42,7 +42,7 @@ SastMswsaArgs = _struct("SastMswsaArgs", [
     (P, "mean1 rstd1 mean2 rstd2 S QKV O lse Y UG Hh"),
     (P, "dout dxin"),
     (P, "d_ln1_w d_ln1_b d_ln2_w d_ln2_b d_qkv_w d_qkv_b d_proj_w d_proj_b d_ls1 d_fc1_w d_fc1_b d_fc2_w d_fc2_b d_ls2"),
-    (P, "ws cb_m cb_sum"),
+    (P, "ws cb_m cb_sum raw_ws"),
 ])
 SastLstmArgs = _struct("SastLstmArgs", [
     (I32, "B L C"),
@@ -66,6 +66,7 @@ _SIGNATURES = {
     "sast_select": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), P]),
     "sast_select_pair": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), C.POINTER(SastSel), P]),
     "sast_mswsa_bwd_ws_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sast_mswsa_raw_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "sast_mswsa_fwd": (C.c_int, [C.POINTER(SastMswsaArgs), P]),
     "sast_mswsa_bwd": (C.c_int, [C.POINTER(SastMswsaArgs), P]),
     "sast_lstm_fwd": (C.c_int, [C.POINTER(SastLstmArgs), P]),

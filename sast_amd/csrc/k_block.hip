@@ -229,7 +229,7 @@ int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   ProfScope ps_("score_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
   if (!a || a->C % 4) return SAST_EINVAL;
   const int M = a->B * a->L, C = a->C;
-  int rc = controls_fwd_launch(a->wc, a->r, a->r_stride, a->scale, a->B, C, 20, st);
+  int rc = controls_fwd_launch(a->wc, a->r, a->r_stride, a->scale, a->B, C, 20, a->dscale_ws, st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->xp, C, nullptr}, LdWeightNT{a->ws_w, C, 0}, EpBiasRelu{a->s, C, a->ws_b}, M, C, C, nullptr, st);
   if (rc) return rc;
@@ -241,8 +241,8 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   ProfScope ps_("score_bwd", a->C, a->B * a->L, st);
   const int M = a->B * a->L, C = a->C;
   float* dz = a->ws;
-  float* dscale = a->ws + (size_t)M * C;
-  zero_fill(dscale, sizeof(float) * a->B * C, st);
+  float* dscale = a->dscale_ws ? a->dscale_ws : a->ws + (size_t)M * C;   // dscale_ws was cleared by the forward
+  if (!a->dscale_ws) zero_fill(dscale, sizeof(float) * a->B * C, st);
   int rc = stp_bwd_launch(a->xp, a->s, a->scale, a->dxw, a->dxp, dz, dscale, a->B, a->L, C, st);
   if (rc) return rc;
   // dxp = direct + dz Ws
@@ -253,6 +253,8 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
 }
 
 // ------------------------------------------------------------------ MS-WSA
+size_t sast_mswsa_raw_ws_floats(int C, int inner) { return (size_t)C * inner + (size_t)C * C + 2 * C; }
+
 size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
   return (size_t)rows * (2 * inner + C + C + 3 * C + C) + (size_t)C * inner + (size_t)C * C + 2 * C;
 }
@@ -267,7 +269,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   const int* dR = a->sel.counts;  // device-side number of kept tokens
   int rc = ln1_gather_fwd_launch(a->xin, a->out, a->S, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->ln2_b, a->mean1,
-                                 a->rstd1, a->mean2, a->rstd2, R, C, a->eps, st);
+                                 a->rstd1, a->mean2, a->rstd2, R, C, a->eps, a->raw_ws, sast_mswsa_raw_ws_floats(C, inner), st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
@@ -313,11 +315,12 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   float* dO = dY + (size_t)R * C;
   float* dQKV = dO + (size_t)R * C;
   float* dS = dQKV + (size_t)R * 3 * C;
-  float* raw2 = dS + (size_t)R * C;
+  // gamma-free fc2 / proj weight-gradient accumulators: raw_ws was cleared by this layer's forward (no launch here)
+  float* raw2 = a->raw_ws ? a->raw_ws : dS + (size_t)R * C;
   float* raw1 = raw2 + (size_t)C * inner;
   float* s2 = raw1 + (size_t)C * C;
   float* s1 = s2 + C;
-  zero_fill(raw2, sizeof(float) * ((size_t)C * inner + (size_t)C * C + 2 * C), st);
+  if (!a->raw_ws) zero_fill(raw2, sizeof(float) * sast_mswsa_raw_ws_floats(C, inner), st);
   int rc;
   // Context Broadcasting: the gradient reaching the MLP output is dZ'[r] = 0.5 dZ[r] + (0.5/L) sum_{r' in sample} dZ[r']
   // (gamma2 factored out exactly as without CB); everything downstream of the MLP output consumes dZ' in compact form.

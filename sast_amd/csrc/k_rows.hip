@@ -362,8 +362,10 @@ __global__ __launch_bounds__(256) void ln1_gather_fwd_kernel(const float* __rest
                                                              const float* __restrict__ g2, const float* __restrict__ b2,
                                                              float* __restrict__ mean1, float* __restrict__ rstd1,
                                                              float* __restrict__ mean2, float* __restrict__ rstd2,
-                                                             int rows, float eps) {
+                                                             int rows, float eps, float* __restrict__ zero_ptr, size_t zero_n4) {
   using IO = RowIO<GL, VPL>;
+  // side job: clear the accumulators the backward of this layer will add into (saves a launch there)
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (size_t)gridDim.x * 256) st4(zero_ptr + 4 * i, zero4());
   const int gl = threadIdx.x % GL;
   const int row = (blockIdx.x * 256 + threadIdx.x) / GL;
   if (row >= rows) return;
@@ -432,9 +434,10 @@ __global__ __launch_bounds__(256) void ln1_gather_bwd_kernel(const float* __rest
 
 int ln1_gather_fwd_launch(const float* xin, float* out, float* sc, const int* tok_slot, const float* g1, const float* b1,
                           const float* g2, const float* b2, float* mean1, float* rstd1, float* mean2, float* rstd2,
-                          int rows, int C, float eps, hipStream_t st) {
+                          int rows, int C, float eps, float* zero_ptr, size_t zero_floats, hipStream_t st) {
   SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0,
-                                        st, xin, out, sc, tok_slot, g1, b1, g2, b2, mean1, rstd1, mean2, rstd2, rows, eps));
+                                        st, xin, out, sc, tok_slot, g1, b1, g2, b2, mean1, rstd1, mean2, rstd2, rows, eps, zero_ptr,
+                                        zero_ptr ? zero_floats / 4 : (size_t)0));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -453,9 +456,10 @@ int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc,
 // ============================================================ STP scoring (a5)
 // scale[b,c] = sum_j exp(Wc[c,j]) * (r[b,j] + 1e-6)      (SAST.py:109, :325-328)
 __global__ void controls_fwd_kernel(const float* __restrict__ wc, const float* __restrict__ r, int r_stride,
-                                    float* __restrict__ scale, int B, int C, int J) {
+                                    float* __restrict__ scale, int B, int C, int J, float* __restrict__ zero_bc) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
+  if (zero_bc) zero_bc[i] = 0.f;   // the backward's d(scale) accumulator
   const int b = i / C, c = i % C;
   float s = 0.f;
   for (int j = 0; j < J; ++j) s = fmaf(expf(wc[c * J + j]), r[b * r_stride + j] + 1e-6f, s);
@@ -557,8 +561,9 @@ __global__ __launch_bounds__(256) void stp_bwd_kernel(const float* __restrict__ 
   flush_channel_partials<GL, VPL>(red, ds, dscale + (size_t)b * IO::C);
 }
 
-int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, hipStream_t st) {
-  hipLaunchKernelGGL(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, wc, r, r_stride, scale, B, C, J);
+int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, float* zero_bc,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, wc, r, r_stride, scale, B, C, J, zero_bc);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -16,12 +16,13 @@ int ln_bwd_launch(const float* x, const float* dy, const float* gamma, const flo
                   float* dgamma, float* dbeta, int rows, int C, hipStream_t st);
 int ln1_gather_fwd_launch(const float* xin, float* out, float* sc, const int* tok_slot, const float* g1, const float* b1,
                           const float* g2, const float* b2, float* mean1, float* rstd1, float* mean2, float* rstd2,
-                          int rows, int C, float eps, hipStream_t st);
+                          int rows, int C, float eps, float* zero_ptr, size_t zero_floats, hipStream_t st);
 int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc, const int* tok_slot, const float* g1,
                           const float* b1, const float* g2, const float* mean1, const float* rstd1, const float* mean2,
                           const float* rstd2, float* dxin, float* dg1, float* db1, float* dg2, float* db2, int rows, int C,
                           hipStream_t st);
-int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, hipStream_t st);
+int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, float* zero_bc,
+                        hipStream_t st);
 int controls_bwd_launch(const float* wc, const float* r, int r_stride, const float* dscale, float* dwc, int B, int C, int J,
                         hipStream_t st);
 int stp_fwd_launch(const float* xp, const float* s, const float* scale, float amp, float* xw, float* tok, int B, int L, int C,

@@ -183,10 +183,11 @@ class _ScoreSTP(torch.autograd.Function):
         s = torch.empty(B * Lt, Cc, device=dev)
         xw = torch.empty_like(xp)
         tok = torch.empty(B, Lt, device=dev)
+        dscale = torch.empty(B, Cc, device=dev)    # cleared by the forward kernels, accumulated into by the backward
         a = _fill(L.SastScoreArgs(), B=B, L=Lt, C=Cc, r_stride=r.stride(0), amp=amp, xp=xp, r=r, ws_w=ws_w, ws_b=ws_b, wc=wc,
-                  scale=scale, s=s, xw=xw, tok=tok)
+                  scale=scale, s=s, xw=xw, tok=tok, dscale_ws=dscale)
         L.check(L.lib().sast_score_stp_fwd(C.byref(a), _stream()), "score_stp_fwd")
-        ctx.save_for_backward(xp, r, scale, s)
+        ctx.save_for_backward(xp, r, scale, s, dscale)
         ctx.params = (ws_w, ws_b, wc)
         ctx.meta = (B, Lt, Cc, amp)
         ctx.mark_non_differentiable(tok)
@@ -194,7 +195,7 @@ class _ScoreSTP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxw, _dtok):
-        xp, r, scale, s = ctx.saved_tensors
+        xp, r, scale, s, dscale = ctx.saved_tensors
         ws_w, ws_b, wc = ctx.params
         B, Lt, Cc, amp = ctx.meta
         if dxw is None:
@@ -203,7 +204,7 @@ class _ScoreSTP(torch.autograd.Function):
         dxp = torch.empty_like(xp)
         ws = torch.empty(B * Lt * Cc + B * Cc, device=xp.device)
         a = _fill(L.SastScoreArgs(), B=B, L=Lt, C=Cc, r_stride=r.stride(0), amp=amp, xp=xp, r=r, ws_w=ws_w, ws_b=ws_b, wc=wc,
-                  scale=scale, s=s, dxw=dxw, dxp=dxp, d_ws_w=_g(ws_w), d_ws_b=_g(ws_b), d_wc=_g(wc), ws=ws)
+                  scale=scale, s=s, dxw=dxw, dxp=dxp, d_ws_w=_g(ws_w), d_ws_b=_g(ws_b), d_wc=_g(wc), ws=ws, dscale_ws=dscale)
         L.check(L.lib().sast_score_stp_bwd(C.byref(a), _stream()), "score_stp_bwd")
         return dxp, None, None, None, None, None
 
@@ -424,9 +425,10 @@ class _MSWSA(torch.autograd.Function):
             return t
 
         S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
+        raw = torch.empty(L.lib().sast_mswsa_raw_ws_floats(Cc, inner), device=dev)   # cleared by the forward, used by the backward
         a = L.SastMswsaArgs()
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, xin=xin, out=out,
-              mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
+              raw_ws=raw, mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
         if cb_tps:
             if R % cb_tps:
                 raise RuntimeError(f"sast_amd: Context Broadcasting needs rows ({R}) divisible by tokens per sample ({cb_tps})")
@@ -435,13 +437,13 @@ class _MSWSA(torch.autograd.Function):
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
-        ctx.save_for_backward(xin, stats, big)
+        ctx.save_for_backward(xin, stats, big, raw)
         ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xin, stats, big = ctx.saved_tensors
+        xin, stats, big, raw = ctx.saved_tensors
         sel, params, inner = ctx.sel, ctx.params, ctx.inner
         p = dict(zip(_MSWSA_PARAMS, params))
         Cc = xin.shape[-1]
@@ -463,7 +465,7 @@ class _MSWSA(torch.autograd.Function):
         a = L.SastMswsaArgs()
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, dim_head=ctx.dim_head, xin=xin,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh,
-              dout=dout, dxin=dxin, ws=ws)
+              dout=dout, dxin=dxin, ws=ws, raw_ws=raw)
         if ctx.cb_tps:
             cb_m, cb_sum = torch.empty(R, Cc, device=xin.device), torch.empty(R // ctx.cb_tps, Cc, device=xin.device)
             _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
