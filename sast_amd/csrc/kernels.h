@@ -44,15 +44,6 @@ int cb_apply_fwd_launch(const float* m, const float* y, const float* gamma, cons
 int cb_apply_bwd_launch(const float* dout, const float* gsum, const int* row_tok, const int* nrows_dev, int rows_max, int tps, int C,
                         float* dz, hipStream_t st);
 
-// k_side.hip
-struct Side {
-  hipStream_t main, side; bool used;
-  Side(hipStream_t m, int which = 0);
-  void after_main();
-  void join();
-  ~Side() { join(); }
-};
-
 // k_select.hip
 int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mode, float thr_win, float thr_tok,
                   int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,
