@@ -152,6 +152,8 @@ typedef struct SastConvBnArgs {
   int32_t B, H, W, Cin, Cout, ksize, stride, training;
   int32_t ldx, ldy, lddy, lddx;   /* channel strides of x, y, dy, dx rows (slices of concat buffers) */
   int32_t bn_ws_zeroed;           /* 1: caller guarantees bn_ws is zero-filled (one memset for the whole FPN) */
+  int32_t Cin1, ldx2;             /* 1x1 convs only, with x2 != NULL: input = channel concat [x (Cin1 ch) | x2 (Cin - Cin1 ch, row stride ldx2)]
+                                     read in place (th.cat of network_blocks.py:140 / yolo_pafpn.py:129,134 never materialised) */
   float momentum, eps;
   const float* x; const float* w; const float* bn_w; const float* bn_b;
   float* run_mean; float* run_var;  /* updated in training mode */
@@ -162,6 +164,8 @@ typedef struct SastConvBnArgs {
   const float* dy; float* dx; float* dw; float* d_bn_w; float* d_bn_b;
   float* bn_ws;          /* fp32[8*Cout] reduction scratch: fwd uses [0,4C) as fp64 sums, bwd uses [4C,6C) */
   float* ws;             /* bwd only: fp32[M*Cout] (dconv) */
+  const float* x2;       /* second input of the virtual concat (NULL = single input) */
+  float* dx2;            /* its gradient, dense [M, Cin - Cin1] */
 } SastConvBnArgs;
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);

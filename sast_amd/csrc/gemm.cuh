@@ -932,4 +932,15 @@ struct EpStoreClass {  // C[pixel(m) * ldc + j] = v, pixel(m) from the parity-cl
   }
 };
 
+struct EpSplit2 {  // j < C1 -> a, else b (two dense outputs: the split of a channel concat)
+  float* a; float* b; int C1, C2;
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
+    if (j < C1) a[(size_t)m * C1 + j] = v[0];
+    else if (b) b[(size_t)m * C2 + (j - C1)] = v[0];
+  }
+};
+
 }  // namespace sast

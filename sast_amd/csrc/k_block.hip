@@ -148,16 +148,6 @@ struct EpLstm {  // rnn.py:57-67
     gp[0] = f; gp[C] = i; gp[2 * C] = o; gp[3 * C] = g;
   }
 };
-struct EpSplit2 {  // j < C1 -> a, else b
-  float* a; float* b; int C1, C2;
-  using Col = EpNone; using Aux = EpNone;
-  __device__ __forceinline__ Col col(int) const { return Col{}; }
-  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
-  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
-    if (j < C1) a[(size_t)m * C1 + j] = v[0];
-    else if (b) b[(size_t)m * C2 + (j - C1)] = v[0];
-  }
-};
 
 __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c0,
                                                                  const float* __restrict__ c1, const float* __restrict__ dh1,

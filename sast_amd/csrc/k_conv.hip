@@ -355,14 +355,19 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   int rc;
   static int sep = -1;
   if (sep < 0) { const char* e = getenv("SAST_BN_STATS_SEPARATE"); sep = e ? atoi(e) : 0; }
+  const bool one = k == 1 && a->stride == 1;
+  if (a->x2 && (!one || a->Cin1 % 4 || a->Cin1 <= 0 || a->Cin1 >= a->Cin)) return SAST_EINVAL;
+  const LdRows2 la2{a->x, a->ldx, a->Cin1, a->x2, a->ldx2};    // virtual channel concat [x | x2]
   if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
-    rc = (k == 1 && a->stride == 1) ? gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
-                                    : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+    rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                      : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+             : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   } else {
     const EpStore ep{a->conv_out, C, nullptr};
-    rc = (k == 1 && a->stride == 1) ? gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
-                                    : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+    rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                      : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+             : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (rc) return rc;
   if (a->training && sep) {
@@ -400,6 +405,13 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
                      a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w, a->d_bn_b);
   SAST_CHECK_LAUNCH();
+  if (k == 1 && a->stride == 1 && a->x2) {   // virtual concat input: dW over [x | x2], dX split into the two gradients
+    const LdRowsT2 tb{a->x, a->ldx, a->Cin1, a->x2, a->ldx2};
+    if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, st);
+    if (a->lddx != a->Cin1) return SAST_EINVAL;
+    return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr,
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpSplit2{a->dx, a->dx2, a->Cin1, a->Cin - a->Cin1}, M, a->Cin, C, nullptr, st);
+  }
   if (k == 1 && a->stride == 1) {
     if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, st);
     return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr,

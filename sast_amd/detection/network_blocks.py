@@ -35,6 +35,8 @@ class BaseConv(nn.Module):
         return y
 
     def forward(self, x):
+        if isinstance(x, (tuple, list)):
+            raise TypeError("sast_amd: the two-source (virtual concat) input is an internal NHWC feature; use forward_nhwc")
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
 
 
@@ -95,7 +97,7 @@ class CSPLayer(nn.Module):
         x2 = self.conv2.forward_nhwc(x, arena)
         for b in self.m:
             x1 = b.forward_nhwc(x1, arena)
-        return self.conv3.forward_nhwc(SF.cat2(x1, x2), arena)
+        return self.conv3.forward_nhwc((x1, x2), arena)     # th.cat((x_1, x_2)) read in place by the 1x1 conv
 
     def forward(self, x):
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))

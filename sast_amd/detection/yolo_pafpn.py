@@ -41,9 +41,9 @@ class YOLOPAFPN(nn.Module):
         f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1), ar)  # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
         fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0, ar)
         pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2), ar)
-        p_out1 = SF.cat2(self.bu_conv2.forward_nhwc(pan_out2, ar), fpn_out1)
+        p_out1 = (self.bu_conv2.forward_nhwc(pan_out2, ar), fpn_out1)   # th.cat (yolo_pafpn.py:129) read in place by C3_n3's 1x1 convs
         pan_out1 = self.C3_n3.forward_nhwc(p_out1, ar)
-        p_out0 = SF.cat2(self.bu_conv1.forward_nhwc(pan_out1, ar), fpn_out0)
+        p_out0 = (self.bu_conv1.forward_nhwc(pan_out1, ar), fpn_out0)   # th.cat (yolo_pafpn.py:134)
         pan_out0 = self.C3_n4.forward_nhwc(p_out0, ar)
         ar.finish()
         return pan_out2, pan_out1, pan_out0

@@ -532,12 +532,18 @@ def conv_lstm(x_nhwc, h0, c0, w, b):
 # ---------------------------------------------------------------------------------------------- a13
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws):
+    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws):
         _need_gpu(x, w)
         x = x.contiguous()
         if not is_channels_last_weight(w):
             raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
         B, H, W, Cin = x.shape
+        Cin1 = Cin
+        if x2 is not None:       # virtual channel concat [x | x2] (1x1 convs): read in place, never materialised
+            if ksize != 1 or stride != 1 or x2.shape[:3] != x.shape[:3]:
+                raise RuntimeError("sast_amd: a two-source input is supported for 1x1 stride-1 convs of equal spatial size")
+            x2 = x2.contiguous()
+            Cin = Cin1 + x2.shape[-1]
         Cout = w.shape[0]
         pad = (ksize - 1) // 2
         Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
@@ -548,33 +554,38 @@ class _ConvBnSilu(torch.autograd.Function):
         y = torch.empty(B, Ho, Wo, Cout, device=dev)
         if bn_ws is None:  # zero-filled reduction scratch (a whole FPN passes slices of one arena: one memset per step)
             bn_ws = torch.zeros(8 * Cout, device=dev)
-        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin,
+        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin1,
                   ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
-                  run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws)
+                  run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1)
         L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
-        ctx.save_for_backward(x, conv_out, stats, bn_ws)
+        ctx.save_for_backward(x, x2, conv_out, stats, bn_ws)
         ctx.params = (w, bn_w, bn_b)
-        ctx.meta = (B, H, W, Cin, Cout, ksize, stride, int(training), momentum, eps, M)
+        ctx.meta = (B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, conv_out, stats, bn_ws = ctx.saved_tensors
+        x, x2, conv_out, stats, bn_ws = ctx.saved_tensors
         w, bn_w, bn_b = ctx.params
-        B, H, W, Cin, Cout, ksize, stride, training, momentum, eps, M = ctx.meta
+        B, H, W, Cin, Cin1, Cout, ksize, stride, training, momentum, eps, M = ctx.meta
         dy = dy.contiguous()
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
+        dx = torch.empty_like(x) if need else None
+        dx2 = torch.empty_like(x2) if (need and x2 is not None) else None
         ws = torch.empty(M * Cout, device=x.device)
-        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin,
-                  ldy=Cout, lddy=Cout, lddx=Cin, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b,
-                  conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w), d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws)
+        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
+                  ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b,
+                  conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w), d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws,
+                  x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1)
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
-        return (dx,) + (None,) * 11
+        return (dx, dx2) + (None,) * 11
 
 
 def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None):
-    """bn_ws: optional zero-filled fp32[8*Cout] scratch (consumed: do not reuse within a step)."""
-    return _ConvBnSilu.apply(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws)
+    """x_nhwc: a tensor, or a pair (xa, xb) standing for their channel concat (1x1 convs; the concat is never built).
+    bn_ws: optional zero-filled fp32[8*Cout] scratch (consumed: do not reuse within a step)."""
+    x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
+    return _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws)
 
 
 class _UpsampleCat(torch.autograd.Function):
