@@ -23,18 +23,19 @@ _TILE_DEFAULTS = (None, None, None, None, None, "16", "1", "2", "0")   # Tile<BM
 
 
 def _norm_kernel(name: str) -> str:
-    """canonical spelling of a gemm_kernel instantiation: rocprofv3 prints every Tile<> argument, __PRETTY_FUNCTION__
-    (the roofline leg) omits defaulted ones; the split flag is `true`/`false` in one and `split`/absent in the other."""
-    m = re.search(r"Tile<([^>]*)>", name)
-    if m:
+    """canonical spelling of a GEMM-template instantiation: rocprofv3 prints every Tile<> argument and the split flag as
+    true/false, __PRETTY_FUNCTION__ (the roofline leg) omits defaulted arguments and we tag split launches ourselves."""
+    name = re.sub(r"\(.*$", "", name).replace("> >", ">>")                # drop the argument list rocprof appends
+
+    def fill(m):
         args = [a.strip() for a in m.group(1).split(",")]
-        args += [d for d in _TILE_DEFAULTS[len(args):]]
-        name = name[:m.start()] + "Tile<" + ", ".join(args) + ">" + name[m.end():]
-    name = re.sub(r"\(.*$", "", name)                       # drop the argument list rocprof appends
+        return "Tile<" + ", ".join(args + list(_TILE_DEFAULTS[len(args):])) + ">"
+
+    name = re.sub(r"Tile<([^>]*)>", fill, name)
     name = name.replace(", split>", ", true>")
     if name.startswith("gemm_kernel<") and not re.search(r", (true|false)>$", name):
         name = name[:-1] + ", false>"
-    return name
+    return re.sub(r"\s+", " ", name)
 
 
 def pmc_traffic_bytes(kernel_name: str):
@@ -52,13 +53,21 @@ def pmc_traffic_bytes(kernel_name: str):
     return None
 
 
+def _clean(t: str) -> str:
+    return re.sub(r"sast::|\(anonymous namespace\)::", "", t).strip()
+
+
 def _short(tag: str) -> str:
+    """kernel name (as rocprofv3 spells it, minus defaulted Tile<> arguments) from the __PRETTY_FUNCTION__ of its launcher"""
+    m = re.search(r"launch_gemm_dual\b.*\[TS = (.*?), LA1 = (.*?), LB1 = (.*?), EP1 = (.*?), TP = (.*?), LA2 = (.*?), LB2 = (.*?), EP2 = (.*?)\]", tag)
+    if m:
+        g = [_clean(m.group(i)) for i in range(1, 9)]
+        return (f"gemm_dual_kernel<GemmJob<{g[0]}, {g[1]}, {g[2]}, {g[3]}, true>, GemmJob<{g[4]}, {g[5]}, {g[6]}, {g[7]}, false>>")
     m = re.search(r"launch_gemm(_split)?\b.*\[T = (.*?), LA = (.*?), LB = (.*?), EP = (.*?)\]", tag)
     if not m:
         return tag[:120]
-    t = re.sub(r"sast::|\(anonymous namespace\)::", "", m.group(2))
-    names = [re.sub(r"sast::|\(anonymous namespace\)::", "", m.group(i)) for i in (3, 4, 5)]
-    return f"gemm_kernel<{t}, {names[0]}, {names[1]}, {names[2]}{', split' if m.group(1) else ''}>"
+    names = [_clean(m.group(i)) for i in (2, 3, 4, 5)]
+    return f"gemm_kernel<{names[0]}, {names[1]}, {names[2]}, {names[3]}{', split' if m.group(1) else ''}>"
 
 
 def gemm_report(run_steps, n_steps: int = 3):
