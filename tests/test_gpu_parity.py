@@ -221,6 +221,38 @@ def test_backbone_other_sizes(dev, size, E, dh, depth, hw, part):
         maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_backbone_odd_batches(dev, B):
+    """B = 1 (the reference special-cases it, SAST.py:260-262) and an odd batch through backbone + PAFPN, forward and backward."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    hw, part, E = (128, 160), (4, 5), 32
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=31, ls_init=0.5)
+    fparams = O.init_pafpn_params((64, 128, 256), seed=32)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev)
+    load_params(net, params)
+    load_params(fpn, fparams)
+    fpn.train()
+    x = O.count_events(B, hw, seed=33 + B, density=0.05)
+    out, _st, P = net(x.to(dev))
+    outs = fpn({k: out[k] for k in (2, 3, 4)})
+    sum((o ** 2).mean() for o in outs).backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
+    oo, _s, Po = O.backbone(x, None, po, ocfg)
+    oouts = O.pafpn({k: oo[k] for k in (2, 3, 4)}, pf, training=True)
+    sum((o ** 2).mean() for o in oouts).backward()
+    assert [int(p) for p in P] == [int(p) for p in Po]
+    for a, b in zip(outs, oouts):
+        maxnorm_close(a, b, 1e-4, "pafpn out")
+    for k, v in net.named_parameters():
+        if "sub_layers" not in k:
+            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+    for k, v in fpn.named_parameters():
+        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
+
+
 def test_backbone_sequence_bptt(dev):
     """the training loop shape of modules/detection.py:141-177: L timesteps with the recurrent (h, c) states carried WITHOUT
     detaching, PAFPN on the last timestep's features, one backward through time; gradients against the oracle run the same way."""
