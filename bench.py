@@ -43,7 +43,7 @@ def synthetic_events(B, hw, seed):
 class Trainer:
     """minimal training step of the hot path (the reference's is Lightning's, modules/detection.py:113-221)."""
 
-    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False):
+    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.dist import FlatParams, FusedAdamW
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -52,6 +52,13 @@ class Trainer:
         # host copy of the initial weights under the reference's state_dict names: the CPU baseline leg runs on them
         self.init_state = {"net": {k: v.clone() for k, v in self.net.state_dict().items() if "sub_layers" not in k},
                            "fpn": {k: v.clone() for k, v in self.fpn.state_dict().items()}}
+        self.infer = infer       # --infer: backbone + PAFPN + YOLOX head in eval mode -> decoded predictions (validation.py's model part)
+        self.head = None
+        if infer:
+            from sast_amd.detection import YOLOXHead
+            self.head = YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=(128, 256, 512)).to(dev).eval()
+            self.fpn.eval()
+            fwd_only = True
         self.net.to(dev)
         self.fpn.to(dev)
         self.flat = FlatParams([self.net, self.fpn])
@@ -62,13 +69,19 @@ class Trainer:
         # recurrent states carried, PAFPN + loss on the last one, one backward through time.  Default 1 = BASELINE's metric.
         self.xs = [synthetic_events(BATCH, HW, seed=rank + 1000 * t).to(dev) for t in range(seq_len)]
         self.x = self.xs[0]
-        self.fwd_only = fwd_only     # --fwd-only: backbone forward, the reference's own benchmark.py protocol (BASELINE config C2)
+        self.fwd_only = fwd_only or infer     # --fwd-only: backbone forward, the reference's own benchmark.py protocol (BASELINE config C2)
         self.loss = None
         self.P = None
         self.graph = None
         self.use_graph = use_graph
 
     def fwd_bwd(self):
+        if self.infer:
+            with torch.no_grad():
+                feats, _states, P = self.net.forward_nhwc(self.x)
+                pred = self.head.forward_nhwc(self.fpn.forward_nhwc(feats))
+            self.loss, self.P, self.feats = pred[..., 4].sum(), P, feats
+            return
         if self.fwd_only:
             with torch.no_grad():
                 feats, _states, P = self.net.forward_nhwc(self.x)
@@ -185,6 +198,7 @@ def main():
     ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
     ap.add_argument("--seq-len", type=int, default=1, help="timesteps per step with recurrent state + BPTT (1 = BASELINE metric)")
     ap.add_argument("--fwd-only", action="store_true", help="backbone forward only (reference benchmark.py protocol; BASELINE config C2 with --res gen1)")
+    ap.add_argument("--infer", action="store_true", help="backbone + PAFPN + YOLOX head, eval mode, forward only (decoded predictions)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -217,7 +231,7 @@ def main():
     run_stream = torch.cuda.Stream()
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
-    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only)
+    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer)
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -250,7 +264,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
-                                   (" full SAST backbone, forward only (benchmark.py protocol), " if args.fwd_only else
+                                   (" full SAST backbone + PAFPN + YOLOX head (3 classes), eval forward -> decoded predictions, " if args.infer else
+                                    " full SAST backbone, forward only (benchmark.py protocol), " if args.fwd_only else
                                     " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
@@ -261,7 +276,7 @@ def main():
         if not args.no_roofline:
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr)
-        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1:
+        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer:
             res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only)
         print(json.dumps(res))
     if world > 1:

@@ -178,6 +178,15 @@ int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H,
 int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream);
 int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int C2, sast_stream_t stream);
 
+/* SURVEY 8(f) rank 1, inference path only: last step of one YOLOX head level -- the 1x1 prediction convs reg(4) / obj(1) on the
+ * regression feature and cls(nc) on the classification feature (NHWC rows [B*H*W, hidden]), sigmoid on obj / cls and, with
+ * decode != 0, the box decode of YOLOXHead.decode_outputs -- yolox/models/yolo_head.py:184-186,207-210,264-289.
+ * out[B, anchors_total, 5 + nc], this level occupies anchors [anchor_offset, anchor_offset + H*W).  The 3x3 / 1x1 BaseConvs of the
+ * head go through sast_conv_bn_silu_fwd (training = 0).  The training branch (SimOTA loss) is not built. */
+int sast_head_pred_decode(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
+                          const float* b_obj, const float* w_cls, const float* b_cls, float* out, int B, int H, int W, int hidden,
+                          int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream);
+
 /* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441) */
 int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,
                const float* lr_step /* device fp32[2]: learning rate, step count (already incremented) */,

@@ -382,6 +382,69 @@ def pafpn(feats: Dict[int, Tensor], p: Params, pre: str = "", depth: float = 0.6
     return pan2, pan1, pan0
 
 
+# --------------------------------------------------------------------------- YOLOX head, inference path (forward only)
+def head_hidden_dim(in_channels) -> int:
+    """yolo_head.py:48-56: width = in_channels[-1] / 1024, hidden = int(256 * width)."""
+    return int(256 * (in_channels[-1] / 1024))
+
+
+def yolox_head_eval(feats: Sequence[Tensor], p: Params, strides=(8, 16, 32), pre: str = "", decode: bool = True) -> Tensor:
+    """YOLOXHead.forward in eval mode (yolo_head.py:165-246 without the training branch) + decode_outputs (:264-289).
+    feats: the three PAFPN maps (B,C,H,W), strides ascending -> (B, sum H*W, 5 + num_classes):
+    [cx, cy, w, h, sigmoid(obj), sigmoid(cls...)] (decoded: (xy + grid) * stride, exp(wh) * stride)."""
+    outs, grids, strs = [], [], []
+    for k, (x, stride) in enumerate(zip(feats, strides)):
+        x = base_conv(x, p, f"{pre}stems.{k}.", 1, False)
+        cf = x
+        rf = x
+        for i in range(2):
+            cf = base_conv(cf, p, f"{pre}cls_convs.{k}.{i}.", 1, False)
+            rf = base_conv(rf, p, f"{pre}reg_convs.{k}.{i}.", 1, False)
+        cls = F.conv2d(cf, p[f"{pre}cls_preds.{k}.weight"], p[f"{pre}cls_preds.{k}.bias"])
+        reg = F.conv2d(rf, p[f"{pre}reg_preds.{k}.weight"], p[f"{pre}reg_preds.{k}.bias"])
+        obj = F.conv2d(rf, p[f"{pre}obj_preds.{k}.weight"], p[f"{pre}obj_preds.{k}.bias"])
+        o = torch.cat([reg, obj.sigmoid(), cls.sigmoid()], 1)
+        H, W = o.shape[-2:]
+        outs.append(o.flatten(start_dim=2))
+        yv, xv = torch.meshgrid([torch.arange(H, dtype=o.dtype), torch.arange(W, dtype=o.dtype)], indexing="ij")
+        grids.append(torch.stack((xv, yv), 2).view(1, -1, 2))
+        strs.append(torch.full((1, H * W, 1), float(stride), dtype=o.dtype))
+    out = torch.cat(outs, dim=2).permute(0, 2, 1)
+    if not decode:
+        return out
+    g, st = torch.cat(grids, 1), torch.cat(strs, 1)
+    return torch.cat([(out[..., 0:2] + g) * st, torch.exp(out[..., 2:4]) * st, out[..., 4:]], dim=-1)
+
+
+def init_head_params(in_channels=(128, 256, 512), num_classes: int = 3, seed: int = 2, prior_prob: float = 0.01) -> Params:
+    """seeded stand-in for YOLOXHead.__init__ (names / shapes of yolo_head.py:58-133; biases as initialize_biases :154-163);
+    BatchNorm running statistics are randomised so that the eval path is exercised with non-trivial statistics."""
+    g = torch.Generator().manual_seed(seed)
+    hid = head_hidden_dim(in_channels)
+    p: Params = {}
+
+    def conv_bn(name, ci, co, k):
+        b = 1.0 / math.sqrt(ci * k * k)
+        p[name + ".conv.weight"] = (torch.rand((co, ci, k, k), generator=g) * 2 - 1) * b
+        p[name + ".bn.weight"] = 0.5 + torch.rand(co, generator=g)
+        p[name + ".bn.bias"] = (torch.rand(co, generator=g) - 0.5) * 0.2
+        p[name + ".bn.running_mean"] = (torch.rand(co, generator=g) - 0.5) * 0.2
+        p[name + ".bn.running_var"] = 0.5 + torch.rand(co, generator=g)
+
+    for k, ci in enumerate(in_channels):
+        conv_bn(f"stems.{k}", ci, hid, 1)
+        for i in range(2):
+            conv_bn(f"cls_convs.{k}.{i}", hid, hid, 3)
+            conv_bn(f"reg_convs.{k}.{i}", hid, hid, 3)
+        for name, co in (("cls_preds", num_classes), ("reg_preds", 4), ("obj_preds", 1)):
+            p[f"{name}.{k}.weight"] = (torch.rand((co, hid, 1, 1), generator=g) * 2 - 1) / math.sqrt(hid)
+            if name == "reg_preds":
+                p[f"{name}.{k}.bias"] = (torch.rand(co, generator=g) * 2 - 1) / math.sqrt(hid)
+            else:
+                p[f"{name}.{k}.bias"] = torch.full((co,), -math.log((1 - prior_prob) / prior_prob))
+    return p
+
+
 # --------------------------------------------------------------------------- init helpers
 def mlp_inner_dim(C: int, ratio: int = 4) -> int:
     """ops.py:157."""

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "sast_score_stp_fwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
     "sast_score_stp_bwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
     "sast_select": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), P]),
+    "sast_head_pred_decode": (C.c_int, [P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, P]),
     "sast_select_pair": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), C.POINTER(SastSel), P]),
     "sast_mswsa_bwd_ws_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sast_mswsa_raw_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),

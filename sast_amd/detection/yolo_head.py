@@ -1,0 +1,95 @@
+"""YOLOX head, INFERENCE path (reference models/detection/yolox/models/yolo_head.py:21-289).
+
+Same constructor, sub-module names and state_dict keys as the reference `YOLOXHead`, so a reference checkpoint loads with
+`strict=True`.  `forward(xin)` in eval mode returns `(outputs, None)` with outputs (B, n_anchors_all, 5 + num_classes), decoded
+like `decode_outputs` when `decode_in_inference` is set.  The 15 Conv+BN+SiLU units run through the same HIP op as the PAFPN
+(`sast_conv_bn_silu_fwd`, running statistics), the three 1x1 prediction convs + sigmoid + box decode of a level are one kernel
+(`sast_head_pred_decode`).  The TRAINING branch (SimOTA assignment + IoU / BCE losses, yolo_head.py:291-606) is not built and
+raises -- there is no fallback."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import functional as SF
+from .network_blocks import BaseConv
+
+
+class _PredConv(nn.Module):
+    """parameter holder with the names / shapes of the reference's nn.Conv2d(hidden, out, 1) (yolo_head.py:104-133)."""
+
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        k = 1.0 / math.sqrt(cin)
+        self.weight = nn.Parameter((torch.rand(cout, cin, 1, 1) * 2 - 1) * k)
+        self.bias = nn.Parameter((torch.rand(cout) * 2 - 1) * k)
+
+
+class YOLOXHead(nn.Module):
+    def __init__(self, num_classes=80, strides=(8, 16, 32), in_channels=(256, 512, 1024), act="silu", depthwise=False,
+                 compile_cfg: Optional[Dict] = None):
+        super().__init__()
+        if depthwise:
+            raise NotImplementedError("sast_amd: depthwise head convs are not implemented (every shipped config has depthwise: False)")
+        self.num_classes = num_classes
+        self.decode_in_inference = True
+        self.strides = tuple(strides)
+        hidden = int(256 * (in_channels[-1] / 1024))          # yolo_head.py:48-56
+        self.hidden_dim = hidden
+        self.cls_convs, self.reg_convs = nn.ModuleList(), nn.ModuleList()
+        self.cls_preds, self.reg_preds, self.obj_preds, self.stems = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
+        for c in in_channels:
+            self.stems.append(BaseConv(int(c), hidden, 1, stride=1, act=act))
+            self.cls_convs.append(nn.Sequential(BaseConv(hidden, hidden, 3, stride=1, act=act), BaseConv(hidden, hidden, 3, stride=1, act=act)))
+            self.reg_convs.append(nn.Sequential(BaseConv(hidden, hidden, 3, stride=1, act=act), BaseConv(hidden, hidden, 3, stride=1, act=act)))
+            self.cls_preds.append(_PredConv(hidden, num_classes))
+            self.reg_preds.append(_PredConv(hidden, 4))
+            self.obj_preds.append(_PredConv(hidden, 1))
+        self.use_l1 = False
+        self.hw = None
+        self.initialize_biases(prior_prob=0.01)
+
+    def initialize_biases(self, prior_prob):          # yolo_head.py:154-163
+        with torch.no_grad():
+            for conv in list(self.cls_preds) + list(self.obj_preds):
+                conv.bias.fill_(-math.log((1 - prior_prob) / prior_prob))
+
+    @torch.no_grad()
+    def forward_nhwc(self, feats):
+        """feats: three (B,H,W,C) NHWC maps -> (B, n_anchors_all, 5 + num_classes)"""
+        if self.training:
+            raise NotImplementedError("sast_amd: the YOLOX training branch (SimOTA loss, yolo_head.py:291-606) is not built; call .eval()")
+        B = feats[0].shape[0]
+        dev = feats[0].device
+        hw = [tuple(f.shape[1:3]) for f in feats]
+        A = sum(h * w for h, w in hw)
+        no = 5 + self.num_classes
+        out = torch.empty(B, A, no, device=dev)
+        off = 0
+        for k, (x, stride) in enumerate(zip(feats, self.strides)):
+            x = self.stems[k].forward_nhwc(x)
+            cf, rf = x, x
+            for conv in self.cls_convs[k]:
+                cf = conv.forward_nhwc(cf)
+            for conv in self.reg_convs[k]:
+                rf = conv.forward_nhwc(rf)
+            h, w = hw[k]
+            cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
+            L.check(L.lib().sast_head_pred_decode(rf.data_ptr(), cf.data_ptr(), rp.weight.data_ptr(), rp.bias.data_ptr(), op.weight.data_ptr(),
+                                                  op.bias.data_ptr(), cp.weight.data_ptr(), cp.bias.data_ptr(), out.data_ptr(), B, h, w,
+                                                  self.hidden_dim, self.num_classes, float(stride), off, A, int(self.decode_in_inference),
+                                                  SF._stream()), "head_pred_decode")
+            off += h * w
+        self.hw = hw
+        return out
+
+    def forward(self, xin, labels=None):
+        """xin: the three PAFPN maps (B,C,H,W) -> (outputs, None)   (yolo_head.py:165-246, eval branch)"""
+        if labels is not None or self.training:
+            raise NotImplementedError("sast_amd: the YOLOX training branch (SimOTA loss, yolo_head.py:291-606) is not built")
+        SF._need_gpu(*xin)
+        return self.forward_nhwc([SF.as_nhwc(x.float()) for x in xin]), None

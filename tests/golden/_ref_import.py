@@ -3,9 +3,10 @@
 Used by `make_golden.py` (fixture generation) and by the container-only
 cross-checks in tests/ that are skipped when /root/reference is absent
 (it never exists on the GPU box).  Nothing from the reference is copied:
-we put two stub modules in sys.modules (omegaconf, strenum) because the
-reference imports them at module scope (sast_rnn.py:13,21 ->
-data/utils/types.py:3-6) and they are not installed here.
+we put three stub modules in sys.modules (omegaconf, strenum, torchvision)
+because the reference imports them at module scope (sast_rnn.py:13,21 ->
+data/utils/types.py:3-6; yolox/utils/boxes.py:8) and they are not installed
+here.
 """
 import enum
 import os
@@ -60,6 +61,11 @@ def _install_stubs():
         m.OmegaConf = OmegaConf
         m.open_dict = lambda cfg: cfg
         sys.modules["omegaconf"] = m
+    if "torchvision" not in sys.modules:   # models/detection/yolox/utils/boxes.py:8 imports it at module scope (NMS only)
+        m = types.ModuleType("torchvision")
+        m.ops = types.ModuleType("torchvision.ops")
+        sys.modules["torchvision"] = m
+        sys.modules["torchvision.ops"] = m.ops
     if "strenum" not in sys.modules:
         m = types.ModuleType("strenum")
 
@@ -85,6 +91,12 @@ def import_reference():
     from models.layers import rnn as _lstm
     from models.detection.yolox_extension.models import yolo_pafpn as _fpn
     ns.sast_rnn, ns.SAST, ns.ops, ns.rnn, ns.yolo_pafpn = _rnn, _sast, _ops, _lstm, _fpn
+    try:
+        from models.detection.yolox.models import yolo_head as _head
+        ns.yolo_head = _head
+    except Exception as e:   # noqa: BLE001  (the head is a "next" row: fixtures for it are optional)
+        ns.yolo_head = None
+        ns.yolo_head_error = repr(e)
     return ns
 
 

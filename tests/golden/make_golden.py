@@ -275,8 +275,40 @@ def gen_full_stats(ref):
         json.dump(res, f, indent=1)
 
 
+def gen_head_eval(ref):
+    """YOLOX head, inference path: the oracle restatement against the reference module in eval mode."""
+    if ref.yolo_head is None:
+        raise RuntimeError("reference yolo_head not importable: " + ref.yolo_head_error)
+    chans, nc, strides = (64, 128, 256), 2, (8, 16, 32)
+    params = O.init_head_params(chans, num_classes=nc, seed=5)
+    head = ref.yolo_head.YOLOXHead(num_classes=nc, strides=strides, in_channels=chans)
+    sd = head.state_dict()
+    new = {k: (v if k.endswith("num_batches_tracked") else params[k]) for k, v in sd.items()}
+    assert set(params) <= set(sd), sorted(set(params) - set(sd))[:5]
+    head.load_state_dict(new, strict=True)
+    head.eval()
+    g = torch.Generator().manual_seed(77)
+    feats = [torch.randn(2, c, 16 // (2 ** i), 20 // (2 ** i), generator=g) for i, c in enumerate(chans)]
+    with torch.no_grad():
+        out, losses = head(tuple(feats))
+    assert losses is None
+    mine = O.yolox_head_eval(feats, params, strides)
+    assert torch.allclose(mine, out, atol=1e-5, rtol=1e-5), float((mine - out).abs().max())
+    head.decode_in_inference = False
+    with torch.no_grad():
+        raw, _ = head(tuple(feats))
+    assert torch.allclose(O.yolox_head_eval(feats, params, strides, decode=False), raw, atol=1e-5, rtol=1e-5)
+    d = {f"in{i}": np_(f) for i, f in enumerate(feats)}
+    d.update(out=np_(out), raw=np_(raw), num_classes=np.int64(nc), seed=np.int64(5), max_abs_diff_oracle=np.float64(float((mine - out).abs().max())))
+    np.savez_compressed(os.path.join(HERE, "head_eval.npz"), **d)
+    print("head_eval ok:", tuple(out.shape), "oracle max abs diff", float((mine - out).abs().max()))
+
+
 def main():
     ref = RI.import_reference()
+    if "--head-only" in sys.argv:
+        gen_head_eval(ref)
+        return
     if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
         gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
         gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
@@ -292,6 +324,7 @@ def main():
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)
+    gen_head_eval(ref)
     gen_full_stats(ref)
 
 

@@ -221,6 +221,60 @@ def test_backbone_other_sizes(dev, size, E, dh, depth, hw, part):
         maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
 
 
+def test_yolox_head_eval_vs_golden(golden_dir, dev):
+    """YOLOX head, inference path: strict state_dict load of reference-named parameters, decoded and raw
+    outputs against the reference module's (fixture head_eval.npz); the training branch is not built and must say so."""
+    from sast_amd.detection import YOLOXHead
+    g = _load(golden_dir, "head_eval")
+    chans, nc = (64, 128, 256), int(g["num_classes"])
+    params = O.init_head_params(chans, num_classes=nc, seed=int(g["seed"]))
+    head = YOLOXHead(num_classes=nc, strides=(8, 16, 32), in_channels=chans).to(dev)
+    load_params(head, params)
+    head.eval()
+    feats = tuple(torch.from_numpy(g[f"in{i}"]).to(dev) for i in range(3))
+    out, losses = head(feats)
+    assert losses is None and out.shape == g["out"].shape
+    ref = torch.from_numpy(g["out"])
+    assert float((out.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    head.decode_in_inference = False
+    raw, _ = head(feats)
+    assert float((raw.cpu() - torch.from_numpy(g["raw"])).abs().max()) <= 1e-4
+    head.train()
+    with pytest.raises(NotImplementedError):
+        head(feats)
+
+
+def test_detector_inference_end_to_end(dev):
+    """YoloXDetector (detector.py:18-80) in eval mode: events -> backbone -> PAFPN (running statistics) -> head -> decoded
+    predictions, against the oracle run the same way; the training branch (needs the YOLOX loss) must raise."""
+    from sast_amd.config import to_attr
+    from sast_amd.detection import YoloXDetector
+    hw, part, E, nc = (128, 160), (4, 5), 32, 2
+    cfg = to_attr({"backbone": _rcfg(hw, part, E, 2e-2, 0.5), "fpn": {"name": "PAFPN", "depth": 0.67, "in_stages": [2, 3, 4], "depthwise": False,
+                                                                    "act": "silu"},
+                   "head": {"name": "YoloX", "depthwise": False, "act": "silu", "num_classes": nc}})
+    det = YoloXDetector(cfg).to(dev)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    bp = O.init_backbone_params(ocfg, seed=41, ls_init=0.5)
+    fp = O.init_pafpn_params((64, 128, 256), seed=42)
+    hp = O.init_head_params((64, 128, 256), num_classes=nc, seed=43)
+    load_params(det.backbone, bp)
+    load_params(det.fpn, fp)
+    load_params(det.yolox_head, hp)
+    det.eval()
+    x = O.count_events(2, hw, seed=44, density=0.05)
+    with torch.no_grad():
+        out, losses, states, P = det(x.to(dev))
+        oo, _s, Po = O.backbone(x, None, bp, ocfg)
+        ref = O.yolox_head_eval(O.pafpn({k: oo[k] for k in (2, 3, 4)}, fp, training=False), hp, det.backbone.get_strides((2, 3, 4)))
+    assert losses is None and [int(p) for p in P] == [int(p) for p in Po]
+    maxnorm_close(out, ref, 2e-4, "decoded predictions")
+    feats = det.forward_backbone(x.to(dev))[0]
+    det.train()
+    with pytest.raises(NotImplementedError):
+        det.forward_detect(feats)
+
+
 @pytest.mark.parametrize("B", [1, 3])
 def test_backbone_odd_batches(dev, B):
     """B = 1 (the reference special-cases it, SAST.py:260-262) and an odd batch through backbone + PAFPN, forward and backward."""

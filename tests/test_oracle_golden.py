@@ -130,6 +130,16 @@ def test_pafpn(golden_dir):
         assert torch.allclose(o, torch.from_numpy(g[f"eval_out{i}"]), atol=ATOL, rtol=0)
 
 
+def test_yolox_head_eval(golden_dir):
+    """YOLOX head inference path: oracle restatement vs the reference module's outputs (decoded and raw)."""
+    g = _load(golden_dir, "head_eval")
+    chans = (64, 128, 256)
+    params = O.init_head_params(chans, num_classes=int(g["num_classes"]), seed=int(g["seed"]))
+    feats = [torch.from_numpy(g[f"in{i}"]) for i in range(3)]
+    assert torch.allclose(O.yolox_head_eval(feats, params), torch.from_numpy(g["out"]), atol=1e-6, rtol=1e-6)
+    assert torch.allclose(O.yolox_head_eval(feats, params, decode=False), torch.from_numpy(g["raw"]), atol=1e-6, rtol=1e-6)
+
+
 def test_full_size_stats_g1(golden_dir):
     """F-7 (Gen1 size; the 1Mpx twin runs on the GPU box next to the HIP path)."""
     with open(os.path.join(golden_dir, "full_stats.json")) as f:
