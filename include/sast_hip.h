@@ -34,9 +34,15 @@ int sast_version(void);
 /* a1  non_zero_ratio -- models/detection/recurrent_backbone/sast_rnn.py:45-60.
  * x: (B,Cin,H,W) NCHW of `dtype`; cnt_ws: int32[B*4*Cin] scratch; r: fp32 (B,4,Cin). H,W multiples of 32. */
 int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream);
+/* same on an event tensor stored UNPADDED (H x W, multiples of 4) that stands for its zero padding to Hp x Wp at the bottom /
+ * right -- InputPadderFromShape.pad_tensor_ev_repr, utils/padding.py:29-53, modules/detection.py:143-144 -- without building it */
+int sast_nzratio_padded(const void* x, int dtype, int B, int Cin, int H, int W, int Hp, int Wp, int32_t* cnt_ws, float* r,
+                        sast_stream_t stream);
 
 /* layout changes at the NCHW API boundary (reference: ops.py:19-30 nChw_2_nhwC / nhwC_2_nChw, x.float() sast_rnn.py:153) */
 int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream);
+/* cast + layout change + zero padding to Hp x Wp in one pass: y[B, Hp, Wp, C] */
+int sast_nchw_to_nhwc_padded(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, float* y, sast_stream_t stream);
 int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream);
 
 /* a3  x + pos_emb(x) -- SAST.py:105 with the constant sine table of sast_rnn.py:180-219: y[row] = x[row] + table[row % table_rows] */

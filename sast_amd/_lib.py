@@ -57,6 +57,8 @@ _SIGNATURES = {
     "sast_version": (C.c_int, []),
     "sast_nzratio": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
     "sast_nchw_to_nhwc": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    "sast_nzratio_padded": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
+    "sast_nchw_to_nhwc_padded": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_nhwc_to_nchw": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_add_rows": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_downsample_ln_fwd": (C.c_int, [C.POINTER(SastDownArgs), P]),

@@ -178,10 +178,19 @@ int sast_version(void) { return 100; }
 
 int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream) {
   if (!x || !cnt_ws || !r || H % 32 || W % 32) return SAST_EINVAL;
-  return nzr_dispatch(x, dtype, cnt_ws, r, B, Cin, H, W, (hipStream_t)stream);
+  return nzr_dispatch(x, dtype, cnt_ws, r, B, Cin, H, W, H, W, (hipStream_t)stream);
+}
+int sast_nzratio_padded(const void* x, int dtype, int B, int Cin, int H, int W, int Hp, int Wp, int32_t* cnt_ws, float* r,
+                        sast_stream_t stream) {
+  if (!x || !cnt_ws || !r || Hp % 32 || Wp % 32 || H > Hp || W > Wp || H % 4 || W % 4) return SAST_EINVAL;
+  return nzr_dispatch(x, dtype, cnt_ws, r, B, Cin, H, W, Hp, Wp, (hipStream_t)stream);
 }
 int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream) {
-  return nchw_to_nhwc_dispatch(x, dtype, y, B, C, H, W, (hipStream_t)stream);
+  return nchw_to_nhwc_dispatch(x, dtype, y, B, C, H, W, H, W, (hipStream_t)stream);
+}
+int sast_nchw_to_nhwc_padded(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, float* y, sast_stream_t stream) {
+  if (!x || !y || H > Hp || W > Wp) return SAST_EINVAL;
+  return nchw_to_nhwc_dispatch(x, dtype, y, B, C, H, W, Hp, Wp, (hipStream_t)stream);
 }
 int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream) {
   return nhwc_to_nchw_launch(x, y, B, C, H * W, (hipStream_t)stream);

@@ -96,15 +96,17 @@ __global__ void nzr_finish_kernel(const int* __restrict__ cnt, float* __restrict
   r[i] = s * (float)cnt[i];   // fp32(B/numel) * fp32(count), as the reference's scalar*tensor
 }
 
+// (H, W): stored size of x; (Hp, Wp) >= (H, W): the zero-padded size the ratios refer to (InputPadderFromShape pads bottom /
+// right with zeros, utils/padding.py:29-44 -- zeros add no counts, only the denominators change)
 template <typename T>
-int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, hipStream_t st) {
+int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   zero_fill(cnt, sizeof(int) * B * 4 * C, st);
   dim3 grid((W + 127) / 128, (H + 31) / 32, B * C);
   hipLaunchKernelGGL((nzr_count_kernel<T>), grid, dim3(256), 0, st, (const T*)x, cnt, C, H, W);
   float s[4];
   int f = 4;
   for (int l = 0; l < 4; ++l) {
-    const double numel = (double)B * C * (H / f) * (W / f);
+    const double numel = (double)B * C * (Hp / f) * (Wp / f);
     s[l] = (float)((double)B / numel);
     f *= 2;
   }
@@ -114,39 +116,42 @@ int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, hi
   return SAST_OK;
 }
 
-int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int H, int W, hipStream_t st) {
+int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   switch (dtype) {
-    case SAST_DT_F32: return nzr_launch<float>(x, cnt, r, B, C, H, W, st);
-    case SAST_DT_I32: return nzr_launch<int>(x, cnt, r, B, C, H, W, st);
-    case SAST_DT_U8:  return nzr_launch<unsigned char>(x, cnt, r, B, C, H, W, st);
+    case SAST_DT_F32: return nzr_launch<float>(x, cnt, r, B, C, H, W, Hp, Wp, st);
+    case SAST_DT_I32: return nzr_launch<int>(x, cnt, r, B, C, H, W, Hp, Wp, st);
+    case SAST_DT_U8:  return nzr_launch<unsigned char>(x, cnt, r, B, C, H, W, Hp, Wp, st);
     default: return SAST_EINVAL;
   }
 }
 
 // ============================================================ NCHW (any dtype) -> NHWC fp32
 template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int HW) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int H, int W, int Hp,
+                                                           int Wp) {
   extern __shared__ float tile[];  // [64][C+1]
-  const int b = blockIdx.y, p0 = blockIdx.x * 64;
+  const int b = blockIdx.y, p0 = blockIdx.x * 64, HWp = Hp * Wp;
   const int ldt = C + 1;
   for (int e = threadIdx.x; e < 64 * C; e += 256) {
-    const int c = e >> 6, p = e & 63;
-    if (p0 + p < HW) tile[p * ldt + c] = (float)x[((size_t)b * C + c) * HW + p0 + p];
+    const int c = e >> 6, p = p0 + (e & 63);
+    if (p < HWp) {
+      const int py = p / Wp, px = p - py * Wp;      // output pixel of the (zero-padded) map
+      tile[(e & 63) * ldt + c] = (py < H && px < W) ? (float)x[(((size_t)b * C + c) * H + py) * W + px] : 0.f;
+    }
   }
   __syncthreads();
-  const int np = min(64, HW - p0);
-  float* o = y + ((size_t)b * HW + p0) * C;
+  const int np = min(64, HWp - p0);
+  float* o = y + ((size_t)b * HWp + p0) * C;
   for (int e = threadIdx.x; e < np * C; e += 256) o[e] = tile[(e / C) * ldt + (e % C)];
 }
 
-int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int H, int W, hipStream_t st) {
-  const int HW = H * W;
-  dim3 grid((HW + 63) / 64, B);
+int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
+  dim3 grid((Hp * Wp + 63) / 64, B);
   const size_t sh = sizeof(float) * 64 * (C + 1);
   switch (dtype) {
-    case SAST_DT_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, HW); break;
-    case SAST_DT_I32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, HW); break;
-    case SAST_DT_U8:  hipLaunchKernelGGL((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, HW); break;
+    case SAST_DT_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, H, W, Hp, Wp); break;
+    case SAST_DT_I32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, H, W, Hp, Wp); break;
+    case SAST_DT_U8:  hipLaunchKernelGGL((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, H, W, Hp, Wp); break;
     default: return SAST_EINVAL;
   }
   SAST_CHECK_LAUNCH();

@@ -154,6 +154,7 @@ class RNNDetector(nn.Module):
         self.stages = nn.ModuleList()
         self.strides = []
         in_res_h, in_res_w = mdl_config.in_res_hw
+        self.in_res_hw = (int(in_res_h), int(in_res_w))
         size = (1, in_res_h, in_res_w)
         for stage_idx, (num_blocks, T_max) in enumerate(zip(num_blocks_per_stage, T_max_chrono_init_per_stage)):
             f = patch_size if stage_idx == 0 else 2
@@ -183,8 +184,11 @@ class RNNDetector(nn.Module):
         if prev_states is None:
             prev_states = [None] * self.num_stages
         assert len(prev_states) == self.num_stages
-        r = SF.non_zero_ratio(x)
-        xin = SF.nchw_to_nhwc_float(x)
+        # an event tensor smaller than in_res_hw stands for its zero padding (the reference pads it first,
+        # modules/detection.py:143-144 / utils/padding.py:29-53): ratios, cast, layout change and padding in two passes over x
+        pad = self.in_res_hw if (x.shape[-2] < self.in_res_hw[0] or x.shape[-1] < self.in_res_hw[1]) else None
+        r = SF.non_zero_ratio(x, pad)
+        xin = SF.nchw_to_nhwc_float(x, pad)
         states, output, P = [], {}, []
         for i, stage in enumerate(self.stages):
             xin, state, p = stage.forward_nhwc(xin, prev_states[i], r[:, i])

@@ -68,8 +68,9 @@ def is_channels_last_weight(w: torch.Tensor) -> bool:
 
 # ---------------------------------------------------------------------------------------------- a1
 @torch.no_grad()
-def non_zero_ratio(x: torch.Tensor) -> torch.Tensor:
-    """sast_rnn.py:45-60.  x (B,Cin,H,W) NCHW {uint8,int32,float32} -> (B,4,Cin) fp32."""
+def non_zero_ratio(x: torch.Tensor, pad_hw=None) -> torch.Tensor:
+    """sast_rnn.py:45-60.  x (B,Cin,H,W) NCHW {uint8,int32,float32} -> (B,4,Cin) fp32.
+    pad_hw: x stands for its zero padding (bottom / right) to this size (InputPadderFromShape, utils/padding.py:29-53)."""
     _need_gpu(x)
     if x.dtype not in _DT:
         x = x.float()
@@ -77,18 +78,28 @@ def non_zero_ratio(x: torch.Tensor) -> torch.Tensor:
     B, Cin, H, W = x.shape
     r = torch.empty(B, 4, Cin, device=x.device, dtype=torch.float32)
     cnt = torch.empty(B * 4 * Cin, device=x.device, dtype=torch.int32)
+    if pad_hw is not None and tuple(pad_hw) != (H, W):
+        L.check(L.lib().sast_nzratio_padded(x.data_ptr(), _DT[x.dtype], B, Cin, H, W, int(pad_hw[0]), int(pad_hw[1]), cnt.data_ptr(),
+                                            r.data_ptr(), _stream()), "nzratio_padded")
+        return r
     L.check(L.lib().sast_nzratio(x.data_ptr(), _DT[x.dtype], B, Cin, H, W, cnt.data_ptr(), r.data_ptr(), _stream()), "nzratio")
     return r
 
 
 @torch.no_grad()
-def nchw_to_nhwc_float(x: torch.Tensor) -> torch.Tensor:
-    """x.float() + nChw_2_nhwC (sast_rnn.py:153, ops.py:19-24) in one pass."""
+def nchw_to_nhwc_float(x: torch.Tensor, pad_hw=None) -> torch.Tensor:
+    """x.float() + nChw_2_nhwC (sast_rnn.py:153, ops.py:19-24) in one pass; with pad_hw also the zero padding of
+    InputPadderFromShape (utils/padding.py:29-53), so a uint8 event tensor is read exactly once, unpadded."""
     _need_gpu(x)
     if x.dtype not in _DT:
         x = x.float()
     x = x.contiguous()
     B, Cc, H, W = x.shape
+    if pad_hw is not None and tuple(pad_hw) != (H, W):
+        Hp, Wp = int(pad_hw[0]), int(pad_hw[1])
+        y = torch.empty(B, Hp, Wp, Cc, device=x.device, dtype=torch.float32)
+        L.check(L.lib().sast_nchw_to_nhwc_padded(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, Hp, Wp, y.data_ptr(), _stream()), "nchw_to_nhwc_padded")
+        return y
     y = torch.empty(B, H, W, Cc, device=x.device, dtype=torch.float32)
     L.check(L.lib().sast_nchw_to_nhwc(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, y.data_ptr(), _stream()), "nchw_to_nhwc")
     return y

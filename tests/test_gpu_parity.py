@@ -244,6 +244,30 @@ def test_yolox_head_eval_vs_golden(golden_dir, dev):
         head(feats)
 
 
+def test_unpadded_uint8_input(dev):
+    """the reference pads the uint8 event tensor to in_res_hw before the backbone (modules/detection.py:143-144); here the
+    unpadded tensor is accepted directly -- bit-identical to feeding the explicitly padded one, and equal to the oracle."""
+    from sast_amd import functional as SF
+    from sast_amd.detection import RNNDetector
+    hw, part, E = (128, 160), (4, 5), 32
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=51, ls_init=0.5)
+    load_params(net, params)
+    x = O.count_events(2, (120, 152), seed=52, density=0.05)                 # uint8, unpadded
+    xp = torch.nn.functional.pad(x, (0, hw[1] - 152, 0, hw[0] - 120))
+    assert x.dtype == torch.uint8
+    assert torch.equal(SF.non_zero_ratio(x.to(dev), hw).cpu(), O.non_zero_ratio(xp))
+    with torch.no_grad():
+        a, _sa, Pa = net(x.to(dev))
+        b, _sb, Pb = net(xp.to(dev))
+        oo, _s, Po = O.backbone(xp, None, params, ocfg)
+    assert [int(p) for p in Pa] == [int(p) for p in Pb] == [int(p) for p in Po]
+    for k in (1, 2, 3, 4):
+        assert torch.equal(a[k], b[k])
+        assert float((a[k].cpu() - oo[k]).abs().max()) <= FWD_ATOL
+
+
 def test_detector_inference_end_to_end(dev):
     """YoloXDetector (detector.py:18-80) in eval mode: events -> backbone -> PAFPN (running statistics) -> head -> decoded
     predictions, against the oracle run the same way; the training branch (needs the YOLOX loss) must raise."""
