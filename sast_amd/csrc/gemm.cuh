@@ -18,12 +18,15 @@
 // * row counts can live on the device (dM / dR): the grid is sized for the static
 //   upper bound and surplus tiles exit -- no host sync for the data-dependent number
 //   of selected tokens.
-// * LDS: A and B tiles are stored reduce-major ([r][m]) so a lane's MFMA operand is a
-//   conflict-free ds_read_b32; RC tiles are transposed on the way in with a row pad
-//   chosen so the 4 scalar ds_writes of a float4 hit 32 distinct banks.
-// * split-R form (weight gradients): `nsplit` work items per output tile partition the reduction, the epilogue
-//   accumulates atomically; optionally the column sums of the A operand (bias gradient)
-//   are produced by the same pass (COLSUM) so dY is read once.
+// * LDS: an RC operand keeps its natural [row][k] order (row stride BK + 4: ds_write_b128 /
+//   ds_read_b128), an IC operand is stored [k][row] (ds_read_b32); both conflict-free.
+// * global loads are branch-free and un-predicated (clamped address + select at LDS-store
+//   time): anything else makes hipcc drain vmcnt(0) before every load of the k-loop.
+// * split-R form (weight gradients): `nsplit` work items per output tile partition the
+//   reduction, the epilogue accumulates atomically; optionally the column sums of the A
+//   operand (bias gradient) are produced by the same pass so dY is read once.
+// * two independent GEMMs can share one launch (gemm_dual_kernel): a kernel boundary costs
+//   3-5 us in a captured stream, a fifth of the SAST step before pairing dW with dX.
 #pragma once
 #include <type_traits>
 #include <hip/hip_ext.h>

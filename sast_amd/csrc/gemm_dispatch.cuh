@@ -1,5 +1,10 @@
-// (dW, dX) of one layer's backward in one launch (gemm.cuh: gemm_dual_kernel), with the same tile heuristics as the
-// separate launches.  SAST_GEMM_PAIR=0 restores two launches.
+// Host-side tile / launch heuristics of the GEMM template, shared by k_block.hip and k_conv.hip:
+//   gemm_auto  plain GEMM            64x64 tiles; 2-way intra-block k-split when the reduction is long; 32x64 tiles with a 4-way
+//                                    k-split when the grid would give fewer than ~1.5 tiles per CU
+//   gemm_tn    weight gradient       split-R job of ~SAST_TN_BLOCKS workgroups, atomic epilogue
+//   gemm_pair  (dW, dX) of a layer   both in ONE launch (gemm.cuh: gemm_dual_kernel); SAST_GEMM_PAIR=0 restores two launches
+// All thresholds were measured on the SAST shapes (tools/gemm_micro.py, gemm_tn_micro.py, gemm_small_m.py) and can be overridden
+// through the environment for A/B runs.
 #pragma once
 #include <cstdlib>
 #include "gemm.cuh"
@@ -16,12 +21,34 @@ inline int pair_ks_min_r() { static int v = env_int("SAST_KS_MINR", 256); return
 inline int pair_thin_nb() { static int v = env_int("SAST_THIN_NB", 384); return v; }
 inline int pair_ks_nb() { static int v = env_int("SAST_KS_NB", 1000000); return v; }
 
+template <class LA, class LB, class EP>
+int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
+  const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
+  if (nb <= pair_thin_nb() && R >= pair_ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  if (nb <= pair_ks_nb() && R >= pair_ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+}
+template <class LA, class LB, class EP>
+int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
+  return gemm_auto(la, lb, ep, M, NJ, R, nullptr, st);
+}
+
 inline int tn_splits(int Mo, int NJ, int R) {
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
   int splits = (pair_tn_blocks() + nb - 1) / nb;
   const int max_splits = (R + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   return splits < 1 ? 1 : splits;
+}
+
+// weight-gradient form: out[Mo, NJ] += A^T B over R rows (dR: device-side count), optional column sums of A (bias gradient)
+template <class LA, class LB>
+int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
+  return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, tn_splits(Mo, NJ, R), colsum, st);
+}
+template <class LA, class LB>
+int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
+  return gemm_tn(la, lb, out, ldc, Mo, NJ, R, nullptr, nullptr, st);
 }
 
 // job 1: out[Mo, NJ1] += A1^T B1 over R1 rows (dR1: device-side count), optional column sums of A1 (bias gradient)

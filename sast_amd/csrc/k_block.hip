@@ -2,18 +2,12 @@
 // Each entry point enqueues a short chain of kernels on the caller's stream; the GEMMs are
 // the fp32-MFMA template of gemm.cuh with op-specific loaders / fused epilogues.
 #include <cstdlib>
-#include "gemm_pair.cuh"
+#include "gemm_dispatch.cuh"
 #include "kernels.h"
 
 using namespace sast;
 
 namespace {
-
-inline int tn_total_blocks() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_TN_BLOCKS"); v = e ? atoi(e) : 384; }
-  return v;
-}
 
 // partitions of up to this many tokens use the MFMA attention kernels (k_attn_mfma.hip); SAST_ATTN_MFMA_MAX_T=64 restores the
 // VALU kernel (k_attn.hip) for 64 < T <= 128
@@ -21,50 +15,6 @@ inline int mfma_attn_max_t() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("SAST_ATTN_MFMA_MAX_T"); v = e ? atoi(e) : 128; }
   return v;
-}
-
-inline int ks_min_r() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
-  return v;
-}
-inline int thin_nb_limit() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_THIN_NB"); v = e ? atoi(e) : 384; }
-  return v;
-}
-inline int ks_nb_limit() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_KS_NB"); v = e ? atoi(e) : 1000000; }
-  return v;
-}
-
-template <class LA, class LB, class EP>
-int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
-  // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
-  // when that grid cannot fill the 256 CUs, one-wave 32x32 blocks quadruple the block count.
-  // 64x64 block tiles (one 32x32 MFMA tile per wave) measured best across the SAST shapes (tools/gemm_micro.py);
-  // when the grid gives < 2 blocks per CU and the reduction is long, split k over two wave groups inside the block
-  const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
-  if (nb <= thin_nb_limit() && R >= ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-  if (nb <= ks_nb_limit() && R >= ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-  return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-}
-
-// weight-gradient form: out[Mo, NJ] += A^T B over R (device-side count dR) rows
-template <class LA, class LB>
-int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
-  // measured (tools/gemm_tn_micro.py): the split-R kernel is latency-bound per block, so many short blocks win;
-  // 2-way intra-block k split with ~384+ blocks was the best point (the atomic epilogue costs ~25 %).
-  const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (tn_total_blocks() + nb - 1) / nb;
-  const int max_splits = (R + 127) / 128;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  static int k2 = -1;
-  if (k2 < 0) { const char* e = getenv("SAST_TN_K2"); k2 = e ? atoi(e) : 1; }
-  if (k2) return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
-  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, splits, colsum, st);
 }
 
 // ---------------------------------------------------------------- epilogues (protocol: col / pre / post, see gemm.cuh)
@@ -284,7 +234,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
     const long nb = (long)((R + 63) / 64) * ((inner + 63) / 64);
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("SAST_GLU_TILE"); mode = e ? atoi(e) : 0; }
-    if (mode && C >= 256 && nb <= 2 * thin_nb_limit()) rc = launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    if (mode && C >= 256 && nb <= 2 * pair_thin_nb()) rc = launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
     else if (mode && C >= 256) rc = launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     else rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     if (rc) return rc;
@@ -391,7 +341,7 @@ int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
   const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C};
   static int mode = -1;
   if (mode < 0) { const char* e = getenv("SAST_LSTM_TILE"); mode = e ? atoi(e) : 0; }
-  if (mode && Kred >= 256 && (long)((M + 63) / 64) * ((C + 31) / 32) <= 2 * thin_nb_limit())
+  if (mode && Kred >= 256 && (long)((M + 63) / 64) * ((C + 31) / 32) <= 2 * pair_thin_nb())
     return launch_gemm<TileG4K4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
   return launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
 }

@@ -4,53 +4,12 @@
 //   - nearest x2 upsample + concat, concat                yolo_pafpn.py:117-137
 //   - fused AdamW on the flat parameter buffer
 #include <cstdlib>
-#ifdef SAST_CONV_PF
-#define SAST_PF_DEFAULT SAST_CONV_PF
-#endif
-#include "gemm_pair.cuh"
+#include "gemm_dispatch.cuh"
 #include "kernels.h"
 
 using namespace sast;
 
 namespace {
-
-inline int ks_min_r() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_KS_MINR"); v = e ? atoi(e) : 256; }
-  return v;
-}
-inline int thin_nb_limit() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_THIN_NB"); v = e ? atoi(e) : 384; }
-  return v;
-}
-inline int ks_nb_limit() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_KS_NB"); v = e ? atoi(e) : 1000000; }
-  return v;
-}
-
-template <class LA, class LB, class EP>
-int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
-  const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
-  if (nb <= thin_nb_limit() && R >= ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
-  if (nb <= ks_nb_limit() && R >= ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
-  return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, nullptr, nullptr, st);
-}
-template <class LA, class LB>
-int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
-  const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  static int total = -1;
-  if (total < 0) { const char* e = getenv("SAST_TN_BLOCKS"); total = e ? atoi(e) : 384; }
-  int splits = (total + nb - 1) / nb;
-  const int max_splits = (R + 127) / 128;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  static int k2 = -1;
-  if (k2 < 0) { const char* e = getenv("SAST_TN_K2"); k2 = e ? atoi(e) : 1; }
-  if (k2) return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
-  return launch_gemm_split<TileSmall>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, nullptr, splits, nullptr, st);
-}
 
 // ---------------------------------------------------------------- BatchNorm pieces
 // y = silu(BN(x)); training: batch statistics from the fp64 column sums the conv epilogue accumulated; the threads that
