@@ -416,6 +416,144 @@ def yolox_head_eval(feats: Sequence[Tensor], p: Params, strides=(8, 16, 32), pre
     return torch.cat([(out[..., 0:2] + g) * st, torch.exp(out[..., 2:4]) * st, out[..., 4:]], dim=-1)
 
 
+# ---- YOLOX head, training branch (yolo_head.py:165-246 training path, get_losses :291-443, SimOTA :452-606, IOUloss losses.py:10-55)
+def _bboxes_iou_cxcywh(a: Tensor, b: Tensor) -> Tensor:
+    """yolox/utils/boxes.py:79-103 with xyxy=False: pairwise IoU of (cx,cy,w,h) boxes, a (G,4) x b (N,4) -> (G,N)."""
+    tl = torch.max(a[:, None, :2] - a[:, None, 2:] / 2, b[:, :2] - b[:, 2:] / 2)
+    br = torch.min(a[:, None, :2] + a[:, None, 2:] / 2, b[:, :2] + b[:, 2:] / 2)
+    area_a, area_b = a[:, 2] * a[:, 3], b[:, 2] * b[:, 3]
+    en = (tl < br).type(tl.type())
+    en = en[:, :, 0] * en[:, :, 1]
+    area_i = torch.prod(br - tl, 2) * en
+    return area_i / (area_a[:, None] + area_b - area_i)
+
+
+def _iou_loss(pred: Tensor, target: Tensor) -> Tensor:
+    """losses.py:16-33 (loss_type "iou", reduction none): 1 - iou^2."""
+    tl = torch.max(pred[:, :2] - pred[:, 2:] / 2, target[:, :2] - target[:, 2:] / 2)
+    br = torch.min(pred[:, :2] + pred[:, 2:] / 2, target[:, :2] + target[:, 2:] / 2)
+    area_p, area_g = torch.prod(pred[:, 2:], 1), torch.prod(target[:, 2:], 1)
+    en = (tl < br).type(tl.type()).prod(dim=1)
+    area_i = torch.prod(br - tl, 1) * en
+    iou = area_i / (area_p + area_g - area_i + 1e-16)
+    return 1 - iou ** 2
+
+
+def simota_assign(gt_boxes: Tensor, gt_classes: Tensor, boxes: Tensor, cls_logits: Tensor, obj_logits: Tensor, strides: Tensor,
+                  xs: Tensor, ys: Tensor, num_classes: int):
+    """get_assignments (yolo_head.py:452-538) for ONE image: geometry constraint (:540-571, centre radius 1.5 strides), cost =
+    BCE(sqrt(sigmoid(cls) sigmoid(obj)), one_hot) + 3 * (-log(iou + 1e-8)) + 1e6 * not-in-centre, dynamic-k matching (:573-606).
+    boxes (A,4) decoded predictions, cls_logits (A,nc), obj_logits (A,1), strides / xs / ys (A,).
+    -> fg_mask (A,) bool, matched_gt_inds (num_fg,), pred_ious_this_matching (num_fg,), gt_matched_classes (num_fg,)"""
+    G = gt_boxes.shape[0]
+    xc, yc = ((xs + 0.5) * strides).unsqueeze(0), ((ys + 0.5) * strides).unsqueeze(0)
+    dist = strides.unsqueeze(0) * 1.5
+    c_l = xc - (gt_boxes[:, 0:1] - dist)
+    c_r = (gt_boxes[:, 0:1] + dist) - xc
+    c_t = yc - (gt_boxes[:, 1:2] - dist)
+    c_b = (gt_boxes[:, 1:2] + dist) - yc
+    is_in = torch.stack([c_l, c_t, c_r, c_b], 2).min(dim=-1).values > 0.0
+    fg_mask = is_in.sum(dim=0) > 0
+    geometry = is_in[:, fg_mask]
+    b_fg, cls_fg, obj_fg = boxes[fg_mask], cls_logits[fg_mask], obj_logits[fg_mask]
+    n_in = b_fg.shape[0]
+    ious = _bboxes_iou_cxcywh(gt_boxes, b_fg)
+    onehot = F.one_hot(gt_classes.to(torch.int64), num_classes).float()
+    iou_cost = -torch.log(ious + 1e-8)
+    p = (cls_fg.float().sigmoid() * obj_fg.float().sigmoid()).sqrt()
+    cls_cost = F.binary_cross_entropy(p.unsqueeze(0).repeat(G, 1, 1), onehot.unsqueeze(1).repeat(1, n_in, 1), reduction="none").sum(-1)
+    cost = cls_cost + 3.0 * iou_cost + float(1e6) * (~geometry)
+    matching = torch.zeros_like(cost, dtype=torch.uint8)
+    k_cand = min(10, ious.size(1))
+    topk_ious, _ = torch.topk(ious, k_cand, dim=1)
+    dynamic_ks = torch.clamp(topk_ious.sum(1).int(), min=1)
+    for g in range(G):
+        _, pos = torch.topk(cost[g], k=int(dynamic_ks[g]), largest=False)
+        matching[g][pos] = 1
+    per_anchor = matching.sum(0)
+    if per_anchor.max() > 1:
+        multi = per_anchor > 1
+        _, amin = torch.min(cost[:, multi], dim=0)
+        matching[:, multi] *= 0
+        matching[amin, multi] = 1
+    fg_in = per_anchor > 0
+    fg_mask = fg_mask.clone()
+    fg_mask[fg_mask.clone()] = fg_in
+    matched = matching[:, fg_in].argmax(0)
+    pred_ious = (matching * ious).sum(0)[fg_in]
+    return fg_mask, matched, pred_ious, gt_classes[matched]
+
+
+def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides=(8, 16, 32), pre: str = "", num_classes: int = 3,
+                     bufs: Optional[Params] = None):
+    """YOLOXHead.forward in TRAINING mode (batch-statistics BatchNorm) + get_losses: -> dict(loss, iou_loss, conf_loss, cls_loss,
+    num_fg) and the assignment of every image (for index-level parity checks).  labels (B, max_labels, 5) = (cls, cx, cy, w, h),
+    valid rows first, rows that sum to 0 are padding (yolo_head.py:306)."""
+    outs, xs, ys, ss = [], [], [], []
+    for k, (x, stride) in enumerate(zip(feats, strides)):
+        x = base_conv(x, p, f"{pre}stems.{k}.", 1, True, bufs)
+        cf, rf = x, x
+        for i in range(2):
+            cf = base_conv(cf, p, f"{pre}cls_convs.{k}.{i}.", 1, True, bufs)
+            rf = base_conv(rf, p, f"{pre}reg_convs.{k}.{i}.", 1, True, bufs)
+        cls = F.conv2d(cf, p[f"{pre}cls_preds.{k}.weight"], p[f"{pre}cls_preds.{k}.bias"])
+        reg = F.conv2d(rf, p[f"{pre}reg_preds.{k}.weight"], p[f"{pre}reg_preds.{k}.bias"])
+        obj = F.conv2d(rf, p[f"{pre}obj_preds.{k}.weight"], p[f"{pre}obj_preds.{k}.bias"])
+        o = torch.cat([reg, obj, cls], 1)
+        B, no, H, W = o.shape
+        o = o.view(B, no, H * W).permute(0, 2, 1)
+        yv, xv = torch.meshgrid([torch.arange(H, dtype=o.dtype), torch.arange(W, dtype=o.dtype)], indexing="ij")
+        grid = torch.stack((xv, yv), 2).view(1, -1, 2)
+        o = torch.cat([(o[..., :2] + grid) * stride, torch.exp(o[..., 2:4]) * stride, o[..., 4:]], dim=-1)   # get_output_and_grid :248-262
+        outs.append(o)
+        xs.append(grid[0, :, 0]); ys.append(grid[0, :, 1]); ss.append(torch.full((H * W,), float(stride), dtype=o.dtype))
+    out = torch.cat(outs, 1)
+    xs, ys, ss = torch.cat(xs), torch.cat(ys), torch.cat(ss)
+    boxes, objp, clsp = out[:, :, :4], out[:, :, 4:5], out[:, :, 5:]
+    nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
+    A = out.shape[1]
+    cls_t, reg_t, obj_t, fg_all, assigns = [], [], [], [], []
+    num_fg, num_gts = 0.0, 0.0
+    for b in range(out.shape[0]):
+        G = int(nlabel[b])
+        num_gts += G
+        if G == 0:
+            cls_t.append(out.new_zeros((0, num_classes))); reg_t.append(out.new_zeros((0, 4)))
+            obj_t.append(out.new_zeros((A, 1))); fg_all.append(out.new_zeros(A).bool())
+            assigns.append((fg_all[-1], torch.zeros(0, dtype=torch.long), out.new_zeros(0)))
+            continue
+        gtb, gtc = labels[b, :G, 1:5], labels[b, :G, 0]
+        with torch.no_grad():
+            fg, matched, pious, mcls = simota_assign(gtb, gtc, boxes[b], clsp[b], objp[b], ss, xs, ys, num_classes)
+        num_fg += int(fg.sum())
+        cls_t.append(F.one_hot(mcls.to(torch.int64), num_classes) * pious.unsqueeze(-1))
+        obj_t.append(fg.unsqueeze(-1).to(out.dtype)); reg_t.append(gtb[matched]); fg_all.append(fg)
+        assigns.append((fg, matched, pious))
+    cls_t, reg_t, obj_t, fg_all = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0), torch.cat(fg_all, 0)
+    num_fg = max(num_fg, 1)
+    loss_iou = _iou_loss(boxes.reshape(-1, 4)[fg_all], reg_t).sum() / num_fg
+    loss_obj = F.binary_cross_entropy_with_logits(objp.reshape(-1, 1), obj_t, reduction="none").sum() / num_fg
+    loss_cls = F.binary_cross_entropy_with_logits(clsp.reshape(-1, num_classes)[fg_all], cls_t, reduction="none").sum() / num_fg
+    loss = 5.0 * loss_iou + loss_obj + loss_cls
+    return {"loss": loss, "iou_loss": 5.0 * loss_iou, "conf_loss": loss_obj, "cls_loss": loss_cls, "num_fg": num_fg / max(num_gts, 1),
+            "assign": assigns, "outputs": out}
+
+
+def synthetic_labels(B: int, hw: Tuple[int, int], num_classes: int, max_labels: int = 8, seed: int = 0) -> Tensor:
+    """(B, max_labels, 5) = (cls, cx, cy, w, h) in input pixels; a random number of valid rows first, zero rows after."""
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.zeros(B, max_labels, 5)
+    for b in range(B):
+        n = int(torch.randint(0 if b == B - 1 and B > 2 else 1, max_labels + 1, (1,), generator=g))
+        for i in range(n):
+            w = float(torch.rand(1, generator=g)) * hw[1] * 0.3 + 8
+            h = float(torch.rand(1, generator=g)) * hw[0] * 0.3 + 8
+            cx = float(torch.rand(1, generator=g)) * (hw[1] - w) + w / 2
+            cy = float(torch.rand(1, generator=g)) * (hw[0] - h) + h / 2
+            lab[b, i] = torch.tensor([float(torch.randint(0, num_classes, (1,), generator=g)), cx, cy, w, h])
+    return lab
+
+
 def init_head_params(in_channels=(128, 256, 512), num_classes: int = 3, seed: int = 2, prior_prob: float = 0.01) -> Params:
     """seeded stand-in for YOLOXHead.__init__ (names / shapes of yolo_head.py:58-133; biases as initialize_biases :154-163);
     BatchNorm running statistics are randomised so that the eval path is exercised with non-trivial statistics."""

@@ -304,10 +304,54 @@ def gen_head_eval(ref):
     print("head_eval ok:", tuple(out.shape), "oracle max abs diff", float((mine - out).abs().max()))
 
 
+def gen_head_train(ref):
+    """YOLOX head, training branch (SimOTA assignment + IoU / BCE losses): oracle restatement against the reference module."""
+    chans, nc, strides = (64, 128, 256), 2, (8, 16, 32)
+    params = O.init_head_params(chans, num_classes=nc, seed=6)
+    head = ref.yolo_head.YOLOXHead(num_classes=nc, strides=strides, in_channels=chans)
+    sd = head.state_dict()
+    head.load_state_dict({k: (v if k.endswith("num_batches_tracked") else params[k].clone()) for k, v in sd.items()}, strict=True)
+    head.train()
+    g = torch.Generator().manual_seed(78)
+    B = 3
+    feats = [torch.randn(B, c, 16 // (2 ** i), 20 // (2 ** i), generator=g).requires_grad_(True) for i, c in enumerate(chans)]
+    labels = O.synthetic_labels(B, (128, 160), nc, max_labels=6, seed=4)
+    out, losses = head(tuple(feats), labels)
+    losses["loss"].backward()
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in params.items()}
+    fo = [f.detach().clone().requires_grad_(True) for f in feats]
+    mine = O.yolox_head_train(fo, labels, po, strides, num_classes=nc)
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss"):
+        assert torch.allclose(mine[k], losses[k], atol=1e-6, rtol=1e-6), (k, float(mine[k]), float(losses[k]))
+    assert abs(float(mine["num_fg"]) - float(losses["num_fg"])) < 1e-9
+    mine["loss"].backward()
+    for a, b in zip(fo, feats):
+        assert torch.allclose(a.grad, b.grad, atol=1e-7, rtol=1e-4)
+    named = dict(head.named_parameters())
+    for k, v in named.items():
+        assert torch.allclose(po[k].grad, v.grad, atol=1e-7, rtol=1e-4), k
+    d = {f"in{i}": np_(f) for i, f in enumerate(feats)}
+    d.update({f"din{i}": np_(f.grad) for i, f in enumerate(feats)})
+    d.update(labels=np_(labels), num_classes=np.int64(nc), seed=np.int64(6))
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss"):
+        d[k] = np.float64(float(losses[k]))
+    d["num_fg"] = np.float64(float(losses["num_fg"]))
+    for b, (fg, matched, pious) in enumerate(mine["assign"]):
+        d[f"fg{b}"] = np_(fg).astype(np.uint8); d[f"matched{b}"] = np_(matched).astype(np.int64); d[f"piou{b}"] = np_(pious)
+    for k in ("cls_preds.0.weight", "cls_preds.0.bias", "reg_preds.1.weight", "obj_preds.2.bias", "stems.0.conv.weight", "reg_convs.1.1.bn.weight"):
+        d["g_" + k] = np_(named[k].grad)
+    import json as _json
+    d["grad_norms_json"] = np.array(_json.dumps({k: float(v.grad.double().norm()) for k, v in named.items()}))
+    np.savez_compressed(os.path.join(HERE, "head_train.npz"), **d)
+    print("head_train ok:", {k: round(float(losses[k]), 6) for k in ("loss", "iou_loss", "conf_loss", "cls_loss", "num_fg")},
+          "fg per image", [int(a[0].sum()) for a in mine["assign"]])
+
+
 def main():
     ref = RI.import_reference()
     if "--head-only" in sys.argv:
         gen_head_eval(ref)
+        gen_head_train(ref)
         return
     if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
         gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
@@ -325,6 +369,7 @@ def main():
     gen_backbone_tiny(ref)
     gen_pafpn(ref)
     gen_head_eval(ref)
+    gen_head_train(ref)
     gen_full_stats(ref)
 
 
