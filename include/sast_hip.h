@@ -184,14 +184,39 @@ int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H,
 int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream);
 int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int C2, sast_stream_t stream);
 
-/* SURVEY 8(f) rank 1, inference path only: last step of one YOLOX head level -- the 1x1 prediction convs reg(4) / obj(1) on the
- * regression feature and cls(nc) on the classification feature (NHWC rows [B*H*W, hidden]), sigmoid on obj / cls and, with
- * decode != 0, the box decode of YOLOXHead.decode_outputs -- yolox/models/yolo_head.py:184-186,207-210,264-289.
- * out[B, anchors_total, 5 + nc], this level occupies anchors [anchor_offset, anchor_offset + H*W).  The 3x3 / 1x1 BaseConvs of the
- * head go through sast_conv_bn_silu_fwd (training = 0).  The training branch (SimOTA loss) is not built. */
+/* ---- YOLOX head -- yolox/models/yolo_head.py.  The 15 Conv+BN+SiLU units of the head go through
+ * sast_conv_bn_silu_{fwd,bwd}; below are the 1x1 prediction convs (+ decode), the SimOTA assignment and the losses. */
+typedef struct SastHeadGeom {       /* FPN levels, finest first: anchors of level k are [sum_{i<k} H_i*W_i, ... + H_k*W_k) */
+  int32_t n_levels;                 /* 1..4 */
+  int32_t H[4], W[4];
+  float stride[4];
+} SastHeadGeom;
+/* last step of one head level: prediction convs reg(4) / obj(1) on the regression feature and cls(nc) on the classification feature
+ * (NHWC rows [B*H*W, hidden]); yolo_head.py:184-186,192-210,248-262,264-289.
+ *   pred  (optional) [B, anchors_total, 5+nc]: box (decoded like decode_outputs when decode != 0), sigmoid(obj), sigmoid(cls)
+ *   train (optional) same shape: decoded box ((xy + grid) * stride, exp(wh) * stride) and the RAW obj / cls logits (get_losses' input) */
+int sast_head_pred_fwd(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
+                       const float* b_obj, const float* w_cls, const float* b_cls, float* pred, float* train, int B, int H, int W, int hidden,
+                       int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream);
+/* = sast_head_pred_fwd(..., pred = out, train = NULL, ...) */
 int sast_head_pred_decode(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
                           const float* b_obj, const float* w_cls, const float* b_cls, float* out, int B, int H, int W, int hidden,
                           int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream);
+/* backward of the prediction convs of one level; draw[B, anchors_total, 5+nc] = d loss / d (raw conv outputs) from sast_yolox_loss.
+ * d_*_feat are written, the weight / bias gradients are ACCUMULATED (+=). */
+int sast_head_pred_bwd(const float* draw, const float* reg_feat, const float* cls_feat, const float* w_reg, const float* w_obj,
+                       const float* w_cls, float* d_reg_feat, float* d_cls_feat, float* dw_reg, float* db_reg, float* dw_obj, float* db_obj,
+                       float* dw_cls, float* db_cls, int B, int H, int W, int hidden, int num_classes, int anchor_offset, int anchors_total,
+                       sast_stream_t stream);
+/* get_losses (yolo_head.py:291-443) with the SimOTA assignment (:452-606) for the whole batch, no host sync:
+ *   train_out [B, A, 5+nc] from sast_head_pred_fwd, labels [B, max_labels, 5] = (cls, cx, cy, w, h), valid rows first, all-zero rows = padding
+ *   losses[5] = loss, 5*iou_loss, conf_loss, cls_loss, num_fg / max(num_gts, 1)
+ *   draw [B, A, 5+nc] = d loss / d (raw conv outputs) (chain through the decode included)
+ *   fg_mask / matched_gt / matched_iou [B, A]: the assignment (matched_gt = -1, iou = 0 for background anchors)
+ * use_l1 (the reference's optional L1 term, off by default) is not implemented. */
+size_t sast_yolox_loss_ws_bytes(int B, int anchors_total, int max_labels);
+int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes,
+                    float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream);
 
 /* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441) */
 int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,

@@ -44,6 +44,7 @@ SastMswsaArgs = _struct("SastMswsaArgs", [
     (P, "d_ln1_w d_ln1_b d_ln2_w d_ln2_b d_qkv_w d_qkv_b d_proj_w d_proj_b d_ls1 d_fc1_w d_fc1_b d_fc2_w d_fc2_b d_ls2"),
     (P, "ws cb_m cb_sum raw_ws"),
 ])
+SastHeadGeom = _struct("SastHeadGeom", [(I32, "n_levels"), (I32 * 4, "H"), (I32 * 4, "W"), (F32 * 4, "stride")])
 SastLstmArgs = _struct("SastLstmArgs", [
     (I32, "B L C"),
     (P, "x h0 c0 w b h1 c1 gates dh1 dc1 dx dh0 dc0 dw db ws"),
@@ -67,6 +68,10 @@ _SIGNATURES = {
     "sast_score_stp_bwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
     "sast_select": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), P]),
     "sast_head_pred_decode": (C.c_int, [P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, P]),
+    "sast_head_pred_fwd": (C.c_int, [P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, P]),
+    "sast_head_pred_bwd": (C.c_int, [P] * 14 + [C.c_int] * 7 + [P]),
+    "sast_yolox_loss_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "sast_yolox_loss": (C.c_int, [P, P, C.POINTER(SastHeadGeom), C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "sast_select_pair": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), C.POINTER(SastSel), P]),
     "sast_mswsa_bwd_ws_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sast_mswsa_raw_ws_floats": (C.c_size_t, [C.c_int, C.c_int]),

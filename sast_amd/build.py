@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsast_hip.so")
 ARCH = "gfx950"
-SOURCES = ["k_rows.hip", "k_select.hip", "k_attn.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_test.hip"]
+SOURCES = ["k_rows.hip", "k_select.hip", "k_attn.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_test.hip", "k_head.hip"]
 HEADERS = ["common.cuh", "gemm.cuh", "gemm_dispatch.cuh", "kernels.h", os.path.join("..", "..", "include", "sast_hip.h")]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SAST_EXTRA_FLAGS", "").split()
 

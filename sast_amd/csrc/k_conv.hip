@@ -222,38 +222,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   st4(p + e * 4, pv); st4(m + e * 4, mv); st4(v + e * 4, vv);
 }
 
-// YOLOX head, last step of one FPN level (yolo_head.py:184-186,207-210 + decode_outputs :264-289): the three 1x1 prediction
-// convs (reg 4, obj 1 from the regression feature; cls nc from the classification feature), sigmoid on obj / cls, box decode
-// ((xy + grid) * stride, exp(wh) * stride), written straight into the (B, A_total, 5 + nc) output at this level's anchor offset.
-// One thread per (pixel, output channel); the per-pixel feature row stays in L1 across the 5 + nc threads that share it.
-__global__ __launch_bounds__(256) void head_pred_decode_kernel(const float* __restrict__ reg_feat, const float* __restrict__ cls_feat,
-                                                               const float* __restrict__ w_reg, const float* __restrict__ b_reg,
-                                                               const float* __restrict__ w_obj, const float* __restrict__ b_obj,
-                                                               const float* __restrict__ w_cls, const float* __restrict__ b_cls,
-                                                               float* __restrict__ out, int B, int H, int W, int hid, int nc, float stride,
-                                                               int anchor_off, int A_total, int decode) {
-  const int no = 5 + nc;
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (size_t)B * H * W * no) return;
-  const int o = (int)(e % no);
-  const size_t pix = e / no;
-  const int hw = (int)(pix % ((size_t)H * W)), b = (int)(pix / ((size_t)H * W));
-  const float* f = (o < 5 ? reg_feat : cls_feat) + pix * hid;
-  const float* w = o < 4 ? w_reg + (size_t)o * hid : (o == 4 ? w_obj : w_cls + (size_t)(o - 5) * hid);
-  float acc = 0.f;
-  for (int k = 0; k < hid; k += 4) {
-    const float4 a = ld4(f + k), c = ld4(w + k);
-    acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
-  }
-  acc += o < 4 ? b_reg[o] : (o == 4 ? b_obj[0] : b_cls[o - 5]);
-  float v;
-  if (o >= 4) v = 1.0f / (1.0f + expf(-acc));
-  else if (!decode) v = acc;
-  else if (o < 2) v = (acc + (float)(o == 0 ? hw % W : hw / W)) * stride;
-  else v = expf(acc) * stride;
-  out[((size_t)b * A_total + anchor_off + hw) * no + o] = v;
-}
-
 inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad, int replicate, int ldx) {
   ConvGeom g;
   g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad; g.replicate = replicate; g.ldx = ldx;
@@ -438,18 +406,6 @@ int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int
   int rc = slice_copy(dout, C1 + C2, 0, da, C1, 0, C1, rows, st);
   if (rc) return rc;
   return slice_copy(dout, C1 + C2, C1, db, C2, 0, C2, rows, st);
-}
-
-int sast_head_pred_decode(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
-                          const float* b_obj, const float* w_cls, const float* b_cls, float* out, int B, int H, int W, int hidden,
-                          int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) {
-  if (!reg_feat || !cls_feat || !out || hidden % 4 || num_classes < 1 || anchor_offset < 0 || anchor_offset + H * W > anchors_total)
-    return SAST_EINVAL;
-  const size_t n = (size_t)B * H * W * (5 + num_classes);
-  hipLaunchKernelGGL(head_pred_decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reg_feat, cls_feat, w_reg,
-                     b_reg, w_obj, b_obj, w_cls, b_cls, out, B, H, W, hidden, num_classes, stride, anchor_offset, anchors_total, decode);
-  SAST_CHECK_LAUNCH();
-  return SAST_OK;
 }
 
 int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* lr_step, float beta1, float beta2, float eps,

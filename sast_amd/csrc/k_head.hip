@@ -1,0 +1,455 @@
+// YOLOX head: prediction convs + decode, SimOTA assignment and the training losses, all device-side.
+//
+// reference: models/detection/yolox/models/yolo_head.py
+//   forward (eval / train)            :165-246     get_output_and_grid :248-262     decode_outputs :264-289
+//   get_losses                        :291-443     get_assignments     :452-538
+//   get_geometry_constraint           :540-571     simota_matching     :573-606
+//   IOUloss ("iou")                   losses.py:16-33
+// The reference runs the assignment image by image with a host sync per image (`.item()`, `int(nlabel)`); here the number
+// of ground-truth rows, the foreground counts and the loss normalisation all stay on the device: five launches per step for
+// the whole batch.  Only the 15 Conv+BN+SiLU units of the head go through the GEMM template (sast_conv_bn_silu_*); the
+// prediction convs have 5 + num_classes <= 32 output channels and are plain VALU dot products.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sast {
+
+constexpr int HEAD_MAX_CLASSES = 32;
+
+struct HeadLevels {          // anchors of level k: [off[k], off[k] + H[k]*W[k])
+  int n, A;
+  int H[4], W[4], off[4];
+  float stride[4];
+  __device__ __forceinline__ void anchor(int a, float& x, float& y, float& s) const {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < n && a >= off[i]) k = i;
+    const int l = a - off[k];
+    y = (float)(l / W[k]);
+    x = (float)(l - (l / W[k]) * W[k]);
+    s = stride[k];
+  }
+};
+
+// ---------------------------------------------------------------- prediction convs (+ decode)
+// One thread per (pixel, output channel).  pred (optional): decoded box (or raw when !decode), sigmoid(obj), sigmoid(cls) -- the
+// inference output; train (optional): decoded box, raw obj / cls logits -- what get_losses consumes (yolo_head.py:192-197,248-262).
+__global__ __launch_bounds__(256) void head_pred_kernel(const float* __restrict__ reg_feat, const float* __restrict__ cls_feat,
+                                                        const float* __restrict__ w_reg, const float* __restrict__ b_reg,
+                                                        const float* __restrict__ w_obj, const float* __restrict__ b_obj,
+                                                        const float* __restrict__ w_cls, const float* __restrict__ b_cls,
+                                                        float* __restrict__ pred, float* __restrict__ train, int B, int H, int W, int hid,
+                                                        int nc, float stride, int anchor_off, int A_total, int decode) {
+  const int no = 5 + nc;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)B * H * W * no) return;
+  const int o = (int)(e % no);
+  const size_t pix = e / no;
+  const int hw = (int)(pix % ((size_t)H * W)), b = (int)(pix / ((size_t)H * W));
+  const float* f = (o < 5 ? reg_feat : cls_feat) + pix * hid;
+  const float* w = o < 4 ? w_reg + (size_t)o * hid : (o == 4 ? w_obj : w_cls + (size_t)(o - 5) * hid);
+  float acc = 0.f;
+  for (int k = 0; k < hid; k += 4) {
+    const float4 a = ld4(f + k), c = ld4(w + k);
+    acc = fmaf(a.x, c.x, acc); acc = fmaf(a.y, c.y, acc); acc = fmaf(a.z, c.z, acc); acc = fmaf(a.w, c.w, acc);
+  }
+  acc += o < 4 ? b_reg[o] : (o == 4 ? b_obj[0] : b_cls[o - 5]);
+  float dec = acc;
+  if (o < 2) dec = (acc + (float)(o == 0 ? hw % W : hw / W)) * stride;
+  else if (o < 4) dec = expf(acc) * stride;
+  const size_t idx = ((size_t)b * A_total + anchor_off + hw) * no + o;
+  if (pred) pred[idx] = o >= 4 ? 1.0f / (1.0f + expf(-acc)) : (decode ? dec : acc);
+  if (train) train[idx] = dec;   // o >= 4: dec == acc (raw logit)
+}
+
+// backward of the prediction convs of one level.  draw[B, A_total, no] holds d loss / d (raw conv output).
+// d feat: one thread per (pixel, 4 feature channels)
+__global__ __launch_bounds__(256) void head_pred_bwd_feat_kernel(const float* __restrict__ draw, const float* __restrict__ w_reg,
+                                                                 const float* __restrict__ w_obj, const float* __restrict__ w_cls,
+                                                                 float* __restrict__ d_reg_feat, float* __restrict__ d_cls_feat, int B, int HW,
+                                                                 int hid, int nc, int anchor_off, int A_total) {
+  const int h4 = hid / 4, no = 5 + nc;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)B * HW * h4) return;
+  const int k = (int)(e % h4) * 4;
+  const size_t pix = e / h4;
+  const int hw = (int)(pix % HW), b = (int)(pix / HW);
+  const float* d = draw + ((size_t)b * A_total + anchor_off + hw) * no;
+  float4 r = zero4(), c = zero4();
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    const float4 w = ld4((o < 4 ? w_reg + (size_t)o * hid : w_obj) + k);
+    const float g = d[o];
+    r.x = fmaf(g, w.x, r.x); r.y = fmaf(g, w.y, r.y); r.z = fmaf(g, w.z, r.z); r.w = fmaf(g, w.w, r.w);
+  }
+  for (int o = 0; o < nc; ++o) {
+    const float4 w = ld4(w_cls + (size_t)o * hid + k);
+    const float g = d[5 + o];
+    c.x = fmaf(g, w.x, c.x); c.y = fmaf(g, w.y, c.y); c.z = fmaf(g, w.z, c.z); c.w = fmaf(g, w.w, c.w);
+  }
+  st4(d_reg_feat + pix * hid + k, r);
+  st4(d_cls_feat + pix * hid + k, c);
+}
+// d weights / d bias: block (o, strip of pixels); threads over feature channels; one atomic per (o, k) and block
+__global__ __launch_bounds__(256) void head_pred_bwd_w_kernel(const float* __restrict__ draw, const float* __restrict__ reg_feat,
+                                                              const float* __restrict__ cls_feat, float* __restrict__ dw_reg,
+                                                              float* __restrict__ db_reg, float* __restrict__ dw_obj, float* __restrict__ db_obj,
+                                                              float* __restrict__ dw_cls, float* __restrict__ db_cls, int B, int HW, int hid,
+                                                              int nc, int anchor_off, int A_total, int pix_per_block) {
+  const int o = blockIdx.y, no = 5 + nc;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block, p1 = min((size_t)B * HW, p0 + pix_per_block);
+  const float* feat = o < 5 ? reg_feat : cls_feat;
+  float* dw = o < 4 ? dw_reg + (size_t)o * hid : (o == 4 ? dw_obj : dw_cls + (size_t)(o - 5) * hid);
+  float* db = o < 4 ? db_reg + o : (o == 4 ? db_obj : db_cls + (o - 5));
+  float bsum = 0.f;
+  for (int k = threadIdx.x; k < hid; k += 256) {
+    float acc = 0.f;
+    bsum = 0.f;
+    for (size_t p = p0; p < p1; ++p) {
+      const int hw = (int)(p % HW), b = (int)(p / HW);
+      const float g = draw[((size_t)b * A_total + anchor_off + hw) * no + o];
+      acc = fmaf(g, feat[p * hid + k], acc);
+      bsum += g;
+    }
+    atomicAdd(dw + k, acc);
+  }
+  if (threadIdx.x == 0) {
+    if (hid < 1) return;
+    atomicAdd(db, bsum);
+  }
+}
+
+// ---------------------------------------------------------------- labels
+// nlabel[b] = number of rows with a positive sum (yolo_head.py:306); rows are packed at the front (:335-336 slices [:num_gt])
+__global__ void head_count_labels_kernel(const float* __restrict__ labels, int B, int G, int* __restrict__ nlabel) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  for (int g = 0; g < G; ++g) {
+    const float* l = labels + ((size_t)b * G + g) * 5;
+    n += ((l[0] + l[1]) + (l[2] + l[3]) + l[4]) > 0.f ? 1 : 0;
+  }
+  nlabel[b] = n;
+}
+
+// ---------------------------------------------------------------- SimOTA cost (one thread per anchor, loops over the image's ground truths)
+// cost[b][g][a], iou[b][g][a]; anchors outside every centre region get iou = -1, cost = +inf (they are not candidates, :483-486)
+__global__ __launch_bounds__(256) void simota_cost_kernel(const float* __restrict__ train, const float* __restrict__ labels,
+                                                          const int* __restrict__ nlabel, HeadLevels lv, int G, int nc,
+                                                          float* __restrict__ cost, float* __restrict__ iou) {
+  const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (a >= lv.A) return;
+  const int ng = nlabel[b], no = 5 + nc;
+  float ax, ay, as;
+  lv.anchor(a, ax, ay, as);
+  const float xc = (ax + 0.5f) * as, yc = (ay + 0.5f) * as, dist = as * 1.5f;
+  const float* lab = labels + (size_t)b * G * 5;
+  bool fg = false;
+  for (int g = 0; g < ng; ++g) {
+    const float gx = lab[g * 5 + 1], gy = lab[g * 5 + 2];
+    const float m = fminf(fminf(xc - (gx - dist), yc - (gy - dist)), fminf((gx + dist) - xc, (gy + dist) - yc));
+    fg |= m > 0.f;
+  }
+  float* cb = cost + (size_t)b * G * lv.A + a;
+  float* ib = iou + (size_t)b * G * lv.A + a;
+  if (!fg) {
+    for (int g = 0; g < ng; ++g) { cb[(size_t)g * lv.A] = INFINITY; ib[(size_t)g * lv.A] = -1.f; }
+    return;
+  }
+  const float* t = train + ((size_t)b * lv.A + a) * no;
+  const float px = t[0], py = t[1], pw = t[2], ph = t[3];
+  const float so = 1.0f / (1.0f + expf(-t[4]));
+  // class part of the cost: BCE(p, one_hot) summed over classes = S + d[class], p = sqrt(sigmoid(cls) sigmoid(obj)), logs clamped
+  // at -100 like torch's binary_cross_entropy
+  float S = 0.f, dcl[HEAD_MAX_CLASSES];
+  for (int c = 0; c < nc; ++c) {
+    const float p = sqrtf((1.0f / (1.0f + expf(-t[5 + c]))) * so);
+    const float lp = fmaxf(logf(p), -100.f), l1 = fmaxf(logf(1.0f - p), -100.f);
+    S -= l1;
+    dcl[c] = l1 - lp;
+  }
+  for (int g = 0; g < ng; ++g) {
+    const float gc = lab[g * 5], gx = lab[g * 5 + 1], gy = lab[g * 5 + 2], gw = lab[g * 5 + 3], gh = lab[g * 5 + 4];
+    const float m = fminf(fminf(xc - (gx - dist), yc - (gy - dist)), fminf((gx + dist) - xc, (gy + dist) - yc));
+    const float tlx = fmaxf(gx - gw / 2, px - pw / 2), tly = fmaxf(gy - gh / 2, py - ph / 2);
+    const float brx = fminf(gx + gw / 2, px + pw / 2), bry = fminf(gy + gh / 2, py + ph / 2);
+    const float en = (tlx < brx && tly < bry) ? 1.f : 0.f;
+    const float ai = (brx - tlx) * (bry - tly) * en;
+    const float v = ai / (gw * gh + pw * ph - ai);
+    int cls = (int)gc;
+    cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);
+    cb[(size_t)g * lv.A] = (S + dcl[cls]) + 3.0f * (-logf(v + 1e-8f)) + (m > 0.f ? 0.f : 1e6f);
+    ib[(size_t)g * lv.A] = v;
+  }
+}
+
+// ---------------------------------------------------------------- SimOTA matching: one workgroup per image, one wave per ground truth
+// (value, index) lexicographic selection rounds: nothing is modified, ties resolve to the lower anchor index.
+__device__ __forceinline__ void wave_arg_best(float v, int i, bool larger, float& bv, int& bi) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    const bool take = larger ? (ov > v || (ov == v && oi < i)) : (ov < v || (ov == v && oi < i));
+    if (take) { v = ov; i = oi; }
+  }
+  bv = v; bi = i;
+}
+
+__global__ __launch_bounds__(1024) void simota_match_kernel(const float* __restrict__ cost, const float* __restrict__ iou,
+                                                            const float* __restrict__ labels, const int* __restrict__ nlabel, int A, int G,
+                                                            int* __restrict__ cnt_ws, int* __restrict__ fg_out, int* __restrict__ mg_out,
+                                                            float* __restrict__ piou_out, int* __restrict__ num_fg) {
+  const int b = blockIdx.x, ng = nlabel[b];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  int* cnt = cnt_ws + (size_t)b * 2 * A;     // [A] number of ground truths that picked the anchor
+  int* one = cnt + A;                        // [A] the ground truth that picked it (valid when cnt == 1)
+  for (int a = threadIdx.x; a < A; a += blockDim.x) { cnt[a] = 0; one[a] = 0; }
+  __syncthreads();
+  const float* cb = cost + (size_t)b * G * A;
+  const float* ib = iou + (size_t)b * G * A;
+  for (int g = wave; g < ng; g += nw) {
+    const float* iv = ib + (size_t)g * A;
+    const float* cv = cb + (size_t)g * A;
+    // dynamic k = clamp(int(sum of the 10 largest IoUs among the candidate anchors), min 1)   (:576-578)
+    float sum = 0.f, pv = INFINITY;
+    int pi = -1;
+    for (int r = 0; r < 10; ++r) {
+      float bv = -2.f; int bi = 0x7fffffff;
+      for (int a = lane; a < A; a += 64) {
+        const float v = iv[a];
+        const bool elig = v < pv || (v == pv && a > pi);
+        if (elig && (v > bv || (v == bv && a < bi))) { bv = v; bi = a; }
+      }
+      float wv; int wi;
+      wave_arg_best(bv, bi, true, wv, wi);
+      if (wv < 0.f) break;          // fewer than 10 candidate anchors (non-candidates carry -1)
+      sum += wv; pv = wv; pi = wi;
+    }
+    int k = (int)sum;
+    k = k < 1 ? 1 : k;
+    // the k smallest costs (:579-583)
+    pv = -INFINITY; pi = -1;
+    for (int r = 0; r < k; ++r) {
+      float bv = INFINITY; int bi = 0x7fffffff;
+      for (int a = lane; a < A; a += 64) {
+        const float v = cv[a];
+        const bool elig = v > pv || (v == pv && a > pi);
+        if (elig && (v < bv || (v == bv && a < bi))) { bv = v; bi = a; }
+      }
+      float wv; int wi;
+      wave_arg_best(bv, bi, false, wv, wi);
+      if (wi == 0x7fffffff || wv == INFINITY) break;
+      if (lane == 0) { atomicAdd(cnt + wi, 1); atomicExch(one + wi, g); }
+      pv = wv; pi = wi;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // anchors picked by several ground truths go to the one with the smallest cost over ALL ground truths (:588-592)
+  int nfg = 0;
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    const int c = cnt[a];
+    int mg = one[a];
+    if (c > 1) {
+      float best = INFINITY;
+      mg = 0;
+      for (int g = 0; g < ng; ++g) {
+        const float v = cb[(size_t)g * A + a];
+        if (v < best) { best = v; mg = g; }
+      }
+    }
+    const bool fg = c > 0;
+    fg_out[(size_t)b * A + a] = fg ? 1 : 0;
+    mg_out[(size_t)b * A + a] = fg ? mg : -1;
+    piou_out[(size_t)b * A + a] = fg ? ib[(size_t)mg * A + a] : 0.f;
+    nfg += fg ? 1 : 0;
+  }
+  __shared__ int red[16];
+  for (int o = 32; o > 0; o >>= 1) nfg += __shfl_xor(nfg, o, 64);
+  if (lane == 0) red[wave] = nfg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < nw; ++w) t += red[w];
+    num_fg[b] = t;
+  }
+}
+
+// ---------------------------------------------------------------- losses + gradient w.r.t. the raw conv outputs
+__device__ __forceinline__ float bce_logits(float x, float t) { return fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x))); }
+// d max(p, g) / d p as torch.maximum's backward: 1 if p > g, 0.5 on ties, else 0
+__device__ __forceinline__ float dsel_max(float p, float g) { return p > g ? 1.f : (p == g ? 0.5f : 0.f); }
+__device__ __forceinline__ float dsel_min(float p, float g) { return p < g ? 1.f : (p == g ? 0.5f : 0.f); }
+
+// acc[0] += sum iou loss, acc[1] += sum obj loss, acc[2] += sum cls loss   (all un-normalised)
+__global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict__ train, const float* __restrict__ labels,
+                                                         const int* __restrict__ fg_in, const int* __restrict__ mg_in,
+                                                         const float* __restrict__ piou_in, const int* __restrict__ num_fg, HeadLevels lv,
+                                                         int B, int G, int nc, float* __restrict__ draw, float* __restrict__ acc) {
+  const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, no = 5 + nc, A = lv.A;
+  int nt = 0;
+  for (int i = 0; i < B; ++i) nt += num_fg[i];
+  const float inv = 1.0f / (float)(nt < 1 ? 1 : nt);
+  float l_iou = 0.f, l_obj = 0.f, l_cls = 0.f;
+  if (a < A) {
+    const size_t ia = (size_t)b * A + a;
+    const float* t = train + ia * no;
+    float* d = draw + ia * no;
+    const bool fg = fg_in[ia] != 0;
+    const float xo = t[4];
+    l_obj = bce_logits(xo, fg ? 1.f : 0.f);
+    d[4] = (1.0f / (1.0f + expf(-xo)) - (fg ? 1.f : 0.f)) * inv;
+    if (!fg) {
+      d[0] = 0.f; d[1] = 0.f; d[2] = 0.f; d[3] = 0.f;
+      for (int c = 0; c < nc; ++c) d[5 + c] = 0.f;
+    } else {
+      const int g = mg_in[ia];
+      const float* lab = labels + ((size_t)b * G + g) * 5;
+      const float gx = lab[1], gy = lab[2], gw = lab[3], gh = lab[4];
+      const float px = t[0], py = t[1], pw = t[2], ph = t[3];
+      // IOUloss "iou": 1 - iou^2, iou = I / (Ap + Ag - I + 1e-16)
+      const float pl = px - pw / 2, pt = py - ph / 2, pr = px + pw / 2, pb = py + ph / 2;
+      const float gl = gx - gw / 2, gt = gy - gh / 2, gr = gx + gw / 2, gb = gy + gh / 2;
+      const float tlx = fmaxf(pl, gl), tly = fmaxf(pt, gt), brx = fminf(pr, gr), bry = fminf(pb, gb);
+      const float en = (tlx < brx && tly < bry) ? 1.f : 0.f;
+      const float wx = brx - tlx, wy = bry - tly;
+      const float I = wx * wy * en, U = pw * ph + gw * gh - I + 1e-16f;
+      const float iouv = I / U;
+      l_iou = 1.f - iouv * iouv;
+      const float mtx = dsel_max(pl, gl), mty = dsel_max(pt, gt), mbx = dsel_min(pr, gr), mby = dsel_min(pb, gb);
+      const float dI_cx = (mbx - mtx) * wy * en, dI_w = 0.5f * (mbx + mtx) * wy * en;
+      const float dI_cy = (mby - mty) * wx * en, dI_h = 0.5f * (mby + mty) * wx * en;
+      // d iou = (dI * U - I * dU) / U^2 with dU = dAp - dI ; d loss = -2 iou d iou ; x5 (reg_weight), / num_fg
+      const float k = -2.f * iouv * 5.f * inv / (U * U);
+      const float d_cx = k * (dI_cx * U + I * dI_cx), d_cy = k * (dI_cy * U + I * dI_cy);
+      const float d_w = k * (dI_w * U - I * (ph - dI_w)), d_h = k * (dI_h * U - I * (pw - dI_h));
+      // chain through get_output_and_grid: xy = (raw + grid) * stride, wh = exp(raw) * stride  ->  d raw_xy = d * stride, d raw_wh = d * wh
+      float ax, ay, as;
+      lv.anchor(a, ax, ay, as);
+      d[0] = d_cx * as; d[1] = d_cy * as; d[2] = d_w * pw; d[3] = d_h * ph;
+      // class loss: BCEWithLogits(cls_logit, one_hot * iou of the matching)
+      int cls = (int)lab[0];
+      cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);
+      const float pi = piou_in[ia];
+      for (int c = 0; c < nc; ++c) {
+        const float x = t[5 + c], tt = c == cls ? pi : 0.f;
+        l_cls += bce_logits(x, tt);
+        d[5 + c] = (1.0f / (1.0f + expf(-x)) - tt) * inv;
+      }
+    }
+  }
+  l_iou = wave_sum(l_iou); l_obj = wave_sum(l_obj); l_cls = wave_sum(l_cls);
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = l_iou; red[1][wave] = l_obj; red[2][wave] = l_cls; }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(acc + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+}
+// losses[0..4] = loss, 5 * iou, obj, cls, num_fg / max(num_gts, 1)   (yolo_head.py:412-443)
+__global__ void yolox_loss_finish_kernel(const float* __restrict__ acc, const int* __restrict__ num_fg, const int* __restrict__ nlabel,
+                                         int B, float* __restrict__ losses) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int nf = 0, ng = 0;
+  for (int i = 0; i < B; ++i) { nf += num_fg[i]; ng += nlabel[i]; }
+  const float n = (float)(nf < 1 ? 1 : nf);
+  const float li = 5.f * acc[0] / n, lo = acc[1] / n, lc = acc[2] / n;
+  losses[0] = li + lo + lc; losses[1] = li; losses[2] = lo; losses[3] = lc;
+  losses[4] = n / (float)(ng < 1 ? 1 : ng);
+}
+
+static int make_levels(const SastHeadGeom* g, HeadLevels& lv) {
+  if (!g || g->n_levels < 1 || g->n_levels > 4) return SAST_EINVAL;
+  lv.n = g->n_levels;
+  int off = 0;
+  for (int k = 0; k < 4; ++k) {
+    const bool on = k < g->n_levels;
+    lv.H[k] = on ? g->H[k] : 0; lv.W[k] = on ? g->W[k] : 0; lv.stride[k] = on ? g->stride[k] : 0.f; lv.off[k] = off;
+    if (on) off += g->H[k] * g->W[k];
+  }
+  lv.A = off;
+  return SAST_OK;
+}
+
+}  // namespace sast
+
+using namespace sast;
+
+extern "C" {
+
+int sast_head_pred_decode(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
+                          const float* b_obj, const float* w_cls, const float* b_cls, float* out, int B, int H, int W, int hidden,
+                          int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) {
+  return sast_head_pred_fwd(reg_feat, cls_feat, w_reg, b_reg, w_obj, b_obj, w_cls, b_cls, out, nullptr, B, H, W, hidden, num_classes, stride,
+                            anchor_offset, anchors_total, decode, stream);
+}
+
+int sast_head_pred_fwd(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
+                       const float* b_obj, const float* w_cls, const float* b_cls, float* pred, float* train, int B, int H, int W, int hidden,
+                       int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) {
+  if (!reg_feat || !cls_feat || (!pred && !train) || hidden % 4 || num_classes < 1 || num_classes > HEAD_MAX_CLASSES || anchor_offset < 0 ||
+      anchor_offset + H * W > anchors_total)
+    return SAST_EINVAL;
+  const size_t n = (size_t)B * H * W * (5 + num_classes);
+  hipLaunchKernelGGL(head_pred_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reg_feat, cls_feat, w_reg, b_reg,
+                     w_obj, b_obj, w_cls, b_cls, pred, train, B, H, W, hidden, num_classes, stride, anchor_offset, anchors_total, decode);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+int sast_head_pred_bwd(const float* draw, const float* reg_feat, const float* cls_feat, const float* w_reg, const float* w_obj,
+                       const float* w_cls, float* d_reg_feat, float* d_cls_feat, float* dw_reg, float* db_reg, float* dw_obj, float* db_obj,
+                       float* dw_cls, float* db_cls, int B, int H, int W, int hidden, int num_classes, int anchor_offset, int anchors_total,
+                       sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!draw || hidden % 4 || num_classes < 1 || num_classes > HEAD_MAX_CLASSES) return SAST_EINVAL;
+  const int HW = H * W;
+  const size_t n = (size_t)B * HW * (hidden / 4);
+  hipLaunchKernelGGL(head_pred_bwd_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, draw, w_reg, w_obj, w_cls, d_reg_feat,
+                     d_cls_feat, B, HW, hidden, num_classes, anchor_offset, anchors_total);
+  const int ppb = 256;
+  hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3((unsigned)(((size_t)B * HW + ppb - 1) / ppb), 5 + num_classes), dim3(256), 0, st, draw,
+                     reg_feat, cls_feat, dw_reg, db_reg, dw_obj, db_obj, dw_cls, db_cls, B, HW, hidden, num_classes, anchor_offset, anchors_total,
+                     ppb);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+size_t sast_yolox_loss_ws_bytes(int B, int anchors_total, int max_labels) {
+  const size_t A = (size_t)anchors_total, G = (size_t)max_labels;
+  return 4 * (2 * B * G * A      /* cost, iou */
+              + 2 * B * A        /* per-anchor pick counters */
+              + 2 * B            /* nlabel, num_fg */
+              + 8);              /* loss accumulators */
+}
+
+int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes,
+                    float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  HeadLevels lv;
+  int rc = make_levels(geom, lv);
+  if (rc) return rc;
+  if (!train_out || !labels || !losses || !draw || !fg_mask || !matched_gt || !matched_iou || !ws || num_classes < 1 ||
+      num_classes > HEAD_MAX_CLASSES || max_labels < 1)
+    return SAST_EINVAL;
+  const int A = lv.A, G = max_labels;
+  float* cost = (float*)ws;
+  float* iou = cost + (size_t)B * G * A;
+  int* cnt = (int*)(iou + (size_t)B * G * A);
+  int* nlabel = cnt + (size_t)2 * B * A;
+  int* num_fg = nlabel + B;
+  float* acc = (float*)(num_fg + B);
+  zero_fill(acc, sizeof(float) * 8, st);
+  hipLaunchKernelGGL(head_count_labels_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, B, G, nlabel);
+  hipLaunchKernelGGL(simota_cost_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, nlabel, lv, G, num_classes, cost, iou);
+  hipLaunchKernelGGL(simota_match_kernel, dim3(B), dim3(1024), 0, st, cost, iou, labels, nlabel, A, G, cnt, fg_mask, matched_gt, matched_iou,
+                     num_fg);
+  hipLaunchKernelGGL(yolox_loss_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, fg_mask, matched_gt, matched_iou, num_fg, lv,
+                     B, G, num_classes, draw, acc);
+  hipLaunchKernelGGL(yolox_loss_finish_kernel, dim3(1), dim3(64), 0, st, acc, num_fg, nlabel, B, losses);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+}  // extern "C"

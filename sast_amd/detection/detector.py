@@ -1,6 +1,5 @@
 """models/detection/yolox_extension/models/detector.py:18-80 -- backbone + PAFPN + YOLOX head behind the reference's
-`YoloXDetector` surface.  `forward_detect` supports the inference branch (eval mode); the training branch needs the YOLOX
-loss, which is not built and raises."""
+`YoloXDetector` surface (inference and training branch)."""
 from __future__ import annotations
 
 from typing import Optional
@@ -34,8 +33,8 @@ class YoloXDetector(nn.Module):
     def forward_detect(self, backbone_features, targets: Optional[object] = None):
         fpn_features = self.fpn(backbone_features)
         if self.training:
-            raise NotImplementedError("sast_amd: the YOLOX training loss (yolo_head.py:291-606) is not built; use the backbone + PAFPN "
-                                      "modules with your own loss, or .eval() for inference")
+            assert targets is not None
+            return self.yolox_head(fpn_features, targets)
         outputs, losses = self.yolox_head(fpn_features)
         assert losses is None
         return outputs, losses

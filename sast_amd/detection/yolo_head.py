@@ -4,8 +4,9 @@ Same constructor, sub-module names and state_dict keys as the reference `YOLOXHe
 `strict=True`.  `forward(xin)` in eval mode returns `(outputs, None)` with outputs (B, n_anchors_all, 5 + num_classes), decoded
 like `decode_outputs` when `decode_in_inference` is set.  The 15 Conv+BN+SiLU units run through the same HIP op as the PAFPN
 (`sast_conv_bn_silu_fwd`, running statistics), the three 1x1 prediction convs + sigmoid + box decode of a level are one kernel
-(`sast_head_pred_decode`).  The TRAINING branch (SimOTA assignment + IoU / BCE losses, yolo_head.py:291-606) is not built and
-raises -- there is no fallback."""
+(`sast_head_pred_fwd`).  The TRAINING branch (yolo_head.py:291-606) runs the SimOTA assignment and the IoU / objectness /
+class losses on the device for the whole batch without a host sync (`sast_yolox_loss`); `use_l1` (off by default in the
+reference) is not implemented."""
 from __future__ import annotations
 
 import math
@@ -58,11 +59,33 @@ class YOLOXHead(nn.Module):
             for conv in list(self.cls_preds) + list(self.obj_preds):
                 conv.bias.fill_(-math.log((1 - prior_prob) / prior_prob))
 
+    def forward_train_nhwc(self, feats, labels):
+        """training branch: feats three (B,H,W,C) NHWC maps (autograd tensors), labels (B, max_labels, 5) = (cls, cx, cy, w, h)
+        -> (predictions (B, A, 5+nc), losses dict like yolo_head.py:224-231)"""
+        if self.use_l1:
+            raise NotImplementedError("sast_amd: use_l1 is not implemented")
+        per_level, levels = [], []
+        for k, (x, stride) in enumerate(zip(feats, self.strides)):
+            x = self.stems[k].forward_nhwc(x)
+            cf, rf = x, x
+            for conv in self.cls_convs[k]:
+                cf = conv.forward_nhwc(cf)
+            for conv in self.reg_convs[k]:
+                rf = conv.forward_nhwc(rf)
+            cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
+            per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
+            levels.append((x.shape[1], x.shape[2], stride))
+        losses, pred, fg, mg, piou = SF.head_pred_loss(labels, levels, self.num_classes, self.decode_in_inference, per_level)
+        self.last_assignment = (fg, mg, piou)      # SimOTA result of this step (device tensors), for inspection / tests
+        self.hw = [(h, w) for h, w, _ in levels]
+        det = losses.detach()
+        return pred, {"loss": losses[0], "iou_loss": det[1], "conf_loss": det[2], "cls_loss": det[3], "l1_loss": 0.0, "num_fg": det[4]}
+
     @torch.no_grad()
     def forward_nhwc(self, feats):
-        """feats: three (B,H,W,C) NHWC maps -> (B, n_anchors_all, 5 + num_classes)"""
+        """inference: feats three (B,H,W,C) NHWC maps -> (B, n_anchors_all, 5 + num_classes)"""
         if self.training:
-            raise NotImplementedError("sast_amd: the YOLOX training branch (SimOTA loss, yolo_head.py:291-606) is not built; call .eval()")
+            raise RuntimeError("sast_amd: YOLOXHead.forward_nhwc is the inference path; in training mode call forward(xin, labels)")
         B = feats[0].shape[0]
         dev = feats[0].device
         hw = [tuple(f.shape[1:3]) for f in feats]
@@ -88,8 +111,11 @@ class YOLOXHead(nn.Module):
         return out
 
     def forward(self, xin, labels=None):
-        """xin: the three PAFPN maps (B,C,H,W) -> (outputs, None)   (yolo_head.py:165-246, eval branch)"""
-        if labels is not None or self.training:
-            raise NotImplementedError("sast_amd: the YOLOX training branch (SimOTA loss, yolo_head.py:291-606) is not built")
+        """xin: the three PAFPN maps (B,C,H,W) -> (outputs, losses)   (yolo_head.py:165-246; losses is None in eval mode)"""
         SF._need_gpu(*xin)
-        return self.forward_nhwc([SF.as_nhwc(x.float()) for x in xin]), None
+        feats = [SF.as_nhwc(x.float()) for x in xin]
+        if self.training:
+            if labels is None:
+                raise ValueError("sast_amd: YOLOXHead in training mode needs labels (yolo_head.py:215-231)")
+            return self.forward_train_nhwc(feats, labels)
+        return self.forward_nhwc(feats), None

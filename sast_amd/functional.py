@@ -657,3 +657,80 @@ def adamw_step(p, g, m, v, lr_step, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
     _need_gpu(p, g, m, v, lr_step)
     L.check(L.lib().sast_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_step.data_ptr(), beta1, beta2, eps,
                                weight_decay, grad_scale, clip_value, _stream()), "adamw")
+
+
+# ---------------------------------------------------------------------------------------------- YOLOX head
+class _HeadPredLoss(torch.autograd.Function):
+    """prediction convs of all levels + SimOTA assignment + losses (yolo_head.py:184-246,291-606) as one autograd node.
+    inputs per level: reg_feat, cls_feat (B,H,W,hidden NHWC), w_reg, b_reg, w_obj, b_obj, w_cls, b_cls.
+    -> losses (5,) = loss, 5*iou, conf, cls, num_fg ratio (only [0] carries a gradient) and the inference-style predictions."""
+
+    @staticmethod
+    def forward(ctx, labels, levels, num_classes, decode, *t):
+        nlev = len(levels)
+        assert len(t) == 8 * nlev
+        rf0 = t[0]
+        _need_gpu(rf0, labels)
+        dev = rf0.device
+        B = rf0.shape[0]
+        hid = rf0.shape[-1]
+        geom = L.SastHeadGeom()
+        geom.n_levels = nlev
+        for k, (h, w, s) in enumerate(levels):
+            geom.H[k], geom.W[k], geom.stride[k] = int(h), int(w), float(s)
+        A = sum(int(h) * int(w) for h, w, _ in levels)
+        no = 5 + num_classes
+        labels = labels.to(device=dev, dtype=torch.float32).contiguous()
+        G = labels.shape[1]
+        pred = torch.empty(B, A, no, device=dev)
+        train = torch.empty(B, A, no, device=dev)
+        feats = []
+        off = 0
+        for k, (h, w, s) in enumerate(levels):
+            rf, cf, w_reg, b_reg, w_obj, b_obj, w_cls, b_cls = t[8 * k:8 * k + 8]
+            rf, cf = rf.contiguous(), cf.contiguous()
+            feats.append((rf, cf))
+            L.check(L.lib().sast_head_pred_fwd(rf.data_ptr(), cf.data_ptr(), w_reg.data_ptr(), b_reg.data_ptr(), w_obj.data_ptr(), b_obj.data_ptr(),
+                                               w_cls.data_ptr(), b_cls.data_ptr(), pred.data_ptr(), train.data_ptr(), B, int(h), int(w), hid,
+                                               num_classes, float(s), off, A, int(decode), _stream()), "head_pred_fwd")
+            off += int(h) * int(w)
+        losses = torch.empty(5, device=dev)
+        draw = torch.empty(B, A, no, device=dev)
+        fg = torch.empty(B, A, device=dev, dtype=torch.int32)
+        mg = torch.empty(B, A, device=dev, dtype=torch.int32)
+        piou = torch.empty(B, A, device=dev)
+        ws = torch.empty(L.lib().sast_yolox_loss_ws_bytes(B, A, G), device=dev, dtype=torch.uint8)
+        L.check(L.lib().sast_yolox_loss(train.data_ptr(), labels.data_ptr(), C.byref(geom), B, G, num_classes, losses.data_ptr(), draw.data_ptr(),
+                                        fg.data_ptr(), mg.data_ptr(), piou.data_ptr(), ws.data_ptr(), _stream()), "yolox_loss")
+        ctx.save_for_backward(draw, *[x for pair in feats for x in pair])
+        ctx.params = [t[8 * k + 2:8 * k + 8] for k in range(nlev)]
+        ctx.meta = (levels, num_classes, B, A, hid)
+        ctx.mark_non_differentiable(pred, fg, mg, piou)
+        return losses, pred, fg, mg, piou
+
+    @staticmethod
+    def backward(ctx, dlosses, _dpred, _dfg, _dmg, _dpiou):
+        draw = ctx.saved_tensors[0]
+        feats = ctx.saved_tensors[1:]
+        levels, num_classes, B, A, hid = ctx.meta
+        draw = (draw * dlosses[0]).contiguous()          # only losses[0] (the total) is a training signal
+        grads = [None, None, None, None]
+        off = 0
+        for k, (h, w, _s) in enumerate(levels):
+            rf, cf = feats[2 * k], feats[2 * k + 1]
+            w_reg, b_reg, w_obj, b_obj, w_cls, b_cls = ctx.params[k]
+            drf, dcf = torch.empty_like(rf), torch.empty_like(cf)
+            L.check(L.lib().sast_head_pred_bwd(draw.data_ptr(), rf.data_ptr(), cf.data_ptr(), w_reg.data_ptr(), w_obj.data_ptr(), w_cls.data_ptr(),
+                                               drf.data_ptr(), dcf.data_ptr(), _g(w_reg).data_ptr(), _g(b_reg).data_ptr(), _g(w_obj).data_ptr(),
+                                               _g(b_obj).data_ptr(), _g(w_cls).data_ptr(), _g(b_cls).data_ptr(), B, int(h), int(w), hid,
+                                               num_classes, off, A, _stream()), "head_pred_bwd")
+            off += int(h) * int(w)
+            grads += [drf, dcf, None, None, None, None, None, None]
+        return tuple(grads)
+
+
+def head_pred_loss(labels, levels, num_classes, decode, per_level_tensors):
+    """levels: [(H, W, stride)]; per_level_tensors: [(reg_feat, cls_feat, w_reg, b_reg, w_obj, b_obj, w_cls, b_cls)]
+    -> (losses(5,), pred, fg_mask (B,A) int32, matched_gt (B,A) int32 (-1 = background), matched_iou (B,A))"""
+    flat = [x for lv in per_level_tensors for x in lv]
+    return _HeadPredLoss.apply(labels, tuple((int(h), int(w), float(s)) for h, w, s in levels), int(num_classes), bool(decode), *flat)

@@ -240,8 +240,41 @@ def test_yolox_head_eval_vs_golden(golden_dir, dev):
     raw, _ = head(feats)
     assert float((raw.cpu() - torch.from_numpy(g["raw"])).abs().max()) <= 1e-4
     head.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):          # training mode needs labels, like the reference (yolo_head.py:215-231)
         head(feats)
+
+
+def test_yolox_head_train_vs_golden(golden_dir, dev):
+    """YOLOX training branch on the device (SimOTA assignment + IoU / objectness / class losses for the whole batch, no host sync):
+    losses, the assignment itself (index-exact) and every gradient against the reference module's numbers (head_train.npz)."""
+    import json as _json
+    from sast_amd.detection import YOLOXHead
+    g = _load(golden_dir, "head_train")
+    chans, nc = (64, 128, 256), int(g["num_classes"])
+    params = O.init_head_params(chans, num_classes=nc, seed=int(g["seed"]))
+    head = YOLOXHead(num_classes=nc, strides=(8, 16, 32), in_channels=chans).to(dev)
+    load_params(head, params)
+    head.train()
+    feats = tuple(torch.from_numpy(g[f"in{i}"]).to(dev).requires_grad_(True) for i in range(3))
+    labels = torch.from_numpy(g["labels"]).to(dev)
+    out, losses = head(feats, labels)
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss", "num_fg"):
+        assert abs(float(losses[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(losses[k]), float(g[k]))
+    fg, mg, piou = head.last_assignment
+    for b in range(labels.shape[0]):
+        ref_fg = g[f"fg{b}"].astype(bool)
+        assert np.array_equal(fg[b].cpu().numpy().astype(bool), ref_fg), b
+        assert np.array_equal(mg[b].cpu().numpy()[ref_fg], g[f"matched{b}"]), b
+        assert np.allclose(piou[b].cpu().numpy()[ref_fg], g[f"piou{b}"], atol=1e-5), b
+    losses["loss"].backward()
+    for i, f in enumerate(feats):
+        maxnorm_close(f.grad, torch.from_numpy(g[f"din{i}"]), GRAD_RTOL, f"din{i}")
+    named = dict(head.named_parameters())
+    for k, nrm in _json.loads(str(g["grad_norms_json"])).items():
+        got = float(named[k].grad.double().norm())
+        assert abs(got - nrm) <= GRAD_RTOL * nrm + 1e-8, (k, got, nrm)
+    for k in ("cls_preds.0.weight", "cls_preds.0.bias", "reg_preds.1.weight", "obj_preds.2.bias", "stems.0.conv.weight", "reg_convs.1.1.bn.weight"):
+        maxnorm_close(named[k].grad, torch.from_numpy(g["g_" + k]), GRAD_RTOL, k)
 
 
 def test_unpadded_uint8_input(dev):
@@ -270,7 +303,7 @@ def test_unpadded_uint8_input(dev):
 
 def test_detector_inference_end_to_end(dev):
     """YoloXDetector (detector.py:18-80) in eval mode: events -> backbone -> PAFPN (running statistics) -> head -> decoded
-    predictions, against the oracle run the same way; the training branch (needs the YOLOX loss) must raise."""
+    predictions, against the oracle run the same way; then the training branch with the SimOTA loss, backward through all parts."""
     from sast_amd.config import to_attr
     from sast_amd.detection import YoloXDetector
     hw, part, E, nc = (128, 160), (4, 5), 32, 2
@@ -293,10 +326,24 @@ def test_detector_inference_end_to_end(dev):
         ref = O.yolox_head_eval(O.pafpn({k: oo[k] for k in (2, 3, 4)}, fp, training=False), hp, det.backbone.get_strides((2, 3, 4)))
     assert losses is None and [int(p) for p in P] == [int(p) for p in Po]
     maxnorm_close(out, ref, 2e-4, "decoded predictions")
-    feats = det.forward_backbone(x.to(dev))[0]
+    # training branch end to end: events -> backbone -> PAFPN -> head + SimOTA loss -> backward through everything
     det.train()
-    with pytest.raises(NotImplementedError):
-        det.forward_detect(feats)
+    labels = O.synthetic_labels(2, hw, nc, max_labels=5, seed=45).to(dev)
+    out_t, losses_t, _st, _P = det(x.to(dev), targets=labels)
+    losses_t["loss"].backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    pfo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fp.items()}
+    pho = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in hp.items()}
+    oo2, _s2, _P2 = O.backbone(x, None, po, ocfg)
+    ref_t = O.yolox_head_train(O.pafpn({k: oo2[k] for k in (2, 3, 4)}, pfo, training=True), labels.cpu(), pho, det.backbone.get_strides((2, 3, 4)),
+                               num_classes=nc)
+    ref_t["loss"].backward()
+    assert abs(float(losses_t["loss"]) - float(ref_t["loss"])) <= 1e-4 * abs(float(ref_t["loss"]))
+    for k, v in det.backbone.named_parameters():
+        if "sub_layers" not in k:
+            maxnorm_close(v.grad, po[k].grad, 5e-3, "backbone." + k)
+    for k, v in det.yolox_head.named_parameters():
+        maxnorm_close(v.grad, pho[k].grad, 5e-3, "head." + k)
 
 
 @pytest.mark.parametrize("B", [1, 3])

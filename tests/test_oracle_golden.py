@@ -140,6 +140,24 @@ def test_yolox_head_eval(golden_dir):
     assert torch.allclose(O.yolox_head_eval(feats, params, decode=False), torch.from_numpy(g["raw"]), atol=1e-6, rtol=1e-6)
 
 
+def test_yolox_head_train(golden_dir):
+    """YOLOX training branch (SimOTA assignment, IoU / objectness / class losses): oracle vs the reference module's numbers."""
+    g = _load(golden_dir, "head_train")
+    chans, nc = (64, 128, 256), int(g["num_classes"])
+    params = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone())
+              for k, v in O.init_head_params(chans, num_classes=nc, seed=int(g["seed"])).items()}
+    feats = [torch.from_numpy(g[f"in{i}"]).requires_grad_(True) for i in range(3)]
+    r = O.yolox_head_train(feats, torch.from_numpy(g["labels"]), params, num_classes=nc)
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss", "num_fg"):
+        assert abs(float(r[k]) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), k
+    for b, (fg, matched, pious) in enumerate(r["assign"]):
+        assert np.array_equal(fg.numpy().astype(np.uint8), g[f"fg{b}"]) and np.array_equal(matched.numpy(), g[f"matched{b}"])
+        assert np.allclose(pious.numpy(), g[f"piou{b}"], atol=1e-6)
+    r["loss"].backward()
+    for i, f in enumerate(feats):
+        assert torch.allclose(f.grad, torch.from_numpy(g[f"din{i}"]), atol=1e-7, rtol=1e-4)
+
+
 def test_full_size_stats_g1(golden_dir):
     """F-7 (Gen1 size; the 1Mpx twin runs on the GPU box next to the HIP path)."""
     with open(os.path.join(golden_dir, "full_stats.json")) as f:
