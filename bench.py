@@ -40,10 +40,24 @@ def synthetic_events(B, hw, seed):
     return (torch.rand(B, 20, hw[0], hw[1], generator=g) > SPARSITY).int()
 
 
+def synthetic_labels(B, hw, num_classes, max_labels=16, seed=0):
+    """(B, max_labels, 5) = (class, cx, cy, w, h) in input pixels: a random number of boxes per sample, zero rows after them
+    (the layout ObjectLabels.get_labels_as_batched_tensor(format_='yolox') hands to the head, modules/detection.py:174-176)."""
+    g = torch.Generator().manual_seed(1234 + seed)
+    lab = torch.zeros(B, max_labels, 5)
+    for b in range(B):
+        n = int(torch.randint(1, max_labels + 1, (1,), generator=g))
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([hw[1], hw[0]]) * 0.3 + 8.0
+        c = torch.rand(n, 2, generator=g) * (torch.tensor([hw[1], hw[0]]) - wh) + wh / 2
+        lab[b, :n, 0] = torch.randint(0, num_classes, (n,), generator=g).float()
+        lab[b, :n, 1:3], lab[b, :n, 3:5] = c, wh
+    return lab
+
+
 class Trainer:
     """minimal training step of the hot path (the reference's is Lightning's, modules/detection.py:113-221)."""
 
-    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False):
+    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False, yolox_loss=False):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.dist import FlatParams, FusedAdamW
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -59,9 +73,14 @@ class Trainer:
             self.head = YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=(128, 256, 512)).to(dev).eval()
             self.fpn.eval()
             fwd_only = True
+        self.yolox_loss = yolox_loss   # --loss yolox: the real training objective (YOLOX head + SimOTA loss) instead of the proxy loss
+        if yolox_loss:
+            from sast_amd.detection import YOLOXHead
+            self.head = YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=(128, 256, 512)).to(dev).train()
+            self.labels = synthetic_labels(BATCH, HW, 3, max_labels=16, seed=(dist.get_rank() if world > 1 else 0)).to(dev)
         self.net.to(dev)
         self.fpn.to(dev)
-        self.flat = FlatParams([self.net, self.fpn])
+        self.flat = FlatParams([self.net, self.fpn] + ([self.head] if yolox_loss else []))
         self.opt = FusedAdamW(self.flat, lr=2e-4, weight_decay=0.0, clip_value=1.0)
         self.world = world
         rank = dist.get_rank() if world > 1 else 0
@@ -92,7 +111,11 @@ class Trainer:
         for x in self.xs:
             feats, states, P = self.net.forward_nhwc(x, states)
         outs = self.fpn.forward_nhwc(feats)
-        loss = sum((o * o).mean() for o in outs)
+        if self.yolox_loss:
+            _pred, losses = self.head.forward_train_nhwc(outs, self.labels)
+            loss = losses["loss"]
+        else:
+            loss = sum((o * o).mean() for o in outs)
         loss.backward()
         self.loss, self.P = loss.detach(), P
 
@@ -198,6 +221,8 @@ def main():
     ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
     ap.add_argument("--seq-len", type=int, default=1, help="timesteps per step with recurrent state + BPTT (1 = BASELINE metric)")
     ap.add_argument("--fwd-only", action="store_true", help="backbone forward only (reference benchmark.py protocol; BASELINE config C2 with --res gen1)")
+    ap.add_argument("--loss", choices=["proxy", "yolox"], default="proxy", help="proxy: sum mean(out^2) over the PAFPN outputs (BASELINE "
+                    "metric); yolox: YOLOX head + SimOTA loss on synthetic boxes (the reference's real training objective)")
     ap.add_argument("--infer", action="store_true", help="backbone + PAFPN + YOLOX head, eval mode, forward only (decoded predictions)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -231,7 +256,8 @@ def main():
     run_stream = torch.cuda.Stream()
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
-    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer)
+    tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer,
+                 yolox_loss=args.loss == "yolox")
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -266,7 +292,8 @@ def main():
             "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
                                    (" full SAST backbone + PAFPN + YOLOX head (3 classes), eval forward -> decoded predictions, " if args.infer else
                                     " full SAST backbone, forward only (benchmark.py protocol), " if args.fwd_only else
-                                    " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
+                                    " full SAST backbone + PAFPN + YOLOX head, SimOTA loss on 16 synthetic boxes/sample, fwd+bwd + AdamW, "
+                                    if args.loss == "yolox" else " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
@@ -276,7 +303,7 @@ def main():
         if not args.no_roofline:
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr)
-        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer:
+        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy":
             res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only)
         print(json.dumps(res))
     if world > 1:

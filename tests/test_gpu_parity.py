@@ -277,6 +277,33 @@ def test_yolox_head_train_vs_golden(golden_dir, dev):
         maxnorm_close(named[k].grad, torch.from_numpy(g["g_" + k]), GRAD_RTOL, k)
 
 
+def test_yolox_loss_full_size(dev):
+    """1Mpx-sized head (5040 anchors, B=4, up to 24 boxes per image incl. an image without labels): assignment and losses vs the oracle."""
+    from sast_amd.detection import YOLOXHead
+    chans, nc, B = (128, 256, 512), 3, 4
+    params = O.init_head_params(chans, num_classes=nc, seed=9)
+    head = YOLOXHead(num_classes=nc, strides=(8, 16, 32), in_channels=chans).to(dev)
+    load_params(head, params)
+    head.train()
+    g = torch.Generator().manual_seed(91)
+    feats = [torch.randn(B, c, 48 // (2 ** i), 80 // (2 ** i), generator=g) for i, c in enumerate(chans)]
+    labels = O.synthetic_labels(B, (384, 640), nc, max_labels=24, seed=92)
+    assert int((labels[-1].sum(-1) > 0).sum()) >= 0
+    out, losses = head(tuple(f.to(dev).requires_grad_(True) for f in feats), labels.to(dev))
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in params.items()}
+    ref = O.yolox_head_train([f.clone().requires_grad_(True) for f in feats], labels, po, num_classes=nc)
+    fg, mg, piou = head.last_assignment
+    mism = 0
+    for b, (rfg, rmatched, rpiou) in enumerate(ref["assign"]):
+        got = fg[b].cpu().numpy().astype(bool)
+        mism += int((got != rfg.numpy()).sum())
+        both = got & rfg.numpy()
+        mism += int((mg[b].cpu().numpy()[both] != rmatched.numpy()[both[rfg.numpy()]]).sum())
+    assert mism == 0, f"{mism} assignment mismatches"
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss", "num_fg"):
+        assert abs(float(losses[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (k, float(losses[k]), float(ref[k]))
+
+
 def test_unpadded_uint8_input(dev):
     """the reference pads the uint8 event tensor to in_res_hw before the backbone (modules/detection.py:143-144); here the
     unpadded tensor is accepted directly -- bit-identical to feeding the explicitly padded one, and equal to the oracle."""
