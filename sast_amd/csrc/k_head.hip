@@ -6,7 +6,7 @@
 //   get_geometry_constraint           :540-571     simota_matching     :573-606
 //   IOUloss ("iou")                   losses.py:16-33
 // The reference runs the assignment image by image with a host sync per image (`.item()`, `int(nlabel)`); here the number
-// of ground-truth rows, the foreground counts and the loss normalisation all stay on the device: five launches per step for
+// of ground-truth rows, the foreground counts and the loss normalisation all stay on the device: seven launches per step for
 // the whole batch.  Only the 15 Conv+BN+SiLU units of the head go through the GEMM template (sast_conv_bn_silu_*); the
 // prediction convs have 5 + num_classes <= 32 output channels and are plain VALU dot products.
 #include "common.cuh"
@@ -91,32 +91,76 @@ __global__ __launch_bounds__(256) void head_pred_bwd_feat_kernel(const float* __
   st4(d_reg_feat + pix * hid + k, r);
   st4(d_cls_feat + pix * hid + k, c);
 }
-// d weights / d bias: block (o, strip of pixels); threads over feature channels; one atomic per (o, k) and block
+// d weights / d bias: workgroup = 64 pixels x 8 output channels (blockIdx.y) x all feature channels.  thread = (feature
+// channel k, pixel parity); 8 accumulators in registers, the two parities are folded through LDS, one atomic per (o, k) and block.
 __global__ __launch_bounds__(256) void head_pred_bwd_w_kernel(const float* __restrict__ draw, const float* __restrict__ reg_feat,
                                                               const float* __restrict__ cls_feat, float* __restrict__ dw_reg,
                                                               float* __restrict__ db_reg, float* __restrict__ dw_obj, float* __restrict__ db_obj,
                                                               float* __restrict__ dw_cls, float* __restrict__ db_cls, int B, int HW, int hid,
-                                                              int nc, int anchor_off, int A_total, int pix_per_block) {
-  const int o = blockIdx.y, no = 5 + nc;
-  const size_t p0 = (size_t)blockIdx.x * pix_per_block, p1 = min((size_t)B * HW, p0 + pix_per_block);
-  const float* feat = o < 5 ? reg_feat : cls_feat;
-  float* dw = o < 4 ? dw_reg + (size_t)o * hid : (o == 4 ? dw_obj : dw_cls + (size_t)(o - 5) * hid);
-  float* db = o < 4 ? db_reg + o : (o == 4 ? db_obj : db_cls + (o - 5));
-  float bsum = 0.f;
-  for (int k = threadIdx.x; k < hid; k += 256) {
-    float acc = 0.f;
-    bsum = 0.f;
-    for (size_t p = p0; p < p1; ++p) {
-      const int hw = (int)(p % HW), b = (int)(p / HW);
-      const float g = draw[((size_t)b * A_total + anchor_off + hw) * no + o];
-      acc = fmaf(g, feat[p * hid + k], acc);
-      bsum += g;
+                                                              int nc, int anchor_off, int A_total) {
+  extern __shared__ float red[];            // [8][hid]
+  const int no = 5 + nc, o0 = blockIdx.y * 8;
+  const int nlane = 256 / hid > 0 ? 256 / hid : 1;            // pixel lanes per block (hid <= 256: 1, 2, 4 ...)
+  const size_t P = (size_t)B * HW, p0 = (size_t)blockIdx.x * 64, p1 = min(P, p0 + 64);
+  for (int kb = 0; kb < hid; kb += 256) {                       // one pass unless hid > 256
+    const int k = kb + threadIdx.x % min(hid, 256), pl = threadIdx.x / min(hid, 256);
+    float acc[8], bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { acc[j] = 0.f; bs[j] = 0.f; }
+    if (k < hid && pl < nlane)
+      for (size_t p = p0 + pl; p < p1; p += nlane) {
+        const int hw = (int)(p % HW), b = (int)(p / HW);
+        const float* d = draw + ((size_t)b * A_total + anchor_off + hw) * no;
+        const float fr = reg_feat[p * hid + k], fc = cls_feat[p * hid + k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int o = o0 + j;
+          if (o < no) {
+            const float g = d[o];
+            acc[j] = fmaf(g, o < 5 ? fr : fc, acc[j]);
+            bs[j] += g;
+          }
+        }
+      }
+    for (int l = nlane - 1; l >= 1; --l) {                      // fold the pixel lanes into lane 0
+      if (pl == l && k < hid)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[j * hid + k] = acc[j];
+      __syncthreads();
+      if (pl == 0 && k < hid)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += red[j * hid + k];
+      __syncthreads();
     }
-    atomicAdd(dw + k, acc);
-  }
-  if (threadIdx.x == 0) {
-    if (hid < 1) return;
-    atomicAdd(db, bsum);
+    if (pl == 0 && k < hid) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = o0 + j;
+        if (o < no) {
+          float* dw = o < 4 ? dw_reg + (size_t)o * hid : (o == 4 ? dw_obj : dw_cls + (size_t)(o - 5) * hid);
+          atomicAdd(dw + k, acc[j]);
+        }
+      }
+    }
+    if (kb == 0 && threadIdx.x < 64) {                         // bias gradient = column sums of draw over this block's 64 pixels
+      const size_t p = p0 + threadIdx.x;
+      float tb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tb[j] = 0.f;
+      if (p < p1) {
+        const int hw = (int)(p % HW), b = (int)(p / HW);
+        const float* d = draw + ((size_t)b * A_total + anchor_off + hw) * no;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (o0 + j < no) tb[j] = d[o0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = wave_sum(tb[j]);
+        const int o = o0 + j;
+        if (threadIdx.x == 0 && o < no) atomicAdd(o < 4 ? db_reg + o : (o == 4 ? db_obj : db_cls + (o - 5)), t);
+      }
+    }
   }
 }
 
@@ -184,9 +228,13 @@ __global__ __launch_bounds__(256) void simota_cost_kernel(const float* __restric
   }
 }
 
-// ---------------------------------------------------------------- SimOTA matching: one workgroup per image, one wave per ground truth
-// (value, index) lexicographic selection rounds: nothing is modified, ties resolve to the lower anchor index.
-__device__ __forceinline__ void wave_arg_best(float v, int i, bool larger, float& bv, int& bi) {
+// ---------------------------------------------------------------- SimOTA matching
+// One workgroup (1024 threads) per (ground truth, image): every thread keeps its <= 8 IoU / cost values in registers, the
+// selection rounds are (value, index) lexicographic block arg-reductions -- nothing is modified, ties go to the lower anchor
+// index.  A second kernel resolves anchors picked by several ground truths and emits the assignment.
+constexpr int MATCH_THREADS = 1024, MATCH_PER = 8;     // up to 8192 anchors per image
+
+__device__ __forceinline__ void block_arg_best(float v, int i, bool larger, float* sv, int* si, float& bv, int& bi) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(v, o, 64);
@@ -194,64 +242,88 @@ __device__ __forceinline__ void wave_arg_best(float v, int i, bool larger, float
     const bool take = larger ? (ov > v || (ov == v && oi < i)) : (ov < v || (ov == v && oi < i));
     if (take) { v = ov; i = oi; }
   }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();                     // previous round's readers are done with sv / si
+  if (lane == 0) { sv[wave] = v; si[wave] = i; }
+  __syncthreads();
+  v = sv[0]; i = si[0];
+#pragma unroll
+  for (int w = 1; w < MATCH_THREADS / 64; ++w) {
+    const float ov = sv[w];
+    const int oi = si[w];
+    const bool take = larger ? (ov > v || (ov == v && oi < i)) : (ov < v || (ov == v && oi < i));
+    if (take) { v = ov; i = oi; }
+  }
   bv = v; bi = i;
 }
 
-__global__ __launch_bounds__(1024) void simota_match_kernel(const float* __restrict__ cost, const float* __restrict__ iou,
-                                                            const float* __restrict__ labels, const int* __restrict__ nlabel, int A, int G,
-                                                            int* __restrict__ cnt_ws, int* __restrict__ fg_out, int* __restrict__ mg_out,
-                                                            float* __restrict__ piou_out, int* __restrict__ num_fg) {
-  const int b = blockIdx.x, ng = nlabel[b];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+__global__ __launch_bounds__(MATCH_THREADS) void simota_match_kernel(const float* __restrict__ cost, const float* __restrict__ iou,
+                                                                     const int* __restrict__ nlabel, int A, int G, int* __restrict__ cnt_ws) {
+  __shared__ float sv[MATCH_THREADS / 64];
+  __shared__ int si[MATCH_THREADS / 64];
+  const int g = blockIdx.x, b = blockIdx.y;
+  if (g >= nlabel[b]) return;
   int* cnt = cnt_ws + (size_t)b * 2 * A;     // [A] number of ground truths that picked the anchor
   int* one = cnt + A;                        // [A] the ground truth that picked it (valid when cnt == 1)
-  for (int a = threadIdx.x; a < A; a += blockDim.x) { cnt[a] = 0; one[a] = 0; }
-  __syncthreads();
-  const float* cb = cost + (size_t)b * G * A;
-  const float* ib = iou + (size_t)b * G * A;
-  for (int g = wave; g < ng; g += nw) {
-    const float* iv = ib + (size_t)g * A;
-    const float* cv = cb + (size_t)g * A;
-    // dynamic k = clamp(int(sum of the 10 largest IoUs among the candidate anchors), min 1)   (:576-578)
-    float sum = 0.f, pv = INFINITY;
-    int pi = -1;
-    for (int r = 0; r < 10; ++r) {
-      float bv = -2.f; int bi = 0x7fffffff;
-      for (int a = lane; a < A; a += 64) {
-        const float v = iv[a];
-        const bool elig = v < pv || (v == pv && a > pi);
-        if (elig && (v > bv || (v == bv && a < bi))) { bv = v; bi = a; }
-      }
-      float wv; int wi;
-      wave_arg_best(bv, bi, true, wv, wi);
-      if (wv < 0.f) break;          // fewer than 10 candidate anchors (non-candidates carry -1)
-      sum += wv; pv = wv; pi = wi;
-    }
-    int k = (int)sum;
-    k = k < 1 ? 1 : k;
-    // the k smallest costs (:579-583)
-    pv = -INFINITY; pi = -1;
-    for (int r = 0; r < k; ++r) {
-      float bv = INFINITY; int bi = 0x7fffffff;
-      for (int a = lane; a < A; a += 64) {
-        const float v = cv[a];
-        const bool elig = v > pv || (v == pv && a > pi);
-        if (elig && (v < bv || (v == bv && a < bi))) { bv = v; bi = a; }
-      }
-      float wv; int wi;
-      wave_arg_best(bv, bi, false, wv, wi);
-      if (wi == 0x7fffffff || wv == INFINITY) break;
-      if (lane == 0) { atomicAdd(cnt + wi, 1); atomicExch(one + wi, g); }
-      pv = wv; pi = wi;
-    }
+  const float* iv = iou + ((size_t)b * G + g) * A;
+  const float* cv = cost + ((size_t)b * G + g) * A;
+  float vi[MATCH_PER], vc[MATCH_PER];
+#pragma unroll
+  for (int j = 0; j < MATCH_PER; ++j) {
+    const int a = threadIdx.x + j * MATCH_THREADS;
+    vi[j] = a < A ? iv[a] : -1.f;
+    vc[j] = a < A ? cv[a] : INFINITY;
   }
-  __threadfence_block();
-  __syncthreads();
-  // anchors picked by several ground truths go to the one with the smallest cost over ALL ground truths (:588-592)
+  // dynamic k = clamp(int(sum of the 10 largest IoUs among the candidate anchors), min 1)   (:576-578)
+  float sum = 0.f, pv = INFINITY;
+  int pi = -1;
+  for (int r = 0; r < 10; ++r) {
+    float bv = -2.f; int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < MATCH_PER; ++j) {
+      const int a = threadIdx.x + j * MATCH_THREADS;
+      const float v = vi[j];
+      const bool elig = v < pv || (v == pv && a > pi);
+      if (elig && (v > bv || (v == bv && a < bi))) { bv = v; bi = a; }
+    }
+    float wv; int wi;
+    block_arg_best(bv, bi, true, sv, si, wv, wi);
+    if (wv < 0.f) break;          // fewer than 10 candidate anchors (non-candidates carry -1); block-uniform
+    sum += wv; pv = wv; pi = wi;
+  }
+  int k = (int)sum;
+  k = k < 1 ? 1 : k;
+  // the k smallest costs (:579-583)
+  pv = -INFINITY; pi = -1;
+  for (int r = 0; r < k; ++r) {
+    float bv = INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < MATCH_PER; ++j) {
+      const int a = threadIdx.x + j * MATCH_THREADS;
+      const float v = vc[j];
+      const bool elig = v > pv || (v == pv && a > pi);
+      if (elig && (v < bv || (v == bv && a < bi))) { bv = v; bi = a; }
+    }
+    float wv; int wi;
+    block_arg_best(bv, bi, false, sv, si, wv, wi);
+    if (wi == 0x7fffffff || wv == INFINITY) break;
+    if (threadIdx.x == 0) { atomicAdd(cnt + wi, 1); atomicExch(one + wi, g); }
+    pv = wv; pi = wi;
+  }
+}
+
+// anchors picked by several ground truths go to the one with the smallest cost over ALL ground truths (:588-592)
+__global__ __launch_bounds__(256) void simota_resolve_kernel(const float* __restrict__ cost, const float* __restrict__ iou,
+                                                             const int* __restrict__ nlabel, int A, int G, const int* __restrict__ cnt_ws,
+                                                             int* __restrict__ fg_out, int* __restrict__ mg_out, float* __restrict__ piou_out,
+                                                             int* __restrict__ num_fg) {
+  const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, ng = nlabel[b];
   int nfg = 0;
-  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+  if (a < A) {
+    const int* cnt = cnt_ws + (size_t)b * 2 * A;
+    const float* cb = cost + (size_t)b * G * A;
     const int c = cnt[a];
-    int mg = one[a];
+    int mg = cnt[A + a];
     if (c > 1) {
       float best = INFINITY;
       mg = 0;
@@ -263,18 +335,11 @@ __global__ __launch_bounds__(1024) void simota_match_kernel(const float* __restr
     const bool fg = c > 0;
     fg_out[(size_t)b * A + a] = fg ? 1 : 0;
     mg_out[(size_t)b * A + a] = fg ? mg : -1;
-    piou_out[(size_t)b * A + a] = fg ? ib[(size_t)mg * A + a] : 0.f;
-    nfg += fg ? 1 : 0;
+    piou_out[(size_t)b * A + a] = fg ? iou[((size_t)b * G + mg) * A + a] : 0.f;
+    nfg = fg ? 1 : 0;
   }
-  __shared__ int red[16];
   for (int o = 32; o > 0; o >>= 1) nfg += __shfl_xor(nfg, o, 64);
-  if (lane == 0) red[wave] = nfg;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < nw; ++w) t += red[w];
-    num_fg[b] = t;
-  }
+  if ((threadIdx.x & 63) == 0 && nfg) atomicAdd(num_fg + b, nfg);
 }
 
 // ---------------------------------------------------------------- losses + gradient w.r.t. the raw conv outputs
@@ -408,10 +473,9 @@ int sast_head_pred_bwd(const float* draw, const float* reg_feat, const float* cl
   const size_t n = (size_t)B * HW * (hidden / 4);
   hipLaunchKernelGGL(head_pred_bwd_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, draw, w_reg, w_obj, w_cls, d_reg_feat,
                      d_cls_feat, B, HW, hidden, num_classes, anchor_offset, anchors_total);
-  const int ppb = 256;
-  hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3((unsigned)(((size_t)B * HW + ppb - 1) / ppb), 5 + num_classes), dim3(256), 0, st, draw,
-                     reg_feat, cls_feat, dw_reg, db_reg, dw_obj, db_obj, dw_cls, db_cls, B, HW, hidden, num_classes, anchor_offset, anchors_total,
-                     ppb);
+  hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3((unsigned)(((size_t)B * HW + 63) / 64), (5 + num_classes + 7) / 8), dim3(256),
+                     sizeof(float) * 8 * hidden, st, draw, reg_feat, cls_feat, dw_reg, db_reg, dw_obj, db_obj, dw_cls, db_cls, B, HW, hidden,
+                     num_classes, anchor_offset, anchors_total);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -440,11 +504,14 @@ int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadG
   int* nlabel = cnt + (size_t)2 * B * A;
   int* num_fg = nlabel + B;
   float* acc = (float*)(num_fg + B);
-  zero_fill(acc, sizeof(float) * 8, st);
+  if (A > MATCH_THREADS * MATCH_PER) return SAST_EINVAL;
+  // pick counters, nlabel, num_fg and the loss accumulators are contiguous: one clear
+  zero_fill(cnt, sizeof(int) * ((size_t)2 * B * A + 2 * B) + sizeof(float) * 8, st);
   hipLaunchKernelGGL(head_count_labels_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, B, G, nlabel);
   hipLaunchKernelGGL(simota_cost_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, nlabel, lv, G, num_classes, cost, iou);
-  hipLaunchKernelGGL(simota_match_kernel, dim3(B), dim3(1024), 0, st, cost, iou, labels, nlabel, A, G, cnt, fg_mask, matched_gt, matched_iou,
-                     num_fg);
+  hipLaunchKernelGGL(simota_match_kernel, dim3(G, B), dim3(MATCH_THREADS), 0, st, cost, iou, nlabel, A, G, cnt);
+  hipLaunchKernelGGL(simota_resolve_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, cost, iou, nlabel, A, G, cnt, fg_mask, matched_gt,
+                     matched_iou, num_fg);
   hipLaunchKernelGGL(yolox_loss_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, fg_mask, matched_gt, matched_iou, num_fg, lv,
                      B, G, num_classes, draw, acc);
   hipLaunchKernelGGL(yolox_loss_finish_kernel, dim3(1), dim3(64), 0, st, acc, num_fg, nlabel, B, losses);
