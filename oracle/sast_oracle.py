@@ -539,6 +539,51 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
             "assign": assigns, "outputs": out}
 
 
+# ---- post-processing: yolox/utils/boxes.py:32-76.  The reference calls torchvision.ops.batched_nms, which is
+# not installed here (and not part of /root/reference): greedy NMS is restated from its published definition -- sort by score
+# descending, keep a box unless its IoU with an already kept box OF THE SAME CLASS exceeds the threshold.  (torchvision realises
+# the class separation by shifting the boxes of class c by c * (max coordinate + 1); the decision is the same up to rounding.)
+# Parity for this function is therefore pinned by definition, not by a run of torchvision.
+def _nms_greedy(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float) -> Tensor:
+    order = torch.sort(scores, descending=True, stable=True).indices
+    keep: List[int] = []
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    for i in order.tolist():
+        ok = True
+        for j in keep:
+            if classes[i] != classes[j]:
+                continue
+            w = (torch.min(boxes[i, 2], boxes[j, 2]) - torch.max(boxes[i, 0], boxes[j, 0])).clamp(min=0)
+            h = (torch.min(boxes[i, 3], boxes[j, 3]) - torch.max(boxes[i, 1], boxes[j, 1])).clamp(min=0)
+            inter = w * h
+            if inter / (area[i] + area[j] - inter) > thr:
+                ok = False
+                break
+        if ok:
+            keep.append(i)
+    return torch.tensor(keep, dtype=torch.long)
+
+
+def postprocess(prediction: Tensor, num_classes: int, conf_thre: float = 0.7, nms_thre: float = 0.45):
+    """boxes.py:32-76 (class-aware branch): prediction (B, A, 5+nc) with (cx, cy, w, h, obj, cls...) -> list of (n_i, 7) tensors
+    (x1, y1, x2, y2, obj_conf, class_conf, class_pred) sorted by decreasing score, or None."""
+    pred = prediction.clone()
+    pred[:, :, 0] = prediction[:, :, 0] - prediction[:, :, 2] / 2
+    pred[:, :, 1] = prediction[:, :, 1] - prediction[:, :, 3] / 2
+    pred[:, :, 2] = prediction[:, :, 0] + prediction[:, :, 2] / 2
+    pred[:, :, 3] = prediction[:, :, 1] + prediction[:, :, 3] / 2
+    out = [None] * pred.shape[0]
+    for i, ip in enumerate(pred):
+        class_conf, class_pred = torch.max(ip[:, 5:5 + num_classes], 1, keepdim=True)
+        mask = (ip[:, 4] * class_conf.squeeze(1)) >= conf_thre
+        det = torch.cat((ip[:, :5], class_conf, class_pred.float()), 1)[mask]
+        if not det.size(0):
+            continue
+        keep = _nms_greedy(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thre)
+        out[i] = det[keep]
+    return out
+
+
 def synthetic_labels(B: int, hw: Tuple[int, int], num_classes: int, max_labels: int = 8, seed: int = 0) -> Tensor:
     """(B, max_labels, 5) = (cls, cx, cy, w, h) in input pixels; a random number of valid rows first, zero rows after."""
     g = torch.Generator().manual_seed(seed)

@@ -424,6 +424,128 @@ __global__ void yolox_loss_finish_kernel(const float* __restrict__ acc, const in
   losses[4] = n / (float)(ng < 1 ? 1 : ng);
 }
 
+// ---------------------------------------------------------------- post-processing: confidence filter + class-aware NMS
+// reference: yolox/utils/boxes.py:32-76 (torchvision.ops.batched_nms = greedy NMS per class, boxes by decreasing score).
+// det rows: (x1, y1, x2, y2, obj_conf, class_conf, class_pred, score)
+constexpr int NMS_MAX = 8192;           // anchors per image the sort kernel holds in LDS
+
+// one workgroup per image: candidates (score >= conf_thre), sorted by score descending (ties: lower anchor index first)
+__global__ __launch_bounds__(1024) void nms_candidates_kernel(const float* __restrict__ pred, int A, int nc, float conf_thre,
+                                                              float* __restrict__ det, int* __restrict__ ncand) {
+  __shared__ float key[NMS_MAX];
+  __shared__ unsigned short idx[NMS_MAX];
+  const int b = blockIdx.x, no = 5 + nc;
+  const float* pb = pred + (size_t)b * A * no;
+  int n2 = 1;
+  while (n2 < A) n2 <<= 1;
+  for (int a = threadIdx.x; a < n2; a += 1024) {
+    float sc = -1.f;
+    if (a < A) {
+      const float* p = pb + (size_t)a * no;
+      float cmax = p[5];
+      for (int c = 1; c < nc; ++c) cmax = fmaxf(cmax, p[5 + c]);
+      const float v = p[4] * cmax;
+      sc = v >= conf_thre ? v : -1.f;
+    }
+    key[a] = sc;
+    idx[a] = (unsigned short)a;
+  }
+  __syncthreads();
+  // bitonic sort, descending by (score, then ascending anchor index)
+  for (int k = 2; k <= n2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n2; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool desc = (i & k) == 0;
+          const float ki = key[i], kl = key[l];
+          const unsigned short ii = idx[i], il = idx[l];
+          const bool i_first = ki > kl || (ki == kl && ii < il);     // i should precede l in the final order
+          if (desc ? !i_first : i_first) { key[i] = kl; key[l] = ki; idx[i] = il; idx[l] = ii; }
+        }
+      }
+      __syncthreads();
+    }
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = threadIdx.x; i < n2; i += 1024) local += key[i] >= 0.f ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(&cnt, local);
+  __syncthreads();
+  const int n = cnt;
+  if (threadIdx.x == 0) ncand[b] = n;
+  float* db = det + (size_t)b * A * 8;
+  for (int i = threadIdx.x; i < n; i += 1024) {
+    const float* p = pb + (size_t)idx[i] * no;
+    float cmax = p[5]; int carg = 0;
+    for (int c = 1; c < nc; ++c)
+      if (p[5 + c] > cmax) { cmax = p[5 + c]; carg = c; }
+    float* d = db + (size_t)i * 8;
+    d[0] = p[0] - p[2] / 2; d[1] = p[1] - p[3] / 2; d[2] = p[0] + p[2] / 2; d[3] = p[1] + p[3] / 2;
+    d[4] = p[4]; d[5] = cmax; d[6] = (float)carg; d[7] = key[i];
+  }
+}
+// suppression bit matrix: bit j of mask[i][j/64] set when sorted box j > i has the same class and IoU(i, j) > thr
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ det, const int* __restrict__ ncand, int A, float thr,
+                                                      unsigned long long* __restrict__ mask, int words) {
+  const int b = blockIdx.z, n = ncand[b];
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (i0 >= n || j0 >= n || j0 + 63 < i0) return;
+  __shared__ float bj[64][5];
+  const float* db = det + (size_t)b * A * 8;
+  if (j0 + threadIdx.x < n) {
+    const float* d = db + (size_t)(j0 + threadIdx.x) * 8;
+    bj[threadIdx.x][0] = d[0]; bj[threadIdx.x][1] = d[1]; bj[threadIdx.x][2] = d[2]; bj[threadIdx.x][3] = d[3]; bj[threadIdx.x][4] = d[6];
+  }
+  __syncthreads();
+  const int i = i0 + threadIdx.x;
+  if (i >= n) return;
+  const float* d = db + (size_t)i * 8;
+  const float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3], cl = d[6], ai = (x2 - x1) * (y2 - y1);
+  unsigned long long bits = 0ull;
+  for (int t = 0; t < 64; ++t) {
+    const int j = j0 + t;
+    if (j <= i || j >= n || bj[t][4] != cl) continue;
+    const float w = fmaxf(fminf(x2, bj[t][2]) - fmaxf(x1, bj[t][0]), 0.f), h = fmaxf(fminf(y2, bj[t][3]) - fmaxf(y1, bj[t][1]), 0.f);
+    const float inter = w * h, aj = (bj[t][2] - bj[t][0]) * (bj[t][3] - bj[t][1]);
+    if (inter / (ai + aj - inter) > thr) bits |= 1ull << t;
+  }
+  mask[((size_t)b * A + i) * words + blockIdx.x] = bits;
+}
+// greedy scan (one wave per image): box i survives unless an earlier survivor suppressed it
+__global__ __launch_bounds__(64) void nms_scan_kernel(const float* __restrict__ det, const int* __restrict__ ncand, int A,
+                                                      const unsigned long long* __restrict__ mask, int words, float* __restrict__ out,
+                                                      int* __restrict__ nkeep) {
+  const int b = blockIdx.x, n = ncand[b], lane = threadIdx.x;
+  const int nw = (n + 63) / 64;
+  unsigned long long removed[NMS_MAX / 64 / 64];     // lane holds words lane, lane+64, ...
+#pragma unroll
+  for (int q = 0; q < NMS_MAX / 64 / 64; ++q) removed[q] = 0ull;
+  int kept = 0;
+  const float* db = det + (size_t)b * A * 8;
+  float* ob = out + (size_t)b * A * 7;
+  for (int i = 0; i < n; ++i) {
+    const int w = i >> 6;
+    unsigned long long word = 0ull;
+#pragma unroll
+    for (int q = 0; q < NMS_MAX / 64 / 64; ++q)
+      if ((w >> 6) == q) word = removed[q];
+    word = __shfl(word, w & 63, 64);
+    if ((word >> (i & 63)) & 1ull) continue;          // wave-uniform
+    if (lane < 7) ob[(size_t)kept * 7 + lane] = db[(size_t)i * 8 + lane];
+    ++kept;
+    const unsigned long long* mrow = mask + ((size_t)b * A + i) * words;
+#pragma unroll
+    for (int q = 0; q < NMS_MAX / 64 / 64; ++q) {
+      const int ww = lane + q * 64;
+      if (ww >= w && ww < nw) removed[q] |= mrow[ww];
+    }
+  }
+  if (lane == 0) nkeep[b] = kept;
+}
+
 static int make_levels(const SastHeadGeom* g, HeadLevels& lv) {
   if (!g || g->n_levels < 1 || g->n_levels > 4) return SAST_EINVAL;
   lv.n = g->n_levels;
@@ -515,6 +637,27 @@ int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadG
   hipLaunchKernelGGL(yolox_loss_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, fg_mask, matched_gt, matched_iou, num_fg, lv,
                      B, G, num_classes, draw, acc);
   hipLaunchKernelGGL(yolox_loss_finish_kernel, dim3(1), dim3(64), 0, st, acc, num_fg, nlabel, B, losses);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+size_t sast_postprocess_ws_bytes(int B, int anchors_total) {
+  const size_t A = (size_t)anchors_total, words = (A + 63) / 64;
+  return (size_t)B * A * 8 * sizeof(float) + (size_t)B * A * words * sizeof(unsigned long long) + (size_t)B * sizeof(int) + 64;
+}
+
+int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, float* out,
+                     int32_t* n_out, void* ws, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int A = anchors_total, words = (A + 63) / 64;
+  if (!prediction || !out || !n_out || !ws || A < 1 || A > NMS_MAX || num_classes < 1) return SAST_EINVAL;
+  float* det = (float*)ws;
+  unsigned long long* mask = (unsigned long long*)(det + (size_t)B * A * 8);
+  int* ncand = (int*)(mask + (size_t)B * A * words);
+  zero_fill(mask, sizeof(unsigned long long) * (size_t)B * A * words, st);
+  hipLaunchKernelGGL(nms_candidates_kernel, dim3(B), dim3(1024), 0, st, prediction, A, num_classes, conf_thre, det, ncand);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, A, nms_thre, mask, words);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, det, ncand, A, mask, words, out, n_out);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

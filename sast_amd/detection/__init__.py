@@ -3,6 +3,7 @@ from .yolo_pafpn import YOLOPAFPN  # noqa: F401
 from .network_blocks import BaseConv, Bottleneck, CSPLayer  # noqa: F401
 from .yolo_head import YOLOXHead  # noqa: F401
 from .detector import YoloXDetector  # noqa: F401
+from .boxes import postprocess  # noqa: F401
 
 
 def build_recurrent_backbone(backbone_cfg):

@@ -304,6 +304,29 @@ def test_yolox_loss_full_size(dev):
         assert abs(float(losses[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (k, float(losses[k]), float(ref[k]))
 
 
+@pytest.mark.parametrize("A,thr", [(420, 0.3), (5040, 0.05)])
+def test_postprocess_nms(dev, A, thr):
+    """confidence filter + class-aware greedy NMS (yolox/utils/boxes.py:32-76) on clustered random predictions, incl. an image
+    without any detection: detections and their order against the oracle's restatement."""
+    from sast_amd import functional as SF
+    g = torch.Generator().manual_seed(5 + A)
+    B, nc = 3, 3
+    centres = torch.rand(B, 12, 2, generator=g) * torch.tensor([640.0, 384.0])
+    pick = torch.randint(0, 12, (B, A), generator=g)
+    cxcy = torch.gather(centres, 1, pick.unsqueeze(-1).expand(B, A, 2)) + torch.randn(B, A, 2, generator=g) * 6
+    wh = 20 + torch.rand(B, A, 2, generator=g) * 60
+    obj = torch.rand(B, A, 1, generator=g)
+    cls = torch.rand(B, A, nc, generator=g)
+    pred = torch.cat([cxcy, wh, obj, cls], -1)
+    pred[2, :, 4] = 0.0                                   # image 2: nothing above the confidence threshold
+    ref = O.postprocess(pred, nc, conf_thre=thr, nms_thre=0.45)
+    got = SF.postprocess(pred.to(dev), nc, conf_thre=thr, nms_thre=0.45)
+    assert ref[2] is None and got[2] is None
+    for b in range(2):
+        assert got[b] is not None and got[b].shape == ref[b].shape, (b, None if got[b] is None else got[b].shape, ref[b].shape)
+        assert torch.allclose(got[b].cpu(), ref[b], atol=1e-5, rtol=1e-6), b
+
+
 def test_unpadded_uint8_input(dev):
     """the reference pads the uint8 event tensor to in_res_hw before the backbone (modules/detection.py:143-144); here the
     unpadded tensor is accepted directly -- bit-identical to feeding the explicitly padded one, and equal to the oracle."""

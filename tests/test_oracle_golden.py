@@ -140,6 +140,22 @@ def test_yolox_head_eval(golden_dir):
     assert torch.allclose(O.yolox_head_eval(feats, params, decode=False), torch.from_numpy(g["raw"]), atol=1e-6, rtol=1e-6)
 
 
+def test_postprocess_known_answer():
+    """greedy class-aware NMS of the oracle on a hand-checked case (the reference's torchvision call cannot run here)."""
+    # (cx, cy, w, h, obj, cls0, cls1): boxes 0/1 overlap heavily (IoU 0.68) and share class 0 -> 1 suppressed; box 2 overlaps 0 but is
+    # class 1 -> kept; box 3 is below the confidence threshold; box 4 is far away
+    p = torch.tensor([[[50., 50., 40., 40., 0.9, 0.9, 0.1],
+                       [54., 50., 40., 40., 0.8, 0.9, 0.1],
+                       [52., 50., 40., 40., 0.7, 0.1, 0.9],
+                       [50., 50., 40., 40., 0.2, 0.5, 0.1],
+                       [200., 200., 30., 30., 0.6, 0.8, 0.2]]])
+    out = O.postprocess(p, 2, conf_thre=0.3, nms_thre=0.45)[0]
+    assert out.shape == (3, 7)
+    assert torch.allclose(out[:, 4] * out[:, 5], torch.tensor([0.81, 0.63, 0.48]), atol=1e-6)
+    assert out[:, 6].tolist() == [0.0, 1.0, 0.0]
+    assert torch.allclose(out[0, :4], torch.tensor([30., 30., 70., 70.]))
+
+
 def test_yolox_head_train(golden_dir):
     """YOLOX training branch (SimOTA assignment, IoU / objectness / class losses): oracle vs the reference module's numbers."""
     g = _load(golden_dir, "head_train")
