@@ -307,6 +307,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only)
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()       # rank 0 may still be in its (rank-local) roofline leg: leave the group together
         dist.destroy_process_group()
 
 

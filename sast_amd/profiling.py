@@ -92,10 +92,11 @@ def gemm_report(run_steps, n_steps: int = 3):
 
 
 def dominant_kernel_roofline(trainer, n_steps: int = 3):
+    # rank-local on purpose: this leg runs on rank 0 only, after the timed region -- it must not enter a collective (the
+    # other ranks are already past it), so it replays forward + backward without the gradient all-reduce / optimizer step
     def run(n):
         for _ in range(n):
             trainer.fwd_bwd()
-            trainer.update()
 
     rows = [r for r in gemm_report(run, n_steps) if not r[0].startswith("op:")]
     # GEMM launches are timed with hipExtLaunchKernelGGL start/stop events (stamped at the kernel's own begin / end, the
