@@ -28,62 +28,71 @@ int zero_fill(void* p, size_t bytes, hipStream_t st) {
 // thread -> one 4x4 cell max, then the 2x2 max cascade through LDS (8x8, 16x16, 32x32).
 template <typename T>
 __global__ __launch_bounds__(256) void nzr_count_kernel(const T* __restrict__ x, int* __restrict__ cnt, int C, int H, int W) {
+  // One workgroup walks a 32-row strip of one (b, c) plane in 32 x 128 tiles and keeps the four level counts in registers:
+  // 4 atomics per strip instead of ~7 per tile (same-address atomics serialise at the memory side -- with one workgroup per
+  // tile the 105 atomics per counter cost more than reading the tensor).
   __shared__ float cell[8][33];
   const int plane = blockIdx.z;                 // b*C + c
   const int cy = threadIdx.x >> 5, cx = threadIdx.x & 31;
-  const int y0 = blockIdx.y * 32 + cy * 4, x0 = blockIdx.x * 128 + cx * 4;
-  float mx = -INFINITY;
-  bool valid = (y0 < H) && (x0 < W);
-  if (valid) {
-    const T* p = x + ((size_t)plane * H + y0) * W + x0;
-    struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };            // one 4-pixel cell row per load (16 B for int32/fp32, 4 B for uint8)
+  const int y0 = blockIdx.y * 32 + cy * 4;
+  int n1 = 0, n2 = 0, n3 = 0, n4 = 0;           // wave-0 lane-0 totals (levels 2-4), per-wave level-1 popcounts
+  for (int xb = 0; xb * 128 < W; ++xb) {
+    const int x0 = xb * 128 + cx * 4;
+    float mx = -INFINITY;
+    const bool valid = (y0 < H) && (x0 < W);
+    if (valid) {
+      const T* p = x + ((size_t)plane * H + y0) * W + x0;
+      struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };            // one 4-pixel cell row per load (16 B for int32/fp32, 4 B for uint8)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const Vec4 q4 = *reinterpret_cast<const Vec4*>(p + (size_t)r * W);
+      for (int r = 0; r < 4; ++r) {
+        const Vec4 q4 = *reinterpret_cast<const Vec4*>(p + (size_t)r * W);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mx = fmaxf(mx, (float)q4.v[q]);
+        for (int q = 0; q < 4; ++q) mx = fmaxf(mx, (float)q4.v[q]);
+      }
     }
+    __syncthreads();                            // previous tile's readers of `cell` are done
+    cell[cy][cx] = mx;
+    n1 += __popcll(__ballot(valid && mx != 0.f));
+    __syncthreads();
+    // level 2: 4 x 16 cells of 8x8 px, level 3: 2 x 8, level 4: 1 x 4
+    bool v2 = false, v3 = false, v4 = false;
+    float a = -INFINITY;
+    if (threadIdx.x < 64) {
+      const int yy = threadIdx.x >> 4, xx = threadIdx.x & 15;
+      a = fmaxf(fmaxf(cell[2 * yy][2 * xx], cell[2 * yy][2 * xx + 1]), fmaxf(cell[2 * yy + 1][2 * xx], cell[2 * yy + 1][2 * xx + 1]));
+      v2 = (blockIdx.y * 32 + yy * 8 < H) && (xb * 128 + xx * 8 < W);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) cell[threadIdx.x >> 4][threadIdx.x & 15] = a;
+    const unsigned long long m2 = __ballot(v2 && a != 0.f);
+    __syncthreads();
+    float a3 = -INFINITY;
+    if (threadIdx.x < 16) {
+      const int yy = threadIdx.x >> 3, xx = threadIdx.x & 7;
+      a3 = fmaxf(fmaxf(cell[2 * yy][2 * xx], cell[2 * yy][2 * xx + 1]), fmaxf(cell[2 * yy + 1][2 * xx], cell[2 * yy + 1][2 * xx + 1]));
+      v3 = (blockIdx.y * 32 + yy * 16 < H) && (xb * 128 + xx * 16 < W);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) cell[threadIdx.x >> 3][threadIdx.x & 7] = a3;
+    const unsigned long long m3 = __ballot(v3 && a3 != 0.f);
+    __syncthreads();
+    float a4 = -INFINITY;
+    if (threadIdx.x < 4) {
+      const int xx = threadIdx.x;
+      a4 = fmaxf(fmaxf(cell[0][2 * xx], cell[0][2 * xx + 1]), fmaxf(cell[1][2 * xx], cell[1][2 * xx + 1]));
+      v4 = (blockIdx.y * 32 < H) && (xb * 128 + xx * 32 < W);
+    }
+    const unsigned long long m4 = __ballot(v4 && a4 != 0.f);
+    if (threadIdx.x < 64) { n2 += __popcll(m2); n3 += __popcll(m3); n4 += __popcll(m4); }
   }
-  cell[cy][cx] = mx;
   const int b = plane / C, c = plane % C;
   int* out = cnt + ((size_t)b * 4) * C + c;   // cnt[b][level][c]
-  unsigned long long m1 = __ballot(valid && mx != 0.f);
-  __syncthreads();
-  // level 2: 4 x 16 cells of 8x8 px, level 3: 2 x 8, level 4: 1 x 4
-  bool v2 = false, v3 = false, v4 = false;
-  float a = -INFINITY;
-  if (threadIdx.x < 64) {
-    const int yy = threadIdx.x >> 4, xx = threadIdx.x & 15;
-    a = fmaxf(fmaxf(cell[2 * yy][2 * xx], cell[2 * yy][2 * xx + 1]), fmaxf(cell[2 * yy + 1][2 * xx], cell[2 * yy + 1][2 * xx + 1]));
-    v2 = (blockIdx.y * 32 + yy * 8 < H) && (blockIdx.x * 128 + xx * 8 < W);
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) cell[threadIdx.x >> 4][threadIdx.x & 15] = a;
-  unsigned long long m2 = __ballot(v2 && a != 0.f);
-  __syncthreads();
-  float a3 = -INFINITY;
-  if (threadIdx.x < 16) {
-    const int yy = threadIdx.x >> 3, xx = threadIdx.x & 7;
-    a3 = fmaxf(fmaxf(cell[2 * yy][2 * xx], cell[2 * yy][2 * xx + 1]), fmaxf(cell[2 * yy + 1][2 * xx], cell[2 * yy + 1][2 * xx + 1]));
-    v3 = (blockIdx.y * 32 + yy * 16 < H) && (blockIdx.x * 128 + xx * 16 < W);
-  }
-  __syncthreads();
-  if (threadIdx.x < 16) cell[threadIdx.x >> 3][threadIdx.x & 7] = a3;
-  unsigned long long m3 = __ballot(v3 && a3 != 0.f);
-  __syncthreads();
-  float a4 = -INFINITY;
-  if (threadIdx.x < 4) {
-    const int xx = threadIdx.x;
-    a4 = fmaxf(fmaxf(cell[0][2 * xx], cell[0][2 * xx + 1]), fmaxf(cell[1][2 * xx], cell[1][2 * xx + 1]));
-    v4 = (blockIdx.y * 32 < H) && (blockIdx.x * 128 + xx * 32 < W);
-  }
-  unsigned long long m4 = __ballot(v4 && a4 != 0.f);
   if ((threadIdx.x & 63) == 0) {
-    if (m1) atomicAdd(out + 0 * C, __popcll(m1));
+    if (n1) atomicAdd(out + 0 * C, n1);
     if (threadIdx.x == 0) {
-      if (m2) atomicAdd(out + 1 * C, __popcll(m2));
-      if (m3) atomicAdd(out + 2 * C, __popcll(m3));
-      if (m4) atomicAdd(out + 3 * C, __popcll(m4));
+      if (n2) atomicAdd(out + 1 * C, n2);
+      if (n3) atomicAdd(out + 2 * C, n3);
+      if (n4) atomicAdd(out + 3 * C, n4);
     }
   }
 }
@@ -101,7 +110,7 @@ __global__ void nzr_finish_kernel(const int* __restrict__ cnt, float* __restrict
 template <typename T>
 int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   zero_fill(cnt, sizeof(int) * B * 4 * C, st);
-  dim3 grid((W + 127) / 128, (H + 31) / 32, B * C);
+  dim3 grid(1, (H + 31) / 32, B * C);
   hipLaunchKernelGGL((nzr_count_kernel<T>), grid, dim3(256), 0, st, (const T*)x, cnt, C, H, W);
   float s[4];
   int f = 4;
