@@ -47,6 +47,11 @@ int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast
 
 /* a3  x + pos_emb(x) -- SAST.py:105 with the constant sine table of sast_rnn.py:180-219: y[row] = x[row] + table[row % table_rows] */
 int sast_add_rows(const float* x, const float* table, float* y, int rows, int C, int table_rows, sast_stream_t stream);
+/* a11  mask token (enable_masking) -- sast_rnn.py:271-273: x[token_mask] = mask_token, in place on the [rows, C] rows AFTER the first
+ * block's position embedding was added (pos_emb [L, C] or NULL): masked rows become mask_token + pos_emb[row % L].
+ * backward: dx = dy with masked rows zeroed, d_token += sum of the masked rows of dy. */
+int sast_mask_token_fwd(float* x, const uint8_t* mask, const float* token, const float* pos_emb, int rows, int C, int L, sast_stream_t stream);
+int sast_mask_token_bwd(const float* dy, const uint8_t* mask, float* dx, float* d_token, int rows, int C, sast_stream_t stream);
 
 /* a2  ConvDownsampling_Cf2Cl -- models/layers/SAST/ops.py:54-95 (+ the pos-emb add of SAST.py:105 when pe != NULL) */
 typedef struct SastDownArgs {

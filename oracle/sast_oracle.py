@@ -303,10 +303,14 @@ def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: st
 
 # --------------------------------------------------------------------------- a11
 def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: BackboneCfg, stage_idx: int,
-                   pe: Optional[Tensor] = None):
-    """sast_rnn.py:265-287 (enable_masking False).  NCHW in -> (h NCHW, (h,c), P, index lists)."""
+                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None):
+    """sast_rnn.py:265-287.  NCHW in -> (h NCHW, (h,c), P, index lists).  token_mask (B,H,W) bool: x[token_mask] = mask_token
+    (:271-273, parameter `<pre>mask_token` of shape (1,1,1,C), only stage 0 has one when enable_masking is set)."""
     factor = cfg.patch_size if stage_idx == 0 else 2
     x = conv_downsample_cf2cl(x, p, pre + "downsample_cf2cl.", factor)
+    if token_mask is not None:
+        x = x.clone()
+        x[token_mask] = p[pre + "mask_token"].to(x.dtype)
     B, H, W, C = x.shape
     if pe is None:
         pe = position_embedding_sine(H, W, C)
@@ -323,7 +327,8 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
     return hc[0], hc, P, all_lists
 
 
-def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "", return_lists: bool = False):
+def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "", return_lists: bool = False,
+             token_mask: Optional[Tensor] = None):
     """sast_rnn.py:144-162.  x (B,20,H,W) -> ({1..4: h}, states, P)."""
     if prev_states is None:
         prev_states = [None] * 4
@@ -331,7 +336,8 @@ def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "",
     x = x.float()
     out, states, P, lists = {}, [], [], []
     for s in range(4):
-        x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s)
+        x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s,
+                                        token_mask=token_mask if s == 0 else None)
         states.append(st)
         out[s + 1] = st[0]
         P.append(cnt)

@@ -151,6 +151,15 @@ int sast_add_rows(const float* x, const float* table, float* y, int rows, int C,
   return add_rows_launch(x, table, y, rows, C, table_rows, (hipStream_t)stream);
 }
 
+int sast_mask_token_fwd(float* x, const uint8_t* mask, const float* token, const float* pos_emb, int rows, int C, int L, sast_stream_t stream) {
+  if (!x || !mask || !token || C % 4 || L < 1) return SAST_EINVAL;
+  return mask_token_fwd_launch(x, mask, token, pos_emb, rows, C, L, (hipStream_t)stream);
+}
+int sast_mask_token_bwd(const float* dy, const uint8_t* mask, float* dx, float* d_token, int rows, int C, sast_stream_t stream) {
+  if (!dy || !mask || !dx || !d_token || C % 4) return SAST_EINVAL;
+  return mask_token_bwd_launch(dy, mask, dx, d_token, rows, C, (hipStream_t)stream);
+}
+
 int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode, double bounce, const SastSel* s,
                 sast_stream_t stream) {
   if (!tok || !s) return SAST_EINVAL;

@@ -621,6 +621,47 @@ int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, i
   return SAST_OK;
 }
 
+// ============================================================ mask token (sast_rnn.py:271-273): x[token_mask] = mask_token
+// Forward works in place on the LayerNorm output that already carries the first block's position embedding, so a masked row
+// becomes mask_token + pos_emb[row % L].  Backward: masked rows pass no gradient to x, their gradient sums go to the token.
+__global__ __launch_bounds__(256) void mask_token_fwd_kernel(float* __restrict__ x, const unsigned char* __restrict__ mask,
+                                                             const float* __restrict__ token, const float* __restrict__ pe, size_t n4, int C4,
+                                                             int L) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n4) return;
+  const size_t row = e / C4; const int c = (int)(e % C4);
+  if (!mask[row]) return;
+  float4 t = ld4(token + c * 4);
+  if (pe) { const float4 p = ld4(pe + ((row % L) * C4 + c) * 4); t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+  st4(x + e * 4, t);
+}
+__global__ __launch_bounds__(256) void mask_token_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                             float* __restrict__ dx, float* __restrict__ dtoken, int rows, int C,
+                                                             int rows_per_block) {
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    float4 acc = zero4();
+    for (int r = r0; r < r1; ++r) {
+      const float4 g = ld4(dy + (size_t)r * C + c);
+      if (mask[r]) { acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w; st4(dx + (size_t)r * C + c, zero4()); }
+      else st4(dx + (size_t)r * C + c, g);
+    }
+    atomicAdd(dtoken + c, acc.x); atomicAdd(dtoken + c + 1, acc.y); atomicAdd(dtoken + c + 2, acc.z); atomicAdd(dtoken + c + 3, acc.w);
+  }
+}
+int mask_token_fwd_launch(float* x, const unsigned char* mask, const float* token, const float* pe, int rows, int C, int L, hipStream_t st) {
+  const size_t n4 = (size_t)rows * (C / 4);
+  hipLaunchKernelGGL(mask_token_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, mask, token, pe, n4, C / 4, L);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int mask_token_bwd_launch(const float* dy, const unsigned char* mask, float* dx, float* dtoken, int rows, int C, hipStream_t st) {
+  const int rpb = 256;
+  hipLaunchKernelGGL(mask_token_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dy, mask, dx, dtoken, rows, C, rpb);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
 // ============================================================ column sums: out[c] += sum_rows x[row(idx)][c]
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld, const int* __restrict__ idx,
                                                      int rows, const int* __restrict__ drows, int C, float* __restrict__ out,

@@ -87,8 +87,6 @@ class RNNDetectorStage(nn.Module):
         super().__init__()
         assert isinstance(num_blocks, int) and num_blocks > 0
         downsample_cfg, lstm_cfg, attention_cfg = stage_cfg.downsample, stage_cfg.lstm, stage_cfg.attention
-        if enable_token_masking:
-            raise NotImplementedError("sast_amd: enable_masking=True (mask_token, sast_rnn.py:271-273) is not implemented")
         self.downsample_cf2cl = get_downsample_layer_Cf2Cl(dim_in=dim_in, dim_out=stage_dim,
                                                            downsample_factor=spatial_downsample_factor,
                                                            downsample_cfg=downsample_cfg)
@@ -99,15 +97,20 @@ class RNNDetectorStage(nn.Module):
                                   dws_conv_kernel_size=lstm_cfg.dws_conv_kernel_size,
                                   cell_update_dropout=cfg_get(lstm_cfg, 'drop_cell_update', 0)) if enable_lstm else None
         self.pos_emb = PositionEmbeddingSine(stage_dim // 2, normalize=True, input_size=overload_size)
-        self.mask_token = None
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, 1, stage_dim), requires_grad=True) if enable_token_masking else None
+        if self.mask_token is not None:
+            torch.nn.init.normal_(self.mask_token, std=.02)
 
-    def forward_nhwc(self, x_nhwc, h_and_c_previous, r):
+    def forward_nhwc(self, x_nhwc, h_and_c_previous, r, token_mask=None):
         """x (B,H,W,Cin) fp32 channels-last -> (h (B,H',W',C), (h,c), P)"""
         ds = self.downsample_cf2cl
         H, W = x_nhwc.shape[1] // ds.factor, x_nhwc.shape[2] // ds.factor
         probe = x_nhwc.new_empty((1, H, W, 0))
         table = self.pos_emb.table_for(probe)
         x = ds.forward_nhwc(x_nhwc, table)                       # LN(conv(x)) + pos_emb of the first block
+        if token_mask is not None:                               # sast_rnn.py:271-273 (the rows already carry pos_emb)
+            assert self.mask_token is not None, 'No mask token present in this stage'
+            x = SF.mask_token(x, token_mask, self.mask_token, table)
         P = 0
         index_list = None
         for i, blk in enumerate(self.att_blocks):
@@ -121,12 +124,11 @@ class RNNDetectorStage(nn.Module):
         return x, (x, x), P
 
     def forward(self, x: torch.Tensor, h_and_c_previous=None, token_mask: Optional[torch.Tensor] = None, r: torch.Tensor = None):
-        assert token_mask is None, 'No mask token present in this stage'
         x_nhwc = SF.as_nhwc(x) if x.dtype == torch.float32 else SF.nchw_to_nhwc_float(x)
         hc = None
         if h_and_c_previous is not None:
             hc = (SF.as_nhwc(h_and_c_previous[0]), SF.as_nhwc(h_and_c_previous[1]))
-        h, (h1, c1), P = self.forward_nhwc(x_nhwc, hc, r)
+        h, (h1, c1), P = self.forward_nhwc(x_nhwc, hc, r, token_mask)
         return SF.as_nchw_view(h), (SF.as_nchw_view(h1), SF.as_nchw_view(c1)), P
 
 
@@ -179,7 +181,7 @@ class RNNDetector(nn.Module):
         assert min(idx) >= 0 and max(idx) < len(self.stages), idx
         return tuple(self.strides[i] for i in idx)
 
-    def forward_nhwc(self, x: torch.Tensor, prev_states=None):
+    def forward_nhwc(self, x: torch.Tensor, prev_states=None, token_mask=None):
         """fused path: returns NHWC feature maps {stage: (B,H,W,C)}, states [(h,c)] NHWC, P list."""
         if prev_states is None:
             prev_states = [None] * self.num_stages
@@ -191,7 +193,7 @@ class RNNDetector(nn.Module):
         xin = SF.nchw_to_nhwc_float(x, pad)
         states, output, P = [], {}, []
         for i, stage in enumerate(self.stages):
-            xin, state, p = stage.forward_nhwc(xin, prev_states[i], r[:, i])
+            xin, state, p = stage.forward_nhwc(xin, prev_states[i], r[:, i], token_mask if i == 0 else None)   # sast_rnn.py:157
             states.append(state)
             output[i + 1] = state[0]
             P.append(p)
@@ -199,11 +201,10 @@ class RNNDetector(nn.Module):
 
     def forward(self, x: torch.Tensor, prev_states=None, token_mask: Optional[torch.Tensor] = None):
         """x (B,20,H,W) NCHW any of {uint8,int32,float32}; -> ({1..4: h NCHW}, [(h,c)], P)  (sast_rnn.py:144-162)"""
-        assert token_mask is None, "enable_masking is not implemented"
         ps = None
         if prev_states is not None:
             ps = [None if s is None else (SF.as_nhwc(s[0]), SF.as_nhwc(s[1])) for s in prev_states]
-        out, states, P = self.forward_nhwc(x, ps)
+        out, states, P = self.forward_nhwc(x, ps, token_mask)
         out = {k: SF.as_nchw_view(v) for k, v in out.items()}
         states = [(SF.as_nchw_view(h), SF.as_nchw_view(c)) for h, c in states]
         return out, states, P

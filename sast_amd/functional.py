@@ -178,6 +178,36 @@ def downsample_ln(x_nhwc, w, ln_w, ln_b, pe, factor):
     return _DownsampleLN.apply(x_nhwc, w, ln_w, ln_b, pe, factor)
 
 
+class _MaskToken(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, token, pe):
+        _need_gpu(x, mask, token)
+        y = x.contiguous().clone()
+        Cc = y.shape[-1]
+        rows = y.numel() // Cc
+        m = mask.to(torch.uint8).contiguous()
+        Lt = pe.numel() // Cc if pe is not None else 1
+        L.check(L.lib().sast_mask_token_fwd(y.data_ptr(), m.data_ptr(), token.data_ptr(), _ptr(pe), rows, Cc, Lt, _stream()), "mask_token_fwd")
+        ctx.save_for_backward(m)
+        ctx.token = token
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (m,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        Cc = dy.shape[-1]
+        L.check(L.lib().sast_mask_token_bwd(dy.data_ptr(), m.data_ptr(), dx.data_ptr(), _g(ctx.token).data_ptr(), dy.numel() // Cc, Cc, _stream()),
+                "mask_token_bwd")
+        return dx, None, None, None
+
+
+def mask_token(x_nhwc, token_mask, token, pos_emb_table=None):
+    """sast_rnn.py:271-273 on rows that already carry the position embedding: x[token_mask] = mask_token (+ pos_emb)."""
+    return _MaskToken.apply(x_nhwc, token_mask, token, pos_emb_table)
+
+
 # ---------------------------------------------------------------------------------------------- a5
 class _ScoreSTP(torch.autograd.Function):
     @staticmethod

@@ -304,6 +304,38 @@ def gen_head_eval(ref):
     print("head_eval ok:", tuple(out.shape), "oracle max abs diff", float((mine - out).abs().max()))
 
 
+def gen_masked_backbone(ref):
+    """enable_masking (mask_token write, sast_rnn.py:271-273): oracle vs the reference backbone with a token mask."""
+    hw, part, E = (128, 160), (4, 5), 32
+    cfg = RI.backbone_cfg(hw, part, embed_dim=E, amp=2e-2, ls_init=0.5)
+    cfg["enable_masking"] = True
+    net = ref.sast_rnn.RNNDetector(cfg)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=61, ls_init=0.5)
+    g = torch.Generator().manual_seed(62)
+    params["stages.0.mask_token"] = torch.randn(1, 1, 1, E, generator=g) * 0.02
+    load_into(net, params)
+    x = O.count_events(2, hw, seed=63, density=0.05)
+    mask = torch.rand(2, hw[0] // 4, hw[1] // 4, generator=g) < 0.3
+    out, _st, P = net(x, None, mask)
+    loss = sum((out[k] ** 2).mean() for k in (1, 2, 3, 4))
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    oo, _s, Po = O.backbone(x, None, po, ocfg, token_mask=mask)
+    for k in (1, 2, 3, 4):
+        assert torch.equal(oo[k], out[k]), k
+    assert [int(p) for p in Po] == [int(p) for p in P]
+    sum((oo[k] ** 2).mean() for k in (1, 2, 3, 4)).backward()
+    gm = dict(net.named_parameters())["stages.0.mask_token"].grad
+    assert torch.allclose(po["stages.0.mask_token"].grad, gm, atol=1e-8, rtol=1e-4)
+    d = dict(x=np_(x), mask=np_(mask).astype(np.uint8), seed=np.int64(61), mask_token=np_(params["stages.0.mask_token"]),
+             P=np.array([int(p) for p in P]), g_mask_token=np_(gm), loss=np.float64(float(loss)))
+    for k in (1, 2, 3, 4):
+        d[f"h{k}"] = np_(out[k])
+    np.savez_compressed(os.path.join(HERE, "backbone_masked.npz"), **d)
+    print("backbone_masked ok: P", [int(p) for p in P], "masked tokens", int(mask.sum()))
+
+
 def gen_head_train(ref):
     """YOLOX head, training branch (SimOTA assignment + IoU / BCE losses): oracle restatement against the reference module."""
     chans, nc, strides = (64, 128, 256), 2, (8, 16, 32)
@@ -349,6 +381,9 @@ def gen_head_train(ref):
 
 def main():
     ref = RI.import_reference()
+    if "--mask-only" in sys.argv:
+        gen_masked_backbone(ref)
+        return
     if "--head-only" in sys.argv:
         gen_head_eval(ref)
         gen_head_train(ref)
@@ -370,6 +405,7 @@ def main():
     gen_pafpn(ref)
     gen_head_eval(ref)
     gen_head_train(ref)
+    gen_masked_backbone(ref)
     gen_full_stats(ref)
 
 

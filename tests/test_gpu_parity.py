@@ -135,13 +135,25 @@ def test_ms_wsa_reference_signature(golden_dir, dev):
     assert float((out_cb.cpu() - ref_cb).abs().max()) <= FWD_ATOL
 
 
-def test_token_masking_fails_loudly(dev):
-    """enable_masking (mask_token write, sast_rnn.py:271-273; off in every shipped config) is not implemented: no silent fallback."""
+def test_token_masking_vs_golden(golden_dir, dev):
+    """enable_masking (mask_token write, sast_rnn.py:271-273): backbone with a token mask against the reference's outputs, kept-token
+    counts and the mask token's gradient (fixture backbone_masked.npz)."""
     from sast_amd.detection import RNNDetector
-    cfg = _rcfg((128, 160), (4, 5), 32, 2e-4, 0.5)
+    g = _load(golden_dir, "backbone_masked")
+    hw, part, E = (128, 160), (4, 5), 32
+    cfg = _rcfg(hw, part, E, 2e-2, 0.5)
     cfg["enable_masking"] = True
-    with pytest.raises(NotImplementedError):
-        RNNDetector(cfg)
+    net = RNNDetector(cfg).to(dev)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=int(g["seed"]), ls_init=0.5)
+    params["stages.0.mask_token"] = torch.from_numpy(g["mask_token"])
+    load_params(net, params)
+    out, _st, P = net(torch.from_numpy(g["x"]).to(dev), None, torch.from_numpy(g["mask"]).bool().to(dev))
+    assert [int(p) for p in P] == list(g["P"])
+    for k in (1, 2, 3, 4):
+        assert float((out[k].detach().cpu() - torch.from_numpy(g[f"h{k}"])).abs().max()) <= FWD_ATOL, k
+    sum((out[k] ** 2).mean() for k in (1, 2, 3, 4)).backward()
+    maxnorm_close(net.stages[0].mask_token.grad, torch.from_numpy(g["g_mask_token"]), GRAD_RTOL, "mask_token grad")
 
 
 def _rcfg(hw, part, E, amp, ls, dim_head=32):

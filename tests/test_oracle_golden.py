@@ -140,6 +140,22 @@ def test_yolox_head_eval(golden_dir):
     assert torch.allclose(O.yolox_head_eval(feats, params, decode=False), torch.from_numpy(g["raw"]), atol=1e-6, rtol=1e-6)
 
 
+def test_backbone_masked(golden_dir):
+    """enable_masking (sast_rnn.py:271-273): oracle vs the reference backbone run with a token mask."""
+    g = _load(golden_dir, "backbone_masked")
+    hw, part, E = (128, 160), (4, 5), 32
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=int(g["seed"]), ls_init=0.5)
+    params["stages.0.mask_token"] = torch.from_numpy(g["mask_token"])
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    out, _s, P = O.backbone(torch.from_numpy(g["x"]), None, po, ocfg, token_mask=torch.from_numpy(g["mask"]).bool())
+    assert [int(p) for p in P] == list(g["P"])
+    for k in (1, 2, 3, 4):
+        assert torch.allclose(out[k], torch.from_numpy(g[f"h{k}"]), atol=ATOL, rtol=0)
+    sum((out[k] ** 2).mean() for k in (1, 2, 3, 4)).backward()
+    assert torch.allclose(po["stages.0.mask_token"].grad, torch.from_numpy(g["g_mask_token"]), atol=1e-8, rtol=1e-4)
+
+
 def test_postprocess_known_answer():
     """greedy class-aware NMS of the oracle on a hand-checked case (the reference's torchvision call cannot run here)."""
     # (cx, cy, w, h, obj, cls0, cls1): boxes 0/1 overlap heavily (IoU 0.68) and share class 0 -> 1 suppressed; box 2 overlaps 0 but is
