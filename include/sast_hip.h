@@ -215,12 +215,12 @@ int sast_head_pred_bwd(const float* draw, const float* reg_feat, const float* cl
                        sast_stream_t stream);
 /* get_losses (yolo_head.py:291-443) with the SimOTA assignment (:452-606) for the whole batch, no host sync:
  *   train_out [B, A, 5+nc] from sast_head_pred_fwd, labels [B, max_labels, 5] = (cls, cx, cy, w, h), valid rows first, all-zero rows = padding
- *   losses[5] = loss, 5*iou_loss, conf_loss, cls_loss, num_fg / max(num_gts, 1)
+ *   losses[6] = loss, 5*iou_loss, conf_loss, cls_loss, l1_loss (0 unless use_l1), num_fg / max(num_gts, 1)
  *   draw [B, A, 5+nc] = d loss / d (raw conv outputs) (chain through the decode included)
  *   fg_mask / matched_gt / matched_iou [B, A]: the assignment (matched_gt = -1, iou = 0 for background anchors)
- * use_l1 (the reference's optional L1 term, off by default) is not implemented. */
+ * use_l1 != 0 adds the L1 term on the raw regression outputs (yolo_head.py:199-208,426-430; off by default in the reference). */
 size_t sast_yolox_loss_ws_bytes(int B, int anchors_total, int max_labels);
-int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes,
+int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes, int use_l1,
                     float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream);
 
 /* postprocess -- yolox/utils/boxes.py:32-76: confidence filter (obj * max class conf >= conf_thre), class-aware

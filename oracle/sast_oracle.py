@@ -491,11 +491,11 @@ def simota_assign(gt_boxes: Tensor, gt_classes: Tensor, boxes: Tensor, cls_logit
 
 
 def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides=(8, 16, 32), pre: str = "", num_classes: int = 3,
-                     bufs: Optional[Params] = None):
+                     bufs: Optional[Params] = None, use_l1: bool = False):
     """YOLOXHead.forward in TRAINING mode (batch-statistics BatchNorm) + get_losses: -> dict(loss, iou_loss, conf_loss, cls_loss,
     num_fg) and the assignment of every image (for index-level parity checks).  labels (B, max_labels, 5) = (cls, cx, cy, w, h),
     valid rows first, rows that sum to 0 are padding (yolo_head.py:306)."""
-    outs, xs, ys, ss = [], [], [], []
+    outs, xs, ys, ss, origin = [], [], [], [], []
     for k, (x, stride) in enumerate(zip(feats, strides)):
         x = base_conv(x, p, f"{pre}stems.{k}.", 1, True, bufs)
         cf, rf = x, x
@@ -507,6 +507,7 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
         obj = F.conv2d(rf, p[f"{pre}obj_preds.{k}.weight"], p[f"{pre}obj_preds.{k}.bias"])
         o = torch.cat([reg, obj, cls], 1)
         B, no, H, W = o.shape
+        origin.append(reg.view(B, 4, H * W).permute(0, 2, 1))      # raw regression outputs (use_l1, :199-208)
         o = o.view(B, no, H * W).permute(0, 2, 1)
         yv, xv = torch.meshgrid([torch.arange(H, dtype=o.dtype), torch.arange(W, dtype=o.dtype)], indexing="ij")
         grid = torch.stack((xv, yv), 2).view(1, -1, 2)
@@ -518,6 +519,8 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
     boxes, objp, clsp = out[:, :, :4], out[:, :, 4:5], out[:, :, 5:]
     nlabel = (labels.sum(dim=2) > 0).sum(dim=1)
     A = out.shape[1]
+    origin = torch.cat(origin, 1)
+    l1_t = []
     cls_t, reg_t, obj_t, fg_all, assigns = [], [], [], [], []
     num_fg, num_gts = 0.0, 0.0
     for b in range(out.shape[0]):
@@ -534,14 +537,19 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
         num_fg += int(fg.sum())
         cls_t.append(F.one_hot(mcls.to(torch.int64), num_classes) * pious.unsqueeze(-1))
         obj_t.append(fg.unsqueeze(-1).to(out.dtype)); reg_t.append(gtb[matched]); fg_all.append(fg)
+        gm, sm = gtb[matched], ss[fg]                                 # get_l1_target :445-450
+        l1_t.append(torch.stack([gm[:, 0] / sm - xs[fg], gm[:, 1] / sm - ys[fg], torch.log(gm[:, 2] / sm + 1e-8),
+                                 torch.log(gm[:, 3] / sm + 1e-8)], 1))
         assigns.append((fg, matched, pious))
     cls_t, reg_t, obj_t, fg_all = torch.cat(cls_t, 0), torch.cat(reg_t, 0), torch.cat(obj_t, 0), torch.cat(fg_all, 0)
     num_fg = max(num_fg, 1)
     loss_iou = _iou_loss(boxes.reshape(-1, 4)[fg_all], reg_t).sum() / num_fg
     loss_obj = F.binary_cross_entropy_with_logits(objp.reshape(-1, 1), obj_t, reduction="none").sum() / num_fg
     loss_cls = F.binary_cross_entropy_with_logits(clsp.reshape(-1, num_classes)[fg_all], cls_t, reduction="none").sum() / num_fg
-    loss = 5.0 * loss_iou + loss_obj + loss_cls
-    return {"loss": loss, "iou_loss": 5.0 * loss_iou, "conf_loss": loss_obj, "cls_loss": loss_cls, "num_fg": num_fg / max(num_gts, 1),
+    loss_l1 = (origin.reshape(-1, 4)[fg_all] - torch.cat(l1_t, 0)).abs().sum() / num_fg if (use_l1 and l1_t) else out.new_zeros(())
+    loss = 5.0 * loss_iou + loss_obj + loss_cls + loss_l1
+    return {"loss": loss, "iou_loss": 5.0 * loss_iou, "conf_loss": loss_obj, "cls_loss": loss_cls, "l1_loss": loss_l1,
+            "num_fg": num_fg / max(num_gts, 1),
             "assign": assigns, "outputs": out}
 
 

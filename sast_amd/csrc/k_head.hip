@@ -348,16 +348,17 @@ __device__ __forceinline__ float bce_logits(float x, float t) { return fmaxf(x, 
 __device__ __forceinline__ float dsel_max(float p, float g) { return p > g ? 1.f : (p == g ? 0.5f : 0.f); }
 __device__ __forceinline__ float dsel_min(float p, float g) { return p < g ? 1.f : (p == g ? 0.5f : 0.f); }
 
-// acc[0] += sum iou loss, acc[1] += sum obj loss, acc[2] += sum cls loss   (all un-normalised)
+// acc[0] += sum iou loss, acc[1] += sum obj loss, acc[2] += sum cls loss, acc[3] += sum L1 loss   (all un-normalised)
 __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict__ train, const float* __restrict__ labels,
                                                          const int* __restrict__ fg_in, const int* __restrict__ mg_in,
                                                          const float* __restrict__ piou_in, const int* __restrict__ num_fg, HeadLevels lv,
-                                                         int B, int G, int nc, float* __restrict__ draw, float* __restrict__ acc) {
+                                                         int B, int G, int nc, int use_l1, float* __restrict__ draw,
+                                                         float* __restrict__ acc) {
   const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, no = 5 + nc, A = lv.A;
   int nt = 0;
   for (int i = 0; i < B; ++i) nt += num_fg[i];
   const float inv = 1.0f / (float)(nt < 1 ? 1 : nt);
-  float l_iou = 0.f, l_obj = 0.f, l_cls = 0.f;
+  float l_iou = 0.f, l_obj = 0.f, l_cls = 0.f, l_l1 = 0.f;
   if (a < A) {
     const size_t ia = (size_t)b * A + a;
     const float* t = train + ia * no;
@@ -394,6 +395,16 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
       float ax, ay, as;
       lv.anchor(a, ax, ay, as);
       d[0] = d_cx * as; d[1] = d_cy * as; d[2] = d_w * pw; d[3] = d_h * ph;
+      if (use_l1) {   // L1 on the RAW regression outputs against get_l1_target (yolo_head.py:199-208,391-398,426-430,445-450)
+        const float raw[4] = {px / as - ax, py / as - ay, logf(pw / as), logf(ph / as)};
+        const float tgt[4] = {gx / as - ax, gy / as - ay, logf(gw / as + 1e-8f), logf(gh / as + 1e-8f)};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float df = raw[q] - tgt[q];
+          l_l1 += fabsf(df);
+          d[q] += (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f)) * inv;
+        }
+      }
       // class loss: BCEWithLogits(cls_logit, one_hot * iou of the matching)
       int cls = (int)lab[0];
       cls = cls < 0 ? 0 : (cls >= nc ? nc - 1 : cls);
@@ -405,23 +416,23 @@ __global__ __launch_bounds__(256) void yolox_loss_kernel(const float* __restrict
       }
     }
   }
-  l_iou = wave_sum(l_iou); l_obj = wave_sum(l_obj); l_cls = wave_sum(l_cls);
-  __shared__ float red[3][4];
+  l_iou = wave_sum(l_iou); l_obj = wave_sum(l_obj); l_cls = wave_sum(l_cls); l_l1 = wave_sum(l_l1);
+  __shared__ float red[4][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { red[0][wave] = l_iou; red[1][wave] = l_obj; red[2][wave] = l_cls; }
+  if (lane == 0) { red[0][wave] = l_iou; red[1][wave] = l_obj; red[2][wave] = l_cls; red[3][wave] = l_l1; }
   __syncthreads();
-  if (threadIdx.x < 3) atomicAdd(acc + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
+  if (threadIdx.x < 4) atomicAdd(acc + threadIdx.x, (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]));
 }
-// losses[0..4] = loss, 5 * iou, obj, cls, num_fg / max(num_gts, 1)   (yolo_head.py:412-443)
+// losses[0..5] = loss, 5 * iou, obj, cls, l1, num_fg / max(num_gts, 1)   (yolo_head.py:412-443)
 __global__ void yolox_loss_finish_kernel(const float* __restrict__ acc, const int* __restrict__ num_fg, const int* __restrict__ nlabel,
                                          int B, float* __restrict__ losses) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   int nf = 0, ng = 0;
   for (int i = 0; i < B; ++i) { nf += num_fg[i]; ng += nlabel[i]; }
   const float n = (float)(nf < 1 ? 1 : nf);
-  const float li = 5.f * acc[0] / n, lo = acc[1] / n, lc = acc[2] / n;
-  losses[0] = li + lo + lc; losses[1] = li; losses[2] = lo; losses[3] = lc;
-  losses[4] = n / (float)(ng < 1 ? 1 : ng);
+  const float li = 5.f * acc[0] / n, lo = acc[1] / n, lc = acc[2] / n, l1 = acc[3] / n;
+  losses[0] = li + lo + lc + l1; losses[1] = li; losses[2] = lo; losses[3] = lc; losses[4] = l1;
+  losses[5] = n / (float)(ng < 1 ? 1 : ng);
 }
 
 // ---------------------------------------------------------------- post-processing: confidence filter + class-aware NMS
@@ -610,7 +621,7 @@ size_t sast_yolox_loss_ws_bytes(int B, int anchors_total, int max_labels) {
               + 8);              /* loss accumulators */
 }
 
-int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes,
+int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes, int use_l1,
                     float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   HeadLevels lv;
@@ -635,7 +646,7 @@ int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadG
   hipLaunchKernelGGL(simota_resolve_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, cost, iou, nlabel, A, G, cnt, fg_mask, matched_gt,
                      matched_iou, num_fg);
   hipLaunchKernelGGL(yolox_loss_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, fg_mask, matched_gt, matched_iou, num_fg, lv,
-                     B, G, num_classes, draw, acc);
+                     B, G, num_classes, use_l1, draw, acc);
   hipLaunchKernelGGL(yolox_loss_finish_kernel, dim3(1), dim3(64), 0, st, acc, num_fg, nlabel, B, losses);
   SAST_CHECK_LAUNCH();
   return SAST_OK;

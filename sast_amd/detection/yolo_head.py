@@ -6,7 +6,7 @@ like `decode_outputs` when `decode_in_inference` is set.  The 15 Conv+BN+SiLU un
 (`sast_conv_bn_silu_fwd`, running statistics), the three 1x1 prediction convs + sigmoid + box decode of a level are one kernel
 (`sast_head_pred_fwd`).  The TRAINING branch (yolo_head.py:291-606) runs the SimOTA assignment and the IoU / objectness /
 class losses on the device for the whole batch without a host sync (`sast_yolox_loss`); `use_l1` (off by default in the
-reference) is not implemented."""
+reference) is supported."""
 from __future__ import annotations
 
 import math
@@ -62,8 +62,6 @@ class YOLOXHead(nn.Module):
     def forward_train_nhwc(self, feats, labels):
         """training branch: feats three (B,H,W,C) NHWC maps (autograd tensors), labels (B, max_labels, 5) = (cls, cx, cy, w, h)
         -> (predictions (B, A, 5+nc), losses dict like yolo_head.py:224-231)"""
-        if self.use_l1:
-            raise NotImplementedError("sast_amd: use_l1 is not implemented")
         per_level, levels = [], []
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x)
@@ -75,11 +73,12 @@ class YOLOXHead(nn.Module):
             cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
             per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
             levels.append((x.shape[1], x.shape[2], stride))
-        losses, pred, fg, mg, piou = SF.head_pred_loss(labels, levels, self.num_classes, self.decode_in_inference, per_level)
+        losses, pred, fg, mg, piou = SF.head_pred_loss(labels, levels, self.num_classes, self.decode_in_inference, per_level, self.use_l1)
         self.last_assignment = (fg, mg, piou)      # SimOTA result of this step (device tensors), for inspection / tests
         self.hw = [(h, w) for h, w, _ in levels]
         det = losses.detach()
-        return pred, {"loss": losses[0], "iou_loss": det[1], "conf_loss": det[2], "cls_loss": det[3], "l1_loss": 0.0, "num_fg": det[4]}
+        return pred, {"loss": losses[0], "iou_loss": det[1], "conf_loss": det[2], "cls_loss": det[3], "l1_loss": det[4] if self.use_l1 else 0.0,
+                      "num_fg": det[5]}
 
     @torch.no_grad()
     def forward_nhwc(self, feats):

@@ -693,10 +693,10 @@ def adamw_step(p, g, m, v, lr_step, beta1=0.9, beta2=0.999, eps=1e-8, weight_dec
 class _HeadPredLoss(torch.autograd.Function):
     """prediction convs of all levels + SimOTA assignment + losses (yolo_head.py:184-246,291-606) as one autograd node.
     inputs per level: reg_feat, cls_feat (B,H,W,hidden NHWC), w_reg, b_reg, w_obj, b_obj, w_cls, b_cls.
-    -> losses (5,) = loss, 5*iou, conf, cls, num_fg ratio (only [0] carries a gradient) and the inference-style predictions."""
+    -> losses (6,) = loss, 5*iou, conf, cls, l1, num_fg ratio (only [0] carries a gradient) and the inference-style predictions."""
 
     @staticmethod
-    def forward(ctx, labels, levels, num_classes, decode, *t):
+    def forward(ctx, labels, levels, num_classes, decode, use_l1, *t):
         nlev = len(levels)
         assert len(t) == 8 * nlev
         rf0 = t[0]
@@ -724,13 +724,13 @@ class _HeadPredLoss(torch.autograd.Function):
                                                w_cls.data_ptr(), b_cls.data_ptr(), pred.data_ptr(), train.data_ptr(), B, int(h), int(w), hid,
                                                num_classes, float(s), off, A, int(decode), _stream()), "head_pred_fwd")
             off += int(h) * int(w)
-        losses = torch.empty(5, device=dev)
+        losses = torch.empty(6, device=dev)
         draw = torch.empty(B, A, no, device=dev)
         fg = torch.empty(B, A, device=dev, dtype=torch.int32)
         mg = torch.empty(B, A, device=dev, dtype=torch.int32)
         piou = torch.empty(B, A, device=dev)
         ws = torch.empty(L.lib().sast_yolox_loss_ws_bytes(B, A, G), device=dev, dtype=torch.uint8)
-        L.check(L.lib().sast_yolox_loss(train.data_ptr(), labels.data_ptr(), C.byref(geom), B, G, num_classes, losses.data_ptr(), draw.data_ptr(),
+        L.check(L.lib().sast_yolox_loss(train.data_ptr(), labels.data_ptr(), C.byref(geom), B, G, num_classes, int(use_l1), losses.data_ptr(), draw.data_ptr(),
                                         fg.data_ptr(), mg.data_ptr(), piou.data_ptr(), ws.data_ptr(), _stream()), "yolox_loss")
         ctx.save_for_backward(draw, *[x for pair in feats for x in pair])
         ctx.params = [t[8 * k + 2:8 * k + 8] for k in range(nlev)]
@@ -744,7 +744,7 @@ class _HeadPredLoss(torch.autograd.Function):
         feats = ctx.saved_tensors[1:]
         levels, num_classes, B, A, hid = ctx.meta
         draw = (draw * dlosses[0]).contiguous()          # only losses[0] (the total) is a training signal
-        grads = [None, None, None, None]
+        grads = [None, None, None, None, None]
         off = 0
         for k, (h, w, _s) in enumerate(levels):
             rf, cf = feats[2 * k], feats[2 * k + 1]
@@ -759,11 +759,11 @@ class _HeadPredLoss(torch.autograd.Function):
         return tuple(grads)
 
 
-def head_pred_loss(labels, levels, num_classes, decode, per_level_tensors):
+def head_pred_loss(labels, levels, num_classes, decode, per_level_tensors, use_l1=False):
     """levels: [(H, W, stride)]; per_level_tensors: [(reg_feat, cls_feat, w_reg, b_reg, w_obj, b_obj, w_cls, b_cls)]
-    -> (losses(5,), pred, fg_mask (B,A) int32, matched_gt (B,A) int32 (-1 = background), matched_iou (B,A))"""
+    -> (losses(6,), pred, fg_mask (B,A) int32, matched_gt (B,A) int32 (-1 = background), matched_iou (B,A))"""
     flat = [x for lv in per_level_tensors for x in lv]
-    return _HeadPredLoss.apply(labels, tuple((int(h), int(w), float(s)) for h, w, s in levels), int(num_classes), bool(decode), *flat)
+    return _HeadPredLoss.apply(labels, tuple((int(h), int(w), float(s)) for h, w, s in levels), int(num_classes), bool(decode), bool(use_l1), *flat)
 
 
 @torch.no_grad()

@@ -289,6 +289,32 @@ def test_yolox_head_train_vs_golden(golden_dir, dev):
         maxnorm_close(named[k].grad, torch.from_numpy(g["g_" + k]), GRAD_RTOL, k)
 
 
+def test_yolox_loss_use_l1(golden_dir, dev):
+    """the optional L1 term (head.use_l1).  The reference's own use_l1 branch cannot run (yolo_head.py:199-212 reshapes reg_output
+    and then concatenates it with 4-D maps), so this is pinned by the oracle's reading of get_l1_target (:445-450) only."""
+    from sast_amd.detection import YOLOXHead
+    g = _load(golden_dir, "head_train")
+    chans, nc = (64, 128, 256), int(g["num_classes"])
+    params = O.init_head_params(chans, num_classes=nc, seed=int(g["seed"]))
+    head = YOLOXHead(num_classes=nc, strides=(8, 16, 32), in_channels=chans).to(dev)
+    load_params(head, params)
+    head.train()
+    head.use_l1 = True
+    feats = tuple(torch.from_numpy(g[f"in{i}"]).to(dev).requires_grad_(True) for i in range(3))
+    labels = torch.from_numpy(g["labels"])
+    _out, losses = head(feats, labels.to(dev))
+    losses["loss"].backward()
+    fo = [torch.from_numpy(g[f"in{i}"]).requires_grad_(True) for i in range(3)]
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in params.items()}
+    ref = O.yolox_head_train(fo, labels, po, num_classes=nc, use_l1=True)
+    ref["loss"].backward()
+    assert float(ref["l1_loss"]) > 0.1
+    for k in ("loss", "l1_loss"):
+        assert abs(float(losses[k]) - float(ref[k])) <= 2e-5 * max(1.0, abs(float(ref[k]))), k
+    for a, b in zip(feats, fo):
+        maxnorm_close(a.grad, b.grad, GRAD_RTOL, "d feat (use_l1)")
+
+
 def test_yolox_loss_full_size(dev):
     """1Mpx-sized head (5040 anchors, B=4, up to 24 boxes per image incl. an image without labels): assignment and losses vs the oracle."""
     from sast_amd.detection import YOLOXHead
