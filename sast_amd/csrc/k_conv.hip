@@ -87,15 +87,16 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // backward pass 1: sums[c] += dz, sums[C+c] += dz * xhat, with dz = dy * silu'(z).
 // One block owns a strip of rows and ALL channels (fully coalesced float4 rows), reduces over its rows in LDS and
 // issues one atomic per channel -> (M / rows_per_block) * 2C atomics in total.
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+constexpr int BN_RED_THREADS = 1024;   // few workgroups (one atomic per channel and workgroup), many waves each: per-CU bandwidth needs the loads in flight
+__global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ dy, int lddy, int M, int C,
                                                             float* __restrict__ sums, int rows_per_block) {
   extern __shared__ float4 red[];                 // [RP][C/4][2]
   const int c4n = C / 4;
-  const int RP = 256 / c4n > 0 ? 256 / c4n : 1;   // rows processed in parallel by the block
+  const int RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;   // rows processed in parallel by the block
   const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-  for (int cq = threadIdx.x % min(c4n, 256); cq < c4n; cq += 256) {
+  for (int cq = threadIdx.x % min(c4n, BN_RED_THREADS); cq < c4n; cq += BN_RED_THREADS) {
     const int rl = threadIdx.x / c4n;
     const int c = cq * 4;
     float4 a = zero4(), b = zero4();
@@ -356,8 +357,8 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   int rpb = (M + target - 1) / target;
   rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
   {
-    const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(float4) * 2 * RP * c4n, st, a->conv_out, a->stats,
+    const int c4n = C / 4, RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, a->conv_out, a->stats,
                        a->bn_w, a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
   }
   const size_t n4 = (size_t)M * (C / 4);
