@@ -33,9 +33,15 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hi
   return gemm_auto(la, lb, ep, M, NJ, R, nullptr, st);
 }
 
-inline int tn_splits(int Mo, int NJ, int R) {
+// inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (192 measured best; a target
+// that adapts to the dX job's grid size was not better)
+inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 192); return v; }
+
+// target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)
+inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
   const int nb = ((Mo + 63) / 64) * ((NJ + 63) / 64);
-  int splits = (pair_tn_blocks() + nb - 1) / nb;
+  if (target <= 0) target = pair_tn_blocks();
+  int splits = (target + nb - 1) / nb;
   const int max_splits = (R + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   return splits < 1 ? 1 : splits;
@@ -56,10 +62,10 @@ int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int
 template <class LA1, class LB1, class LA2, class LB2, class EP2>
 int gemm_pair(const LA1& la1, const LB1& lb1, float* out, int ldc, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
               const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st) {
-  const int splits = tn_splits(Mo, NJ1, R1);
   const EpAtomic ep1{out, ldc};
   const long nb2 = (long)((M2 + 63) / 64) * ((NJ2 + 63) / 64);
   const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
+  const int splits = tn_splits(Mo, NJ1, R1, gemm_pair_enabled() ? pair_tn_blocks_paired() : 0);
   if (!gemm_pair_enabled() || Mo <= 0 || NJ1 <= 0 || R1 <= 0 || M2 <= 0 || NJ2 <= 0 || R2 <= 0) {
     int rc = launch_gemm_split<TileSmallK2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);
     if (rc) return rc;
