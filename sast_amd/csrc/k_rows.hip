@@ -283,17 +283,23 @@ __device__ __forceinline__ void ln_row_bwd(const float4 (&x)[VPL], float4 (&dy)[
 }
 
 // block-level reduction of per-thread channel partials into global accumulators (atomicAdd)
+// threads per workgroup of the backward row kernels (the ones that end in per-channel atomics): few workgroups, many waves each
+#ifndef SAST_ROWB_THREADS
+#define SAST_ROWB_THREADS 1024
+#endif
+constexpr int ROWB = SAST_ROWB_THREADS;
+
 template <int GL, int VPL>
-__device__ __forceinline__ void flush_channel_partials(float* red /* [256/GL][C] in LDS */, const float4 (&p)[VPL],
+__device__ __forceinline__ void flush_channel_partials(float* red /* [ROWB/GL][C] in LDS */, const float4 (&p)[VPL],
                                                        float* __restrict__ gout) {
   using IO = RowIO<GL, VPL>;
   const int gl = threadIdx.x % GL, grp = threadIdx.x / GL;
-  constexpr int NG = 256 / GL;
+  constexpr int NG = ROWB / GL;
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < VPL; ++i) st4(red + grp * IO::C + (i * GL + gl) * 4, p[i]);
   __syncthreads();
-  for (int c = threadIdx.x; c < IO::C; c += 256) {
+  for (int c = threadIdx.x; c < IO::C; c += ROWB) {
     float s = 0.f;
     for (int g = 0; g < NG; ++g) s += red[g * IO::C + c];
     atomicAdd(gout + c, s);
@@ -301,14 +307,14 @@ __device__ __forceinline__ void flush_channel_partials(float* red /* [256/GL][C]
 }
 
 template <int GL, int VPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(ROWB) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
   using IO = RowIO<GL, VPL>;
   extern __shared__ float red[];
   const int gl = threadIdx.x % GL;
-  constexpr int RPB = 256 / GL;
+  constexpr int RPB = ROWB / GL;
   float4 gm[VPL], dg[VPL], db[VPL];
   IO::load(gamma, gm, gl);
 #pragma unroll
@@ -361,8 +367,8 @@ int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* bet
 int ln_bwd_launch(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
                   float* dgamma, float* dbeta, int rows, int C, hipStream_t st) {
   if (rows <= 0) return SAST_OK;
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, 256 / GL)), dim3(256),
-                                        sizeof(float) * (256 / GL) * C, st, x, dy, gamma, mean, rstd, dx, dgamma, dbeta, rows));
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, ROWB / GL)), dim3(ROWB),
+                                        sizeof(float) * (ROWB / GL) * C, st, x, dy, gamma, mean, rstd, dx, dgamma, dbeta, rows));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(256) void ln1_gather_fwd_kernel(const float* __rest
 
 // backward of the above.  dout: grad w.r.t. layer output (image layout); dsc: grad w.r.t. compact S rows.
 template <int GL, int VPL>
-__global__ __launch_bounds__(256) void ln1_gather_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dout,
+__global__ __launch_bounds__(ROWB) void ln1_gather_bwd_kernel(const float* __restrict__ xin, const float* __restrict__ dout,
                                                              const float* __restrict__ dsc, const int* __restrict__ tok_slot,
                                                              const float* __restrict__ g1, const float* __restrict__ b1,
                                                              const float* __restrict__ g2,
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256) void ln1_gather_bwd_kernel(const float* __rest
   using IO = RowIO<GL, VPL>;
   extern __shared__ float red[];
   const int gl = threadIdx.x % GL;
-  constexpr int RPB = 256 / GL;
+  constexpr int RPB = ROWB / GL;
   float4 gm1[VPL], bt1[VPL], gm2[VPL], a1[VPL], c1[VPL], a2[VPL], c2[VPL];
   IO::load(g1, gm1, gl);
   IO::load(b1, bt1, gl);
@@ -460,8 +466,8 @@ int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc,
                           const float* b1, const float* g2, const float* mean1, const float* rstd1, const float* mean2,
                           const float* rstd2, float* dxin, float* dg1, float* db1, float* dg2, float* db2, int rows, int C,
                           hipStream_t st) {
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, 256 / GL)), dim3(256),
-                                        sizeof(float) * (256 / GL) * C, st, xin, dout, dsc, tok_slot, g1, b1, g2, mean1, rstd1,
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, ROWB / GL)), dim3(ROWB),
+                                        sizeof(float) * (ROWB / GL) * C, st, xin, dout, dsc, tok_slot, g1, b1, g2, mean1, rstd1,
                                         mean2, rstd2, dxin, dg1, db1, dg2, db2, rows));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -527,14 +533,14 @@ __global__ __launch_bounds__(256) void stp_fwd_kernel(const float* __restrict__ 
 //   dz[m,c]     = g * xp * sig(scale) * sig(s) * (1 - sig(s)) * [s > 0]
 //   dscale[b,c]+= g * xp * sig(s) * sig(scale) * (1 - sig(scale))
 template <int GL, int VPL>
-__global__ __launch_bounds__(256) void stp_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ s,
+__global__ __launch_bounds__(ROWB) void stp_bwd_kernel(const float* __restrict__ xp, const float* __restrict__ s,
                                                       const float* __restrict__ scale, const float* __restrict__ g,
                                                       float* __restrict__ direct, float* __restrict__ dz,
                                                       float* __restrict__ dscale, int L, int rows_per_block) {
   using IO = RowIO<GL, VPL>;
   extern __shared__ float red[];
   const int gl = threadIdx.x % GL;
-  constexpr int RPB = 256 / GL;
+  constexpr int RPB = ROWB / GL;
   const int b = blockIdx.y;
   float4 sc[VPL], ds[VPL];
   IO::load(scale + (size_t)b * IO::C, sc, gl);
@@ -599,8 +605,8 @@ int stp_bwd_launch(const float* xp, const float* s, const float* scale, const fl
                    float* dscale, int B, int L, int C, hipStream_t st) {
   // dscale must be zeroed by the caller
   const int rpb = L >= 8192 ? 128 : (L >= 1024 ? 64 : 32);   // >= ~120 blocks per sample at every stage
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_bwd_kernel<GL, VPL>), dim3((L + rpb - 1) / rpb, B), dim3(256),
-                                        sizeof(float) * (256 / GL) * C, st, xp, s, scale, g, direct, dz, dscale, L, rpb));
+  SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_bwd_kernel<GL, VPL>), dim3((L + rpb - 1) / rpb, B), dim3(ROWB),
+                                        sizeof(float) * (ROWB / GL) * C, st, xp, s, scale, g, direct, dz, dscale, L, rpb));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
