@@ -159,6 +159,11 @@ int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream);
 int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);
 
 /* a13  BaseConv = Conv2d(no bias, same pad) + BatchNorm2d + SiLU -- yolox/models/network_blocks.py:29-54 */
+/* the conv epilogue accumulates the batch statistics with atomics; same-address atomics serialise at the memory side, so
+   the row tiles spread them over SAST_BN_STAT_COPIES copies that the BatchNorm kernel adds up */
+#define SAST_BN_STAT_COPIES 4
+#define SAST_BN_WS_FLOATS(Cout) ((4 * SAST_BN_STAT_COPIES + 4) * (Cout))
+int sast_conv_bn_ws_floats(int Cout);   /* = SAST_BN_WS_FLOATS(Cout), for hosts that cannot read the macro */
 typedef struct SastConvBnArgs {
   int32_t B, H, W, Cin, Cout, ksize, stride, training;
   int32_t ldx, ldy, lddy, lddx;   /* channel strides of x, y, dy, dx rows (slices of concat buffers) */
@@ -173,7 +178,8 @@ typedef struct SastConvBnArgs {
   float* y;
   /* backward */
   const float* dy; float* dx; float* dw; float* d_bn_w; float* d_bn_b;
-  float* bn_ws;          /* fp32[8*Cout] reduction scratch: fwd uses [0,4C) as fp64 sums, bwd uses [4C,6C) */
+  float* bn_ws;          /* fp32[SAST_BN_WS_FLOATS(Cout)] reduction scratch: fwd uses the first 4*COPIES*C floats as fp64
+                            [COPIES][sum | sum of squares][C], bwd the 2C floats after them */
   float* ws;             /* bwd only: fp32[M*Cout] (dconv) */
   const float* x2;       /* second input of the virtual concat (NULL = single input) */
   float* dx2;            /* its gradient, dense [M, Cin - Cin1] */

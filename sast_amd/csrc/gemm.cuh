@@ -31,6 +31,7 @@
 #include <type_traits>
 #include <hip/hip_ext.h>
 #include "common.cuh"
+#include "../../include/sast_hip.h"
 
 // per-block phase timestamps for the micro-benchmarks (k_test.hip defines SAST_TL before including this header; the
 // product translation units compile it away)
@@ -71,7 +72,8 @@ struct LdsLd {
 };
 
 // epilogues may ask for per-column sum / sum-of-squares of the stored values (BatchNorm batch statistics fused
-// into the producing conv): EP::COLSTATS = true, EP::sums -> double[2*EP::C]
+// into the producing conv): EP::COLSTATS = true, EP::sums -> double[BN_STAT_COPIES][2*NJ] (the consumer adds the copies)
+constexpr int BN_STAT_COPIES = SAST_BN_STAT_COPIES;
 // a B-side loader may depend on the block's row tile (LdWeightConvDxP: the parity class of the rows decides the taps)
 template <class L, class = void> struct LoaderWantsM0 : std::false_type {};
 template <class L> struct LoaderWantsM0<L, std::void_t<decltype(L::WANTS_M0)>> : std::bool_constant<L::WANTS_M0> {};
@@ -402,7 +404,9 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     for (int tj = 0; tj < T::TJ; ++tj) {
       const float s = cs[tj] + __shfl_xor(cs[tj], 32, 64), q = cq[tj] + __shfl_xor(cq[tj], 32, 64);
       const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
-      if (lane < 32 && j < NJ) { atomicAdd(ep.sums + j, (double)s); atomicAdd(ep.sums + NJ + j, (double)q); }
+// same-address atomics serialise at the memory side: the row tiles spread their adds over BN_STAT_COPIES copies
+      double* sp = ep.sums + (size_t)(((m0 / BM) * T::WAVES_M + wm) % BN_STAT_COPIES) * 2 * NJ;
+      if (lane < 32 && j < NJ) { atomicAdd(sp + j, (double)s); atomicAdd(sp + NJ + j, (double)q); }
     }
   }
   SAST_TL(4);
@@ -892,7 +896,7 @@ struct EpStore {  // C[m*ldc + j] = v (+bias)
     c[(size_t)m * ldc + j] = v[0] + k.b;
   }
 };
-struct EpStoreStats {  // C[m*ldc + j] = v ; sums[j] += v ; sums[NJ + j] += v*v   (conv -> BatchNorm batch statistics)
+struct EpStoreStats {  // C[m*ldc + j] = v ; sums[copy][j] += v ; sums[copy][NJ + j] += v*v   (conv -> BatchNorm batch statistics)
   static constexpr bool COLSTATS = true;
   float* c; int ldc; double* sums;
   using Col = EpNone; using Aux = EpNone;

@@ -12,43 +12,53 @@ using namespace sast;
 namespace {
 
 // ---------------------------------------------------------------- BatchNorm pieces
-// y = silu(BN(x)); training: batch statistics from the fp64 column sums the conv epilogue accumulated; the threads that
-// own row 0 also publish (mean, rstd) for the backward and update the running statistics (torch BatchNorm2d semantics:
-// momentum, unbiased variance).  eval: running statistics.
+// y = silu(BN(x)); training: batch statistics from the fp64 column sums the conv epilogue accumulated (BN_STAT_COPIES
+// copies, added here); every block derives (mean, rstd) of all channels into LDS once and then streams `iters` x 256
+// float4 of the image; block 0 also publishes (mean, rstd) for the backward and updates the running statistics (torch
+// BatchNorm2d semantics: momentum, unbiased variance).  eval: running statistics.
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restrict__ x, const double* __restrict__ sums, int M, float eps,
                                                             float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
                                                             float* __restrict__ stats, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y, int ldy, size_t n4, int C,
-                                                            int training) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  const int c4 = C / 4;
-  const size_t m = e / c4; const int c = (int)(e % c4) * 4;
-  float mu[4], rs[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
+                                                            int training, int iters) {
+  extern __shared__ float bn_sm[];   // [2C]: scale = rstd * gamma, shift = beta - mean * scale
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float mu, rs;
     if (training) {
-      const double mean = sums[c + k] / M;
-      double var = sums[C + c + k] / M - mean * mean;
+      double s = 0.0, q = 0.0;
+#pragma unroll
+      for (int k = 0; k < BN_STAT_COPIES; ++k) { s += sums[(size_t)k * 2 * C + c]; q += sums[(size_t)k * 2 * C + C + c]; }
+      const double mean = s / M;
+      double var = q / M - mean * mean;
       if (var < 0) var = 0;
-      mu[k] = (float)mean;
-      rs[k] = (float)(1.0 / sqrt(var + (double)eps));
-      if (m == 0 && run_mean) {
+      mu = (float)mean;
+      rs = (float)(1.0 / sqrt(var + (double)eps));
+      if (blockIdx.x == 0 && run_mean) {
         const double unb = M > 1 ? var * M / (M - 1) : var;
-        run_mean[c + k] = (1.f - momentum) * run_mean[c + k] + momentum * (float)mean;
-        run_var[c + k] = (1.f - momentum) * run_var[c + k] + momentum * (float)unb;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
       }
     } else {
-      mu[k] = run_mean[c + k];
-      rs[k] = 1.0f / sqrtf(run_var[c + k] + eps);
+      mu = run_mean[c];
+      rs = 1.0f / sqrtf(run_var[c] + eps);
     }
-    if (m == 0) { stats[c + k] = mu[k]; stats[C + c + k] = rs[k]; }
+    if (blockIdx.x == 0) { stats[c] = mu; stats[C + c] = rs; }
+    bn_sm[c] = mu; bn_sm[C + c] = rs;
   }
-  const float4 v = ld4(x + m * C + c), g = ld4(gamma + c), b = ld4(beta + c);
-  float4 z = make_float4((v.x - mu[0]) * rs[0] * g.x + b.x, (v.y - mu[1]) * rs[1] * g.y + b.y, (v.z - mu[2]) * rs[2] * g.z + b.z,
-                         (v.w - mu[3]) * rs[3] * g.w + b.w);
-  z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
-  st4(y + m * ldy + c, z);
+  __syncthreads();
+  const int c4 = C / 4;
+  const size_t e0 = (size_t)blockIdx.x * 256 * iters + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    const size_t e = e0 + (size_t)it * 256;
+    if (e >= n4) return;
+    const size_t m = e / c4; const int c = (int)(e % c4) * 4;
+    const float4 v = ld4(x + m * C + c), g = ld4(gamma + c), b = ld4(beta + c);
+    const float4 mu = *(const float4*)(bn_sm + c), rs = *(const float4*)(bn_sm + C + c);
+    float4 z = make_float4((v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z,
+                           (v.w - mu.w) * rs.w * g.w + b.w);
+    z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
+    st4(y + m * ldy + c, z);
+  }
 }
 // forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
 // fp64 per-channel sum / sum of squares, one atomic pair per channel per block.
@@ -303,6 +313,8 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
 }
 
 // ------------------------------------------------------------------ conv + BN + SiLU
+int sast_conv_bn_ws_floats(int Cout) { return SAST_BN_WS_FLOATS(Cout); }
+
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("convbn_fwd", a ? a->Cout * 10 + a->ksize : 0, a ? a->B * a->H * a->W : 0, st);
@@ -311,7 +323,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
   double* sums = (double*)a->bn_ws;
-  if (a->training && !a->bn_ws_zeroed) zero_fill(a->bn_ws, sizeof(float) * 8 * C, st);
+  if (a->training && !a->bn_ws_zeroed) zero_fill(a->bn_ws, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
   int rc;
   static int sep = -1;
   if (sep < 0) { const char* e = getenv("SAST_BN_STATS_SEPARATE"); sep = e ? atoi(e) : 0; }
@@ -337,8 +349,11 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
     hipLaunchKernelGGL(bn_stats_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(double) * 2 * RP * C, st, a->conv_out, M, C, sums, rpb);
   }
   const size_t n4 = (size_t)M * (C / 4);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, sums, M, a->eps, a->momentum,
-                     a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, n4, C, a->training);
+  int iters = (int)(n4 / (256 * 512));     // >= 512 blocks while the image allows it; the per-block statistics prologue is 2C*COPIES loads
+  iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters))), dim3(256), sizeof(float) * 2 * C, st,
+                     a->conv_out, sums, M, a->eps, a->momentum, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, n4, C,
+                     a->training, iters);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -349,7 +364,7 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const int k = a->ksize, pad = (k - 1) / 2;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
-  float* sums = a->bn_ws + 4 * C;      // [2C]
+  float* sums = a->bn_ws + 4 * BN_STAT_COPIES * C;      // [2C]
   float* dconv = a->ws;                // [M, C]
   if (!a->bn_ws_zeroed) zero_fill(sums, sizeof(float) * 2 * C, st);
   static int target = -1;

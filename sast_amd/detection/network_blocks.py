@@ -24,7 +24,7 @@ class BaseConv(nn.Module):
         """arena: optional `BnArena` handing out zero-filled reduction scratch (one memset per FPN forward) and
         batching the num_batches_tracked increments."""
         bn = self.bn
-        ws = arena.take(8 * bn.num_features) if arena is not None else None
+        ws = arena.take(SF.bn_ws_floats(bn.num_features)) if arena is not None else None
         y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
                             self.training, bn.momentum, bn.eps, ws)
         if self.training and bn.num_batches_tracked is not None:

@@ -35,7 +35,7 @@ class YOLOPAFPN(nn.Module):
     def forward_nhwc(self, feats: Dict[int, object]):
         x2, x1, x0 = (feats[f] for f in self.in_features)
         if not hasattr(self, "_bn_floats"):
-            self._bn_floats = sum(8 * m.num_features for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+            self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         ar = BnArena(self._bn_floats, x0.device)                            # one memset for all 32 BatchNorm reductions
         fpn_out0 = self.lateral_conv0.forward_nhwc(x0, ar)
         f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1), ar)  # nearest-exact x2 + cat (yolo_pafpn.py:118-121)

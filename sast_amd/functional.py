@@ -594,7 +594,7 @@ class _ConvBnSilu(torch.autograd.Function):
         stats = torch.empty(2 * Cout, device=dev)
         y = torch.empty(B, Ho, Wo, Cout, device=dev)
         if bn_ws is None:  # zero-filled reduction scratch (a whole FPN passes slices of one arena: one memset per step)
-            bn_ws = torch.zeros(8 * Cout, device=dev)
+            bn_ws = torch.zeros(bn_ws_floats(Cout), device=dev)
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin1,
                   ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
                   run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1)
@@ -622,9 +622,14 @@ class _ConvBnSilu(torch.autograd.Function):
         return (dx, dx2) + (None,) * 11
 
 
+def bn_ws_floats(cout: int) -> int:
+    """floats of BatchNorm reduction scratch one conv_bn_silu call consumes (include/sast_hip.h: SAST_BN_WS_FLOATS)"""
+    return int(L.lib().sast_conv_bn_ws_floats(int(cout)))
+
+
 def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None):
     """x_nhwc: a tensor, or a pair (xa, xb) standing for their channel concat (1x1 convs; the concat is never built).
-    bn_ws: optional zero-filled fp32[8*Cout] scratch (consumed: do not reuse within a step)."""
+    bn_ws: optional zero-filled fp32[bn_ws_floats(Cout)] scratch (consumed: do not reuse within a step)."""
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
     return _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws)
 
