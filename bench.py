@@ -115,7 +115,8 @@ class Trainer:
             _pred, losses = self.head.forward_train_nhwc(outs, self.labels)
             loss = losses["loss"]
         else:
-            loss = sum((o * o).mean() for o in outs)
+            from sast_amd import functional as SF
+            loss = SF.mean_squares(*outs)     # = sum((o * o).mean() for o in outs), one launch each way
         loss.backward()
         self.loss, self.P = loss.detach(), P
 

@@ -47,6 +47,14 @@ int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast
 
 /* a3  x + pos_emb(x) -- SAST.py:105 with the constant sine table of sast_rnn.py:180-219: y[row] = x[row] + table[row % table_rows] */
 int sast_add_rows(const float* x, const float* table, float* y, int rows, int C, int table_rows, sast_stream_t stream);
+
+/* mean squares of up to 4 dense fp32 tensors in one launch: partials[t*SAST_MEAN_SQUARE_BLOCKS + b], whose sum is
+   sum_t mean(x_t^2) -- the synthetic training objective of bench.py (the reference's benchmark.py has no loss; its real
+   objective is sast_yolox_loss).  x / n / dx are HOST arrays of `count` device pointers / element counts (n % 4 == 0). */
+#define SAST_MEAN_SQUARE_BLOCKS 32
+int sast_mean_square_fwd(const float* const* x, const size_t* n, int count, float* partials, sast_stream_t stream);
+int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, float* const* dx,
+                         sast_stream_t stream);
 /* a11  mask token (enable_masking) -- sast_rnn.py:271-273: x[token_mask] = mask_token, in place on the [rows, C] rows AFTER the first
  * block's position embedding was added (pos_emb [L, C] or NULL): masked rows become mask_token + pos_emb[row % L].
  * backward: dx = dy with masked rows zeroed, d_token += sum of the masked rows of dy. */

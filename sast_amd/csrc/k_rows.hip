@@ -743,6 +743,50 @@ int ls_linear_finish2_launch(const float* w0, const float* b0, const float* g0, 
   return SAST_OK;
 }
 
+// ============================================================ mean squares of up to 4 tensors in one launch
+// partials[t * MSQ_BLOCKS + b] = sum over block b's grid-stride share of x_t^2 / n_t  (their sum is sum_t mean(x_t^2), the
+// synthetic objective bench.py trains on); backward: dx_t = 2 x_t g[t, b] / n_t with the same element -> block mapping.
+struct MsqJob { const float* x[4]; float* dx[4]; unsigned long long n[4]; };
+__global__ __launch_bounds__(1024) void mean_square_fwd_kernel(MsqJob j, float* __restrict__ partials) {
+  __shared__ float red[16];
+  const int t = blockIdx.y;
+  const float* __restrict__ x = j.x[t];
+  const size_t n4 = j.n[t] / 4;
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 1024) {
+    const float4 v = ld4(x + 4 * i);
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int w = 0; w < 16; ++w) a += red[w];
+    partials[t * gridDim.x + blockIdx.x] = a / (float)j.n[t];
+  }
+}
+__global__ __launch_bounds__(1024) void mean_square_bwd_kernel(MsqJob j, const float* __restrict__ g) {
+  const int t = blockIdx.y;
+  const float* __restrict__ x = j.x[t];
+  float* __restrict__ dx = j.dx[t];
+  const size_t n4 = j.n[t] / 4;
+  const float k = 2.f * g[t * gridDim.x + blockIdx.x] / (float)j.n[t];
+  for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 1024) {
+    const float4 v = ld4(x + 4 * i);
+    st4(dx + 4 * i, make_float4(k * v.x, k * v.y, k * v.z, k * v.w));
+  }
+}
+int mean_square_launch(const float* const* x, float* const* dx, const size_t* n, int count, int blocks, float* partials,
+                       const float* g, hipStream_t st) {
+  MsqJob j{};
+  for (int t = 0; t < count; ++t) { j.x[t] = x[t]; j.dx[t] = dx ? dx[t] : nullptr; j.n[t] = n[t]; }
+  if (!dx) hipLaunchKernelGGL(mean_square_fwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, partials);
+  else hipLaunchKernelGGL(mean_square_bwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, g);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
 // ============================================================ Context Broadcasting (SAST.py:240-246)
 //   x_cb = 0.5 * m + 0.5 * mean_over_all_L_tokens_of_the_sample(m placed at the kept tokens, zero elsewhere)
 // Compact rows are in ascending (sample-major) group order by construction (k_select.hip / selection_from_index_lists), so a

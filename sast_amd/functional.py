@@ -116,6 +116,43 @@ def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
     return x_nhwc.permute(0, 3, 1, 2)
 
 
+MEAN_SQUARE_BLOCKS = 32   # include/sast_hip.h: SAST_MEAN_SQUARE_BLOCKS
+
+
+class _MeanSquares(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        _need_gpu(*xs)
+        xs = tuple(x.contiguous() for x in xs)
+        k = len(xs)
+        ptrs = (C.c_void_p * k)(*[x.data_ptr() for x in xs])
+        ns = (C.c_size_t * k)(*[x.numel() for x in xs])
+        partials = torch.empty(k * MEAN_SQUARE_BLOCKS, device=xs[0].device, dtype=torch.float32)
+        L.check(L.lib().sast_mean_square_fwd(ptrs, ns, k, partials.data_ptr(), _stream()), "mean_square_fwd")
+        ctx.save_for_backward(*xs)
+        return partials
+
+    @staticmethod
+    def backward(ctx, g):
+        xs = ctx.saved_tensors
+        k = len(xs)
+        g = g.contiguous()
+        dxs = tuple(torch.empty_like(x) for x in xs)
+        ptrs = (C.c_void_p * k)(*[x.data_ptr() for x in xs])
+        dptrs = (C.c_void_p * k)(*[d.data_ptr() for d in dxs])
+        ns = (C.c_size_t * k)(*[x.numel() for x in xs])
+        L.check(L.lib().sast_mean_square_bwd(ptrs, ns, k, g.data_ptr(), dptrs, _stream()), "mean_square_bwd")
+        return dxs
+
+
+def mean_squares(*xs: torch.Tensor) -> torch.Tensor:
+    """sum_t mean(x_t ** 2) of up to 4 fp32 tensors with one launch forward and one backward (bench.py's synthetic
+    objective on the PAFPN outputs; the partial sums are added by torch)."""
+    if not 1 <= len(xs) <= 4 or any(x.dtype != torch.float32 or x.numel() % 4 for x in xs):
+        raise ValueError("mean_squares: 1..4 fp32 tensors with numel % 4 == 0")
+    return _MeanSquares.apply(*xs).sum()
+
+
 class _AddRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, table):

@@ -704,3 +704,19 @@ def test_conv_reads_stay_inside_the_input_buffer(dev):
     torch.cuda.synchronize()
     del x, store
     hip.hipFree(ptr)
+
+
+def test_mean_squares_matches_torch(dev):
+    """bench.py's synthetic objective: sum_t mean(x_t^2) in one launch each way == the torch expression"""
+    from sast_amd import functional as SF
+    torch.manual_seed(3)
+    xs = [torch.randn(4, 12, 20, 64, device="cuda"), torch.randn(4, 6, 10, 128, device="cuda"), torch.randn(1000, device="cuda")]
+    a = [x.clone().requires_grad_(True) for x in xs]
+    b = [x.clone().requires_grad_(True) for x in xs]
+    la = SF.mean_squares(*a)
+    lb = sum((x * x).mean() for x in b)
+    (3.0 * la).backward()
+    (3.0 * lb).backward()
+    assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
+    for p, q in zip(a, b):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-9)
