@@ -181,7 +181,8 @@ typedef struct SastConvBnArgs {
   float momentum, eps;
   const float* x; const float* w; const float* bn_w; const float* bn_b;
   float* run_mean; float* run_var;  /* updated in training mode */
-  float* conv_out;       /* [M,Cout] saved, M = B*Ho*Wo */
+  float* conv_out;       /* [M,Cout] saved, M = B*Ho*Wo.  NULL with training == 0: inference, BatchNorm + SiLU run in the conv
+                            epilogue (one launch) and nothing is kept for a backward (stats unused) */
   float* stats;          /* [2*Cout] saved: mean, rstd actually used */
   float* y;
   /* backward */

@@ -60,6 +60,19 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restr
     st4(y + m * ldy + c, z);
   }
 }
+// eval mode with nothing saved for a backward: BatchNorm (running statistics) + SiLU applied in the conv epilogue, same
+// arithmetic order as bn_silu_apply_kernel
+struct EpBnSilu {
+  float* y; int ldy; const float* run_mean; const float* run_var; const float* gamma; const float* beta; float eps;
+  struct Col { float mu, rs, g, b; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const { return Col{run_mean[j], 1.0f / sqrtf(run_var[j] + eps), gamma[j], beta[j]}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
+    const float z = (v[0] - k.mu) * k.rs * k.g + k.b;
+    y[(size_t)m * ldy + j] = z * sigmoid_exact(z);
+  }
+};
 // forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
 // fp64 per-channel sum / sum of squares, one atomic pair per channel per block.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
@@ -330,6 +343,13 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const bool one = k == 1 && a->stride == 1;
   if (a->x2 && (!one || a->Cin1 % 4 || a->Cin1 <= 0 || a->Cin1 >= a->Cin)) return SAST_EINVAL;
   const LdRows2 la2{a->x, a->ldx, a->Cin1, a->x2, a->ldx2};    // virtual channel concat [x | x2]
+  if (!a->training && !a->conv_out) {   // inference: one launch, nothing kept for a backward
+    if (!a->run_mean || !a->run_var) return SAST_EINVAL;
+    const EpBnSilu ep{a->y, a->ldy, a->run_mean, a->run_var, a->bn_w, a->bn_b, a->eps};
+    return one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                        : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+               : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+  }
   if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
     rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)

@@ -668,7 +668,33 @@ def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, traini
     """x_nhwc: a tensor, or a pair (xa, xb) standing for their channel concat (1x1 convs; the concat is never built).
     bn_ws: optional zero-filled fp32[bn_ws_floats(Cout)] scratch (consumed: do not reuse within a step)."""
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
+    if not training and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, x2, w, bn_w, bn_b))):
+        return _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, float(eps))
     return _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws)
+
+
+def _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, eps):
+    """eval mode, no autograd: conv + BatchNorm(running statistics) + SiLU in ONE launch (BN + SiLU in the GEMM epilogue)."""
+    _need_gpu(x, w)
+    x = x.contiguous()
+    if not is_channels_last_weight(w):
+        raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
+    B, H, W, Cin = x.shape
+    Cin1 = Cin
+    if x2 is not None:
+        if ksize != 1 or stride != 1 or x2.shape[:3] != x.shape[:3]:
+            raise RuntimeError("sast_amd: a two-source input is supported for 1x1 stride-1 convs of equal spatial size")
+        x2 = x2.contiguous()
+        Cin = Cin1 + x2.shape[-1]
+    Cout = w.shape[0]
+    pad = (ksize - 1) // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device)
+    a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=0, ldx=Cin1, ldy=Cout,
+              bn_ws_zeroed=1, momentum=0.0, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=run_mean, run_var=run_var, y=y,
+              x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1)
+    L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
+    return y
 
 
 class _UpsampleCat(torch.autograd.Function):

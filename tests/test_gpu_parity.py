@@ -532,6 +532,11 @@ def test_pafpn_vs_golden(golden_dir, dev):
         ev = net({k: v.detach() for k, v in feats.items()})
     for i, o in enumerate(ev):
         assert float((o.cpu() - torch.from_numpy(g[f"eval_out{i}"])).abs().max()) <= 1e-4, i
+    # under no_grad the eval convs run BatchNorm + SiLU in the GEMM epilogue (one launch); with autograd on they keep the
+    # conv output for a backward: same arithmetic, same values
+    ev_grad = net({k: v.detach() for k, v in feats.items()})
+    for a, b in zip(ev, ev_grad):
+        assert float((a - b.detach()).abs().max()) <= 1e-6
 
 
 @pytest.mark.parametrize("tag,hw,part", [("G1", (256, 320), (8, 10)), ("M1", (384, 640), (6, 10))])
