@@ -140,7 +140,8 @@ class Trainer:
             return False
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: calls made by other threads (the RCCL watchdog of torch.distributed) must not invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.fwd_bwd()
                 if self.world == 1:
                     self.update()
