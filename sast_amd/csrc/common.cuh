@@ -20,28 +20,50 @@ constexpr int WAVE = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane all-reduces without ds_bpermute_b32 (the LDS-crossbar round trip __shfl_xor compiles to): DPP inside a
+// row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror; fused into the VALU op), ds_swizzle (xor 16)
+// across the two rows of a half wave, v_permlane32_swap (gfx950) across the halves.  Steps go from near to far, so the
+// mirror steps see values that are already uniform inside the group they mirror; both lanes of every pair combine the
+// same two partial results, so all lanes of a group end with identical bits.
+template <int CTRL>
+__device__ __forceinline__ int dpp_peer_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int STEP>   // STEP = 1, 2, 4, 8, 16, 32: the partner's value at that butterfly distance
+__device__ __forceinline__ int lane_peer_i(int v) {
+  if constexpr (STEP == 1) return dpp_peer_i<0xB1>(v);
+  else if constexpr (STEP == 2) return dpp_peer_i<0x4E>(v);
+  else if constexpr (STEP == 4) return dpp_peer_i<0x141>(v);
+  else if constexpr (STEP == 8) return dpp_peer_i<0x140>(v);
+  else if constexpr (STEP == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401F);
+  else {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // r[0]: low half <- own, high half <- low's; r[1]: the converse
+    return (threadIdx.x & 32) ? r[0] : r[1];
+  }
+}
+template <int STEP> __device__ __forceinline__ float lane_peer(float v) { return __int_as_float(lane_peer_i<STEP>(__float_as_int(v))); }
+template <int STEP> __device__ __forceinline__ double lane_peer(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = lane_peer_i<STEP>((int)(b & 0xffffffffll)), hi = lane_peer_i<STEP>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+struct OpSum { template <class T> __device__ __forceinline__ T operator()(T a, T b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+template <int G, class T, class OP>
+__device__ __forceinline__ T group_reduce(T v, OP op) {
+  if constexpr (G > 1) v = op(v, lane_peer<1>(v));
+  if constexpr (G > 2) v = op(v, lane_peer<2>(v));
+  if constexpr (G > 4) v = op(v, lane_peer<4>(v));
+  if constexpr (G > 8) v = op(v, lane_peer<8>(v));
+  if constexpr (G > 16) v = op(v, lane_peer<16>(v));
+  if constexpr (G > 32) v = op(v, lane_peer<32>(v));
   return v;
 }
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_reduce<64>(v, OpSum{}); }
+__device__ __forceinline__ double wave_sum_d(double v) { return group_reduce<64>(v, OpSum{}); }
+__device__ __forceinline__ float wave_max(float v) { return group_reduce<64>(v, OpMax{}); }
 // reduction inside aligned sub-groups of G lanes (G power of two <= 64)
 template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, OpSum{}); }
 
 // sigmoid on the hardware exp2 path (v_exp_f32 is 1 ulp; the x*log2e pre-multiply adds ~|x|*6e-8 relative)
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + __expf(-x)); }

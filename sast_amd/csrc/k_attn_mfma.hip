@@ -19,29 +19,9 @@ namespace sast {
 
 constexpr int ADH = 32;    // LDS tile height = maximum dim_head
 
-// all-reduce over the 32 lanes of a half wave without the LDS crossbar round trips of __shfl_xor (ds_bpermute_b32): four
-// DPP steps inside a row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- fused into the VALU op) and
-// one ds_swizzle (xor 16) across the two rows.  Every lane ends with the same bits (each step combines the same two
-// partial results in both lanes of a pair).
-template <int CTRL>
-__device__ __forceinline__ float dpp_peer(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float swz_xor16(float v) { return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F)); }
-__device__ __forceinline__ float half_max(float v) {
-  v = fmaxf(v, dpp_peer<0xB1>(v));
-  v = fmaxf(v, dpp_peer<0x4E>(v));
-  v = fmaxf(v, dpp_peer<0x141>(v));
-  v = fmaxf(v, dpp_peer<0x140>(v));
-  return fmaxf(v, swz_xor16(v));
-}
-__device__ __forceinline__ float half_sum(float v) {
-  v += dpp_peer<0xB1>(v);
-  v += dpp_peer<0x4E>(v);
-  v += dpp_peer<0x141>(v);
-  v += dpp_peer<0x140>(v);
-  return v + swz_xor16(v);
-}
+// all-reduce over the 32 lanes of a half wave (common.cuh: DPP + ds_swizzle, no ds_bpermute)
+__device__ __forceinline__ float half_max(float v) { return group_reduce<32>(v, OpMax{}); }
+__device__ __forceinline__ float half_sum(float v) { return group_reduce<32>(v, OpSum{}); }
 __device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // stage rows [r0, r0+K) x dh channels of `src` (row stride ld, channel offset coff) transposed into dst[d][tok].
