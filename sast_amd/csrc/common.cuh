@@ -39,6 +39,7 @@ __device__ __forceinline__ int lane_peer_i(int v) {
     return (threadIdx.x & 32) ? r[0] : r[1];
   }
 }
+template <int STEP> __device__ __forceinline__ int lane_peer(int v) { return lane_peer_i<STEP>(v); }
 template <int STEP> __device__ __forceinline__ float lane_peer(float v) { return __int_as_float(lane_peer_i<STEP>(__float_as_int(v))); }
 template <int STEP> __device__ __forceinline__ double lane_peer(double v) {
   const long long b = __double_as_longlong(v);

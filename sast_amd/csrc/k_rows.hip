@@ -522,8 +522,7 @@ __global__ __launch_bounds__(256) void stp_fwd_kernel(const float* __restrict__ 
       xo[e] = (sigmoid_exact(cp[e]) * sigmoid_exact(sp[e])) * xo[e];
     }
   }
-#pragma unroll
-  for (int o = GL / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  acc = group_reduce<GL>(acc, OpSum{});
   IO::store(xw + (size_t)row * IO::C, xv, gl);
   if (gl == 0) tok[row] = (float)acc;
 }

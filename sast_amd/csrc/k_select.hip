@@ -20,114 +20,110 @@ struct SelOut {
 };
 struct SelPair { SelOut o[2]; int mode[2]; };
 
-// one block per sample: L1 norm per window -> softmax over the N windows -> keep flags
-__global__ __launch_bounds__(256) void win_select_kernel(const float* __restrict__ tok, PartMap pm, int L, float thr, SelPair sp) {
+constexpr int SEL_WAVES = 16;   // windows per workgroup (one wave each)
+
+// window keep + token keep in one launch.  A workgroup serves SEL_WAVES consecutive windows of ONE sample:
+//   1. all waves together: mean token score of each of the sample's N windows (L1 norm / T, SAST.py:84-86) into LDS
+//      (recomputed by every workgroup of the sample: N/16 x redundant reads of a 4*L byte row that sits in L2);
+//   2. softmax over the N windows -> keep flag of the wave's own window (window_selection);
+//   3. softmax over the T <= 128 tokens of the own window, keep mask by ballot, K by popcount (token_selection).
+__global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float* __restrict__ tok, PartMap pm, int L, float thr_win,
+                                                                     float thr_tok, SelPair sp) {
   pm.mode = sp.mode[blockIdx.y];
   int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
-  extern __shared__ float wv[];  // [N]
-  __shared__ float redf[4];
-  __shared__ double redd[4];
-  const int b = blockIdx.x, N = pm.N(), T = pm.T();
-  const float* tb = tok + (size_t)b * L;
-  float lmax = -INFINITY;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    double s = 0.0;
-    for (int t = 0; t < T; ++t) s += (double)tb[pm.token(n, t)];
-    const float w = (float)s / (float)T;
-    wv[n] = w;
-    lmax = fmaxf(lmax, w);
-  }
-  lmax = wave_max(lmax);
-  if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = lmax;
-  __syncthreads();
-  const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-  double lsum = 0.0;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float e = expf(wv[n] - mx);
-    wv[n] = e;
-    lsum += (double)e;
-  }
-  lsum = wave_sum_d(lsum);
-  if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = lsum;
-  __syncthreads();
-  const float sum = (float)(redd[0] + redd[1] + redd[2] + redd[3]);
-  for (int n = threadIdx.x; n < N; n += 256) win_keep[b * N + n] = (wv[n] / sum >= thr) ? 1 : 0;
-}
-
-// one wave per window: softmax over its T <= 128 tokens, keep mask by ballot, K by popcount
-__global__ __launch_bounds__(256) void tok_select_kernel(const float* __restrict__ tok, PartMap pm, int L, int W, float thr, SelPair sp) {
-  pm.mode = sp.mode[blockIdx.y];
-  const int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
   unsigned long long* __restrict__ mask = sp.o[blockIdx.y].mask;
   int* __restrict__ Kout = sp.o[blockIdx.y].K;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (w >= W) return;
+  extern __shared__ float wv[];  // [N]
+  __shared__ float redf[SEL_WAVES];
+  __shared__ double redd[SEL_WAVES];
   const int N = pm.N(), T = pm.T();
-  if (!win_keep[w]) {
-    if (lane == 0) { mask[2 * w] = 0ull; mask[2 * w + 1] = 0ull; Kout[w] = 0; }
-    return;
-  }
-  const int b = w / N, n = w % N;
+  const int chunks = (N + SEL_WAVES - 1) / SEL_WAVES;
+  const int b = blockIdx.x / chunks, n_own = (blockIdx.x % chunks) * SEL_WAVES + (threadIdx.x >> 6);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* tb = tok + (size_t)b * L;
   const bool h0 = lane < T, h1 = lane + 64 < T;
-  const float v0 = h0 ? tb[pm.token(n, lane)] : -INFINITY;
-  const float v1 = h1 ? tb[pm.token(n, lane + 64)] : -INFINITY;
-  const float mx = wave_max(fmaxf(v0, v1));
-  const float e0 = h0 ? expf(v0 - mx) : 0.f, e1 = h1 ? expf(v1 - mx) : 0.f;
-  const float sum = (float)wave_sum_d((double)e0 + (double)e1);
-  const unsigned long long m0 = __ballot(h0 && (e0 / sum >= thr));
-  const unsigned long long m1 = __ballot(h1 && (e1 / sum >= thr));
-  if (lane == 0) { mask[2 * w] = m0; mask[2 * w + 1] = m1; Kout[w] = __popcll(m0) + __popcll(m1); }
-}
-
-// single block: exclusive scan over the W windows (flat b*N+n order == reference's ascending index order)
-__global__ __launch_bounds__(1024) void select_scan_kernel(int W, int B, SelPair sp) {
-  const int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
-  const int* __restrict__ K = sp.o[blockIdx.y].K;
-  int* __restrict__ row_off = sp.o[blockIdx.y].row_off;
-  int* __restrict__ win_rank = sp.o[blockIdx.y].win_rank;
-  int* __restrict__ counts = sp.o[blockIdx.y].counts;
-  __shared__ int sk[1024], sw[1024];
-  const int per = (W + 1023) / 1024;
-  const int w0 = threadIdx.x * per, w1 = min(W, w0 + per);
-  int ak = 0, aw = 0;
-  for (int w = w0; w < w1; ++w) { ak += K[w]; aw += win_keep[w]; }
-  sk[threadIdx.x] = ak; sw[threadIdx.x] = aw;
+  float v0 = 0.f, v1 = 0.f;     // the own window's token scores (kept from pass 1 when it is this wave's turn)
+  for (int n = wave; n < N; n += SEL_WAVES) {
+    const float a0 = h0 ? tb[pm.token(n, lane)] : 0.f, a1 = h1 ? tb[pm.token(n, lane + 64)] : 0.f;
+    const double s = wave_sum_d((double)a0 + (double)a1);
+    if (lane == 0) wv[n] = (float)s / (float)T;
+    if (n == n_own) { v0 = a0; v1 = a1; }
+  }
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    int vk = 0, vw = 0;
-    if (threadIdx.x >= o) { vk = sk[threadIdx.x - o]; vw = sw[threadIdx.x - o]; }
-    __syncthreads();
-    sk[threadIdx.x] += vk; sw[threadIdx.x] += vw;
-    __syncthreads();
+  float lmax = -INFINITY;
+  for (int n = threadIdx.x; n < N; n += 64 * SEL_WAVES) lmax = fmaxf(lmax, wv[n]);
+  lmax = wave_max(lmax);
+  if (lane == 0) redf[wave] = lmax;
+  __syncthreads();
+  float mx = redf[0];
+#pragma unroll
+  for (int i = 1; i < SEL_WAVES; ++i) mx = fmaxf(mx, redf[i]);
+  double lsum = 0.0;
+  for (int n = threadIdx.x; n < N; n += 64 * SEL_WAVES) lsum += (double)expf(wv[n] - mx);
+  lsum = wave_sum_d(lsum);
+  if (lane == 0) redd[wave] = lsum;
+  __syncthreads();
+  if (n_own >= N) return;
+  double tot = 0.0;
+#pragma unroll
+  for (int i = 0; i < SEL_WAVES; ++i) tot += redd[i];
+  const float sum = (float)tot;
+  const int w = b * N + n_own;
+  const bool keep = expf(wv[n_own] - mx) / sum >= thr_win;
+  if (!keep) {
+    if (lane == 0) { win_keep[w] = 0; mask[2 * w] = 0ull; mask[2 * w + 1] = 0ull; Kout[w] = 0; }
+    return;
   }
-  int bk = sk[threadIdx.x] - ak, bw = sw[threadIdx.x] - aw;
-  for (int w = w0; w < w1; ++w) {
-    row_off[w] = bk; win_rank[w] = win_keep[w] ? bw : -1;
-    bk += K[w]; bw += win_keep[w];
-  }
-  if (threadIdx.x == 1023) {
-    const int total = sk[1023];
-    counts[0] = total;            // sum K  (= len(asy_index))
-    counts[1] = sw[1023];         // M      (= len(index_window))
-    counts[2] = total / B;        // index_count contribution (SAST.py:136,159)
-    counts[3] = 0;
-  }
+  if (!h0) v0 = -INFINITY;
+  if (!h1) v1 = -INFINITY;
+  const float tmx = wave_max(fmaxf(v0, v1));
+  const float e0 = h0 ? expf(v0 - tmx) : 0.f, e1 = h1 ? expf(v1 - tmx) : 0.f;
+  const float tsum = (float)wave_sum_d((double)e0 + (double)e1);
+  const unsigned long long m0 = __ballot(h0 && (e0 / tsum >= thr_tok));
+  const unsigned long long m1 = __ballot(h1 && (e1 / tsum >= thr_tok));
+  if (lane == 0) { win_keep[w] = 1; mask[2 * w] = m0; mask[2 * w + 1] = m1; Kout[w] = __popcll(m0) + __popcll(m1); }
 }
 
-// one wave per window: scatter compact row ids (mbcnt-style rank = popcount of lower mask bits)
-__global__ __launch_bounds__(256) void select_fill_kernel(PartMap pm, int L, int W, SelPair sp) {
+// exclusive scan over the W windows (flat b*N+n order == reference's ascending index order) + scatter of the compact row
+// ids, one wave per window (mbcnt-style rank = popcount of lower mask bits).  Every workgroup first sums K / win_keep of all
+// windows before its own SEL_WAVES (W <= a few thousand ints), so no separate scan launch is needed; the last workgroup
+// publishes the totals.
+__global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm, int L, int W, int B, SelPair sp) {
   pm.mode = sp.mode[blockIdx.y];
-  const unsigned long long* __restrict__ mask = sp.o[blockIdx.y].mask;
-  const int* __restrict__ row_off = sp.o[blockIdx.y].row_off;
-  int* __restrict__ tok_slot = sp.o[blockIdx.y].tok_slot;
-  int* __restrict__ row_tok = sp.o[blockIdx.y].row_tok;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const SelOut& o = sp.o[blockIdx.y];
+  const int* __restrict__ win_keep = o.win_keep;
+  const int* __restrict__ K = o.K;
+  const unsigned long long* __restrict__ mask = o.mask;
+  int* __restrict__ tok_slot = o.tok_slot;
+  int* __restrict__ row_tok = o.row_tok;
+  __shared__ int pk[SEL_WAVES], pw[SEL_WAVES], ok[SEL_WAVES], ow[SEL_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w_first = blockIdx.x * SEL_WAVES, w = w_first + wave;
+  int ak = 0, aw = 0;
+  for (int i = threadIdx.x; i < w_first; i += 64 * SEL_WAVES) { ak += K[i]; aw += win_keep[i]; }
+  ak = group_reduce<64>(ak, OpSum{});
+  aw = group_reduce<64>(aw, OpSum{});
+  const int myk = w < W ? K[w] : 0, myw = w < W ? win_keep[w] : 0;
+  if (lane == 0) { pk[wave] = ak; pw[wave] = aw; ok[wave] = myk; ow[wave] = myw; }
+  __syncthreads();
+  int base = 0, rank = 0;
+#pragma unroll
+  for (int i = 0; i < SEL_WAVES; ++i) {
+    base += pk[i]; rank += pw[i];
+    if (i < wave) { base += ok[i]; rank += ow[i]; }
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 64 * SEL_WAVES - 1) {   // the last wave's exclusive prefix + its own = totals
+    const int total = base + myk;
+    o.counts[0] = total;            // sum K  (= len(asy_index))
+    o.counts[1] = rank + myw;       // M      (= len(index_window))
+    o.counts[2] = total / B;        // index_count contribution (SAST.py:136,159)
+    o.counts[3] = 0;
+  }
   if (w >= W) return;
+  if (lane == 0) { o.row_off[w] = base; o.win_rank[w] = myw ? rank : -1; }
   const int N = pm.N(), T = pm.T();
   const int b = w / N, n = w % N;
   const unsigned long long m0 = mask[2 * w], m1 = mask[2 * w + 1];
-  const int base = row_off[w];
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   if (lane < T) {
     const int p = b * L + pm.token(n, lane);
@@ -148,10 +144,10 @@ static int select_launch_n(const float* tok, int B, int H, int W_, int ph, int p
   PartMap pm{H, W_, ph, pw, 0};
   if (H % ph || W_ % pw || pm.T() > 128) return SAST_EINVAL;
   const int L = H * W_, N = pm.N(), W = B * N;
-  hipLaunchKernelGGL(win_select_kernel, dim3(B, nsel), dim3(256), sizeof(float) * N, st, tok, pm, L, thr_win, sp);
-  hipLaunchKernelGGL(tok_select_kernel, dim3((W + 3) / 4, nsel), dim3(256), 0, st, tok, pm, L, W, thr_tok, sp);
-  hipLaunchKernelGGL(select_scan_kernel, dim3(1, nsel), dim3(1024), 0, st, W, B, sp);
-  hipLaunchKernelGGL(select_fill_kernel, dim3((W + 3) / 4, nsel), dim3(256), 0, st, pm, L, W, sp);
+  const int chunks = (N + SEL_WAVES - 1) / SEL_WAVES;
+  hipLaunchKernelGGL(select_mask_kernel, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win,
+                     thr_tok, sp);
+  hipLaunchKernelGGL(select_fill_kernel, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, sp);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
