@@ -170,12 +170,13 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);
 /* the conv epilogue accumulates the batch statistics with atomics; same-address atomics serialise at the memory side, so
    the row tiles spread them over SAST_BN_STAT_COPIES copies that the BatchNorm kernel adds up */
 #define SAST_BN_STAT_COPIES 4
-#define SAST_BN_WS_FLOATS(Cout) ((4 * SAST_BN_STAT_COPIES + 4) * (Cout))
+#define SAST_BN_WS_FLOATS(Cout) ((4 * SAST_BN_STAT_COPIES + 2 * SAST_BN_STAT_COPIES) * (Cout))
 int sast_conv_bn_ws_floats(int Cout);   /* = SAST_BN_WS_FLOATS(Cout), for hosts that cannot read the macro */
 typedef struct SastConvBnArgs {
   int32_t B, H, W, Cin, Cout, ksize, stride, training;
   int32_t ldx, ldy, lddy, lddx;   /* channel strides of x, y, dy, dx rows (slices of concat buffers) */
   int32_t bn_ws_zeroed;           /* 1: caller guarantees bn_ws is zero-filled (one memset for the whole FPN) */
+  int32_t bn_red_done;            /* bwd: 1 = the conv consuming y already accumulated this conv's BatchNorm-backward sums (see p_*) */
   int32_t Cin1, ldx2;             /* 1x1 convs only, with x2 != NULL: input = channel concat [x (Cin1 ch) | x2 (Cin - Cin1 ch, row stride ldx2)]
                                      read in place (th.cat of network_blocks.py:140 / yolo_pafpn.py:129,134 never materialised) */
   float momentum, eps;
@@ -188,10 +189,16 @@ typedef struct SastConvBnArgs {
   /* backward */
   const float* dy; float* dx; float* dw; float* d_bn_w; float* d_bn_b;
   float* bn_ws;          /* fp32[SAST_BN_WS_FLOATS(Cout)] reduction scratch: fwd uses the first 4*COPIES*C floats as fp64
-                            [COPIES][sum | sum of squares][C], bwd the 2C floats after them */
+                            [COPIES][sum | sum of squares][C], bwd the 2*COPIES*C floats after them ([COPIES][sum dz | sum dz*xhat][C]) */
   float* ws;             /* bwd only: fp32[M*Cout] (dconv) */
   const float* x2;       /* second input of the virtual concat (NULL = single input) */
   float* dx2;            /* its gradient, dense [M, Cin - Cin1] */
+  /* backward, training mode, stride 1, optional: the conv_bn_silu that PRODUCED x (p_*) / x2 (p2_*), when this conv is the
+     ONLY consumer of that output (so the dx / dx2 written here IS the producer's dy).  The dX epilogue then also accumulates
+     the producer's BatchNorm-backward column sums (sum dz, sum dz*xhat) into the producer's bn_ws, and the producer's own
+     backward is called with bn_red_done = 1 and skips its reduction launch.  All NULL: no folding. */
+  const float* p_conv_out; const float* p_stats; const float* p_bn_w; const float* p_bn_b; float* p_bn_ws;
+  const float* p2_conv_out; const float* p2_stats; const float* p2_bn_w; const float* p2_bn_b; float* p2_bn_ws;
 } SastConvBnArgs;
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);

@@ -395,7 +395,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
           for (int g = 0; g < G; ++g) v[g] = acc[ta][tj * G + g][reg];
           ep.post(m, j, v, col, aux[reg]);
-          if constexpr (STATS) { cs[tj] += v[0]; cq[tj] += v[0] * v[0]; }
+          if constexpr (STATS) ep.stat(v[0], col, aux[reg], cs[tj], cq[tj]);
         }
       }
     }
@@ -405,8 +405,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       const float s = cs[tj] + __shfl_xor(cs[tj], 32, 64), q = cq[tj] + __shfl_xor(cq[tj], 32, 64);
       const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
 // same-address atomics serialise at the memory side: the row tiles spread their adds over BN_STAT_COPIES copies
-      double* sp = ep.sums + (size_t)(((m0 / BM) * T::WAVES_M + wm) % BN_STAT_COPIES) * 2 * NJ;
-      if (lane < 32 && j < NJ) { atomicAdd(sp + j, (double)s); atomicAdd(sp + NJ + j, (double)q); }
+      if (lane < 32 && j < NJ) ep.flush(((m0 / BM) * T::WAVES_M + wm) % BN_STAT_COPIES, j, NJ, s, q);
     }
   }
   SAST_TL(4);
@@ -903,6 +902,46 @@ struct EpStoreStats {  // C[m*ldc + j] = v ; sums[copy][j] += v ; sums[copy][NJ 
   __device__ __forceinline__ Col col(int) const { return Col{}; }
   __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const { c[(size_t)m * ldc + j] = v[0]; }
+  __device__ __forceinline__ void stat(float v, const Col&, const Aux&, float& a, float& b) const { a += v; b += v * v; }
+  __device__ __forceinline__ void flush(int copy, int j, int NJ, float s, float q) const {
+    double* sp = sums + (size_t)copy * 2 * NJ;
+    atomicAdd(sp + j, (double)s); atomicAdd(sp + NJ + j, (double)q);
+  }
+};
+
+// ---- BatchNorm-backward reduction of the PRODUCING conv folded into the epilogue that writes its dy (the dX job of the
+// consuming conv): the producer's backward needs  s1[c] = sum_m dz,  s2[c] = sum_m dz * xhat  with dz = dy * silu'(BN(x))
+// before it can form its own dconv; when this epilogue is the only writer of dy (sole consumer) it has every dy element in
+// registers once, so it loads the producer's saved conv output x, accumulates both sums per column and adds them (float
+// atomics, BN_STAT_COPIES copies) -- the producer then skips its bn_bwd_reduce launch.
+struct BnProducer {
+  const float* x;        // [M, C] saved conv output of the producer (NULL: no folding for this output)
+  const float* stats;    // [2C] mean, rstd
+  const float* gamma; const float* beta;
+  float* sums;           // [BN_STAT_COPIES][2C] zero-filled
+  int C;
+};
+struct BnCol { float mu, rs, g, b; };
+__device__ __forceinline__ BnCol bn_col(const BnProducer& p, int j) { return BnCol{p.stats[j], p.stats[p.C + j], p.gamma[j], p.beta[j]}; }
+__device__ __forceinline__ void bn_stat(float dy, float x, const BnCol& k, float& a, float& b) {
+  const float xh = (x - k.mu) * k.rs;
+  const float z = xh * k.g + k.b, sg = sigmoid_exact(z);
+  const float dz = dy * sg * (1.f + z * (1.f - sg));
+  a += dz; b += dz * xh;
+}
+struct EpStoreBnRed {  // C[m*ldc + j] = v, + the producer's reduction
+  static constexpr bool COLSTATS = true;
+  float* c; int ldc; BnProducer p;
+  using Col = BnCol;
+  struct Aux { float x; };
+  __device__ __forceinline__ Col col(int j) const { return bn_col(p, j); }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{p.x[(size_t)m * p.C + j]}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const { c[(size_t)m * ldc + j] = v[0]; }
+  __device__ __forceinline__ void stat(float v, const Col& k, const Aux& x, float& a, float& b) const { bn_stat(v, x.x, k, a, b); }
+  __device__ __forceinline__ void flush(int copy, int j, int, float s, float q) const {
+    float* sp = p.sums + (size_t)copy * 2 * p.C;
+    atomicAdd(sp + j, s); atomicAdd(sp + p.C + j, q);
+  }
 };
 struct EpStoreAdd {  // C[m*ldc+j] = v + add[m*ldadd + j]
   float* c; int ldc; const float* add; int ldadd;
@@ -936,6 +975,33 @@ struct EpStoreClass {  // C[pixel(m) * ldc + j] = v, pixel(m) from the parity-cl
   }
   __device__ __forceinline__ void post(int, int j, const float (&v)[1], const Col&, const Aux& a) const {
     c[(size_t)a.p * ldc + j] = v[0];
+  }
+};
+
+struct EpSplit2BnRed {  // EpSplit2 + the reductions of the two producers of the concat halves (either may be absent: x == NULL)
+  static constexpr bool COLSTATS = true;
+  float* a; float* b; int C1, C2; BnProducer pa, pb;
+  using Col = BnCol;
+  struct Aux { float x; };
+  __device__ __forceinline__ Col col(int j) const {
+    if (j < C1) return pa.x ? bn_col(pa, j) : BnCol{0.f, 0.f, 0.f, 0.f};
+    return pb.x ? bn_col(pb, j - C1) : BnCol{0.f, 0.f, 0.f, 0.f};
+  }
+  __device__ __forceinline__ Aux pre(int m, int j) const {
+    if (j < C1) return Aux{pa.x ? pa.x[(size_t)m * C1 + j] : 0.f};
+    return Aux{pb.x ? pb.x[(size_t)m * C2 + (j - C1)] : 0.f};
+  }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
+    if (j < C1) a[(size_t)m * C1 + j] = v[0];
+    else if (b) b[(size_t)m * C2 + (j - C1)] = v[0];
+  }
+  __device__ __forceinline__ void stat(float v, const Col& k, const Aux& x, float& s, float& q) const { bn_stat(v, x.x, k, s, q); }
+  __device__ __forceinline__ void flush(int copy, int j, int, float s, float q) const {
+    if (j < C1) {
+      if (pa.x) { float* sp = pa.sums + (size_t)copy * 2 * C1; atomicAdd(sp + j, s); atomicAdd(sp + C1 + j, q); }
+    } else if (pb.x) {
+      float* sp = pb.sums + (size_t)copy * 2 * C2; atomicAdd(sp + (j - C1), s); atomicAdd(sp + C2 + (j - C1), q);
+    }
   }
 };
 

@@ -152,30 +152,42 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(const flo
   }
 }
 // backward pass 2: dconv = gamma * rstd * (dz - mean(dz) - xhat * mean(dz*xhat))   [training]
+// Every block first folds the BN_STAT_COPIES copies of the two sums (written by bn_bwd_reduce_kernel into copy 0, or by the
+// consuming conv's dX epilogue into all of them) and the per-channel constants into LDS, then streams `iters` x 256 float4;
+// block 0 also publishes the affine gradients.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            const float* __restrict__ dy, int lddy, const float* __restrict__ sums,
                                                            float* __restrict__ dconv, size_t n4, int C, float invM, int training,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e4 >= n4) return;
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int iters) {
+  extern __shared__ float bsm[];   // [6][C]: mean, rstd, gamma, beta, mean(dz), mean(dz*xhat)
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_STAT_COPIES; ++k) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
+    if (blockIdx.x == 0) { dbeta[c] += s1; dgamma[c] += s2; }
+    bsm[c] = stats[c]; bsm[C + c] = stats[C + c]; bsm[2 * C + c] = gamma[c]; bsm[3 * C + c] = beta[c];
+    bsm[4 * C + c] = s1 * invM; bsm[5 * C + c] = s2 * invM;
+  }
+  __syncthreads();
   const int c4 = C / 4;
-  const size_t m = e4 / c4; const int c = (int)(e4 % c4) * 4;
-  if (m == 0) {   // the row-0 threads also publish the affine gradients (sums are complete: previous kernel)
+  const size_t e0 = (size_t)blockIdx.x * 256 * iters + threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+    const size_t e4 = e0 + (size_t)it * 256;
+    if (e4 >= n4) return;
+    const size_t m = e4 / c4; const int c = (int)(e4 % c4) * 4;
+    const float4 v = ld4(x + m * C + c), d = ld4(dy + m * lddy + c);
+    float out[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { dbeta[c + e] += sums[c + e]; dgamma[c + e] += sums[C + c + e]; }
+    for (int e = 0; e < 4; ++e) {
+      const float mu = bsm[c + e], rs = bsm[C + c + e], g = bsm[2 * C + c + e];
+      const float xh = ((&v.x)[e] - mu) * rs;
+      const float z = xh * g + bsm[3 * C + c + e], sg = sigmoid_exact(z);
+      const float dz = (&d.x)[e] * sg * (1.f + z * (1.f - sg));
+      out[e] = training ? g * rs * (dz - bsm[4 * C + c + e] - xh * bsm[5 * C + c + e]) : g * rs * dz;
+    }
+    st4(dconv + m * C + c, make_float4(out[0], out[1], out[2], out[3]));
   }
-  const float4 v = ld4(x + m * C + c), d = ld4(dy + m * lddy + c);
-  float out[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const float mu = stats[c + e], rs = stats[C + c + e], g = gamma[c + e];
-    const float xh = ((&v.x)[e] - mu) * rs;
-    const float z = xh * g + beta[c + e], sg = sigmoid_exact(z);
-    const float dz = (&d.x)[e] * sg * (1.f + z * (1.f - sg));
-    out[e] = training ? g * rs * (dz - sums[c + e] * invM - xh * sums[C + c + e] * invM) : g * rs * dz;
-  }
-  st4(dconv + m * C + c, make_float4(out[0], out[1], out[2], out[3]));
 }
 // ---------------------------------------------------------------- upsample / concat
 __global__ __launch_bounds__(256) void upsample_cat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -261,7 +273,7 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
 // generic gather.
 // dW (TN over the im2col rows) and dX of a k x k convolution in one launch
 int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cout, const float* w, float* dw, float* dx, int lddx,
-                  hipStream_t st) {
+                  hipStream_t st, const BnProducer* prod = nullptr) {
   const int k = g.KH, shift = pow2_shift(Cout), K = k * k * g.Cin, M = g.B * g.Ho * g.Wo;
   const LdRowsT ta{dconv, Cout};
   const LdIm2colT tb{x, g};
@@ -269,6 +281,11 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
   static int parity = -1;
   if (parity < 0) { const char* e = getenv("SAST_CONVDX_PARITY"); parity = e ? atoi(e) : 1; }
   const int Mc = g.B * (g.H / 2) * (g.W / 2);
+  if (prod && prod->x) {   // stride-1 convs only (the caller checks): dX epilogue also reduces the producer's BatchNorm backward sums
+    if (g.stride != 1 || lddx != g.Cin || prod->C != g.Cin) return SAST_EINVAL;
+    return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
+                     LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStoreBnRed{dx, lddx, *prod}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st);
+  }
   if (!(parity && g.stride == 2 && k == 3 && g.pad == 1 && g.H % 2 == 0 && g.W % 2 == 0 && Mc % 64 == 0))
     return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
                      LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st);
@@ -384,35 +401,58 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const int k = a->ksize, pad = (k - 1) / 2;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
-  float* sums = a->bn_ws + 4 * BN_STAT_COPIES * C;      // [2C]
+  float* sums = a->bn_ws + 4 * BN_STAT_COPIES * C;      // [COPIES][2C]
   float* dconv = a->ws;                // [M, C]
-  if (!a->bn_ws_zeroed) zero_fill(sums, sizeof(float) * 2 * C, st);
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
-  int rpb = (M + target - 1) / target;
-  rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
-  {
+  if (!a->bn_ws_zeroed) {
+    if (a->bn_red_done) return SAST_EINVAL;   // the consumer has already accumulated into it
+    zero_fill(sums, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
+  }
+  if (!a->bn_red_done) {   // (dz, dz * xhat) column sums; skipped when the conv consuming y folded them into its dX epilogue
+    static int target = -1;
+    if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
+    int rpb = (M + target - 1) / target;
+    rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
     const int c4n = C / 4, RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, a->conv_out, a->stats,
                        a->bn_w, a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
   }
   const size_t n4 = (size_t)M * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a->conv_out, a->stats, a->bn_w, a->bn_b,
-                     a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w, a->d_bn_b);
+  int iters = (int)(n4 / (256 * 512));
+  iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters))), dim3(256), sizeof(float) * 6 * C, st,
+                     a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w,
+                     a->d_bn_b, iters);
   SAST_CHECK_LAUNCH();
+  // producers of x / x2 whose only consumer is this conv: their reductions ride on this conv's dX epilogue
+  const int C2 = a->Cin - a->Cin1;
+  BnProducer p1{a->p_conv_out, a->p_stats, a->p_bn_w, a->p_bn_b, a->p_bn_ws ? a->p_bn_ws + 4 * BN_STAT_COPIES * a->Cin1 : nullptr, a->Cin1};
+  BnProducer p2{a->p2_conv_out, a->p2_stats, a->p2_bn_w, a->p2_bn_b, a->p2_bn_ws ? a->p2_bn_ws + 4 * BN_STAT_COPIES * C2 : nullptr, C2};
+  const bool fold = a->training && a->dx && (p1.x || p2.x);
+  if (fold && (a->stride != 1 || (p1.x && !(p1.stats && p1.gamma && p1.beta && p1.sums)) || (p2.x && !(a->x2 && p2.stats && p2.gamma && p2.beta && p2.sums))))
+    return SAST_EINVAL;
   if (k == 1 && a->stride == 1 && a->x2) {   // virtual concat input: dW over [x | x2], dX split into the two gradients
     const LdRowsT2 tb{a->x, a->ldx, a->Cin1, a->x2, a->ldx2};
     if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, st);
     if (a->lddx != a->Cin1) return SAST_EINVAL;
+    if (fold) {
+      if ((p1.x && a->ldx != a->Cin1) || (p2.x && (a->ldx2 != C2 || !a->dx2))) return SAST_EINVAL;
+      return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K},
+                       EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, a->Cin, C, nullptr, st);
+    }
     return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr,
-                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpSplit2{a->dx, a->dx2, a->Cin1, a->Cin - a->Cin1}, M, a->Cin, C, nullptr, st);
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, a->Cin, C, nullptr, st);
   }
   if (k == 1 && a->stride == 1) {
     if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, st);
+    if (fold) {
+      if (a->lddx != a->Cin || a->ldx != a->Cin) return SAST_EINVAL;
+      return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr},
+                       LdWeightNN{a->w, K}, EpStoreBnRed{a->dx, a->lddx, p1}, M, a->Cin, C, nullptr, st);
+    }
     return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr,
                      LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st);
   }
-  return conv_bwd_pair(dconv, a->x, g, C, a->w, a->dw, a->dx, a->lddx, st);
+  return conv_bwd_pair(dconv, a->x, g, C, a->w, a->dw, a->dx, a->lddx, st, fold ? &p1 : nullptr);
 }
 
 // ------------------------------------------------------------------ upsample / concat

@@ -20,13 +20,14 @@ class BaseConv(nn.Module):
         self.conv.weight = channels_last_conv_weight(out_channels, in_channels, ksize)
         self.bn = nn.BatchNorm2d(out_channels)
 
-    def forward_nhwc(self, x, arena=None):
+    def forward_nhwc(self, x, arena=None, sole=False):
         """arena: optional `BnArena` handing out zero-filled reduction scratch (one memset per FPN forward) and
-        batching the num_batches_tracked increments."""
+        batching the num_batches_tracked increments.  sole: the caller guarantees this conv is the only consumer of x
+        (functional.conv_bn_silu: the producing conv's BatchNorm-backward reduction then rides on this conv's dX epilogue)."""
         bn = self.bn
         ws = arena.take(SF.bn_ws_floats(bn.num_features)) if arena is not None else None
         y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
-                            self.training, bn.momentum, bn.eps, ws)
+                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole)
         if self.training and bn.num_batches_tracked is not None:
             if arena is not None:
                 arena.counters.append(bn.num_batches_tracked)
@@ -73,8 +74,9 @@ class Bottleneck(nn.Module):
         self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
-    def forward_nhwc(self, x, arena=None):
-        y = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x, arena), arena)
+    def forward_nhwc(self, x, arena=None, sole_input=False):
+        # sole_input: x has no consumer besides this block (with the shortcut the add is a second one)
+        y = self.conv2.forward_nhwc(self.conv1.forward_nhwc(x, arena, sole=sole_input and not self.use_add), arena, sole=True)
         return y + x if self.use_add else y
 
     def forward(self, x):
@@ -96,8 +98,8 @@ class CSPLayer(nn.Module):
         x1 = self.conv1.forward_nhwc(x, arena)
         x2 = self.conv2.forward_nhwc(x, arena)
         for b in self.m:
-            x1 = b.forward_nhwc(x1, arena)
-        return self.conv3.forward_nhwc((x1, x2), arena)     # th.cat((x_1, x_2)) read in place by the 1x1 conv
+            x1 = b.forward_nhwc(x1, arena, sole_input=True)
+        return self.conv3.forward_nhwc((x1, x2), arena, sole=True)     # th.cat((x_1, x_2)) read in place by the 1x1 conv
 
     def forward(self, x):
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))

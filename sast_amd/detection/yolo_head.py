@@ -65,11 +65,11 @@ class YOLOXHead(nn.Module):
         per_level, levels = [], []
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x)
-            cf, rf = x, x
-            for conv in self.cls_convs[k]:
-                cf = conv.forward_nhwc(cf)
-            for conv in self.reg_convs[k]:
-                rf = conv.forward_nhwc(rf)
+            cf, rf = x, x          # the stem output feeds both towers; inside a tower every conv has one consumer
+            for i, conv in enumerate(self.cls_convs[k]):
+                cf = conv.forward_nhwc(cf, sole=i > 0)
+            for i, conv in enumerate(self.reg_convs[k]):
+                rf = conv.forward_nhwc(rf, sole=i > 0)
             cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
             per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
             levels.append((x.shape[1], x.shape[2], stride))

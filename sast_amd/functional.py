@@ -11,6 +11,7 @@ There is no CPU implementation: every op raises if its tensors are not on a HIP 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -608,9 +609,19 @@ def conv_lstm(x_nhwc, h0, c0, w, b):
 
 
 # ---------------------------------------------------------------------------------------------- a13
+class BnHandle:
+    """what the conv that consumes a conv_bn_silu output needs to fold that producer's BatchNorm-backward reduction into its
+    own dX epilogue (include/sast_hip.h: SastConvBnArgs.p_*), plus the flag telling the producer's backward it was done."""
+    __slots__ = ("conv_out", "stats", "bn_w", "bn_b", "bn_ws", "cout", "red_done")
+
+    def __init__(self, conv_out, stats, bn_w, bn_b, bn_ws, cout):
+        self.conv_out, self.stats, self.bn_w, self.bn_b, self.bn_ws, self.cout = conv_out, stats, bn_w, bn_b, bn_ws, cout
+        self.red_done = False
+
+
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws):
+    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers=(None, None)):
         _need_gpu(x, w)
         x = x.contiguous()
         if not is_channels_last_weight(w):
@@ -639,6 +650,14 @@ class _ConvBnSilu(torch.autograd.Function):
         ctx.save_for_backward(x, x2, conv_out, stats, bn_ws)
         ctx.params = (w, bn_w, bn_b)
         ctx.meta = (B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M)
+        ctx.handle = BnHandle(conv_out, stats, bn_w, bn_b, bn_ws, Cout) if training else None
+        p1, p2 = producers if (training and stride == 1) else (None, None)
+        if p1 is not None and p1.cout != Cin1:
+            p1 = None
+        if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
+            p2 = None
+        ctx.producers = (p1, p2)
+        _LAST_BN_HANDLE[0] = ctx.handle
         return y
 
     @staticmethod
@@ -651,12 +670,26 @@ class _ConvBnSilu(torch.autograd.Function):
         dx = torch.empty_like(x) if need else None
         dx2 = torch.empty_like(x2) if (need and x2 is not None) else None
         ws = torch.empty(M * Cout, device=x.device)
+        p1, p2 = ctx.producers if need else (None, None)
+        if p1 is not None and p1.red_done:
+            p1 = None
+        if p2 is not None and (p2.red_done or dx2 is None):
+            p2 = None
+        pk = {}
+        for pre, h in (("p_", p1), ("p2_", p2)):
+            if h is not None:
+                pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
+                           pre + "bn_ws": h.bn_ws})
+        own = ctx.handle
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
-                  ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b,
-                  conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w), d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws,
-                  x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1)
+                  ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
+                  eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w),
+                  d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, **pk)
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
-        return (dx, dx2) + (None,) * 11
+        for h in (p1, p2):
+            if h is not None:
+                h.red_done = True
+        return (dx, dx2) + (None,) * 12
 
 
 def bn_ws_floats(cout: int) -> int:
@@ -664,13 +697,26 @@ def bn_ws_floats(cout: int) -> int:
     return int(L.lib().sast_conv_bn_ws_floats(int(cout)))
 
 
-def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None):
+_LAST_BN_HANDLE = [None]
+BN_FOLD = os.environ.get("SAST_BN_FOLD", "1") != "0"   # fold producers' BatchNorm-backward reductions into consumers' dX epilogues
+
+
+def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None,
+                 sole_consumer=False):
     """x_nhwc: a tensor, or a pair (xa, xb) standing for their channel concat (1x1 convs; the concat is never built).
     bn_ws: optional zero-filled fp32[bn_ws_floats(Cout)] scratch (consumed: do not reuse within a step)."""
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
     if not training and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, x2, w, bn_w, bn_b))):
         return _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, float(eps))
-    return _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws)
+    # sole_consumer: the caller guarantees that this conv is the ONLY consumer of its input tensor(s); where such an input
+    # is itself a conv_bn_silu output (it carries a BnHandle), that producer's BatchNorm-backward reduction is folded into
+    # this conv's dX epilogue (one launch fewer per conv in the backward pass)
+    prods = (getattr(x, "_sast_bn", None), getattr(x2, "_sast_bn", None) if x2 is not None else None) if (sole_consumer and BN_FOLD) else (None, None)
+    y = _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws, prods)
+    if training and _LAST_BN_HANDLE[0] is not None:
+        y._sast_bn = _LAST_BN_HANDLE[0]
+        _LAST_BN_HANDLE[0] = None
+    return y
 
 
 def _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, eps):

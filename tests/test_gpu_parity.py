@@ -675,7 +675,9 @@ def test_graph_replay_matches_eager(dev):
         ref = eager[k][1]
         err = float((gr[2].grad - ref).abs().max())
         assert torch.isfinite(gr[2].grad).all()
-        assert err <= 1e-2 * float(ref.abs().max()) + 1e-7, (k, err)      # atomics order + 3 optimizer steps of drift
+        # atomics order + optimizer steps of drift: two EAGER runs of this loop differ by up to 3e-2 of the max-norm at the
+        # third / fourth step (measured, bimodal), a buffer that is not cleared on replay is an O(1) error
+        assert err <= (1e-2 if k == 1 else 8e-2) * float(ref.abs().max()) + 1e-7, (k, err)
 
 
 # kept last: if this ever regresses the symptom is a GPU memory fault that aborts the process
@@ -709,6 +711,33 @@ def test_conv_reads_stay_inside_the_input_buffer(dev):
     torch.cuda.synchronize()
     del x, store
     hip.hipFree(ptr)
+
+
+def test_bn_backward_reduction_folded_into_consumer_matches_separate_launch(dev):
+    """a CSP layer (1x1 / 3x3 / two-source 1x1 consumers) trained with the producers' BatchNorm-backward reductions folded
+    into the consumers' dX epilogues and with the stand-alone reduction launches: same gradients"""
+    from sast_amd import functional as SF
+    from sast_amd.detection.network_blocks import CSPLayer
+    torch.manual_seed(5)
+    net = CSPLayer(96, 64, n=2, shortcut=False).to(dev).train()
+    x0 = torch.randn(2, 12, 20, 96, device=dev)
+    res = []
+    for fold in (True, False):
+        old = SF.BN_FOLD
+        SF.BN_FOLD = fold
+        try:
+            net.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = net.forward_nhwc(x)
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            res.append((y.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+        finally:
+            SF.BN_FOLD = old
+    (ya, xa, ga), (yb, xb, gb) = res
+    assert torch.equal(ya, yb)
+    maxnorm_close(xa, xb, 1e-5, "dx")
+    for k in ga:
+        maxnorm_close(ga[k], gb[k], 1e-5, k)
 
 
 def test_mean_squares_matches_torch(dev):
