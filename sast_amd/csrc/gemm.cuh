@@ -548,6 +548,7 @@ using TileSmall = Tile<64, 64, 2, 2, 1>;    // wave tile 32x32
 using TileSmallK2 = Tile<64, 64, 2, 2, 1, 16, 2>;   // + 2-way intra-block k split (8 waves)
 using TileSmallK4 = Tile<64, 64, 2, 2, 1, 16, 4>;   // + 4-way intra-block k split (16 waves)
 using TileThinK4  = Tile<32, 64, 1, 2, 1, 16, 4>;   // 32x64 block, 4 k-groups of 2 waves: for grids of < ~1.5 64x64-tiles per CU
+using TileTinyK8 = Tile<32, 32, 1, 1, 1, 16, 8>;   // 32x32 block, 8 single-wave k-groups: grids of < ~half a 32x64-tile per CU with a long reduction
 using TileTiny  = Tile<32, 32, 1, 1, 1>;    // one wave per block: fills the chip when M*N is small (stage 3/4, PAFPN)
 using TileN64   = Tile<128, 64, 4, 1, 1>;   // N = 64 layers (stage 1): wave tile 32x64
 using TileG2    = Tile<64, 128, 2, 2, 2>;   // GLU: 64 rows x (64 ch x 2 groups), wave tile 32x(32x2)

@@ -20,10 +20,15 @@ inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 384); ret
 inline int pair_ks_min_r() { static int v = env_int("SAST_KS_MINR", 256); return v; }
 inline int pair_thin_nb() { static int v = env_int("SAST_THIN_NB", 384); return v; }
 inline int pair_ks_nb() { static int v = env_int("SAST_KS_NB", 1000000); return v; }
+// 32x32 tiles with 8 k-groups when even the 32x64 tiling leaves more than half of the CUs idle (PAFPN level-32 convs, M = 960)
+inline int tiny_nb() { static int v = env_int("SAST_TINY_NB", 128); return v; }
+// (stand-alone launches only: as the dX job of a paired launch it measured slower, +0.02 ms/step)
+inline bool use_tiny(int M, int NJ, int R) { return (long)((M + 31) / 32) * ((NJ + 63) / 64) <= tiny_nb() && R >= 512; }
 
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
   const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
+  if (!dM && use_tiny(M, NJ, R)) return launch_gemm<TileTinyK8>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   if (nb <= pair_thin_nb() && R >= pair_ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   if (nb <= pair_ks_nb() && R >= pair_ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
   return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
