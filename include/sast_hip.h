@@ -203,6 +203,30 @@ typedef struct SastConvBnArgs {
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);
 
+/* a13b  TWO BaseConvs (1x1, stride 1, equal Cout) of the SAME input in training mode -- CSPLayer.conv1 / conv2
+   (yolox/models/network_blocks.py:131-133) -- evaluated as one GEMM over the stacked weights [w0; w1]: one launch for both
+   convs (+ one for both BatchNorm/SiLU passes); backward: one BatchNorm-backward pass for both, then ONE (dW || dX) launch
+   in which dX = [dconv0 | dconv1] [w0; w1] is the SUM of both input gradients (no separate accumulation).  Fields with a
+   0 / 1 suffix belong to conv 0 / conv 1 and mean what they mean in SastConvBnArgs. */
+typedef struct SastConvBn2Args {
+  int32_t B, H, W, Cin, Cout, ldx, Cin1, ldx2;   /* Cout of EACH conv; input = x (Cin1 == Cin) or the virtual concat [x | x2] */
+  int32_t bn_ws_zeroed, bn_red_done0, bn_red_done1;
+  float momentum0, momentum1, eps0, eps1;
+  const float* x; const float* x2;
+  const float* w0; const float* w1; const float* bn_w0; const float* bn_w1; const float* bn_b0; const float* bn_b1;
+  float* run_mean0; float* run_mean1; float* run_var0; float* run_var1;
+  float* conv_out0; float* conv_out1; float* stats0; float* stats1; float* y0; float* y1; float* bn_ws0; float* bn_ws1;
+  /* backward */
+  const float* dy0; const float* dy1; float* dw0; float* dw1; float* d_bn_w0; float* d_bn_w1; float* d_bn_b0; float* d_bn_b1;
+  float* ws0; float* ws1;      /* fp32[M*Cout] each (dconv) */
+  float* dx; float* dx2;       /* dense [M, Cin1] and [M, Cin - Cin1]; dx == NULL: weight gradients only */
+  /* producers of x / x2 whose only consumers are these two convs (see SastConvBnArgs.p_*) */
+  const float* p_conv_out; const float* p_stats; const float* p_bn_w; const float* p_bn_b; float* p_bn_ws;
+  const float* p2_conv_out; const float* p2_stats; const float* p2_bn_w; const float* p2_bn_b; float* p2_bn_ws;
+} SastConvBn2Args;
+int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream);
+int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream);
+
 /* a13  nearest-exact x2 upsample + channel concat -- yolo_pafpn.py:49,119-120.
  * out[B,2H,2W,C1+C2] = cat(up2(a[B,H,W,C1]), b[B,2H,2W,C2]) ; backward splits/sums. */
 int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream);

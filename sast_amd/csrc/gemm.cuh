@@ -651,6 +651,7 @@ struct LdRowsT2 {  // dual source along j (for d[W_x | W_h])
     if (j < I1) return Ctx{p1 + j, ld1, true};
     return p2 ? Ctx{p2 + (j - I1), ld2, true} : Ctx{p1, 0, false};
   }
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return prep(i, 0, Ieff); }   // as the A operand
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
     v = ld4(c.base + (size_t)min(r, Reff - 1) * c.ld);
@@ -674,6 +675,24 @@ struct LdWeightNT {
   }
   SAST_DEFAULT_FINISH
 };
+// two weight matrices stacked along the output index j: rows [0, J1) from w1, the rest from w2 (two convs of the same
+// input evaluated as one GEMM)
+struct LdWeightNT2 {
+  static constexpr bool RC = true;
+  const float* w1; const float* w2; int ldw; int J1;
+  struct Ctx { const float* row; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
+    const bool ok = j < NJ;
+    const int jj = ok ? j : 0;
+    return Ctx{jj < J1 ? w1 + (size_t)jj * ldw : w2 + (size_t)(jj - J1) * ldw, ok};
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = ld4(c.row + (ok ? r : 0));
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
 // weights used as B[r][j] = w[r*ldw + j]  (dx = dy W)
 struct LdWeightNN {
   static constexpr bool RC = false;
@@ -683,6 +702,21 @@ struct LdWeightNN {
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
     v = ld4(c.col + (size_t)min(r, Reff - 1) * ldw);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+// the stacked pair [w1; w2] as B[r][j]: reduce rows [0, R1) from w1, the rest from w2 (dx = [dy1 | dy2] [W1; W2])
+struct LdWeightNN2 {
+  static constexpr bool RC = false;
+  const float* w1; const float* w2; int ldw; int R1;
+  struct Ctx { int j; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    const int rr = min(r, Reff - 1);
+    const float* row = rr < R1 ? w1 + (size_t)rr * ldw : w2 + (size_t)(rr - R1) * ldw;   // address select, not a branch
+    v = ld4(row + c.j);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -952,6 +986,32 @@ struct EpStoreAdd {  // C[m*ldc+j] = v + add[m*ldadd + j]
   __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{add[(size_t)m * ldadd + j]}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
     c[(size_t)m * ldc + j] = v[0] + x.a;
+  }
+};
+struct EpStoreStats2 {  // EpStoreStats for two convs evaluated as one GEMM: columns [0, C) -> (c1, sums1), [C, 2C) -> (c2, sums2)
+  static constexpr bool COLSTATS = true;
+  float* c1; float* c2; int C; double* sums1; double* sums2;
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
+    if (j < C) c1[(size_t)m * C + j] = v[0];
+    else c2[(size_t)m * C + (j - C)] = v[0];
+  }
+  __device__ __forceinline__ void stat(float v, const Col&, const Aux&, float& a, float& b) const { a += v; b += v * v; }
+  __device__ __forceinline__ void flush(int copy, int j, int, float s, float q) const {
+    double* sp = (j < C ? sums1 : sums2) + (size_t)copy * 2 * C;
+    const int jj = j < C ? j : j - C;
+    atomicAdd(sp + jj, (double)s); atomicAdd(sp + C + jj, (double)q);
+  }
+};
+struct EpAtomic2 {  // rows [0, M1) accumulate into c1, the rest into c2 (weight gradients of two stacked convs)
+  float* c1; float* c2; int ldc; int M1;
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const {
+    atomicAdd((m < M1 ? c1 + (size_t)m * ldc : c2 + (size_t)(m - M1) * ldc) + j, v[0]);
   }
 };
 struct EpAtomic {  // C[m*ldc + j] += v   (split-R weight gradients)

@@ -64,10 +64,18 @@ int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int
 
 // job 1: out[Mo, NJ1] += A1^T B1 over R1 rows (dR1: device-side count), optional column sums of A1 (bias gradient)
 // job 2: plain GEMM (M2 rows, device-side count dM2) with epilogue ep2
+template <class LA1, class LB1, class EP1, class LA2, class LB2, class EP2>
+int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
+                 const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st);
 template <class LA1, class LB1, class LA2, class LB2, class EP2>
 int gemm_pair(const LA1& la1, const LB1& lb1, float* out, int ldc, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
               const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st) {
-  const EpAtomic ep1{out, ldc};
+  return gemm_pair_ep(la1, lb1, EpAtomic{out, ldc}, Mo, NJ1, R1, dR1, colsum, la2, lb2, ep2, M2, NJ2, R2, dM2, st);
+}
+// the same with any accumulating epilogue for job 1
+template <class LA1, class LB1, class EP1, class LA2, class LB2, class EP2>
+int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
+                 const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st) {
   const long nb2 = (long)((M2 + 63) / 64) * ((NJ2 + 63) / 64);
   const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
   const int splits = tn_splits(Mo, NJ1, R1, gemm_pair_enabled() ? pair_tn_blocks_paired() : 0);
@@ -79,12 +87,12 @@ int gemm_pair(const LA1& la1, const LB1& lb1, float* out, int ldc, int Mo, int N
     return launch_gemm<TileSmall>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
   }
   if (thin)
-    return launch_gemm_dual<TileSmallK2, LA1, LB1, EpAtomic, TileThinK4, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+    return launch_gemm_dual<TileSmallK2, LA1, LB1, EP1, TileThinK4, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                       ep2, M2, NJ2, R2, dM2, st);
   if (k2)
-    return launch_gemm_dual<TileSmallK2, LA1, LB1, EpAtomic, TileSmallK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+    return launch_gemm_dual<TileSmallK2, LA1, LB1, EP1, TileSmallK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                        ep2, M2, NJ2, R2, dM2, st);
-  return launch_gemm_dual<TileSmallK2, LA1, LB1, EpAtomic, TileSmall, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
+  return launch_gemm_dual<TileSmallK2, LA1, LB1, EP1, TileSmall, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
                                                                                    M2, NJ2, R2, dM2, st);
 }
 

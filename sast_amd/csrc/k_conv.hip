@@ -16,11 +16,17 @@ namespace {
 // copies, added here); every block derives (mean, rstd) of all channels into LDS once and then streams `iters` x 256
 // float4 of the image; block 0 also publishes (mean, rstd) for the backward and updates the running statistics (torch
 // BatchNorm2d semantics: momentum, unbiased variance).  eval: running statistics.
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(const float* __restrict__ x, const double* __restrict__ sums, int M, float eps,
-                                                            float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                            float* __restrict__ stats, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y, int ldy, size_t n4, int C,
-                                                            int training, int iters) {
+struct BnFwdJob {
+  const float* x; const double* sums; float* run_mean; float* run_var; float* stats; const float* gamma; const float* beta;
+  float* y; int ldy; float momentum, eps;
+};
+// blockIdx.y selects the job: one conv, or the two convs of sast_conv_bn_silu2 (same M, C)
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJob j1, int M, size_t n4, int C, int training, int iters) {
+  const BnFwdJob& jb = blockIdx.y == 0 ? j0 : j1;
+  const float* __restrict__ x = jb.x; const double* __restrict__ sums = jb.sums;
+  float* __restrict__ run_mean = jb.run_mean; float* __restrict__ run_var = jb.run_var; float* __restrict__ stats = jb.stats;
+  const float* __restrict__ gamma = jb.gamma; const float* __restrict__ beta = jb.beta; float* __restrict__ y = jb.y;
+  const int ldy = jb.ldy; const float momentum = jb.momentum, eps = jb.eps;
   extern __shared__ float bn_sm[];   // [2C]: scale = rstd * gamma, shift = beta - mean * scale
   for (int c = threadIdx.x; c < C; c += 256) {
     float mu, rs;
@@ -111,10 +117,15 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // One block owns a strip of rows and ALL channels (fully coalesced float4 rows), reduces over its rows in LDS and
 // issues one atomic per channel -> (M / rows_per_block) * 2C atomics in total.
 constexpr int BN_RED_THREADS = 1024;   // few workgroups (one atomic per channel and workgroup), many waves each: per-CU bandwidth needs the loads in flight
-__global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            const float* __restrict__ dy, int lddy, int M, int C,
-                                                            float* __restrict__ sums, int rows_per_block) {
+struct BnBwdJob {
+  const float* x; const float* stats; const float* gamma; const float* beta; const float* dy; int lddy;
+  float* sums; float* dconv; float* dgamma; float* dbeta;
+};
+__global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob j0, BnBwdJob j1, int M, int C, int rows_per_block) {
+  const BnBwdJob& jb = blockIdx.y == 0 ? j0 : j1;
+  const float* __restrict__ x = jb.x; const float* __restrict__ stats = jb.stats; const float* __restrict__ gamma = jb.gamma;
+  const float* __restrict__ beta = jb.beta; const float* __restrict__ dy = jb.dy; const int lddy = jb.lddy;
+  float* __restrict__ sums = jb.sums;
   extern __shared__ float4 red[];                 // [RP][C/4][2]
   const int c4n = C / 4;
   const int RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;   // rows processed in parallel by the block
@@ -155,11 +166,12 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(const flo
 // Every block first folds the BN_STAT_COPIES copies of the two sums (written by bn_bwd_reduce_kernel into copy 0, or by the
 // consuming conv's dX epilogue into all of them) and the per-channel constants into LDS, then streams `iters` x 256 float4;
 // block 0 also publishes the affine gradients.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ dy, int lddy, const float* __restrict__ sums,
-                                                           float* __restrict__ dconv, size_t n4, int C, float invM, int training,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int iters) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob j1, size_t n4, int C, float invM, int training, int iters) {
+  const BnBwdJob& jb = blockIdx.y == 0 ? j0 : j1;
+  const float* __restrict__ x = jb.x; const float* __restrict__ stats = jb.stats; const float* __restrict__ gamma = jb.gamma;
+  const float* __restrict__ beta = jb.beta; const float* __restrict__ dy = jb.dy; const int lddy = jb.lddy;
+  const float* __restrict__ sums = jb.sums; float* __restrict__ dconv = jb.dconv;
+  float* __restrict__ dgamma = jb.dgamma; float* __restrict__ dbeta = jb.dbeta;
   extern __shared__ float bsm[];   // [6][C]: mean, rstd, gamma, beta, mean(dz), mean(dz*xhat)
   for (int c = threadIdx.x; c < C; c += 256) {
     float s1 = 0.f, s2 = 0.f;
@@ -256,6 +268,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     pp[k] -= (lr / bc1) * (mp[k] / denom);
   }
   st4(p + e * 4, pv); st4(m + e * 4, mv); st4(v + e * 4, vv);
+}
+
+// (dz, dz * xhat) column sums of `njobs` convs of equal shape (blockIdx.y = job)
+void bn_bwd_reduce_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int M, int C, hipStream_t st) {
+  static int target = -1;
+  if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
+  int rpb = (M + target - 1) / target;
+  rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
+  const int c4n = C / 4, RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb, njobs), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, j0, j1, M, C,
+                     rpb);
+}
+void bn_bwd_apply_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int M, int C, int training, hipStream_t st) {
+  const size_t n4 = (size_t)M * (C / 4);
+  int iters = (int)(n4 / (256 * 512));
+  iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), njobs), dim3(256), sizeof(float) * 6 * C, st,
+                     j0, j1, n4, C, 1.0f / (float)M, training, iters);
 }
 
 inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad, int replicate, int ldx) {
@@ -388,9 +418,11 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const size_t n4 = (size_t)M * (C / 4);
   int iters = (int)(n4 / (256 * 512));     // >= 512 blocks while the image allows it; the per-block statistics prologue is 2C*COPIES loads
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters))), dim3(256), sizeof(float) * 2 * C, st,
-                     a->conv_out, sums, M, a->eps, a->momentum, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, n4, C,
-                     a->training, iters);
+  {
+    const BnFwdJob jb{a->conv_out, sums, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, a->momentum, a->eps};
+    hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 1), dim3(256), sizeof(float) * 2 * C, st,
+                       jb, jb, M, n4, C, a->training, iters);
+  }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -407,21 +439,9 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
     if (a->bn_red_done) return SAST_EINVAL;   // the consumer has already accumulated into it
     zero_fill(sums, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
   }
-  if (!a->bn_red_done) {   // (dz, dz * xhat) column sums; skipped when the conv consuming y folded them into its dX epilogue
-    static int target = -1;
-    if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
-    int rpb = (M + target - 1) / target;
-    rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
-    const int c4n = C / 4, RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, a->conv_out, a->stats,
-                       a->bn_w, a->bn_b, a->dy, a->lddy, M, C, sums, rpb);
-  }
-  const size_t n4 = (size_t)M * (C / 4);
-  int iters = (int)(n4 / (256 * 512));
-  iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters))), dim3(256), sizeof(float) * 6 * C, st,
-                     a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, n4, C, 1.0f / (float)M, a->training, a->d_bn_w,
-                     a->d_bn_b, iters);
+  const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b};
+  if (!a->bn_red_done) bn_bwd_reduce_launch(jb, jb, 1, M, C, st);   // skipped when the conv consuming y folded it into its dX epilogue
+  bn_bwd_apply_launch(jb, jb, 1, M, C, a->training, st);
   SAST_CHECK_LAUNCH();
   // producers of x / x2 whose only consumer is this conv: their reductions ride on this conv's dX epilogue
   const int C2 = a->Cin - a->Cin1;
@@ -453,6 +473,70 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
                      LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st);
   }
   return conv_bwd_pair(dconv, a->x, g, C, a->w, a->dw, a->dx, a->lddx, st, fold ? &p1 : nullptr);
+}
+
+// ------------------------------------------------------------------ two 1x1 conv + BN + SiLU of the same input
+int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || a->Cin % 4 || a->Cout % 4 || a->Cin1 % 4 || a->Cin1 <= 0 || a->Cin1 > a->Cin || (a->Cin1 < a->Cin && !a->x2)) return SAST_EINVAL;
+  ProfScope ps_("convbn2_fwd", a->Cout * 10 + 1, a->B * a->H * a->W, st);
+  const int M = a->B * a->H * a->W, K = a->Cin, C = a->Cout;
+  if (!a->bn_ws_zeroed) {
+    zero_fill(a->bn_ws0, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
+    zero_fill(a->bn_ws1, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
+  }
+  const LdRows2 la{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2};
+  const EpStoreStats2 ep{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1};
+  int rc = gemm_auto(la, LdWeightNT2{a->w0, a->w1, K, C}, ep, M, 2 * C, K, st);
+  if (rc) return rc;
+  const size_t n4 = (size_t)M * (C / 4);
+  int iters = (int)(n4 / (256 * 512));
+  iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
+  const BnFwdJob j0{a->conv_out0, (const double*)a->bn_ws0, a->run_mean0, a->run_var0, a->stats0, a->bn_w0, a->bn_b0, a->y0, C, a->momentum0, a->eps0};
+  const BnFwdJob j1{a->conv_out1, (const double*)a->bn_ws1, a->run_mean1, a->run_var1, a->stats1, a->bn_w1, a->bn_b1, a->y1, C, a->momentum1, a->eps1};
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 2), dim3(256), sizeof(float) * 2 * C, st, j0, j1,
+                     M, n4, C, 1, iters);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!a || (a->Cin1 < a->Cin && !a->x2)) return SAST_EINVAL;
+  ProfScope ps_("convbn2_bwd", a->Cout * 10 + 1, a->B * a->H * a->W, st);
+  const int M = a->B * a->H * a->W, K = a->Cin, C = a->Cout, C2 = a->Cin - a->Cin1;
+  float* sums0 = a->bn_ws0 + 4 * BN_STAT_COPIES * C;
+  float* sums1 = a->bn_ws1 + 4 * BN_STAT_COPIES * C;
+  if (!a->bn_ws_zeroed) {
+    if (a->bn_red_done0 || a->bn_red_done1) return SAST_EINVAL;
+    zero_fill(sums0, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
+    zero_fill(sums1, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
+  }
+  const BnBwdJob j0{a->conv_out0, a->stats0, a->bn_w0, a->bn_b0, a->dy0, C, sums0, a->ws0, a->d_bn_w0, a->d_bn_b0};
+  const BnBwdJob j1{a->conv_out1, a->stats1, a->bn_w1, a->bn_b1, a->dy1, C, sums1, a->ws1, a->d_bn_w1, a->d_bn_b1};
+  if (!a->bn_red_done0 && !a->bn_red_done1) bn_bwd_reduce_launch(j0, j1, 2, M, C, st);
+  else if (!a->bn_red_done0) bn_bwd_reduce_launch(j0, j0, 1, M, C, st);
+  else if (!a->bn_red_done1) bn_bwd_reduce_launch(j1, j1, 1, M, C, st);
+  bn_bwd_apply_launch(j0, j1, 2, M, C, 1, st);
+  SAST_CHECK_LAUNCH();
+  // dW of both convs: [dconv0 | dconv1]^T [x | x2] -> (dw0, dw1);  dX = [dconv0 | dconv1] [w0; w1]
+  const LdRowsT2 ta{a->ws0, C, C, a->ws1, C};
+  const LdRowsT2 tb{a->x, a->ldx, a->Cin1, C2 > 0 ? a->x2 : nullptr, a->ldx2};
+  const EpAtomic2 ep1{a->dw0, a->dw1, K, C};
+  if (!a->dx) return launch_gemm_split<TileSmallK2>(ta, tb, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
+  if (C2 > 0 && !a->dx2) return SAST_EINVAL;
+  const LdRows2 la{a->ws0, C, C, a->ws1, C};
+  const LdWeightNN2 lb{a->w0, a->w1, K, C};
+  BnProducer p1{a->p_conv_out, a->p_stats, a->p_bn_w, a->p_bn_b, a->p_bn_ws ? a->p_bn_ws + 4 * BN_STAT_COPIES * a->Cin1 : nullptr, a->Cin1};
+  BnProducer p2{a->p2_conv_out, a->p2_stats, a->p2_bn_w, a->p2_bn_b, a->p2_bn_ws ? a->p2_bn_ws + 4 * BN_STAT_COPIES * C2 : nullptr, C2};
+  if (p1.x || p2.x) {
+    if ((p1.x && (a->ldx != a->Cin1 || !(p1.stats && p1.gamma && p1.beta && p1.sums))) ||
+        (p2.x && (C2 <= 0 || a->ldx2 != C2 || !(p2.stats && p2.gamma && p2.beta && p2.sums))))
+      return SAST_EINVAL;
+    return gemm_pair_ep(ta, tb, ep1, 2 * C, K, M, nullptr, nullptr, la, lb, EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, K, 2 * C,
+                        nullptr, st);
+  }
+  return gemm_pair_ep(ta, tb, ep1, 2 * C, K, M, nullptr, nullptr, la, lb, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, K, 2 * C, nullptr, st);
 }
 
 // ------------------------------------------------------------------ upsample / concat

@@ -94,9 +94,29 @@ class CSPLayer(nn.Module):
         self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
-    def forward_nhwc(self, x, arena=None):
-        x1 = self.conv1.forward_nhwc(x, arena)
-        x2 = self.conv2.forward_nhwc(x, arena)
+    def _conv12(self, x, arena, sole_input):
+        cs = (self.conv1, self.conv2)
+        ws = tuple(arena.take(SF.bn_ws_floats(c.bn.num_features)) if arena is not None else None for c in cs)
+        args = tuple((c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.momentum, c.bn.eps) for c in cs)
+        ys = SF.conv_bn_silu2(x, args[0], args[1], ws, sole_consumer=sole_input)
+        for c in cs:
+            if c.bn.num_batches_tracked is not None:
+                if arena is not None:
+                    arena.counters.append(c.bn.num_batches_tracked)
+                else:
+                    c.bn.num_batches_tracked.add_(1)
+        return ys
+
+    def forward_nhwc(self, x, arena=None, sole_input=False):
+        """sole_input: nothing but this layer consumes x (then the BatchNorm-backward reductions of the convs that produced x
+        ride on this layer's input-gradient launch)"""
+        if self.training and SF.CONV_PAIR:
+            # conv1 and conv2 read the same input: one GEMM over the stacked weights, one BatchNorm pass for both, and a
+            # backward whose dX is already the sum of the two input gradients
+            x1, x2 = self._conv12(x, arena, sole_input)
+        else:
+            x1 = self.conv1.forward_nhwc(x, arena)
+            x2 = self.conv2.forward_nhwc(x, arena)
         for b in self.m:
             x1 = b.forward_nhwc(x1, arena, sole_input=True)
         return self.conv3.forward_nhwc((x1, x2), arena, sole=True)     # th.cat((x_1, x_2)) read in place by the 1x1 conv

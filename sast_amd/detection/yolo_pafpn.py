@@ -38,13 +38,13 @@ class YOLOPAFPN(nn.Module):
             self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         ar = BnArena(self._bn_floats, x0.device)                            # one memset for all 32 BatchNorm reductions
         fpn_out0 = self.lateral_conv0.forward_nhwc(x0, ar)
-        f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1), ar)  # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
+        f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1), ar, sole_input=True)  # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
         fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0, ar, sole=True)      # f_out0 has no other consumer
-        pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2), ar)
+        pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2), ar, sole_input=True)
         p_out1 = (self.bu_conv2.forward_nhwc(pan_out2, ar), fpn_out1)   # th.cat (yolo_pafpn.py:129) read in place by C3_n3's 1x1 convs
-        pan_out1 = self.C3_n3.forward_nhwc(p_out1, ar)
+        pan_out1 = self.C3_n3.forward_nhwc(p_out1, ar, sole_input=(True, False))   # the bottom-up conv feeds only this layer; fpn_out1 also the top-down path
         p_out0 = (self.bu_conv1.forward_nhwc(pan_out1, ar), fpn_out0)   # th.cat (yolo_pafpn.py:134)
-        pan_out0 = self.C3_n4.forward_nhwc(p_out0, ar)
+        pan_out0 = self.C3_n4.forward_nhwc(p_out0, ar, sole_input=(True, False))
         ar.finish()
         return pan_out2, pan_out1, pan_out0
 

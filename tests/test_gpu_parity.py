@@ -740,6 +740,49 @@ def test_bn_backward_reduction_folded_into_consumer_matches_separate_launch(dev)
         maxnorm_close(ga[k], gb[k], 1e-5, k)
 
 
+@pytest.mark.parametrize("pair_input", [False, True])
+def test_csp_conv_pair_matches_separate_convs(dev, pair_input):
+    """CSPLayer.conv1 / conv2 (same input) as one stacked GEMM + shared BatchNorm launches (sast_conv_bn_silu2) against the
+    two separate convs: outputs, running statistics and every gradient; with a plain input and with a virtual-concat pair
+    whose first source is itself a conv output (its BatchNorm-backward reduction then rides on the pair's dX epilogue)"""
+    from sast_amd import functional as SF
+    from sast_amd.detection.network_blocks import BaseConv, CSPLayer
+    torch.manual_seed(7)
+    pre = BaseConv(48, 32, 3, 2).to(dev).train()
+    net = CSPLayer(96 if pair_input else 64, 64, n=1, shortcut=False).to(dev).train()
+    xa0 = torch.randn(2, 24, 40, 48, device=dev)
+    xb0 = torch.randn(2, 12, 20, 64, device=dev)
+    res = []
+    for pair in (True, False):
+        old = SF.CONV_PAIR
+        SF.CONV_PAIR = pair
+        try:
+            for m in (pre, net):
+                m.zero_grad()
+                for mod in m.modules():
+                    if isinstance(mod, torch.nn.BatchNorm2d):
+                        mod.reset_running_stats()
+            xa, xb = xa0.clone().requires_grad_(True), xb0.clone().requires_grad_(True)
+            inp = (pre.forward_nhwc(xa), xb) if pair_input else xb
+            y = net.forward_nhwc(inp, sole_input=(True, False))
+            (y * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            named = list(net.named_parameters()) + ([("pre." + k, p) for k, p in pre.named_parameters()] if pair_input else [])
+            g = {k: p.grad.clone() for k, p in named}
+            res.append((y.detach().clone(), xb.grad.clone(), xa.grad.clone() if pair_input else None, g,
+                        net.conv1.bn.running_var.clone(), net.conv2.bn.running_mean.clone()))
+        finally:
+            SF.CONV_PAIR = old
+    (ya, xba, xaa, ga, rva, rma), (yb, xbb, xab, gb, rvb, rmb) = res
+    maxnorm_close(ya, yb, 1e-5, "y")
+    maxnorm_close(rva, rvb, 1e-6, "running_var")
+    maxnorm_close(rma, rmb, 1e-6, "running_mean")
+    maxnorm_close(xba, xbb, 1e-5, "dx")
+    if pair_input:
+        maxnorm_close(xaa, xab, 1e-5, "dx of the producing conv's input")
+    for k in ga:
+        maxnorm_close(ga[k], gb[k], 2e-5, k)
+
+
 def test_mean_squares_matches_torch(dev):
     """bench.py's synthetic objective: sum_t mean(x_t^2) in one launch each way == the torch expression"""
     from sast_amd import functional as SF
