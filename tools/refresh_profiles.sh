@@ -1,6 +1,6 @@
 set -x
 export TMPDIR=/tmp
-O=gpurun_out/r01_j
+O=gpurun_out/${SAST_PROFILE_TAG:-r01_k}
 mkdir -p $O
 timeout 600 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 bench.py --no-cpu-baseline > $O/kt.log 2>&1
