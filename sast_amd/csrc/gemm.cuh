@@ -126,7 +126,9 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   const int bj = tile_id % nbj, bm = tile_id / nbj;
   const int m0 = bm * BM, j0 = bj * BJ;
   const int Meff = dM ? min(M, *dM) : M;
-  const int Reff = dR ? min(R, *dR) : R;
+  int Reff_ = dR ? min(R, *dR) : R;
+  if constexpr (LoaderWantsM0<LB>::value) Reff_ = min(Reff_, lb.reduce_len(m0));   // row-tile dependent reduction length (parity classes)
+  const int Reff = Reff_;
   SAST_TL(0);
   if (m0 >= Meff) return;
   const int nkt = (Reff + BK - 1) / BK;
@@ -846,10 +848,13 @@ struct LdWeightConvDx {
 // the input pixels are re-ordered into the 4 classes (iy & 1, ix & 1) -- row m = class * Mc + (b, yy, xx), pixel
 // (2 yy + py, 2 xx + px) -- and every class reduces over its own list of at most 2 x 2 taps (3x3: 1, 2, 2 and 4 taps; with
 // replicate padding the border-only taps kh < pad join the even classes), padded to 4 slots so that all classes share one
-// launch: 16 tap slots instead of 36.  Mc must be a multiple of the row tile so that a block sees a single class.
+// launch: 16 tap slots instead of 36, of which a row tile reduces only over the used ones of its class (9 of the 16 for a 3x3
+// kernel with zero padding).  Mc must be a multiple of the row tile so that a block sees a single class.
 struct ConvDxClasses {
   int Hc, Wc, Mc;
-  unsigned kh_pack[4], kw_pack[4];   // per class: 4 bits per tap slot, 15 = empty slot
+  unsigned kh_pack[4], kw_pack[4];   // per class: 4 bits per tap slot, 15 = empty slot; the used slots come first
+  int nslot[4];                      // per class: number of used slots (the reduction of a row tile stops there)
+  __device__ __forceinline__ int slots(int cls) const { return cls == 0 ? nslot[0] : cls == 1 ? nslot[1] : cls == 2 ? nslot[2] : nslot[3]; }
   __device__ __forceinline__ void packs(int cls, unsigned& kh, unsigned& kw) const {
     kh = cls == 0 ? kh_pack[0] : cls == 1 ? kh_pack[1] : cls == 2 ? kh_pack[2] : kh_pack[3];
     kw = cls == 0 ? kw_pack[0] : cls == 1 ? kw_pack[1] : cls == 2 ? kw_pack[2] : kw_pack[3];
@@ -865,7 +870,8 @@ struct LdConvDxP {
     const int cls = ii / k.Mc, ic = ii - cls * k.Mc;
     const int xx = ic % k.Wc, t = ic / k.Wc, yy = t % k.Hc, b = t / k.Hc;
     Ctx c;
-    c.img = dy + (size_t)b * g.Ho * g.Wo * lddy; c.iy = 2 * yy + (cls >> 1); c.ix = 2 * xx + (cls & 1); c.ok = ok;
+    const int q = 3 - cls;   // the classes are laid out heaviest first (odd-odd pixels see 4 taps, even-even 1): parity = 3 - position
+    c.img = dy + (size_t)b * g.Ho * g.Wo * lddy; c.iy = 2 * yy + (q >> 1); c.ix = 2 * xx + (q & 1); c.ok = ok;
     k.packs(cls, c.kh, c.kw);
     return c;
   }
@@ -900,6 +906,7 @@ struct LdWeightConvDxP {
     k.packs(m0 / k.Mc, c.kh, c.kw);
     return c;
   }
+  __device__ __forceinline__ int reduce_len(int m0) const { return k.slots(m0 / k.Mc) * Cout; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 1);
     const int slot = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - slot * Cout;
@@ -1032,7 +1039,8 @@ struct EpStoreClass {  // C[pixel(m) * ldc + j] = v, pixel(m) from the parity-cl
   __device__ __forceinline__ Aux pre(int m, int) const {
     const int cls = m / k.Mc, ic = m - cls * k.Mc;
     const int xx = ic % k.Wc, t = ic / k.Wc, yy = t % k.Hc, b = t / k.Hc;
-    return Aux{(b * H + 2 * yy + (cls >> 1)) * W + 2 * xx + (cls & 1)};
+    const int q = 3 - cls;
+    return Aux{(b * H + 2 * yy + (q >> 1)) * W + 2 * xx + (q & 1)};
   }
   __device__ __forceinline__ void post(int, int j, const float (&v)[1], const Col&, const Aux& a) const {
     c[(size_t)a.p * ldc + j] = v[0];

@@ -38,9 +38,9 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hi
   return gemm_auto(la, lb, ep, M, NJ, R, nullptr, st);
 }
 
-// inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (192 measured best; a target
+// inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (152 measured best, re-swept after the parity-class dX job stopped multiplying its empty tap slots; a target
 // that adapts to the dX job's grid size was not better)
-inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 192); return v; }
+inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 152); return v; }
 
 // target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)
 inline int tn_splits(int Mo, int NJ, int R, int target = 0) {

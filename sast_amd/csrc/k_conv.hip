@@ -322,7 +322,7 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
   ConvDxClasses c;
   c.Hc = g.H / 2; c.Wc = g.W / 2; c.Mc = Mc;
   for (int cls = 0; cls < 4; ++cls) {
-    const int py = cls >> 1, px = cls & 1;
+    const int py = (3 - cls) >> 1, px = (3 - cls) & 1;   // row order: heaviest class first (gemm.cuh: LdConvDxP)
     // taps that can be non-zero for this class: matching parity, plus (replicate padding) the border tap kk < pad that folds
     // onto output row / column 0 for input row / column 0 (an even one); unused slots are marked 15
     int ty[2] = {15, 15}, tx[2] = {15, 15}, ny = 0, nx = 0;
@@ -331,12 +331,17 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
       if ((px + g.pad - kk) % 2 == 0 || (g.replicate && px == 0 && kk < g.pad)) tx[nx++] = kk;
     }
     c.kh_pack[cls] = c.kw_pack[cls] = 0;
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < 2; ++b) {
-        const int slot = a * 2 + b;
-        c.kh_pack[cls] |= (unsigned)ty[a] << (4 * slot);
-        c.kw_pack[cls] |= (unsigned)tx[b] << (4 * slot);
-      }
+    int slot = 0;
+    for (int pass = 0; pass < 2; ++pass)      // used (tap row, tap column) pairs first, empty slots after them
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+          const bool used = ty[a] != 15 && tx[b] != 15;
+          if (used != (pass == 0)) continue;
+          c.kh_pack[cls] |= (unsigned)(used ? ty[a] : 15) << (4 * slot);
+          c.kw_pack[cls] |= (unsigned)(used ? tx[b] : 15) << (4 * slot);
+          ++slot;
+        }
+    c.nslot[cls] = ny * nx;
   }
   return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDxP{dconv, g, Cout, Cout, shift, c},
                    LdWeightConvDxP{w, Cout, k * k, g.Cin, shift, g.KW, c}, EpStoreClass{dx, lddx, g.H, g.W, c}, 4 * Mc, g.Cin, 4 * Cout,
