@@ -40,6 +40,8 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hi
 
 // inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (152 measured best, re-swept after the parity-class dX job stopped multiplying its empty tap slots; a target
 // that adapts to the dX job's grid size was not better)
+// the same for the k x k conv pairs (im2col / backward-data jobs)
+inline int pair_tn_blocks_conv() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_CONV", 152); return v; }
 inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 152); return v; }
 
 // target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)
@@ -66,19 +68,19 @@ int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int
 // job 2: plain GEMM (M2 rows, device-side count dM2) with epilogue ep2
 template <class LA1, class LB1, class EP1, class LA2, class LB2, class EP2>
 int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
-                 const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st);
+                 const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st, int tn_target = 0);
 template <class LA1, class LB1, class LA2, class LB2, class EP2>
 int gemm_pair(const LA1& la1, const LB1& lb1, float* out, int ldc, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
-              const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st) {
-  return gemm_pair_ep(la1, lb1, EpAtomic{out, ldc}, Mo, NJ1, R1, dR1, colsum, la2, lb2, ep2, M2, NJ2, R2, dM2, st);
+              const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st, int tn_target = 0) {
+  return gemm_pair_ep(la1, lb1, EpAtomic{out, ldc}, Mo, NJ1, R1, dR1, colsum, la2, lb2, ep2, M2, NJ2, R2, dM2, st, tn_target);
 }
 // the same with any accumulating epilogue for job 1
 template <class LA1, class LB1, class EP1, class LA2, class LB2, class EP2>
 int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
-                 const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st) {
+                 const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st, int tn_target) {
   const long nb2 = (long)((M2 + 63) / 64) * ((NJ2 + 63) / 64);
   const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
-  const int splits = tn_splits(Mo, NJ1, R1, gemm_pair_enabled() ? pair_tn_blocks_paired() : 0);
+  const int splits = tn_splits(Mo, NJ1, R1, gemm_pair_enabled() ? (tn_target > 0 ? tn_target : pair_tn_blocks_paired()) : 0);
   if (!gemm_pair_enabled() || Mo <= 0 || NJ1 <= 0 || R1 <= 0 || M2 <= 0 || NJ2 <= 0 || R2 <= 0) {
     int rc = launch_gemm_split<TileSmallK2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);
     if (rc) return rc;

@@ -314,11 +314,11 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
   if (prod && prod->x) {   // stride-1 convs only (the caller checks): dX epilogue also reduces the producer's BatchNorm backward sums
     if (g.stride != 1 || lddx != g.Cin || prod->C != g.Cin) return SAST_EINVAL;
     return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
-                     LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStoreBnRed{dx, lddx, *prod}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st);
+                     LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStoreBnRed{dx, lddx, *prod}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
   }
   if (!(parity && g.stride == 2 && k == 3 && g.pad == 1 && g.H % 2 == 0 && g.W % 2 == 0 && Mc % 64 == 0))
     return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
-                     LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st);
+                     LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
   ConvDxClasses c;
   c.Hc = g.H / 2; c.Wc = g.W / 2; c.Mc = Mc;
   for (int cls = 0; cls < 4; ++cls) {
@@ -345,7 +345,7 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
   }
   return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDxP{dconv, g, Cout, Cout, shift, c},
                    LdWeightConvDxP{w, Cout, k * k, g.Cin, shift, g.KW, c}, EpStoreClass{dx, lddx, g.H, g.W, c}, 4 * Mc, g.Cin, 4 * Cout,
-                   nullptr, st);
+                   nullptr, st, pair_tn_blocks_conv());
 }
 
 }  // namespace
