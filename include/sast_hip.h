@@ -269,13 +269,13 @@ size_t sast_yolox_loss_ws_bytes(int B, int anchors_total, int max_labels);
 int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes, int use_l1,
                     float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream);
 
-/* postprocess -- yolox/utils/boxes.py:32-76: confidence filter (obj * max class conf >= conf_thre), class-aware
- * greedy NMS (the reference delegates it to torchvision.ops.batched_nms).  prediction [B, A, 5+nc] = (cx, cy, w, h, obj, cls...) as
+/* postprocess -- yolox/utils/boxes.py:32-76: confidence filter (obj * max class conf >= conf_thre), greedy NMS --
+ * class-aware (torchvision.ops.batched_nms in the reference) or, with class_agnostic != 0, over all boxes (torchvision.ops.nms).  prediction [B, A, 5+nc] = (cx, cy, w, h, obj, cls...) as
  * returned by the head; out [B, A, 7] = (x1, y1, x2, y2, obj_conf, class_conf, class_pred), the first n_out[b] rows of image b are
  * its detections by decreasing score.  A <= 8192. */
 size_t sast_postprocess_ws_bytes(int B, int anchors_total);
-int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, float* out,
-                     int32_t* n_out, void* ws, sast_stream_t stream);
+int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, int class_agnostic,
+                     float* out, int32_t* n_out, void* ws, sast_stream_t stream);
 
 /* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441) */
 int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,

@@ -558,14 +558,14 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
 # descending, keep a box unless its IoU with an already kept box OF THE SAME CLASS exceeds the threshold.  (torchvision realises
 # the class separation by shifting the boxes of class c by c * (max coordinate + 1); the decision is the same up to rounding.)
 # Parity for this function is therefore pinned by definition, not by a run of torchvision.
-def _nms_greedy(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float) -> Tensor:
+def _nms_greedy(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float, class_agnostic: bool = False) -> Tensor:
     order = torch.sort(scores, descending=True, stable=True).indices
     keep: List[int] = []
     area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
     for i in order.tolist():
         ok = True
         for j in keep:
-            if classes[i] != classes[j]:
+            if not class_agnostic and classes[i] != classes[j]:
                 continue
             w = (torch.min(boxes[i, 2], boxes[j, 2]) - torch.max(boxes[i, 0], boxes[j, 0])).clamp(min=0)
             h = (torch.min(boxes[i, 3], boxes[j, 3]) - torch.max(boxes[i, 1], boxes[j, 1])).clamp(min=0)
@@ -578,8 +578,8 @@ def _nms_greedy(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float) -> T
     return torch.tensor(keep, dtype=torch.long)
 
 
-def postprocess(prediction: Tensor, num_classes: int, conf_thre: float = 0.7, nms_thre: float = 0.45):
-    """boxes.py:32-76 (class-aware branch): prediction (B, A, 5+nc) with (cx, cy, w, h, obj, cls...) -> list of (n_i, 7) tensors
+def postprocess(prediction: Tensor, num_classes: int, conf_thre: float = 0.7, nms_thre: float = 0.45, class_agnostic: bool = False):
+    """boxes.py:32-76 (class-aware branch, or torchvision.ops.nms over all boxes with class_agnostic): prediction (B, A, 5+nc) with (cx, cy, w, h, obj, cls...) -> list of (n_i, 7) tensors
     (x1, y1, x2, y2, obj_conf, class_conf, class_pred) sorted by decreasing score, or None."""
     pred = prediction.clone()
     pred[:, :, 0] = prediction[:, :, 0] - prediction[:, :, 2] / 2
@@ -593,7 +593,7 @@ def postprocess(prediction: Tensor, num_classes: int, conf_thre: float = 0.7, nm
         det = torch.cat((ip[:, :5], class_conf, class_pred.float()), 1)[mask]
         if not det.size(0):
             continue
-        keep = _nms_greedy(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thre)
+        keep = _nms_greedy(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thre, class_agnostic)
         out[i] = det[keep]
     return out
 

@@ -80,7 +80,7 @@ _SIGNATURES = {
     "sast_head_pred_fwd": (C.c_int, [P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, P]),
     "sast_head_pred_bwd": (C.c_int, [P] * 14 + [C.c_int] * 7 + [P]),
     "sast_postprocess_ws_bytes": (C.c_size_t, [C.c_int, C.c_int]),
-    "sast_postprocess": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, P, P, P, P]),
+    "sast_postprocess": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, P, P, P, P]),
     "sast_yolox_loss_ws_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "sast_yolox_loss": (C.c_int, [P, P, C.POINTER(SastHeadGeom), C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P]),
     "sast_mask_token_fwd": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P]),

@@ -498,9 +498,9 @@ __global__ __launch_bounds__(1024) void nms_candidates_kernel(const float* __res
     d[4] = p[4]; d[5] = cmax; d[6] = (float)carg; d[7] = key[i];
   }
 }
-// suppression bit matrix: bit j of mask[i][j/64] set when sorted box j > i has the same class and IoU(i, j) > thr
+// suppression bit matrix: bit j of mask[i][j/64] set when sorted box j > i has the same class (or class_agnostic) and IoU(i, j) > thr
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ det, const int* __restrict__ ncand, int A, float thr,
-                                                      unsigned long long* __restrict__ mask, int words) {
+                                                      unsigned long long* __restrict__ mask, int words, int class_agnostic) {
   const int b = blockIdx.z, n = ncand[b];
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   if (i0 >= n || j0 >= n || j0 + 63 < i0) return;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   unsigned long long bits = 0ull;
   for (int t = 0; t < 64; ++t) {
     const int j = j0 + t;
-    if (j <= i || j >= n || bj[t][4] != cl) continue;
+    if (j <= i || j >= n || (!class_agnostic && bj[t][4] != cl)) continue;
     const float w = fmaxf(fminf(x2, bj[t][2]) - fmaxf(x1, bj[t][0]), 0.f), h = fmaxf(fminf(y2, bj[t][3]) - fmaxf(y1, bj[t][1]), 0.f);
     const float inter = w * h, aj = (bj[t][2] - bj[t][0]) * (bj[t][3] - bj[t][1]);
     if (inter / (ai + aj - inter) > thr) bits |= 1ull << t;
@@ -657,8 +657,8 @@ size_t sast_postprocess_ws_bytes(int B, int anchors_total) {
   return (size_t)B * A * 8 * sizeof(float) + (size_t)B * A * words * sizeof(unsigned long long) + (size_t)B * sizeof(int) + 64;
 }
 
-int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, float* out,
-                     int32_t* n_out, void* ws, sast_stream_t stream) {
+int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, int class_agnostic,
+                     float* out, int32_t* n_out, void* ws, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const int A = anchors_total, words = (A + 63) / 64;
   if (!prediction || !out || !n_out || !ws || A < 1 || A > NMS_MAX || num_classes < 1) return SAST_EINVAL;
@@ -667,7 +667,7 @@ int sast_postprocess(const float* prediction, int B, int anchors_total, int num_
   int* ncand = (int*)(mask + (size_t)B * A * words);
   zero_fill(mask, sizeof(unsigned long long) * (size_t)B * A * words, st);
   hipLaunchKernelGGL(nms_candidates_kernel, dim3(B), dim3(1024), 0, st, prediction, A, num_classes, conf_thre, det, ncand);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, A, nms_thre, mask, words);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, A, nms_thre, mask, words, class_agnostic);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, det, ncand, A, mask, words, out, n_out);
   SAST_CHECK_LAUNCH();
   return SAST_OK;

@@ -988,8 +988,6 @@ def head_pred_loss(labels, levels, num_classes, decode, per_level_tensors, use_l
 def postprocess(prediction: torch.Tensor, num_classes: int, conf_thre: float = 0.7, nms_thre: float = 0.45, class_agnostic: bool = False):
     """yolox/utils/boxes.py:32-76: prediction (B, A, 5+nc) from the head -> list of (n_i, 7) tensors (x1, y1, x2, y2, obj_conf,
     class_conf, class_pred) by decreasing score, None for images without detections.  One host sync (the detection counts)."""
-    if class_agnostic:
-        raise NotImplementedError("sast_amd: class_agnostic NMS is not implemented (the reference calls postprocess without it)")
     _need_gpu(prediction)
     prediction = prediction.float().contiguous()
     B, A, no = prediction.shape
@@ -997,7 +995,7 @@ def postprocess(prediction: torch.Tensor, num_classes: int, conf_thre: float = 0
     out = torch.empty(B, A, 7, device=prediction.device)
     n_out = torch.empty(B, device=prediction.device, dtype=torch.int32)
     ws = torch.empty(L.lib().sast_postprocess_ws_bytes(B, A), device=prediction.device, dtype=torch.uint8)
-    L.check(L.lib().sast_postprocess(prediction.data_ptr(), B, A, num_classes, float(conf_thre), float(nms_thre), out.data_ptr(),
+    L.check(L.lib().sast_postprocess(prediction.data_ptr(), B, A, num_classes, float(conf_thre), float(nms_thre), int(bool(class_agnostic)), out.data_ptr(),
                                      n_out.data_ptr(), ws.data_ptr(), _stream()), "postprocess")
     counts = n_out.tolist()
     return [out[b, :n].clone() if n else None for b, n in enumerate(counts)]

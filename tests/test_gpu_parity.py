@@ -342,8 +342,8 @@ def test_yolox_loss_full_size(dev):
         assert abs(float(losses[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (k, float(losses[k]), float(ref[k]))
 
 
-@pytest.mark.parametrize("A,thr", [(420, 0.3), (5040, 0.05)])
-def test_postprocess_nms(dev, A, thr):
+@pytest.mark.parametrize("A,thr,agnostic", [(420, 0.3, False), (5040, 0.05, False), (420, 0.3, True)])
+def test_postprocess_nms(dev, A, thr, agnostic):
     """confidence filter + class-aware greedy NMS (yolox/utils/boxes.py:32-76) on clustered random predictions, incl. an image
     without any detection: detections and their order against the oracle's restatement."""
     from sast_amd import functional as SF
@@ -357,8 +357,8 @@ def test_postprocess_nms(dev, A, thr):
     cls = torch.rand(B, A, nc, generator=g)
     pred = torch.cat([cxcy, wh, obj, cls], -1)
     pred[2, :, 4] = 0.0                                   # image 2: nothing above the confidence threshold
-    ref = O.postprocess(pred, nc, conf_thre=thr, nms_thre=0.45)
-    got = SF.postprocess(pred.to(dev), nc, conf_thre=thr, nms_thre=0.45)
+    ref = O.postprocess(pred, nc, conf_thre=thr, nms_thre=0.45, class_agnostic=agnostic)
+    got = SF.postprocess(pred.to(dev), nc, conf_thre=thr, nms_thre=0.45, class_agnostic=agnostic)
     assert ref[2] is None and got[2] is None
     for b in range(2):
         assert got[b] is not None and got[b].shape == ref[b].shape, (b, None if got[b] is None else got[b].shape, ref[b].shape)
