@@ -614,14 +614,19 @@ class BnHandle:
     own dX epilogue (include/sast_hip.h: SastConvBnArgs.p_*), plus the flag telling the producer's backward it was done."""
     __slots__ = ("conv_out", "stats", "bn_w", "bn_b", "bn_ws", "cout", "red_done")
 
-    def __init__(self, conv_out, stats, bn_w, bn_b, bn_ws, cout):
-        self.conv_out, self.stats, self.bn_w, self.bn_b, self.bn_ws, self.cout = conv_out, stats, bn_w, bn_b, bn_ws, cout
+    def __init__(self):
+        self.conv_out = self.stats = self.bn_w = self.bn_b = self.bn_ws = None
+        self.cout = -1
         self.red_done = False
+
+    def fill(self, conv_out, stats, bn_w, bn_b, bn_ws, cout):
+        self.conv_out, self.stats, self.bn_w, self.bn_b, self.bn_ws, self.cout = conv_out, stats, bn_w, bn_b, bn_ws, cout
+        return self
 
 
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers=(None, None)):
+    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers, handle):
         _need_gpu(x, w)
         x = x.contiguous()
         if not is_channels_last_weight(w):
@@ -650,14 +655,13 @@ class _ConvBnSilu(torch.autograd.Function):
         ctx.save_for_backward(x, x2, conv_out, stats, bn_ws)
         ctx.params = (w, bn_w, bn_b)
         ctx.meta = (B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M)
-        ctx.handle = BnHandle(conv_out, stats, bn_w, bn_b, bn_ws, Cout) if training else None
+        ctx.handle = handle.fill(conv_out, stats, bn_w, bn_b, bn_ws, Cout) if (training and handle is not None) else None
         p1, p2 = producers if (training and stride == 1) else (None, None)
         if p1 is not None and p1.cout != Cin1:
             p1 = None
         if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
             p2 = None
         ctx.producers = (p1, p2)
-        _LAST_BN_HANDLE[0] = ctx.handle
         return y
 
     @staticmethod
@@ -689,7 +693,7 @@ class _ConvBnSilu(torch.autograd.Function):
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 12
+        return (dx, dx2) + (None,) * 13
 
 
 def bn_ws_floats(cout: int) -> int:
@@ -702,7 +706,7 @@ class _ConvBnSilu2(torch.autograd.Function):
     the stacked weights; the backward's dX is the sum of both input gradients (include/sast_hip.h: SastConvBn2Args)."""
 
     @staticmethod
-    def forward(ctx, x, x2, w0, bnw0, bnb0, rm0, rv0, w1, bnw1, bnb1, rm1, rv1, mom0, eps0, mom1, eps1, ws0, ws1, producers):
+    def forward(ctx, x, x2, w0, bnw0, bnb0, rm0, rv0, w1, bnw1, bnb1, rm1, rv1, mom0, eps0, mom1, eps1, ws0, ws1, producers, handles):
         _need_gpu(x, w0, w1)
         x = x.contiguous()
         for w in (w0, w1):
@@ -732,14 +736,13 @@ class _ConvBnSilu2(torch.autograd.Function):
         ctx.save_for_backward(x, x2, co[0], co[1], st[0], st[1], ws0, ws1)
         ctx.params = (w0, bnw0, bnb0, w1, bnw1, bnb1)
         ctx.meta = (B, H, W, Cin, Cin1, Cout, mom0, eps0, mom1, eps1, M)
-        ctx.handles = (BnHandle(co[0], st[0], bnw0, bnb0, ws0, Cout), BnHandle(co[1], st[1], bnw1, bnb1, ws1, Cout))
+        ctx.handles = (handles[0].fill(co[0], st[0], bnw0, bnb0, ws0, Cout), handles[1].fill(co[1], st[1], bnw1, bnb1, ws1, Cout))
         p1, p2 = producers
         if p1 is not None and p1.cout != Cin1:
             p1 = None
         if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
             p2 = None
         ctx.producers = (p1, p2)
-        _LAST_BN_HANDLE[0] = ctx.handles
         return ys[0], ys[1]
 
     @staticmethod
@@ -773,7 +776,7 @@ class _ConvBnSilu2(torch.autograd.Function):
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 17
+        return (dx, dx2) + (None,) * 18
 
 
 def conv_bn_silu2(x_nhwc, conv0, conv1, bn_ws=(None, None), sole_consumer=False):
@@ -783,16 +786,11 @@ def conv_bn_silu2(x_nhwc, conv0, conv1, bn_ws=(None, None), sole_consumer=False)
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
     prods = _producers(x, x2, sole_consumer)
     (w0, g0, b0, rm0, rv0, m0, e0), (w1, g1, b1, rm1, rv1, m1, e1) = conv0, conv1
+    hs = (BnHandle(), BnHandle())
     y0, y1 = _ConvBnSilu2.apply(x, x2, w0, g0, b0, rm0, rv0, w1, g1, b1, rm1, rv1, float(m0), float(e0), float(m1), float(e1),
-                                bn_ws[0], bn_ws[1], prods)
-    hs = _LAST_BN_HANDLE[0]
-    if hs is not None:
-        y0._sast_bn, y1._sast_bn = hs
-        _LAST_BN_HANDLE[0] = None
+                                bn_ws[0], bn_ws[1], prods, hs)
+    y0._sast_bn, y1._sast_bn = hs
     return y0, y1
-
-
-_LAST_BN_HANDLE = [None]
 
 
 def _producers(x, x2, sole):
@@ -816,10 +814,11 @@ def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, traini
     # is itself a conv_bn_silu output (it carries a BnHandle), that producer's BatchNorm-backward reduction is folded into
     # this conv's dX epilogue (one launch fewer per conv in the backward pass)
     prods = _producers(x, x2, sole_consumer)
-    y = _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws, prods)
-    if training and _LAST_BN_HANDLE[0] is not None:
-        y._sast_bn = _LAST_BN_HANDLE[0]
-        _LAST_BN_HANDLE[0] = None
+    handle = BnHandle() if training else None
+    y = _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws, prods,
+                          handle)
+    if handle is not None:
+        y._sast_bn = handle      # lets a sole consumer of y fold this conv's BatchNorm-backward reduction into its dX epilogue
     return y
 
 
