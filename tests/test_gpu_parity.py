@@ -740,18 +740,20 @@ def test_bn_backward_reduction_folded_into_consumer_matches_separate_launch(dev)
         maxnorm_close(ga[k], gb[k], 1e-5, k)
 
 
-@pytest.mark.parametrize("pair_input", [False, True])
-def test_csp_conv_pair_matches_separate_convs(dev, pair_input):
+@pytest.mark.parametrize("pair_input,width", [(False, 64), (True, 64), (True, 96)])
+def test_csp_conv_pair_matches_separate_convs(dev, pair_input, width):
     """CSPLayer.conv1 / conv2 (same input) as one stacked GEMM + shared BatchNorm launches (sast_conv_bn_silu2) against the
     two separate convs: outputs, running statistics and every gradient; with a plain input and with a virtual-concat pair
     whose first source is itself a conv output (its BatchNorm-backward reduction then rides on the pair's dX epilogue)"""
     from sast_amd import functional as SF
     from sast_amd.detection.network_blocks import BaseConv, CSPLayer
     torch.manual_seed(7)
-    pre = BaseConv(48, 32, 3, 2).to(dev).train()
-    net = CSPLayer(96 if pair_input else 64, 64, n=1, shortcut=False).to(dev).train()
+    # width 96: hidden = 48 channels, not a multiple of the 32-column MFMA tile (the tiny / small model sizes)
+    c_pre = width // 2
+    pre = BaseConv(48, c_pre, 3, 2).to(dev).train()
+    net = CSPLayer(c_pre + width if pair_input else width, width, n=1, shortcut=False).to(dev).train()
     xa0 = torch.randn(2, 24, 40, 48, device=dev)
-    xb0 = torch.randn(2, 12, 20, 64, device=dev)
+    xb0 = torch.randn(2, 12, 20, width, device=dev)
     res = []
     for pair in (True, False):
         old = SF.CONV_PAIR
