@@ -93,6 +93,7 @@ class Trainer:
         self.P = None
         self.graph = None
         self.use_graph = use_graph
+        self._one = torch.ones((), device=dev)
 
     def fwd_bwd(self):
         if self.infer:
@@ -117,7 +118,7 @@ class Trainer:
         else:
             from sast_amd import functional as SF
             loss = SF.mean_squares(*outs)     # = sum((o * o).mean() for o in outs), one launch each way
-        loss.backward()
+        loss.backward(gradient=self._one)     # a resident 1.0 instead of a ones_like fill launch per step
         self.loss, self.P = loss.detach(), P
 
     def update(self):

@@ -53,8 +53,8 @@ int sast_add_rows(const float* x, const float* table, float* y, int rows, int C,
    objective is sast_yolox_loss).  x / n / dx are HOST arrays of `count` device pointers / element counts (n % 4 == 0). */
 #define SAST_MEAN_SQUARE_BLOCKS 32
 int sast_mean_square_fwd(const float* const* x, const size_t* n, int count, float* partials, sast_stream_t stream);
-int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, float* const* dx,
-                         sast_stream_t stream);
+int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, int d_stride, float* const* dx,
+                         sast_stream_t stream);   /* d_stride 1: one gradient per partial; 0: d_partials[0] for all (the broadcast gradient of a .sum()) */
 /* a11  mask token (enable_masking) -- sast_rnn.py:271-273: x[token_mask] = mask_token, in place on the [rows, C] rows AFTER the first
  * block's position embedding was added (pos_emb [L, C] or NULL): masked rows become mask_token + pos_emb[row % L].
  * backward: dx = dy with masked rows zeroed, d_token += sum of the masked rows of dy. */

@@ -70,7 +70,7 @@ _SIGNATURES = {
     "sast_nhwc_to_nchw": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_add_rows": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_mean_square_fwd": (C.c_int, [P, P, C.c_int, P, P]),
-    "sast_mean_square_bwd": (C.c_int, [P, P, C.c_int, P, P, P]),
+    "sast_mean_square_bwd": (C.c_int, [P, P, C.c_int, P, C.c_int, P, P]),
     "sast_downsample_ln_fwd": (C.c_int, [C.POINTER(SastDownArgs), P]),
     "sast_downsample_ln_bwd": (C.c_int, [C.POINTER(SastDownArgs), P]),
     "sast_score_stp_fwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),

@@ -154,12 +154,13 @@ int sast_add_rows(const float* x, const float* table, float* y, int rows, int C,
 int sast_mean_square_fwd(const float* const* x, const size_t* n, int count, float* partials, sast_stream_t stream) {
   if (!x || !n || !partials || count < 1 || count > 4) return SAST_EINVAL;
   for (int t = 0; t < count; ++t) if (!x[t] || n[t] % 4) return SAST_EINVAL;
-  return mean_square_launch(x, nullptr, n, count, SAST_MEAN_SQUARE_BLOCKS, partials, nullptr, (hipStream_t)stream);
+  return mean_square_launch(x, nullptr, n, count, SAST_MEAN_SQUARE_BLOCKS, partials, nullptr, 1, (hipStream_t)stream);
 }
-int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, float* const* dx, sast_stream_t stream) {
-  if (!x || !n || !d_partials || !dx || count < 1 || count > 4) return SAST_EINVAL;
+int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, int d_stride, float* const* dx,
+                         sast_stream_t stream) {
+  if (!x || !n || !d_partials || !dx || count < 1 || count > 4 || (d_stride != 0 && d_stride != 1)) return SAST_EINVAL;
   for (int t = 0; t < count; ++t) if (!x[t] || !dx[t] || n[t] % 4) return SAST_EINVAL;
-  return mean_square_launch(x, dx, n, count, SAST_MEAN_SQUARE_BLOCKS, nullptr, d_partials, (hipStream_t)stream);
+  return mean_square_launch(x, dx, n, count, SAST_MEAN_SQUARE_BLOCKS, nullptr, d_partials, d_stride, (hipStream_t)stream);
 }
 
 int sast_mask_token_fwd(float* x, const uint8_t* mask, const float* token, const float* pos_emb, int rows, int C, int L, sast_stream_t stream) {

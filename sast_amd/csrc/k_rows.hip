@@ -765,23 +765,23 @@ __global__ __launch_bounds__(1024) void mean_square_fwd_kernel(MsqJob j, float* 
     partials[t * gridDim.x + blockIdx.x] = a / (float)j.n[t];
   }
 }
-__global__ __launch_bounds__(1024) void mean_square_bwd_kernel(MsqJob j, const float* __restrict__ g) {
+__global__ __launch_bounds__(1024) void mean_square_bwd_kernel(MsqJob j, const float* __restrict__ g, int g_stride) {
   const int t = blockIdx.y;
   const float* __restrict__ x = j.x[t];
   float* __restrict__ dx = j.dx[t];
   const size_t n4 = j.n[t] / 4;
-  const float k = 2.f * g[t * gridDim.x + blockIdx.x] / (float)j.n[t];
+  const float k = 2.f * g[(size_t)(t * gridDim.x + blockIdx.x) * g_stride] / (float)j.n[t];
   for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 1024) {
     const float4 v = ld4(x + 4 * i);
     st4(dx + 4 * i, make_float4(k * v.x, k * v.y, k * v.z, k * v.w));
   }
 }
 int mean_square_launch(const float* const* x, float* const* dx, const size_t* n, int count, int blocks, float* partials,
-                       const float* g, hipStream_t st) {
+                       const float* g, int g_stride, hipStream_t st) {
   MsqJob j{};
   for (int t = 0; t < count; ++t) { j.x[t] = x[t]; j.dx[t] = dx ? dx[t] : nullptr; j.n[t] = n[t]; }
   if (!dx) hipLaunchKernelGGL(mean_square_fwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, partials);
-  else hipLaunchKernelGGL(mean_square_bwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, g);
+  else hipLaunchKernelGGL(mean_square_bwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, g, g_stride);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -34,7 +34,7 @@ int mask_token_fwd_launch(float* x, const unsigned char* mask, const float* toke
 int mask_token_bwd_launch(const float* dy, const unsigned char* mask, float* dx, float* dtoken, int rows, int C, hipStream_t st);
 int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* drows, int C, float* out, hipStream_t st);
 int mean_square_launch(const float* const* x, float* const* dx, const size_t* n, int count, int blocks, float* partials,
-                       const float* g, hipStream_t st);
+                       const float* g, int g_stride, hipStream_t st);
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st);
 int ls_linear_finish2_launch(const float* w0, const float* b0, const float* g0, const float* raw0, const float* s0, float* dw0, float* db0,

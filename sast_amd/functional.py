@@ -137,12 +137,16 @@ class _MeanSquares(torch.autograd.Function):
     def backward(ctx, g):
         xs = ctx.saved_tensors
         k = len(xs)
-        g = g.contiguous()
+        g_stride = 1
+        if g.stride(0) == 0:       # the expanded scalar gradient of `.sum()`: read element 0 for every partial, no copy
+            g, g_stride = g.as_strided((1,), (1,)), 0
+        else:
+            g = g.contiguous()
         dxs = tuple(torch.empty_like(x) for x in xs)
         ptrs = (C.c_void_p * k)(*[x.data_ptr() for x in xs])
         dptrs = (C.c_void_p * k)(*[d.data_ptr() for d in dxs])
         ns = (C.c_size_t * k)(*[x.numel() for x in xs])
-        L.check(L.lib().sast_mean_square_bwd(ptrs, ns, k, g.data_ptr(), dptrs, _stream()), "mean_square_bwd")
+        L.check(L.lib().sast_mean_square_bwd(ptrs, ns, k, g.data_ptr(), g_stride, dptrs, _stream()), "mean_square_bwd")
         return dxs
 
 
