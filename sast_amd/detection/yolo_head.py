@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import functional as SF
-from .network_blocks import BaseConv
+from .network_blocks import BaseConv, BnArena
 
 
 class _PredConv(nn.Module):
@@ -63,16 +63,20 @@ class YOLOXHead(nn.Module):
         """training branch: feats three (B,H,W,C) NHWC maps (autograd tensors), labels (B, max_labels, 5) = (cls, cx, cy, w, h)
         -> (predictions (B, A, 5+nc), losses dict like yolo_head.py:224-231)"""
         per_level, levels = [], []
+        if not hasattr(self, "_bn_floats"):
+            self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+        ar = BnArena(self._bn_floats, feats[0].device)     # one memset / one counter update for the 15 BatchNorms
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
-            x = self.stems[k].forward_nhwc(x)
+            x = self.stems[k].forward_nhwc(x, ar)
             cf, rf = x, x          # the stem output feeds both towers; inside a tower every conv has one consumer
             for i, conv in enumerate(self.cls_convs[k]):
-                cf = conv.forward_nhwc(cf, sole=i > 0)
+                cf = conv.forward_nhwc(cf, ar, sole=i > 0)
             for i, conv in enumerate(self.reg_convs[k]):
-                rf = conv.forward_nhwc(rf, sole=i > 0)
+                rf = conv.forward_nhwc(rf, ar, sole=i > 0)
             cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
             per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
             levels.append((x.shape[1], x.shape[2], stride))
+        ar.finish()
         losses, pred, fg, mg, piou = SF.head_pred_loss(labels, levels, self.num_classes, self.decode_in_inference, per_level, self.use_l1)
         self.last_assignment = (fg, mg, piou)      # SimOTA result of this step (device tensors), for inspection / tests
         self.hw = [(h, w) for h, w, _ in levels]
