@@ -155,16 +155,20 @@ __global__ __launch_bounds__(64 * NTMAX) void attn_fwd_mfma_kernel(const float* 
 }
 
 // ------------------------------------------------------------------ backward
-template <int NTMAX, int NT>
+// PROWS: rows of the P / dS buffer = upper bound of the tokens per partition.  The buffer ALIASES the V tile (dead once dP is
+// in registers) and is the last LDS region; for the 1Mpx partitions (T = 60) the kernel then needs 40.6 KB instead of 49.9 KB
+// of LDS: 4 workgroups per CU instead of 3.
+template <int NTMAX, int NT, int PROWS>
 __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
                                               const float* __restrict__ lse, float* __restrict__ dqkv, int r0, int K, int C, int heads,
                                               int h, float scale, int dh) {
   constexpr int LDT = 32 * NTMAX + 1, KT = NT * 32;
+  constexpr int KTR = KT < PROWS ? KT : PROWS;   // reduce length over QUERY rows of P / dS (rows >= PROWS do not exist)
   float* Qt = sm;                 // pre-scaled q
   float* Kt = Qt + 32 * LDT;
-  float* Vt = Kt + 32 * LDT;
-  float* Gt = Vt + 32 * LDT;      // dO
-  float* PB = Gt + 32 * LDT;      // [32*NTMAX][LDT]: P, then dS
+  float* Gt = Kt + 32 * LDT;      // dO
+  float* Vt = Gt + 32 * LDT;
+  float* PB = Vt;                 // [PROWS][LDT]: P, then dS -- over the V tile
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
   const int C3 = 3 * C, coff = h * 3 * dh;
   {
@@ -209,11 +213,19 @@ __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict
         dloc += pt * dp[t][e];
       }
       const float D = half_sum(dloc);
-      float* pr = PB + i * LDT + l31;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        dp[t][e] = s[t][e] * (dp[t][e] - D);     // dS
-        pr[t * 32] = s[t][e];
+      for (int t = 0; t < NT; ++t) dp[t][e] = s[t][e] * (dp[t][e] - D);     // dS
+    }
+  }
+  __syncthreads();   // every wave is done with the V tile -> P may overwrite it
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = w * 32 + crow(e, lane);
+      if (i < PROWS) {
+        float* pr = PB + i * LDT + l31;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) pr[t * 32] = s[t][e];
       }
     }
   }
@@ -225,7 +237,7 @@ __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const float* gb = Gt + l31 * LDT;
 #pragma unroll 8
-    for (int ks = 0; ks < KT / 2; ++ks) {
+    for (int ks = 0; ks < KTR / 2; ++ks) {
       const int kk = ks * 2 + (lane >> 5);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PB[kk * LDT + w * 32 + l31], gb[kk], acc, 0, 0, 0);
     }
@@ -239,9 +251,12 @@ __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict
   if (active) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float* pr = PB + (w * 32 + crow(e, lane)) * LDT + l31;
+      const int i = w * 32 + crow(e, lane);
+      if (i < PROWS) {
+        float* pr = PB + i * LDT + l31;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) pr[t * 32] = dp[t][e];
+        for (int t = 0; t < NT; ++t) pr[t * 32] = dp[t][e];
+      }
     }
   }
   __syncthreads();
@@ -252,7 +267,7 @@ __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict
   {
     const float* qb = Qt + l31 * LDT;
 #pragma unroll 8
-    for (int ks = 0; ks < KT / 2; ++ks) {
+    for (int ks = 0; ks < KTR / 2; ++ks) {
       const int kk = ks * 2 + (lane >> 5);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PB[kk * LDT + w * 32 + l31], qb[kk], acc, 0, 0, 0);
     }
@@ -266,7 +281,7 @@ __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   {
-    const float* da = PB + (w * 32 + l31) * LDT;
+    const float* da = PB + min(w * 32 + l31, PROWS - 1) * LDT;   // query rows >= PROWS do not exist (their results are never stored)
     const float* kb = Kt + l31 * LDT;
 #pragma unroll 8
     for (int ks = 0; ks < KT / 2; ++ks) {
@@ -281,22 +296,23 @@ __device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict
   }
 }
 
-template <int NTMAX>
+template <int NTMAX, int PROWS>
 __global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                    const int* __restrict__ row_off, const int* __restrict__ Kw, int C,
                                                                    int heads, float scale, int dh) {
   constexpr int LDT = 32 * NTMAX + 1;
-  __shared__ float sm[4 * 32 * LDT + 32 * NTMAX * LDT];
+  static_assert(PROWS >= 32 && PROWS <= 32 * NTMAX, "P rows");
+  __shared__ float sm[3 * 32 * LDT + PROWS * LDT];
   const int g = blockIdx.x, h = blockIdx.y;
   const int K = Kw[g];
   if (K == 0) return;
   const int r0 = row_off[g];
   switch ((K + 31) >> 5) {
-    case 1: attn_bwd_body<NTMAX, 1>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
-    case 2: attn_bwd_body<NTMAX, 2>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
-    case 3: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 3>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
-    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 1: attn_bwd_body<NTMAX, 1, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 2: attn_bwd_body<NTMAX, 2, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 3: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 3, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
   }
 }
 
@@ -316,8 +332,9 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
   if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (T <= 64) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2>), dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
-  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<4>), dim3(W, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
+  if (T <= 60) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 60>), dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
+  else if (T <= 64) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 64>), dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
+  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<4, 128>), dim3(W, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
