@@ -162,6 +162,7 @@ typedef struct SastLstmArgs {
   float* dx; float* dh0; float* dc0;                   /* dh0/dc0 may be NULL */
   float* dw; float* db;
   float* ws;             /* fp32[B*L*4C] */
+  const float* dh1b;     /* bwd, optional: a second gradient of h1 (h1 consumed by two ops), added to dh1 on the fly */
 } SastLstmArgs;
 int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream);
 int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);
@@ -199,6 +200,7 @@ typedef struct SastConvBnArgs {
      backward is called with bn_red_done = 1 and skips its reduction launch.  All NULL: no folding. */
   const float* p_conv_out; const float* p_stats; const float* p_bn_w; const float* p_bn_b; float* p_bn_ws;
   const float* p2_conv_out; const float* p2_stats; const float* p2_bn_w; const float* p2_bn_b; float* p2_bn_ws;
+  const float* dy2;      /* bwd, optional: a second gradient of y (y consumed by two ops; row stride lddy), added to dy on the fly */
 } SastConvBnArgs;
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);

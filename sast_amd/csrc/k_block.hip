@@ -101,7 +101,8 @@ struct EpLstm {  // rnn.py:57-67
 
 __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __restrict__ gates, const float* __restrict__ c0,
                                                                  const float* __restrict__ c1, const float* __restrict__ dh1,
-                                                                 const float* __restrict__ dc1, float* __restrict__ dmix,
+                                                                 const float* __restrict__ dh1b, const float* __restrict__ dc1,
+                                                                 float* __restrict__ dmix,
                                                                  float* __restrict__ dc0, size_t n, int C) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
   const float* gp = gates + m * 4 * C + j;
   const float f = gp[0], i = gp[C], o = gp[2 * C], g = gp[3 * C];
   const float tc = tanhf(c1[e]);
-  const float dh = dh1[e];
+  const float dh = dh1[e] + (dh1b ? dh1b[e] : 0.f);   // h1 may have been handed out twice (next stage and FPN): the gradients are summed here
   const float dc = (dc1 ? dc1[e] : 0.f) + dh * o * (1.f - tc * tc);
   const float cp = c0 ? c0[e] : 0.f;
   float* dp = dmix + m * 4 * C + j;
@@ -374,7 +375,7 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   float* dmix = a->ws;
   const size_t n = (size_t)M * C;
   hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
-                     a->dc1, dmix, a->dc0, n, C);
+                     a->dh1b, a->dc1, dmix, a->dc0, n, C);
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
   return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
                    LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);

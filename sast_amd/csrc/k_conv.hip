@@ -120,7 +120,13 @@ constexpr int BN_RED_THREADS = 1024;   // few workgroups (one atomic per channel
 struct BnBwdJob {
   const float* x; const float* stats; const float* gamma; const float* beta; const float* dy; int lddy;
   float* sums; float* dconv; float* dgamma; float* dbeta;
+  const float* dy2;   // optional second gradient of y (two consumers): dy + dy2 is formed on the fly
 };
+__device__ __forceinline__ float4 bn_ld_dy(const float* __restrict__ dy, const float* __restrict__ dy2, size_t off) {
+  float4 d = ld4(dy + off);
+  if (dy2) { const float4 e = ld4(dy2 + off); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+  return d;
+}
 __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob j0, BnBwdJob j1, int M, int C, int rows_per_block) {
   const BnBwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const float* __restrict__ stats = jb.stats; const float* __restrict__ gamma = jb.gamma;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob 
     if (rl < RP) {
       const float4 mu = ld4(stats + c), rs = ld4(stats + C + c), g = ld4(gamma + c), bt = ld4(beta + c);
       for (int r = r0 + rl; r < r1; r += RP) {
-        const float4 v = ld4(x + (size_t)r * C + c), d = ld4(dy + (size_t)r * lddy + c);
+        const float4 v = ld4(x + (size_t)r * C + c), d = bn_ld_dy(dy, jb.dy2, (size_t)r * lddy + c);
         const float xh[4] = {(v.x - mu.x) * rs.x, (v.y - mu.y) * rs.y, (v.z - mu.z) * rs.z, (v.w - mu.w) * rs.w};
         const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {bt.x, bt.y, bt.z, bt.w}, dd[4] = {d.x, d.y, d.z, d.w};
         float* ap = &a.x; float* bp = &b.x;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
     const size_t e4 = e0 + (size_t)it * 256;
     if (e4 >= n4) return;
     const size_t m = e4 / c4; const int c = (int)(e4 % c4) * 4;
-    const float4 v = ld4(x + m * C + c), d = ld4(dy + m * lddy + c);
+    const float4 v = ld4(x + m * C + c), d = bn_ld_dy(dy, jb.dy2, m * lddy + c);
     float out[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -444,7 +450,7 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
     if (a->bn_red_done) return SAST_EINVAL;   // the consumer has already accumulated into it
     zero_fill(sums, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
   }
-  const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b};
+  const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b, a->dy2};
   if (!a->bn_red_done) bn_bwd_reduce_launch(jb, jb, 1, M, C, st);   // skipped when the conv consuming y folded it into its dX epilogue
   bn_bwd_apply_launch(jb, jb, 1, M, C, a->training, st);
   SAST_CHECK_LAUNCH();
@@ -517,8 +523,8 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
     zero_fill(sums0, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
     zero_fill(sums1, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
   }
-  const BnBwdJob j0{a->conv_out0, a->stats0, a->bn_w0, a->bn_b0, a->dy0, C, sums0, a->ws0, a->d_bn_w0, a->d_bn_b0};
-  const BnBwdJob j1{a->conv_out1, a->stats1, a->bn_w1, a->bn_b1, a->dy1, C, sums1, a->ws1, a->d_bn_w1, a->d_bn_b1};
+  const BnBwdJob j0{a->conv_out0, a->stats0, a->bn_w0, a->bn_b0, a->dy0, C, sums0, a->ws0, a->d_bn_w0, a->d_bn_b0, nullptr};
+  const BnBwdJob j1{a->conv_out1, a->stats1, a->bn_w1, a->bn_b1, a->dy1, C, sums1, a->ws1, a->d_bn_w1, a->d_bn_b1, nullptr};
   if (!a->bn_red_done0 && !a->bn_red_done1) bn_bwd_reduce_launch(j0, j1, 2, M, C, st);
   else if (!a->bn_red_done0) bn_bwd_reduce_launch(j0, j0, 1, M, C, st);
   else if (!a->bn_red_done1) bn_bwd_reduce_launch(j1, j1, 1, M, C, st);

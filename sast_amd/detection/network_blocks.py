@@ -20,14 +20,16 @@ class BaseConv(nn.Module):
         self.conv.weight = channels_last_conv_weight(out_channels, in_channels, ksize)
         self.bn = nn.BatchNorm2d(out_channels)
 
-    def forward_nhwc(self, x, arena=None, sole=False):
+    def forward_nhwc(self, x, arena=None, sole=False, two_outputs=False):
         """arena: optional `BnArena` handing out zero-filled reduction scratch (one memset per FPN forward) and
         batching the num_batches_tracked increments.  sole: the caller guarantees this conv is the only consumer of x
-        (functional.conv_bn_silu: the producing conv's BatchNorm-backward reduction then rides on this conv's dX epilogue)."""
+        (functional.conv_bn_silu: the producing conv's BatchNorm-backward reduction then rides on this conv's dX epilogue).
+        two_outputs: return (y, y_alias) for an output that has two consumers (their gradients are then added inside this
+        conv's BatchNorm-backward kernels, not by an autograd launch)."""
         bn = self.bn
         ws = arena.take(SF.bn_ws_floats(bn.num_features)) if arena is not None else None
         y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
-                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole)
+                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole, two_outputs=two_outputs)
         if self.training and bn.num_batches_tracked is not None:
             if arena is not None:
                 arena.counters.append(bn.num_batches_tracked)
@@ -107,9 +109,9 @@ class CSPLayer(nn.Module):
                     c.bn.num_batches_tracked.add_(1)
         return ys
 
-    def forward_nhwc(self, x, arena=None, sole_input=False):
+    def forward_nhwc(self, x, arena=None, sole_input=False, two_outputs=False):
         """sole_input: nothing but this layer consumes x (then the BatchNorm-backward reductions of the convs that produced x
-        ride on this layer's input-gradient launch)"""
+        ride on this layer's input-gradient launch); two_outputs: see BaseConv.forward_nhwc"""
         if self.training and SF.CONV_PAIR:
             # conv1 and conv2 read the same input: one GEMM over the stacked weights, one BatchNorm pass for both, and a
             # backward whose dX is already the sum of the two input gradients
@@ -119,7 +121,7 @@ class CSPLayer(nn.Module):
             x2 = self.conv2.forward_nhwc(x, arena)
         for b in self.m:
             x1 = b.forward_nhwc(x1, arena, sole_input=True)
-        return self.conv3.forward_nhwc((x1, x2), arena, sole=True)     # th.cat((x_1, x_2)) read in place by the 1x1 conv
+        return self.conv3.forward_nhwc((x1, x2), arena, sole=True, two_outputs=two_outputs)   # th.cat((x_1, x_2)) read in place by the 1x1 conv
 
     def forward(self, x):
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))

@@ -119,8 +119,9 @@ class RNNDetectorStage(nn.Module):
             x, p_loss, index_list = blk.att.forward_posadded(x, r, index_list)
             P = P + p_loss
         if self.lstm is not None:
-            h1, c1 = self.lstm.forward_nhwc(x, h_and_c_previous)
-            return h1, (h1, c1), P
+            # h1 goes to the next stage and, through the state, to the FPN / the next time step: two aliases, one per consumer
+            h1, h1b, c1 = self.lstm.forward_nhwc(x, h_and_c_previous, two_h=True)
+            return h1, (h1b, c1), P
         return x, (x, x), P
 
     def forward(self, x: torch.Tensor, h_and_c_previous=None, token_mask: Optional[torch.Tensor] = None, r: torch.Tensor = None):

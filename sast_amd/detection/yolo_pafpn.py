@@ -37,13 +37,15 @@ class YOLOPAFPN(nn.Module):
         if not hasattr(self, "_bn_floats"):
             self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         ar = BnArena(self._bn_floats, x0.device)                            # one memset for all 32 BatchNorm reductions
-        fpn_out0 = self.lateral_conv0.forward_nhwc(x0, ar)
+        # outputs with two consumers come as (y, alias) pairs: autograd then delivers the two gradients separately and the producing
+        # conv's BatchNorm-backward kernels add them while reading (no accumulation launch)
+        fpn_out0, fpn_out0b = self.lateral_conv0.forward_nhwc(x0, ar, two_outputs=True)
         f_out0 = self.C3_p4.forward_nhwc(SF.upsample_cat(fpn_out0, x1), ar, sole_input=True)  # nearest-exact x2 + cat (yolo_pafpn.py:118-121)
-        fpn_out1 = self.reduce_conv1.forward_nhwc(f_out0, ar, sole=True)      # f_out0 has no other consumer
-        pan_out2 = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2), ar, sole_input=True)
-        p_out1 = (self.bu_conv2.forward_nhwc(pan_out2, ar), fpn_out1)   # th.cat (yolo_pafpn.py:129) read in place by C3_n3's 1x1 convs
-        pan_out1 = self.C3_n3.forward_nhwc(p_out1, ar, sole_input=(True, False))   # the bottom-up conv feeds only this layer; fpn_out1 also the top-down path
-        p_out0 = (self.bu_conv1.forward_nhwc(pan_out1, ar), fpn_out0)   # th.cat (yolo_pafpn.py:134)
+        fpn_out1, fpn_out1b = self.reduce_conv1.forward_nhwc(f_out0, ar, sole=True, two_outputs=True)      # f_out0 has no other consumer
+        pan_out2, pan_out2b = self.C3_p3.forward_nhwc(SF.upsample_cat(fpn_out1, x2), ar, sole_input=True, two_outputs=True)
+        p_out1 = (self.bu_conv2.forward_nhwc(pan_out2b, ar), fpn_out1b)   # th.cat (yolo_pafpn.py:129) read in place by C3_n3's 1x1 convs
+        pan_out1, pan_out1b = self.C3_n3.forward_nhwc(p_out1, ar, sole_input=(True, False), two_outputs=True)   # the bottom-up conv feeds only this layer
+        p_out0 = (self.bu_conv1.forward_nhwc(pan_out1b, ar), fpn_out0b)   # th.cat (yolo_pafpn.py:134)
         pan_out0 = self.C3_n4.forward_nhwc(p_out0, ar, sole_input=(True, False))
         ar.finish()
         return pan_out2, pan_out1, pan_out0

@@ -585,16 +585,21 @@ class _LSTM(torch.autograd.Function):
         ctx.save_for_backward(x, h0, c0, c1, gates)
         ctx.params = (w, b)
         ctx.meta = (B, Lt, Cc)
-        return h1, c1
+        # h1 twice: a stage's output feeds the next stage AND the FPN / the next time step; handing the two consumers two
+        # aliases makes autograd deliver their gradients separately, and the backward kernel adds them while it reads them
+        return h1, h1.view_as(h1), c1
 
     @staticmethod
-    def backward(ctx, dh1, dc1):
+    def backward(ctx, dh1, dh1b, dc1):
         x, h0, c0, c1, gates = ctx.saved_tensors
         w, b = ctx.params
         B, Lt, Cc = ctx.meta
         if dh1 is None:
+            dh1, dh1b = dh1b, None
+        if dh1 is None:
             dh1 = torch.zeros_like(x)
         dh1 = dh1.contiguous()
+        dh1b = dh1b.contiguous() if dh1b is not None else None
         dc1 = dc1.contiguous() if dc1 is not None else None
         dx = torch.empty_like(x)
         need_h = h0 is not None and ctx.needs_input_grad[1]
@@ -603,13 +608,16 @@ class _LSTM(torch.autograd.Function):
         dc0 = torch.empty_like(x) if need_c else None
         ws = torch.empty(B * Lt * 4 * Cc, device=x.device)
         a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, c1=c1, gates=gates, dh1=dh1,
-                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=_g(w), db=_g(b), ws=ws)
+                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=_g(w), db=_g(b), ws=ws, dh1b=_ptr(dh1b))
         L.check(L.lib().sast_lstm_bwd(C.byref(a), _stream()), "lstm_bwd")
         return dx, dh0, dc0, None, None
 
 
-def conv_lstm(x_nhwc, h0, c0, w, b):
-    return _LSTM.apply(x_nhwc, h0, c0, w, b)
+def conv_lstm(x_nhwc, h0, c0, w, b, two_h=False):
+    """-> (h1, c1), or with two_h (h1, h1_alias, c1): two handles on the same h1 for its two consumers (their gradients
+    are then summed inside the backward kernel instead of by an autograd add launch)"""
+    h1, h1b, c1 = _LSTM.apply(x_nhwc, h0, c0, w, b)
+    return (h1, h1b if TWO_OUT else h1, c1) if two_h else (h1, c1)
 
 
 # ---------------------------------------------------------------------------------------------- a13
@@ -630,7 +638,7 @@ class BnHandle:
 
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers, handle):
+    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers, handle, two_y):
         _need_gpu(x, w)
         x = x.contiguous()
         if not is_channels_last_weight(w):
@@ -666,11 +674,17 @@ class _ConvBnSilu(torch.autograd.Function):
         if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
             p2 = None
         ctx.producers = (p1, p2)
-        return y
+        ctx.two_y = bool(two_y)
+        return (y, y.view_as(y)) if two_y else y     # two aliases for two consumers: see _LSTM.forward
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dy2=None):
         x, x2, conv_out, stats, bn_ws = ctx.saved_tensors
+        if dy is None:
+            dy, dy2 = dy2, None
+        if dy is None:
+            dy = torch.zeros(conv_out.shape, device=conv_out.device)
+        dy2 = dy2.contiguous() if dy2 is not None else None
         w, bn_w, bn_b = ctx.params
         B, H, W, Cin, Cin1, Cout, ksize, stride, training, momentum, eps, M = ctx.meta
         dy = dy.contiguous()
@@ -692,12 +706,12 @@ class _ConvBnSilu(torch.autograd.Function):
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
                   ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
                   eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w),
-                  d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, **pk)
+                  d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2), **pk)
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 13
+        return (dx, dx2) + (None,) * 14
 
 
 def bn_ws_floats(cout: int) -> int:
@@ -803,24 +817,31 @@ def _producers(x, x2, sole):
     if not BN_FOLD:
         return (None, None)
     return (getattr(x, "_sast_bn", None) if s1 else None, getattr(x2, "_sast_bn", None) if (s2 and x2 is not None) else None)
+TWO_OUT = os.environ.get("SAST_TWO_OUT", "1") != "0"       # outputs with two consumers as two aliases (gradients summed inside the backward kernels)
 CONV_PAIR = os.environ.get("SAST_CONV_PAIR", "1") != "0"   # CSPLayer.conv1 / conv2 (same input) through conv_bn_silu2
 BN_FOLD = os.environ.get("SAST_BN_FOLD", "1") != "0"   # fold producers' BatchNorm-backward reductions into consumers' dX epilogues
 
 
 def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None,
-                 sole_consumer=False):
+                 sole_consumer=False, two_outputs=False):
     """x_nhwc: a tensor, or a pair (xa, xb) standing for their channel concat (1x1 convs; the concat is never built).
     bn_ws: optional zero-filled fp32[bn_ws_floats(Cout)] scratch (consumed: do not reuse within a step)."""
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
+    if two_outputs and (not TWO_OUT or not training or not torch.is_grad_enabled()):    # nothing to gain without a training-mode backward
+        y = conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, sole_consumer)
+        return y, y
     if not training and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, x2, w, bn_w, bn_b))):
         return _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, float(eps))
     # sole_consumer: the caller guarantees that this conv is the ONLY consumer of its input tensor(s); where such an input
     # is itself a conv_bn_silu output (it carries a BnHandle), that producer's BatchNorm-backward reduction is folded into
     # this conv's dX epilogue (one launch fewer per conv in the backward pass)
     prods = _producers(x, x2, sole_consumer)
+    if two_outputs:     # (y, y_alias) for an output with two consumers: their gradients meet inside the BatchNorm-backward kernels
+        return _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, True, float(momentum), float(eps), bn_ws, prods,
+                                 None, True)
     handle = BnHandle() if training else None
     y = _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws, prods,
-                          handle)
+                          handle, False)
     if handle is not None:
         y._sast_bn = handle      # lets a sole consumer of y fold this conv's BatchNorm-backward reduction into its dX epilogue
     return y

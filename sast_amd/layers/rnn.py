@@ -26,9 +26,10 @@ class DWSConvLSTM2d(nn.Module):
         self.conv1x1 = nn.Conv2d(in_channels=dim * 2, out_channels=dim * 4, kernel_size=1)
         self.conv_only_hidden = dws_conv_only_hidden
 
-    def forward_nhwc(self, x, h_and_c_previous=None):
+    def forward_nhwc(self, x, h_and_c_previous=None, two_h=False):
+        """two_h: (h1, h1_alias, c1) -- two handles on h1 for its two consumers (functional.conv_lstm)"""
         h0, c0 = (None, None) if h_and_c_previous is None else h_and_c_previous
-        return SF.conv_lstm(x, h0, c0, self.conv1x1.weight, self.conv1x1.bias)
+        return SF.conv_lstm(x, h0, c0, self.conv1x1.weight, self.conv1x1.bias, two_h=two_h)
 
     def forward(self, x: torch.Tensor, h_and_c_previous: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
         """x, h, c: (N C H W) -> (h_t, c_t) (N C H W) (channels-last memory)."""
