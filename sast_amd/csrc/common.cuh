@@ -93,6 +93,26 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- LayerScale'd linear y = gamma * (x W^T + b): parameter gradients from the raw (gamma-free) ones
+//   raw = dy^T x, s = colsum(dy):  dW += gamma[c]*raw[c,:]; db += gamma*s; dgamma += <W[c,:], raw[c,:]> + b[c]*s[c]
+// One wave per output channel c.  Runs as its own kernel (k_rows.hip) or as side workgroups of the attention backward launch.
+struct LsFinish { const float* w; const float* b; const float* gamma; const float* raw; const float* s; float* dw; float* db; float* dgamma; int K; };
+__device__ __forceinline__ void ls_finish_row(const LsFinish& p, int c, int lane) {
+  const int K = p.K;
+  const float g = p.gamma ? p.gamma[c] : 1.f;   // gamma == NULL: LayerScale disabled (ls_init_value <= 0, SAST.py:187)
+  float dot = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float rv = p.raw[(size_t)c * K + k];
+    dot += p.w[(size_t)c * K + k] * rv;
+    p.dw[(size_t)c * K + k] += g * rv;
+  }
+  dot = wave_sum(dot);
+  if (lane == 0) {
+    p.db[c] += g * p.s[c];
+    if (p.gamma) p.dgamma[c] += dot + p.b[c] * p.s[c];
+  }
+}
+
 // token <-> (window|grid group, slot) maps on an H x W map with partition (ph, pw)
 // (reference: ops.py:189-220).  mode 0 = window, 1 = grid.
 struct PartMap {

@@ -300,10 +300,19 @@ template <int NTMAX, int PROWS>
 __global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                    const int* __restrict__ row_off, const int* __restrict__ Kw, int C,
-                                                                   int heads, float scale, int dh) {
+                                                                   int heads, float scale, int dh, int W, LsFinish f0, LsFinish f1,
+                                                                   int fC) {
   constexpr int LDT = 32 * NTMAX + 1;
   static_assert(PROWS >= 32 && PROWS <= 32 * NTMAX, "P rows");
   __shared__ float sm[3 * 32 * LDT + PROWS * LDT];
+  if (blockIdx.x >= W) {   // side workgroups: the LayerScale'd fc2 / proj gradient finish of the same MS-WSA layer (independent work
+    if (blockIdx.y == 0) {  // that used to be a launch of its own), one wave per output channel
+      const int row = (blockIdx.x - W) * NTMAX + (threadIdx.x >> 6);
+      if (row < fC) ls_finish_row(f0, row, threadIdx.x & 63);
+      else if (row < 2 * fC) ls_finish_row(f1, row - fC, threadIdx.x & 63);
+    }
+    return;
+  }
   const int g = blockIdx.x, h = blockIdx.y;
   const int K = Kw[g];
   if (K == 0) return;
@@ -328,13 +337,18 @@ int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_
   return SAST_OK;
 }
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int T, int C, int dh, hipStream_t st) {
+                         int T, int C, int dh, hipStream_t st, const LsFinish* f0, const LsFinish* f1, int fC) {
   if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (T <= 60) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 60>), dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
-  else if (T <= 64) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 64>), dim3(W, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
-  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<4, 128>), dim3(W, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh);
+  const LsFinish z{};
+  const LsFinish& a0 = f0 ? *f0 : z;
+  const LsFinish& a1 = f1 ? *f1 : z;
+  if (!f0 || !f1) fC = 0;
+  const int wpb = T <= 64 ? 2 : 4, side = (2 * fC + wpb - 1) / wpb;
+  if (T <= 60) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 60>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else if (T <= 64) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 64>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<4, 128>), dim3(W + side, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

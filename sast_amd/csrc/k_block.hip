@@ -335,12 +335,17 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   }
   if (rc) return rc;
   // raw (gamma-free) fc2 and proj gradients -> parameter gradients incl. the LayerScale gammas, one launch for both
-  rc = ls_linear_finish2_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner,
-                                a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
-  if (rc) return rc;
-  // attention backward
-  rc = T <= mfma_attn_max_t() ? attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st)
-                              : attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
+  // (with the MFMA attention kernel they ride as side workgroups of the attention backward launch)
+  if (T <= mfma_attn_max_t()) {
+    const LsFinish f2{a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner};
+    const LsFinish f1{a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C};
+    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C);
+  } else {
+    rc = ls_linear_finish2_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner,
+                                  a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
+    if (rc) return rc;
+    rc = attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
+  }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv
   rc = gemm_pair(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b,

@@ -705,25 +705,12 @@ int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* d
 // ============================================================ LayerScale'd linear: finalize grads from the raw (gamma-free) ones
 //   y = gamma * (x W^T + b):  raw = dy^T x, s = colsum(dy)
 //   dW += gamma[c]*raw[c,:]; db += gamma*s ; dgamma += <W[c,:], raw[c,:]> + b[c]*s[c]
-struct LsFinish { const float* w; const float* b; const float* gamma; const float* raw; const float* s; float* dw; float* db; float* dgamma; int K; };
 // two LayerScale'd linears (fc2 and proj of one MS-WSA layer) per launch: blockIdx.y selects the problem
 __global__ __launch_bounds__(64) void ls_linear_finish_kernel(LsFinish p0, LsFinish p1, int C0) {
   const LsFinish& p = blockIdx.y == 0 ? p0 : p1;
   const int c = blockIdx.x;
   if (blockIdx.y == 0 && c >= C0) return;
-  const int K = p.K;
-  const float g = p.gamma ? p.gamma[c] : 1.f;   // gamma == NULL: LayerScale disabled (ls_init_value <= 0, SAST.py:187)
-  float dot = 0.f;
-  for (int k = threadIdx.x; k < K; k += 64) {
-    const float rv = p.raw[(size_t)c * K + k];
-    dot += p.w[(size_t)c * K + k] * rv;
-    p.dw[(size_t)c * K + k] += g * rv;
-  }
-  dot = wave_sum(dot);
-  if (threadIdx.x == 0) {
-    p.db[c] += g * p.s[c];
-    if (p.gamma) p.dgamma[c] += dot + p.b[c] * p.s[c];
-  }
+  ls_finish_row(p, c, threadIdx.x);
 }
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st) {

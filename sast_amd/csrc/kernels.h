@@ -65,7 +65,8 @@ int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const f
 // k_attn_mfma.hip (T <= 128)
 int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
                          hipStream_t st);
+struct LsFinish;
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int T, int C, int dh, hipStream_t st);
+                         int T, int C, int dh, hipStream_t st, const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
 
 }  // namespace sast
