@@ -93,6 +93,26 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// ---- STP controls (SAST.py:109, :325-328): scale[b,c] = sum_j exp(Wc[c,j]) * (r[b,j] + 1e-6) and its weight gradient
+// dWc[c,j] += exp(Wc[c,j]) * sum_b dscale[b,c] * (r[b,j]+1e-6).  Tiny (B*C resp. C*J outputs): own kernels in k_rows.hip, or
+// side workgroups of the scoring GEMM launches (k_block.hip).  i = global element index.
+struct ControlsJob { const float* wc; const float* r; int r_stride; float* scale; float* zero_bc; const float* dscale; float* dwc; int B, C, J; };
+__device__ __forceinline__ void controls_fwd_elem(const ControlsJob& k, int i) {
+  if (i >= k.B * k.C) return;
+  if (k.zero_bc) k.zero_bc[i] = 0.f;   // the backward's d(scale) accumulator
+  const int b = i / k.C, c = i % k.C;
+  float s = 0.f;
+  for (int j = 0; j < k.J; ++j) s = fmaf(expf(k.wc[c * k.J + j]), k.r[b * k.r_stride + j] + 1e-6f, s);
+  k.scale[i] = s;
+}
+__device__ __forceinline__ void controls_bwd_elem(const ControlsJob& k, int i) {
+  if (i >= k.C * k.J) return;
+  const int c = i / k.J, j = i % k.J;
+  float s = 0.f;
+  for (int b = 0; b < k.B; ++b) s += k.dscale[b * k.C + c] * (k.r[b * k.r_stride + j] + 1e-6f);
+  k.dwc[i] += s * expf(k.wc[i]);
+}
+
 // ---- LayerScale'd linear y = gamma * (x W^T + b): parameter gradients from the raw (gamma-free) ones
 //   raw = dy^T x, s = colsum(dy):  dW += gamma[c]*raw[c,:]; db += gamma*s; dgamma += <W[c,:], raw[c,:]> + b[c]*s[c]
 // One wave per output channel c.  Runs as its own kernel (k_rows.hip) or as side workgroups of the attention backward launch.

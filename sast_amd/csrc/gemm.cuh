@@ -77,6 +77,13 @@ constexpr int BN_STAT_COPIES = SAST_BN_STAT_COPIES;
 // a B-side loader may depend on the block's row tile (LdWeightConvDxP: the parity class of the rows decides the taps)
 template <class L, class = void> struct LoaderWantsM0 : std::false_type {};
 template <class L> struct LoaderWantsM0<L, std::void_t<decltype(L::WANTS_M0)>> : std::bool_constant<L::WANTS_M0> {};
+// an epilogue may carry SIDE WORK for extra workgroups appended to the launch (small independent kernels that would otherwise
+// pay a launch boundary of their own): EP::SIDE = true, ep.side_blocks (host + device), ep.side(side_block_index)
+template <class EP, class = void> struct EpHasSide : std::false_type {};
+template <class EP> struct EpHasSide<EP, std::void_t<decltype(EP::SIDE)>> : std::bool_constant<EP::SIDE> {};
+template <class EP> inline int ep_side_blocks(const EP& ep) {
+  if constexpr (EpHasSide<EP>::value) return ep.side_blocks; else return 0;
+}
 template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
@@ -418,7 +425,12 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
                                                               const int* __restrict__ dM, const int* __restrict__ dR,
                                                               float* __restrict__ colsum, int nsplit, int xcd_remap) {
   __shared__ __attribute__((aligned(16))) float smem[GemmSmem<T, LA, LB>::FLOATS];
-  gemm_body<T, LA, LB, EP, SPLIT>(la, lb, ep, M, NJ, R, dM, dR, colsum, nsplit, xcd_remap, blockIdx.x, gridDim.x, smem);
+  int nmain = gridDim.x;
+  if constexpr (EpHasSide<EP>::value) {
+    nmain -= ep.side_blocks;
+    if ((int)blockIdx.x >= nmain) { ep.side(blockIdx.x - nmain); return; }
+  }
+  gemm_body<T, LA, LB, EP, SPLIT>(la, lb, ep, M, NJ, R, dM, dR, colsum, nsplit, xcd_remap, blockIdx.x, nmain, smem);
 }
 
 // ---- two independent GEMMs in ONE launch: workgroups [0, n1) run problem 1, the rest problem 2.  Used for the (dW, dX)
@@ -441,9 +453,14 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
     gemm_body<typename J1::T, typename J1::LA, typename J1::LB, typename J1::EP, J1::SPLIT>(
         a.la, a.lb, a.ep, a.M, a.NJ, a.R, a.dM, a.dR, a.colsum, a.nsplit, a.xcd_remap, blockIdx.x, n1, smem);
   } else {
+    int n2 = gridDim.x - n1;
+    if constexpr (EpHasSide<typename J2::EP>::value) {
+      n2 -= b.ep.side_blocks;
+      if ((int)blockIdx.x >= n1 + n2) { b.ep.side(blockIdx.x - n1 - n2); return; }
+    }
     if (threadIdx.x >= J2::T::NT) return;
     gemm_body<typename J2::T, typename J2::LA, typename J2::LB, typename J2::EP, J2::SPLIT>(
-        b.la, b.lb, b.ep, b.M, b.NJ, b.R, b.dM, b.dR, b.colsum, b.nsplit, b.xcd_remap, blockIdx.x - n1, gridDim.x - n1, smem);
+        b.la, b.lb, b.ep, b.M, b.NJ, b.R, b.dM, b.dR, b.colsum, b.nsplit, b.xcd_remap, blockIdx.x - n1, n2, smem);
   }
 }
 
@@ -473,10 +490,10 @@ inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, 
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R, dM, dR,
-                          (float*)nullptr, 1, remap);
+    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ,
+                          R, dM, dR, (float*)nullptr, 1, remap);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
+    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
                        (float*)nullptr, 1, remap);
   }
   SAST_CHECK_LAUNCH();
@@ -535,9 +552,9 @@ inline int launch_gemm_dual(const LA1& la1, const LB1& lb1, const EP1& ep1, int 
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events2(__PRETTY_FUNCTION__, 0.0, TS::G, M1, NJ1, R1, nullptr, dR1, TP::G, M2, NJ2, R2, dM2, nullptr, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
+    hipExtLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
   } else {
-    hipLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2), dim3(NTHREADS), 0, st, a, b, n1);
+    hipLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, a, b, n1);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;

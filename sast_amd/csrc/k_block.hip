@@ -28,6 +28,18 @@ struct EpBiasRelu {
     c[(size_t)m * ldc + j] = fmaxf(v[0] + k.b, 0.f);
   }
 };
+// EpBiasRelu + the STP controls as side workgroups of the same launch (scale is first read by the NEXT kernel)
+struct EpBiasReluCtl : EpBiasRelu {
+  static constexpr bool SIDE = true;
+  ControlsJob k; int side_blocks;     // 256 elements per side workgroup (the smallest workgroup of the GEMM tiles)
+  __device__ __forceinline__ void side(int sb) const { if (threadIdx.x < 256) controls_fwd_elem(k, sb * 256 + threadIdx.x); }
+};
+// the same for the backward: d(Wc) rides on the (dW || dX) launch of the scoring linear
+struct EpStoreAddCtl : EpStoreAdd {
+  static constexpr bool SIDE = true;
+  ControlsJob k; int side_blocks;
+  __device__ __forceinline__ void side(int sb) const { if (threadIdx.x < 256) controls_bwd_elem(k, sb * 256 + threadIdx.x); }
+};
 struct EpResidualLS {  // y = res + gamma * (v + bias)
   float* y; const float* res; const float* bias; const float* gamma; int C;
   struct Col { float b, g; };
@@ -200,9 +212,12 @@ int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   ProfScope ps_("score_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
   if (!a || a->C % 4) return SAST_EINVAL;
   const int M = a->B * a->L, C = a->C;
-  int rc = controls_fwd_launch(a->wc, a->r, a->r_stride, a->scale, a->B, C, 20, a->dscale_ws, st);
-  if (rc) return rc;
-  rc = gemm_auto(LdRows{a->xp, C, nullptr}, LdWeightNT{a->ws_w, C, 0}, EpBiasRelu{a->s, C, a->ws_b}, M, C, C, nullptr, st);
+  // the controls (B*C outputs) ride as side workgroups of the scoring GEMM; 256 is the smallest workgroup of gemm_auto's tiles
+  EpBiasReluCtl ep{};
+  ep.c = a->s; ep.ldc = C; ep.bias = a->ws_b;
+  ep.k = ControlsJob{a->wc, a->r, a->r_stride, a->scale, a->dscale_ws, nullptr, nullptr, a->B, C, 20};
+  ep.side_blocks = (a->B * C + 255) / 256;
+  int rc = gemm_auto(LdRows{a->xp, C, nullptr}, LdWeightNT{a->ws_w, C, 0}, ep, M, C, C, nullptr, st);
   if (rc) return rc;
   return stp_fwd_launch(a->xp, a->s, a->scale, a->amp, a->xw, a->tok, a->B, a->L, C, st);
 }
@@ -217,10 +232,12 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   int rc = stp_bwd_launch(a->xp, a->s, a->scale, a->dxw, a->dxp, dz, dscale, a->B, a->L, C, st);
   if (rc) return rc;
   // dxp = direct + dz Ws
-  rc = controls_bwd_launch(a->wc, a->r, a->r_stride, dscale, a->d_wc, a->B, C, 20, st);
-  if (rc) return rc;
+  EpStoreAddCtl ep{};     // d(Wc) from the complete dscale: side workgroups of the pair launch
+  ep.c = a->dxp; ep.ldc = C; ep.add = a->dxp; ep.ldadd = C;
+  ep.k = ControlsJob{a->wc, a->r, a->r_stride, nullptr, nullptr, dscale, a->d_wc, a->B, C, 20};
+  ep.side_blocks = (C * 20 + 255) / 256;
   return gemm_pair(LdRowsT{dz, C}, LdRowsT{a->xp, C}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b,
-                   LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C}, EpStoreAdd{a->dxp, C, a->dxp, C}, M, C, C, nullptr, st);
+                   LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C}, ep, M, C, C, nullptr, st);
 }
 
 // ------------------------------------------------------------------ MS-WSA

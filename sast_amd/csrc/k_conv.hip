@@ -224,10 +224,19 @@ __global__ __launch_bounds__(256) void upsample_cat_fwd_kernel(const float* __re
   }
   st4(out + row * Ct + c, v);
 }
-__global__ __launch_bounds__(256) void upsample_cat_bwd_a_kernel(const float* __restrict__ dout, float* __restrict__ da, int H, int W,
-                                                                 int C1, int Ct, size_t n4) {
+// backward of upsample + concat in one launch: elements [0, n4) reduce the 2x2 children of the upsampled half into da, elements
+// [n4, n4 + n4b) copy the other half of the channels into db
+__global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ db,
+                                                               int H, int W, int C1, int Ct, size_t n4, size_t n4b) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
+  if (e >= n4) {
+    const size_t eb = e - n4;
+    if (eb >= n4b) return;
+    const int C2 = Ct - C1, c4b = C2 / 4;
+    const size_t row = eb / c4b; const int c = (int)(eb % c4b) * 4;
+    st4(db + row * C2 + c, ld4(dout + row * Ct + C1 + c));
+    return;
+  }
   const int c4n = C1 / 4;
   const size_t row = e / c4n; const int c = (int)(e % c4n) * 4;
   const int x = (int)(row % W); const size_t t = row / W; const int y = (int)(t % H); const size_t bb = t / H;
@@ -560,10 +569,12 @@ int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int
 }
 int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H, int W, int C1, int C2, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-  const size_t n4 = (size_t)B * H * W * (C1 / 4);
-  hipLaunchKernelGGL(upsample_cat_bwd_a_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dout, da, H, W, C1, C1 + C2, n4);
+  if (C1 % 4 || C2 % 4) return SAST_EINVAL;
+  const size_t n4 = (size_t)B * H * W * (C1 / 4), n4b = (size_t)B * 4 * H * W * (C2 / 4);
+  hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, st, dout, da, db, H, W, C1, C1 + C2, n4,
+                     n4b);
   SAST_CHECK_LAUNCH();
-  return slice_copy(dout, C1 + C2, C1, db, C2, 0, C2, (size_t)B * 4 * H * W, st);
+  return SAST_OK;
 }
 int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -475,26 +475,9 @@ int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc,
 
 // ============================================================ STP scoring (a5)
 // scale[b,c] = sum_j exp(Wc[c,j]) * (r[b,j] + 1e-6)      (SAST.py:109, :325-328)
-__global__ void controls_fwd_kernel(const float* __restrict__ wc, const float* __restrict__ r, int r_stride,
-                                    float* __restrict__ scale, int B, int C, int J, float* __restrict__ zero_bc) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  if (zero_bc) zero_bc[i] = 0.f;   // the backward's d(scale) accumulator
-  const int b = i / C, c = i % C;
-  float s = 0.f;
-  for (int j = 0; j < J; ++j) s = fmaf(expf(wc[c * J + j]), r[b * r_stride + j] + 1e-6f, s);
-  scale[i] = s;
-}
+__global__ void controls_fwd_kernel(ControlsJob k) { controls_fwd_elem(k, blockIdx.x * blockDim.x + threadIdx.x); }
 // dWc[c,j] += dscale[b,c] * exp(Wc[c,j]) * (r[b,j]+1e-6)
-__global__ void controls_bwd_kernel(const float* __restrict__ wc, const float* __restrict__ r, int r_stride,
-                                    const float* __restrict__ dscale, float* __restrict__ dwc, int B, int C, int J) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= C * J) return;
-  const int c = i / J, j = i % J;
-  float s = 0.f;
-  for (int b = 0; b < B; ++b) s += dscale[b * C + c] * (r[b * r_stride + j] + 1e-6f);
-  dwc[i] += s * expf(wc[i]);
-}
+__global__ void controls_bwd_kernel(ControlsJob k) { controls_bwd_elem(k, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // xw = sigmoid(scale) * sigmoid(s) * xp ; tok = sum_c (AMP/scale) * s      (SAST.py:113-119, :94)
 template <int GL, int VPL>
@@ -582,13 +565,13 @@ __global__ __launch_bounds__(ROWB) void stp_bwd_kernel(const float* __restrict__
 
 int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, float* zero_bc,
                         hipStream_t st) {
-  hipLaunchKernelGGL(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, wc, r, r_stride, scale, B, C, J, zero_bc);
+  hipLaunchKernelGGL(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ControlsJob{wc, r, r_stride, scale, zero_bc, nullptr, nullptr, B, C, J});
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int controls_bwd_launch(const float* wc, const float* r, int r_stride, const float* dscale, float* dwc, int B, int C, int J,
                         hipStream_t st) {
-  hipLaunchKernelGGL(controls_bwd_kernel, dim3((C * J + 255) / 256), dim3(256), 0, st, wc, r, r_stride, dscale, dwc, B, C, J);
+  hipLaunchKernelGGL(controls_bwd_kernel, dim3((C * J + 255) / 256), dim3(256), 0, st, ControlsJob{wc, r, r_stride, nullptr, nullptr, dscale, dwc, B, C, J});
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
