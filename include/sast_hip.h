@@ -213,6 +213,9 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);
 typedef struct SastConvBn2Args {
   int32_t B, H, W, Cin, Cout, ldx, Cin1, ldx2;   /* Cout of EACH conv; input = x (Cin1 == Cin) or the virtual concat [x | x2] */
   int32_t bn_ws_zeroed, bn_red_done0, bn_red_done1;
+  int32_t training;               /* 1: batch statistics (1x1 only, everything below applies); 0: inference -- running statistics, BatchNorm +
+                                     SiLU in the GEMM epilogue, ONE launch for both convs, nothing kept (conv_out / stats / bn_ws unused) */
+  int32_t ksize;                  /* 1, or 3 (stride 1, same padding; inference only: the two first tower convs of a YOLOX head level) */
   float momentum0, momentum1, eps0, eps1;
   const float* x; const float* x2;
   const float* w0; const float* w1; const float* bn_w0; const float* bn_w1; const float* bn_b0; const float* bn_b1;

@@ -45,7 +45,7 @@ SastMswsaArgs = _struct("SastMswsaArgs", [
     (P, "ws cb_m cb_sum raw_ws"),
 ])
 SastConvBn2Args = _struct("SastConvBn2Args", [
-    (I32, "B H W Cin Cout ldx Cin1 ldx2 bn_ws_zeroed bn_red_done0 bn_red_done1"), (F32, "momentum0 momentum1 eps0 eps1"),
+    (I32, "B H W Cin Cout ldx Cin1 ldx2 bn_ws_zeroed bn_red_done0 bn_red_done1 training ksize"), (F32, "momentum0 momentum1 eps0 eps1"),
     (P, "x x2 w0 w1 bn_w0 bn_w1 bn_b0 bn_b1 run_mean0 run_mean1 run_var0 run_var1 conv_out0 conv_out1 stats0 stats1 y0 y1 "
         "bn_ws0 bn_ws1 dy0 dy1 dw0 dw1 d_bn_w0 d_bn_w1 d_bn_b0 d_bn_b1 ws0 ws1 dx dx2 "
         "p_conv_out p_stats p_bn_w p_bn_b p_bn_ws p2_conv_out p2_stats p2_bn_w p2_bn_b p2_bn_ws"),

@@ -79,6 +79,21 @@ struct EpBnSilu {
     y[(size_t)m * ldy + j] = z * sigmoid_exact(z);
   }
 };
+// EpBnSilu for two convs evaluated as one GEMM over the stacked weights (columns [0, C) -> conv 0, [C, 2C) -> conv 1)
+struct EpBnSilu2 {
+  float* y0; float* y1; int C; const float* rm0; const float* rv0; const float* g0; const float* b0; float eps0;
+  const float* rm1; const float* rv1; const float* g1; const float* b1; float eps1;
+  struct Col { float mu, rs, g, b; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const {
+    return j < C ? Col{rm0[j], 1.0f / sqrtf(rv0[j] + eps0), g0[j], b0[j]} : Col{rm1[j - C], 1.0f / sqrtf(rv1[j - C] + eps1), g1[j - C], b1[j - C]};
+  }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
+    const float z = (v[0] - k.mu) * k.rs * k.g + k.b;
+    (j < C ? y0 + (size_t)m * C + j : y1 + (size_t)m * C + (j - C))[0] = z * sigmoid_exact(z);
+  }
+};
 // forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
 // fp64 per-channel sum / sum of squares, one atomic pair per channel per block.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
@@ -500,7 +515,20 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!a || a->Cin % 4 || a->Cout % 4 || a->Cin1 % 4 || a->Cin1 <= 0 || a->Cin1 > a->Cin || (a->Cin1 < a->Cin && !a->x2)) return SAST_EINVAL;
   ProfScope ps_("convbn2_fwd", a->Cout * 10 + 1, a->B * a->H * a->W, st);
-  const int M = a->B * a->H * a->W, K = a->Cin, C = a->Cout;
+  const int M = a->B * a->H * a->W, C = a->Cout;
+  if (!a->training) {   // inference: one launch, nothing kept
+    if (!a->run_mean0 || !a->run_var0 || !a->run_mean1 || !a->run_var1 || (a->ksize != 1 && a->ksize != 3)) return SAST_EINVAL;
+    const EpBnSilu2 ep{a->y0, a->y1, C, a->run_mean0, a->run_var0, a->bn_w0, a->bn_b0, a->eps0, a->run_mean1, a->run_var1, a->bn_w1, a->bn_b1, a->eps1};
+    if (a->ksize == 3) {
+      if (a->Cin1 != a->Cin) return SAST_EINVAL;
+      const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx);
+      return gemm_auto(LdIm2col{a->x, g}, LdWeightNT2{a->w0, a->w1, 9 * a->Cin, C}, ep, M, 2 * C, 9 * a->Cin, st);
+    }
+    return gemm_auto(LdRows2{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2}, LdWeightNT2{a->w0, a->w1, a->Cin, C}, ep, M,
+                     2 * C, a->Cin, st);
+  }
+  if (a->ksize != 1) return SAST_EINVAL;
+  const int K = a->Cin;
   if (!a->bn_ws_zeroed) {
     zero_fill(a->bn_ws0, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
     zero_fill(a->bn_ws1, sizeof(float) * SAST_BN_WS_FLOATS(C), st);

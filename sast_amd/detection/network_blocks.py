@@ -96,10 +96,14 @@ class CSPLayer(nn.Module):
         self.conv3 = BaseConv(2 * hidden, out_channels, 1, stride=1, act=act)
         self.m = nn.Sequential(*[Bottleneck(hidden, hidden, shortcut, 1.0, depthwise, act=act) for _ in range(n)])
 
+    def _pair_args(self):
+        return tuple((c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.momentum, c.bn.eps)
+                     for c in (self.conv1, self.conv2))
+
     def _conv12(self, x, arena, sole_input):
         cs = (self.conv1, self.conv2)
         ws = tuple(arena.take(SF.bn_ws_floats(c.bn.num_features)) if arena is not None else None for c in cs)
-        args = tuple((c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.momentum, c.bn.eps) for c in cs)
+        args = self._pair_args()
         ys = SF.conv_bn_silu2(x, args[0], args[1], ws, sole_consumer=sole_input)
         for c in cs:
             if c.bn.num_batches_tracked is not None:
@@ -116,6 +120,8 @@ class CSPLayer(nn.Module):
             # conv1 and conv2 read the same input: one GEMM over the stacked weights, one BatchNorm pass for both, and a
             # backward whose dX is already the sum of the two input gradients
             x1, x2 = self._conv12(x, arena, sole_input)
+        elif not self.training and SF.CONV_PAIR and not torch.is_grad_enabled():
+            x1, x2 = SF.conv_bn_silu2_infer(x, self._pair_args()[0], self._pair_args()[1])     # inference: one launch for both
         else:
             x1 = self.conv1.forward_nhwc(x, arena)
             x2 = self.conv2.forward_nhwc(x, arena)

@@ -98,11 +98,20 @@ class YOLOXHead(nn.Module):
         off = 0
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x)
-            cf, rf = x, x
-            for conv in self.cls_convs[k]:
-                cf = conv.forward_nhwc(cf)
-            for conv in self.reg_convs[k]:
-                rf = conv.forward_nhwc(rf)
+            if SF.CONV_PAIR:     # the first conv of both towers reads the stem output: one launch over the stacked 3x3 weights
+                c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]
+                cf, rf = SF.conv_bn_silu2_infer(x, *[(c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var,
+                                                     c.bn.momentum, c.bn.eps) for c in (c0, r0)], ksize=3)
+                for conv in list(self.cls_convs[k])[1:]:
+                    cf = conv.forward_nhwc(cf)
+                for conv in list(self.reg_convs[k])[1:]:
+                    rf = conv.forward_nhwc(rf)
+            else:
+                cf, rf = x, x
+                for conv in self.cls_convs[k]:
+                    cf = conv.forward_nhwc(cf)
+                for conv in self.reg_convs[k]:
+                    rf = conv.forward_nhwc(rf)
             h, w = hw[k]
             cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
             L.check(L.lib().sast_head_pred_decode(rf.data_ptr(), cf.data_ptr(), rp.weight.data_ptr(), rp.bias.data_ptr(), op.weight.data_ptr(),

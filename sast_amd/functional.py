@@ -746,7 +746,7 @@ class _ConvBnSilu2(torch.autograd.Function):
         ys = [torch.empty(B, H, W, Cout, device=dev) for _ in range(2)]
         if ws0 is None or ws1 is None:
             ws0, ws1 = torch.zeros(bn_ws_floats(Cout), device=dev), torch.zeros(bn_ws_floats(Cout), device=dev)
-        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1,
+        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=1,
                   momentum0=mom0, momentum1=mom1, eps0=eps0, eps1=eps1, x=x, x2=_ptr(x2), w0=w0, w1=w1, bn_w0=bnw0, bn_w1=bnw1,
                   bn_b0=bnb0, bn_b1=bnb1, run_mean0=_ptr(rm0), run_mean1=_ptr(rm1), run_var0=_ptr(rv0), run_var1=_ptr(rv1),
                   conv_out0=co[0], conv_out1=co[1], stats0=st[0], stats1=st[1], y0=ys[0], y1=ys[1], bn_ws0=ws0, bn_ws1=ws1)
@@ -785,7 +785,7 @@ class _ConvBnSilu2(torch.autograd.Function):
                 pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
                            pre + "bn_ws": h.bn_ws})
         h0, h1 = ctx.handles
-        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1,
+        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=1,
                   bn_red_done0=int(h0.red_done), bn_red_done1=int(h1.red_done), momentum0=mom0, momentum1=mom1, eps0=eps0, eps1=eps1,
                   x=x, x2=_ptr(x2), w0=w0, w1=w1, bn_w0=bnw0, bn_w1=bnw1, bn_b0=bnb0, bn_b1=bnb1, conv_out0=co0, conv_out1=co1,
                   stats0=st0, stats1=st1, bn_ws0=ws0, bn_ws1=ws1, dy0=dy0, dy1=dy1, dw0=_g(w0), dw1=_g(w1), d_bn_w0=_g(bnw0),
@@ -795,6 +795,35 @@ class _ConvBnSilu2(torch.autograd.Function):
             if h is not None:
                 h.red_done = True
         return (dx, dx2) + (None,) * 18
+
+
+@torch.no_grad()
+def conv_bn_silu2_infer(x_nhwc, conv0, conv1, ksize=1):
+    """eval mode, no autograd: two convs (1x1, or 3x3 stride 1) of the same input + BatchNorm(running statistics) + SiLU in ONE
+    launch over the stacked weights.  conv0 / conv1 as in conv_bn_silu2."""
+    x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
+    _need_gpu(x)
+    x = x.contiguous()
+    (w0, g0, b0, rm0, rv0, _m0, e0), (w1, g1, b1, rm1, rv1, _m1, e1) = conv0, conv1
+    for w in (w0, w1):
+        if not is_channels_last_weight(w):
+            raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
+    B, H, W, Cin1 = x.shape
+    Cin = Cin1
+    if x2 is not None:
+        if ksize != 1 or x2.shape[:3] != x.shape[:3]:
+            raise RuntimeError("sast_amd: a two-source input is supported for 1x1 convs of equal spatial size")
+        x2 = x2.contiguous()
+        Cin = Cin1 + x2.shape[-1]
+    Cout = w0.shape[0]
+    if w1.shape[0] != Cout or tuple(w0.shape[1:]) != (Cin, ksize, ksize) or tuple(w1.shape[1:]) != (Cin, ksize, ksize):
+        raise RuntimeError("sast_amd: conv_bn_silu2_infer needs two convs of the same input with equal shapes")
+    y0, y1 = torch.empty(B, H, W, Cout, device=x.device), torch.empty(B, H, W, Cout, device=x.device)
+    a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, training=0, ksize=ksize,
+              eps0=float(e0), eps1=float(e1), x=x, x2=_ptr(x2), w0=w0, w1=w1, bn_w0=g0, bn_w1=g1, bn_b0=b0, bn_b1=b1, run_mean0=rm0,
+              run_mean1=rm1, run_var0=rv0, run_var1=rv1, y0=y0, y1=y1)
+    L.check(L.lib().sast_conv_bn_silu2_fwd(C.byref(a), _stream()), "conv_bn_silu2_fwd")
+    return y0, y1
 
 
 def conv_bn_silu2(x_nhwc, conv0, conv1, bn_ws=(None, None), sole_consumer=False):
