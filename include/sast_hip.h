@@ -213,9 +213,9 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);
 typedef struct SastConvBn2Args {
   int32_t B, H, W, Cin, Cout, ldx, Cin1, ldx2;   /* Cout of EACH conv; input = x (Cin1 == Cin) or the virtual concat [x | x2] */
   int32_t bn_ws_zeroed, bn_red_done0, bn_red_done1;
-  int32_t training;               /* 1: batch statistics (1x1 only, everything below applies); 0: inference -- running statistics, BatchNorm +
+  int32_t training;               /* 1: batch statistics (everything below applies); 0: inference -- running statistics, BatchNorm +
                                      SiLU in the GEMM epilogue, ONE launch for both convs, nothing kept (conv_out / stats / bn_ws unused) */
-  int32_t ksize;                  /* 1, or 3 (stride 1, same padding; inference only: the two first tower convs of a YOLOX head level) */
+  int32_t ksize;                  /* 1, or 3 (stride 1, same padding, single-source input: the two first tower convs of a YOLOX head level) */
   float momentum0, momentum1, eps0, eps1;
   const float* x; const float* x2;
   const float* w0; const float* w1; const float* bn_w0; const float* bn_w1; const float* bn_b0; const float* bn_b1;
@@ -223,7 +223,7 @@ typedef struct SastConvBn2Args {
   float* conv_out0; float* conv_out1; float* stats0; float* stats1; float* y0; float* y1; float* bn_ws0; float* bn_ws1;
   /* backward */
   const float* dy0; const float* dy1; float* dw0; float* dw1; float* d_bn_w0; float* d_bn_w1; float* d_bn_b0; float* d_bn_b1;
-  float* ws0; float* ws1;      /* fp32[M*Cout] each (dconv) */
+  float* ws0; float* ws1;      /* ws0: fp32[M * 2*Cout] (rows [dconv0 | dconv1]); ws1 unused */
   float* dx; float* dx2;       /* dense [M, Cin1] and [M, Cin - Cin1]; dx == NULL: weight gradients only */
   /* producers of x / x2 whose only consumers are these two convs (see SastConvBnArgs.p_*) */
   const float* p_conv_out; const float* p_stats; const float* p_bn_w; const float* p_bn_b; float* p_bn_ws;

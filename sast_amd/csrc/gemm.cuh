@@ -860,6 +860,23 @@ struct LdWeightConvDx {
   SAST_DEFAULT_FINISH
 };
 
+// the same for two convs stacked along Cout (co < C1 -> w0, else w1): dX = [dy0 | dy1] * [w0; w1]
+struct LdWeightConvDx2 {
+  static constexpr bool RC = false;
+  const float* w0; const float* w1; int Cout, C1, taps, Cin, cout_shift;   // Cout = total stacked output channels
+  struct Ctx { int j; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 1);
+    const int tap = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - tap * Cout;
+    ok = c.ok && r < Reff;
+    const float* row = co < C1 ? w0 + ((size_t)co * taps + tap) * Cin : w1 + ((size_t)(co - C1) * taps + tap) * Cin;   // address select
+    v = ld4(row + c.j);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+
 // ---- stride-2 backward-data by input-pixel parity class.  For stride 2 an input pixel (iy, ix) only receives the taps with
 // kh = (iy + pad) mod 2 (same for x): the generic LdConvDx gather multiplies zeros for the other 3/4 of the k*k taps.  Here
 // the input pixels are re-ordered into the 4 classes (iy & 1, ix & 1) -- row m = class * Mc + (b, yy, xx), pixel

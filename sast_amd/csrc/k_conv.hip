@@ -136,6 +136,7 @@ struct BnBwdJob {
   const float* x; const float* stats; const float* gamma; const float* beta; const float* dy; int lddy;
   float* sums; float* dconv; float* dgamma; float* dbeta;
   const float* dy2;   // optional second gradient of y (two consumers): dy + dy2 is formed on the fly
+  int lddconv;        // row stride of dconv (two stacked convs write the halves of one [M, 2C] buffer)
 };
 __device__ __forceinline__ float4 bn_ld_dy(const float* __restrict__ dy, const float* __restrict__ dy2, size_t off) {
   float4 d = ld4(dy + off);
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
       const float dz = (&d.x)[e] * sg * (1.f + z * (1.f - sg));
       out[e] = training ? g * rs * (dz - bsm[4 * C + c + e] - xh * bsm[5 * C + c + e]) : g * rs * dz;
     }
-    st4(dconv + m * C + c, make_float4(out[0], out[1], out[2], out[3]));
+    st4(dconv + m * jb.lddconv + c, make_float4(out[0], out[1], out[2], out[3]));
   }
 }
 // ---------------------------------------------------------------- upsample / concat
@@ -474,7 +475,7 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
     if (a->bn_red_done) return SAST_EINVAL;   // the consumer has already accumulated into it
     zero_fill(sums, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
   }
-  const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b, a->dy2};
+  const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b, a->dy2, C};
   if (!a->bn_red_done) bn_bwd_reduce_launch(jb, jb, 1, M, C, st);   // skipped when the conv consuming y folded it into its dX epilogue
   bn_bwd_apply_launch(jb, jb, 1, M, C, a->training, st);
   SAST_CHECK_LAUNCH();
@@ -527,15 +528,17 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
     return gemm_auto(LdRows2{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2}, LdWeightNT2{a->w0, a->w1, a->Cin, C}, ep, M,
                      2 * C, a->Cin, st);
   }
-  if (a->ksize != 1) return SAST_EINVAL;
-  const int K = a->Cin;
+  if (a->ksize != 1 && !(a->ksize == 3 && a->Cin1 == a->Cin)) return SAST_EINVAL;
+  const int K = a->ksize * a->ksize * a->Cin;
   if (!a->bn_ws_zeroed) {
     zero_fill(a->bn_ws0, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
     zero_fill(a->bn_ws1, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
   }
   const LdRows2 la{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2};
   const EpStoreStats2 ep{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1};
-  int rc = gemm_auto(la, LdWeightNT2{a->w0, a->w1, K, C}, ep, M, 2 * C, K, st);
+  int rc = a->ksize == 3 ? gemm_auto(LdIm2col{a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx)}, LdWeightNT2{a->w0, a->w1, K, C}, ep, M,
+                                     2 * C, K, st)
+                         : gemm_auto(la, LdWeightNT2{a->w0, a->w1, K, C}, ep, M, 2 * C, K, st);
   if (rc) return rc;
   const size_t n4 = (size_t)M * (C / 4);
   int iters = (int)(n4 / (256 * 512));
@@ -552,7 +555,8 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!a || (a->Cin1 < a->Cin && !a->x2)) return SAST_EINVAL;
   ProfScope ps_("convbn2_bwd", a->Cout * 10 + 1, a->B * a->H * a->W, st);
-  const int M = a->B * a->H * a->W, K = a->Cin, C = a->Cout, C2 = a->Cin - a->Cin1;
+  if (a->ksize != 1 && !(a->ksize == 3 && a->Cin1 == a->Cin)) return SAST_EINVAL;
+  const int M = a->B * a->H * a->W, K = a->ksize * a->ksize * a->Cin, C = a->Cout, C2 = a->Cin - a->Cin1;
   float* sums0 = a->bn_ws0 + 4 * BN_STAT_COPIES * C;
   float* sums1 = a->bn_ws1 + 4 * BN_STAT_COPIES * C;
   if (!a->bn_ws_zeroed) {
@@ -560,22 +564,38 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
     zero_fill(sums0, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
     zero_fill(sums1, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
   }
-  const BnBwdJob j0{a->conv_out0, a->stats0, a->bn_w0, a->bn_b0, a->dy0, C, sums0, a->ws0, a->d_bn_w0, a->d_bn_b0, nullptr};
-  const BnBwdJob j1{a->conv_out1, a->stats1, a->bn_w1, a->bn_b1, a->dy1, C, sums1, a->ws1, a->d_bn_w1, a->d_bn_b1, nullptr};
+  float* dconv = a->ws0;     // [M, 2C]: rows [dconv0 | dconv1]
+  const BnBwdJob j0{a->conv_out0, a->stats0, a->bn_w0, a->bn_b0, a->dy0, C, sums0, dconv, a->d_bn_w0, a->d_bn_b0, nullptr, 2 * C};
+  const BnBwdJob j1{a->conv_out1, a->stats1, a->bn_w1, a->bn_b1, a->dy1, C, sums1, dconv + C, a->d_bn_w1, a->d_bn_b1, nullptr, 2 * C};
   if (!a->bn_red_done0 && !a->bn_red_done1) bn_bwd_reduce_launch(j0, j1, 2, M, C, st);
   else if (!a->bn_red_done0) bn_bwd_reduce_launch(j0, j0, 1, M, C, st);
   else if (!a->bn_red_done1) bn_bwd_reduce_launch(j1, j1, 1, M, C, st);
   bn_bwd_apply_launch(j0, j1, 2, M, C, 1, st);
   SAST_CHECK_LAUNCH();
   // dW of both convs: [dconv0 | dconv1]^T [x | x2] -> (dw0, dw1);  dX = [dconv0 | dconv1] [w0; w1]
-  const LdRowsT2 ta{a->ws0, C, C, a->ws1, C};
-  const LdRowsT2 tb{a->x, a->ldx, a->Cin1, C2 > 0 ? a->x2 : nullptr, a->ldx2};
+  const LdRowsT ta{dconv, 2 * C};
   const EpAtomic2 ep1{a->dw0, a->dw1, K, C};
+  BnProducer p1{a->p_conv_out, a->p_stats, a->p_bn_w, a->p_bn_b, a->p_bn_ws ? a->p_bn_ws + 4 * BN_STAT_COPIES * a->Cin1 : nullptr, a->Cin1};
+  if (a->ksize == 3) {   // two 3x3 stride-1 convs (the first convs of the two YOLOX head towers)
+    const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx);
+    const LdIm2colT tbc{a->x, g};
+    if (!a->dx) return launch_gemm_split<TileSmallK2>(ta, tbc, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
+    const int shift = pow2_shift(2 * C);
+    const LdConvDx lac{dconv, g, 2 * C, 2 * C, shift};
+    const LdWeightConvDx2 lbc{a->w0, a->w1, 2 * C, C, 9, a->Cin, shift};
+    if (p1.x) {
+      if (a->ldx != a->Cin || !(p1.stats && p1.gamma && p1.beta && p1.sums)) return SAST_EINVAL;
+      return gemm_pair_ep(ta, tbc, ep1, 2 * C, K, M, nullptr, nullptr, lac, lbc, EpStoreBnRed{a->dx, a->Cin, p1}, M, a->Cin, 9 * 2 * C, nullptr, st,
+                          pair_tn_blocks_conv());
+    }
+    return gemm_pair_ep(ta, tbc, ep1, 2 * C, K, M, nullptr, nullptr, lac, lbc, EpStore{a->dx, a->Cin, nullptr}, M, a->Cin, 9 * 2 * C, nullptr, st,
+                        pair_tn_blocks_conv());
+  }
+  const LdRowsT2 tb{a->x, a->ldx, a->Cin1, C2 > 0 ? a->x2 : nullptr, a->ldx2};
   if (!a->dx) return launch_gemm_split<TileSmallK2>(ta, tb, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
   if (C2 > 0 && !a->dx2) return SAST_EINVAL;
-  const LdRows2 la{a->ws0, C, C, a->ws1, C};
+  const LdRows la{dconv, 2 * C, nullptr};
   const LdWeightNN2 lb{a->w0, a->w1, K, C};
-  BnProducer p1{a->p_conv_out, a->p_stats, a->p_bn_w, a->p_bn_b, a->p_bn_ws ? a->p_bn_ws + 4 * BN_STAT_COPIES * a->Cin1 : nullptr, a->Cin1};
   BnProducer p2{a->p2_conv_out, a->p2_stats, a->p2_bn_w, a->p2_bn_b, a->p2_bn_ws ? a->p2_bn_ws + 4 * BN_STAT_COPIES * C2 : nullptr, C2};
   if (p1.x || p2.x) {
     if ((p1.x && (a->ldx != a->Cin1 || !(p1.stats && p1.gamma && p1.beta && p1.sums))) ||

@@ -68,11 +68,24 @@ class YOLOXHead(nn.Module):
         ar = BnArena(self._bn_floats, feats[0].device)     # one memset / one counter update for the 15 BatchNorms
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x, ar)
-            cf, rf = x, x          # the stem output feeds both towers; inside a tower every conv has one consumer
+            if SF.CONV_PAIR:
+                # the first conv of both towers reads the stem output: one stacked 3x3 GEMM + shared BatchNorm launches, and (sole
+                # consumer of the stem output) the stem's BatchNorm-backward reduction in the pair's dX epilogue
+                c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]
+                args = [(c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.momentum, c.bn.eps) for c in (c0, r0)]
+                ws = tuple(ar.take(SF.bn_ws_floats(c.bn.num_features)) for c in (c0, r0))
+                cf, rf = SF.conv_bn_silu2(x, args[0], args[1], ws, sole_consumer=True, ksize=3)
+                ar.counters.extend(c.bn.num_batches_tracked for c in (c0, r0) if c.bn.num_batches_tracked is not None)
+                first = 1
+            else:
+                cf, rf = x, x          # the stem output feeds both towers; inside a tower every conv has one consumer
+                first = 0
             for i, conv in enumerate(self.cls_convs[k]):
-                cf = conv.forward_nhwc(cf, ar, sole=i > 0)
+                if i >= first:
+                    cf = conv.forward_nhwc(cf, ar, sole=i > 0)
             for i, conv in enumerate(self.reg_convs[k]):
-                rf = conv.forward_nhwc(rf, ar, sole=i > 0)
+                if i >= first:
+                    rf = conv.forward_nhwc(rf, ar, sole=i > 0)
             cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
             per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
             levels.append((x.shape[1], x.shape[2], stride))

@@ -724,7 +724,7 @@ class _ConvBnSilu2(torch.autograd.Function):
     the stacked weights; the backward's dX is the sum of both input gradients (include/sast_hip.h: SastConvBn2Args)."""
 
     @staticmethod
-    def forward(ctx, x, x2, w0, bnw0, bnb0, rm0, rv0, w1, bnw1, bnb1, rm1, rv1, mom0, eps0, mom1, eps1, ws0, ws1, producers, handles):
+    def forward(ctx, x, x2, w0, bnw0, bnb0, rm0, rv0, w1, bnw1, bnb1, rm1, rv1, mom0, eps0, mom1, eps1, ws0, ws1, producers, handles, ksize):
         _need_gpu(x, w0, w1)
         x = x.contiguous()
         for w in (w0, w1):
@@ -738,22 +738,23 @@ class _ConvBnSilu2(torch.autograd.Function):
             x2 = x2.contiguous()
             Cin = Cin1 + x2.shape[-1]
         Cout = w0.shape[0]
-        if w1.shape[0] != Cout or w0.shape[1] != Cin or w1.shape[1] != Cin or w0.shape[2:] != (1, 1) or w1.shape[2:] != (1, 1):
-            raise RuntimeError("sast_amd: conv_bn_silu2 needs two 1x1 convs of the same input with equal Cout")
+        if w1.shape[0] != Cout or tuple(w0.shape[1:]) != (Cin, ksize, ksize) or tuple(w1.shape[1:]) != (Cin, ksize, ksize) or \
+                ksize not in (1, 3) or (ksize == 3 and x2 is not None):
+            raise RuntimeError("sast_amd: conv_bn_silu2 needs two 1x1 (or 3x3, single-source) convs of the same input with equal Cout")
         M, dev = B * H * W, x.device
         co = [torch.empty(M, Cout, device=dev) for _ in range(2)]
         st = [torch.empty(2 * Cout, device=dev) for _ in range(2)]
         ys = [torch.empty(B, H, W, Cout, device=dev) for _ in range(2)]
         if ws0 is None or ws1 is None:
             ws0, ws1 = torch.zeros(bn_ws_floats(Cout), device=dev), torch.zeros(bn_ws_floats(Cout), device=dev)
-        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=1,
+        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=ksize,
                   momentum0=mom0, momentum1=mom1, eps0=eps0, eps1=eps1, x=x, x2=_ptr(x2), w0=w0, w1=w1, bn_w0=bnw0, bn_w1=bnw1,
                   bn_b0=bnb0, bn_b1=bnb1, run_mean0=_ptr(rm0), run_mean1=_ptr(rm1), run_var0=_ptr(rv0), run_var1=_ptr(rv1),
                   conv_out0=co[0], conv_out1=co[1], stats0=st[0], stats1=st[1], y0=ys[0], y1=ys[1], bn_ws0=ws0, bn_ws1=ws1)
         L.check(L.lib().sast_conv_bn_silu2_fwd(C.byref(a), _stream()), "conv_bn_silu2_fwd")
         ctx.save_for_backward(x, x2, co[0], co[1], st[0], st[1], ws0, ws1)
         ctx.params = (w0, bnw0, bnb0, w1, bnw1, bnb1)
-        ctx.meta = (B, H, W, Cin, Cin1, Cout, mom0, eps0, mom1, eps1, M)
+        ctx.meta = (B, H, W, Cin, Cin1, Cout, mom0, eps0, mom1, eps1, M, ksize)
         ctx.handles = (handles[0].fill(co[0], st[0], bnw0, bnb0, ws0, Cout), handles[1].fill(co[1], st[1], bnw1, bnb1, ws1, Cout))
         p1, p2 = producers
         if p1 is not None and p1.cout != Cin1:
@@ -767,13 +768,13 @@ class _ConvBnSilu2(torch.autograd.Function):
     def backward(ctx, dy0, dy1):
         x, x2, co0, co1, st0, st1, ws0, ws1 = ctx.saved_tensors
         w0, bnw0, bnb0, w1, bnw1, bnb1 = ctx.params
-        B, H, W, Cin, Cin1, Cout, mom0, eps0, mom1, eps1, M = ctx.meta
+        B, H, W, Cin, Cin1, Cout, mom0, eps0, mom1, eps1, M, ksize = ctx.meta
         dy0 = dy0.contiguous() if dy0 is not None else torch.zeros(B, H, W, Cout, device=x.device)
         dy1 = dy1.contiguous() if dy1 is not None else torch.zeros(B, H, W, Cout, device=x.device)
         need = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
         dx = torch.empty_like(x) if need else None
         dx2 = torch.empty_like(x2) if (need and x2 is not None) else None
-        dws = torch.empty(2, M * Cout, device=x.device)
+        dws = torch.empty(M, 2 * Cout, device=x.device)      # rows [dconv0 | dconv1]
         p1, p2 = ctx.producers if need else (None, None)
         if p1 is not None and p1.red_done:
             p1 = None
@@ -785,16 +786,16 @@ class _ConvBnSilu2(torch.autograd.Function):
                 pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
                            pre + "bn_ws": h.bn_ws})
         h0, h1 = ctx.handles
-        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=1,
+        a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=ksize,
                   bn_red_done0=int(h0.red_done), bn_red_done1=int(h1.red_done), momentum0=mom0, momentum1=mom1, eps0=eps0, eps1=eps1,
                   x=x, x2=_ptr(x2), w0=w0, w1=w1, bn_w0=bnw0, bn_w1=bnw1, bn_b0=bnb0, bn_b1=bnb1, conv_out0=co0, conv_out1=co1,
                   stats0=st0, stats1=st1, bn_ws0=ws0, bn_ws1=ws1, dy0=dy0, dy1=dy1, dw0=_g(w0), dw1=_g(w1), d_bn_w0=_g(bnw0),
-                  d_bn_w1=_g(bnw1), d_bn_b0=_g(bnb0), d_bn_b1=_g(bnb1), ws0=dws[0], ws1=dws[1], dx=_ptr(dx), dx2=_ptr(dx2), **pk)
+                  d_bn_w1=_g(bnw1), d_bn_b0=_g(bnb0), d_bn_b1=_g(bnb1), ws0=dws, dx=_ptr(dx), dx2=_ptr(dx2), **pk)
         L.check(L.lib().sast_conv_bn_silu2_bwd(C.byref(a), _stream()), "conv_bn_silu2_bwd")
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 18
+        return (dx, dx2) + (None,) * 19
 
 
 @torch.no_grad()
@@ -826,8 +827,8 @@ def conv_bn_silu2_infer(x_nhwc, conv0, conv1, ksize=1):
     return y0, y1
 
 
-def conv_bn_silu2(x_nhwc, conv0, conv1, bn_ws=(None, None), sole_consumer=False):
-    """(y0, y1) = two training-mode 1x1 conv + BatchNorm + SiLU of the same input in shared launches.  conv0 / conv1:
+def conv_bn_silu2(x_nhwc, conv0, conv1, bn_ws=(None, None), sole_consumer=False, ksize=1):
+    """(y0, y1) = two training-mode 1x1 (or 3x3 stride-1) conv + BatchNorm + SiLU of the same input in shared launches.  conv0 / conv1:
     (weight, bn_weight, bn_bias, running_mean, running_var, momentum, eps); x_nhwc a tensor or a pair standing for a channel
     concat; sole_consumer: nothing else consumes the input (see conv_bn_silu)."""
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
@@ -835,7 +836,7 @@ def conv_bn_silu2(x_nhwc, conv0, conv1, bn_ws=(None, None), sole_consumer=False)
     (w0, g0, b0, rm0, rv0, m0, e0), (w1, g1, b1, rm1, rv1, m1, e1) = conv0, conv1
     hs = (BnHandle(), BnHandle())
     y0, y1 = _ConvBnSilu2.apply(x, x2, w0, g0, b0, rm0, rv0, w1, g1, b1, rm1, rv1, float(m0), float(e0), float(m1), float(e1),
-                                bn_ws[0], bn_ws[1], prods, hs)
+                                bn_ws[0], bn_ws[1], prods, hs, int(ksize))
     y0._sast_bn, y1._sast_bn = hs
     return y0, y1
 
