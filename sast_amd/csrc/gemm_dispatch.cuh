@@ -42,6 +42,8 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hi
 // that adapts to the dX job's grid size was not better)
 // the same for the k x k conv pairs (im2col / backward-data jobs)
 inline int pair_tn_blocks_conv() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_CONV", 152); return v; }
+// and for the 1x1 conv pairs of the FPN / head (k_conv.hip)
+inline int pair_tn_blocks_1x1() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_1X1", 152); return v; }
 inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 152); return v; }
 
 // target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)

@@ -493,20 +493,20 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
     if (fold) {
       if ((p1.x && a->ldx != a->Cin1) || (p2.x && (a->ldx2 != C2 || !a->dx2))) return SAST_EINVAL;
       return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K},
-                       EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, a->Cin, C, nullptr, st);
+                       EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
     }
     return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr,
-                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, a->Cin, C, nullptr, st);
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
   }
   if (k == 1 && a->stride == 1) {
     if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, st);
     if (fold) {
       if (a->lddx != a->Cin || a->ldx != a->Cin) return SAST_EINVAL;
       return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr},
-                       LdWeightNN{a->w, K}, EpStoreBnRed{a->dx, a->lddx, p1}, M, a->Cin, C, nullptr, st);
+                       LdWeightNN{a->w, K}, EpStoreBnRed{a->dx, a->lddx, p1}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
     }
     return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr,
-                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st);
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
   }
   return conv_bwd_pair(dconv, a->x, g, C, a->w, a->dw, a->dx, a->lddx, st, fold ? &p1 : nullptr);
 }
@@ -602,9 +602,9 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
         (p2.x && (C2 <= 0 || a->ldx2 != C2 || !(p2.stats && p2.gamma && p2.beta && p2.sums))))
       return SAST_EINVAL;
     return gemm_pair_ep(ta, tb, ep1, 2 * C, K, M, nullptr, nullptr, la, lb, EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, K, 2 * C,
-                        nullptr, st);
+                        nullptr, st, pair_tn_blocks_1x1());
   }
-  return gemm_pair_ep(ta, tb, ep1, 2 * C, K, M, nullptr, nullptr, la, lb, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, K, 2 * C, nullptr, st);
+  return gemm_pair_ep(ta, tb, ep1, 2 * C, K, M, nullptr, nullptr, la, lb, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, K, 2 * C, nullptr, st, pair_tn_blocks_1x1());
 }
 
 // ------------------------------------------------------------------ upsample / concat
