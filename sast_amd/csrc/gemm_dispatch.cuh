@@ -16,7 +16,7 @@ inline int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 inline bool gemm_pair_enabled() { static int v = env_int("SAST_GEMM_PAIR", 1); return v != 0; }
-inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 384); return v; }
+inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 512); return v; }
 inline int pair_ks_min_r() { static int v = env_int("SAST_KS_MINR", 256); return v; }
 inline int pair_thin_nb() { static int v = env_int("SAST_THIN_NB", 384); return v; }
 inline int pair_ks_nb() { static int v = env_int("SAST_KS_NB", 1000000); return v; }
