@@ -785,6 +785,42 @@ def test_csp_conv_pair_matches_separate_convs(dev, pair_input, width):
         maxnorm_close(ga[k], gb[k], 2e-5, k)
 
 
+def test_pafpn_fused_paths_match_plain_on_odd_widths(dev):
+    """the whole PAFPN at the tiny / small model widths (96 / 192 / 384 channels: halves of 48, not a multiple of the 32-column
+    MFMA tile) with every cross-layer fusion on (stacked conv pairs, BatchNorm-backward reductions in the consumers' dX epilogues,
+    aliased two-consumer outputs) against the plain one-op-per-call path: outputs, input gradients and all parameter gradients"""
+    from sast_amd import functional as SF
+    from sast_amd.detection import YOLOPAFPN
+    torch.manual_seed(11)
+    chans = (96, 192, 384)
+    net = YOLOPAFPN(depth=0.33, in_stages=(2, 3, 4), in_channels=chans).to(dev).train()
+    f0 = {2: torch.randn(2, 24, 40, chans[0], device=dev), 3: torch.randn(2, 12, 20, chans[1], device=dev),
+          4: torch.randn(2, 6, 10, chans[2], device=dev)}
+    res = []
+    for fused in (True, False):
+        old = (SF.CONV_PAIR, SF.BN_FOLD, SF.TWO_OUT)
+        SF.CONV_PAIR = SF.BN_FOLD = SF.TWO_OUT = fused
+        try:
+            net.zero_grad()
+            for mod in net.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.reset_running_stats()
+            feats = {k: v.clone().requires_grad_(True) for k, v in f0.items()}
+            outs = net.forward_nhwc(feats)
+            sum((o * torch.linspace(-1, 1, o.numel(), device=dev).view_as(o)).sum() for o in outs).backward()
+            res.append(([o.detach().clone() for o in outs], {k: v.grad.clone() for k, v in feats.items()},
+                        {k: p.grad.clone() for k, p in net.named_parameters()}))
+        finally:
+            SF.CONV_PAIR, SF.BN_FOLD, SF.TWO_OUT = old
+    (oa, xa, ga), (ob, xb, gb) = res
+    for a, b in zip(oa, ob):
+        maxnorm_close(a, b, 1e-5, "out")
+    for k in xa:
+        maxnorm_close(xa[k], xb[k], 2e-5, f"din{k}")
+    for k in ga:
+        maxnorm_close(ga[k], gb[k], 5e-5, k)
+
+
 def test_mean_squares_matches_torch(dev):
     """bench.py's synthetic objective: sum_t mean(x_t^2) in one launch each way == the torch expression"""
     from sast_amd import functional as SF
