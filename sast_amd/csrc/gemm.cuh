@@ -761,7 +761,14 @@ struct LdWeightNNS {
 struct ConvGeom {
   int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad, replicate, ldx;  // ldx: channel stride of the input rows
   int cin_shift, kw_mul;                                           // Cin == 1 << cin_shift (or -1); kw_mul = small_div_mul(KW)
+  unsigned wo_mul, ho_mul;   // n / Wo == umulhi(n, wo_mul) for every row index n of the problem (0: use the division); same for Ho
 };
+// exact n / d for n * d < 2^32 with mul = 2^32 / d + 1 (one v_mul_hi_u32 instead of the ~35-instruction integer division the
+// weight-gradient im2col loader used to run twice per load inside its k-loop)
+__host__ __device__ inline unsigned div_mul_of(unsigned d, unsigned long long n_max) {
+  return (d > 1 && n_max * d < (1ull << 32)) ? (unsigned)((1ull << 32) / d + 1) : 0u;
+}
+__device__ __forceinline__ int fast_div(int n, int d, unsigned mul) { return mul ? (int)__umulhi((unsigned)n, mul) : n / d; }
 __device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, int shift, int r, int& kh, int& kw, int& c) {
   const int tap = shift >= 0 ? (r >> shift) : (r / chans);
   c = r - tap * chans;
@@ -803,7 +810,7 @@ struct LdIm2colT {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 1);
-    const int ox = rr % g.Wo, t = rr / g.Wo, oy = t % g.Ho, b = t / g.Ho;
+    const int t = fast_div(rr, g.Wo, g.wo_mul), ox = rr - t * g.Wo, b = fast_div(t, g.Ho, g.ho_mul), oy = t - b * g.Ho;
     const int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));

@@ -326,6 +326,9 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   g.Wo = (W + 2 * pad - k) / stride + 1;
   g.cin_shift = pow2_shift(Cin);
   g.kw_mul = small_div_mul(k);
+  const unsigned long long rows = (unsigned long long)B * g.Ho * g.Wo;
+  g.wo_mul = div_mul_of((unsigned)g.Wo, rows);
+  g.ho_mul = div_mul_of((unsigned)g.Ho, rows);
   return g;
 }
 
