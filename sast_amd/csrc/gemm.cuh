@@ -893,6 +893,7 @@ struct LdWeightConvDx2 {
 // kernel with zero padding).  Mc must be a multiple of the row tile so that a block sees a single class.
 struct ConvDxClasses {
   int Hc, Wc, Mc;
+  unsigned mc_mul, wc_mul, hc_mul;   // fast_div multipliers for row indices < 4 * Mc (0: plain division)
   unsigned kh_pack[4], kw_pack[4];   // per class: 4 bits per tap slot, 15 = empty slot; the used slots come first
   int nslot[4];                      // per class: number of used slots (the reduction of a row tile stops there)
   __device__ __forceinline__ int slots(int cls) const { return cls == 0 ? nslot[0] : cls == 1 ? nslot[1] : cls == 2 ? nslot[2] : nslot[3]; }
@@ -908,8 +909,8 @@ struct LdConvDxP {
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
     const bool ok = i < Ieff;
     const int ii = ok ? i : 0;
-    const int cls = ii / k.Mc, ic = ii - cls * k.Mc;
-    const int xx = ic % k.Wc, t = ic / k.Wc, yy = t % k.Hc, b = t / k.Hc;
+    const int cls = fast_div(ii, k.Mc, k.mc_mul), ic = ii - cls * k.Mc;
+    const int t = fast_div(ic, k.Wc, k.wc_mul), xx = ic - t * k.Wc, b = fast_div(t, k.Hc, k.hc_mul), yy = t - b * k.Hc;
     Ctx c;
     const int q = 3 - cls;   // the classes are laid out heaviest first (odd-odd pixels see 4 taps, even-even 1): parity = 3 - position
     c.img = dy + (size_t)b * g.Ho * g.Wo * lddy; c.iy = 2 * yy + (q >> 1); c.ix = 2 * xx + (q & 1); c.ok = ok;
@@ -1078,8 +1079,8 @@ struct EpStoreClass {  // C[pixel(m) * ldc + j] = v, pixel(m) from the parity-cl
   struct Aux { int p; };
   __device__ __forceinline__ Col col(int) const { return Col{}; }
   __device__ __forceinline__ Aux pre(int m, int) const {
-    const int cls = m / k.Mc, ic = m - cls * k.Mc;
-    const int xx = ic % k.Wc, t = ic / k.Wc, yy = t % k.Hc, b = t / k.Hc;
+    const int cls = fast_div(m, k.Mc, k.mc_mul), ic = m - cls * k.Mc;
+    const int t = fast_div(ic, k.Wc, k.wc_mul), xx = ic - t * k.Wc, b = fast_div(t, k.Hc, k.hc_mul), yy = t - b * k.Hc;
     const int q = 3 - cls;
     return Aux{(b * H + 2 * yy + (q >> 1)) * W + 2 * xx + (q & 1)};
   }

@@ -21,7 +21,8 @@ struct BnFwdJob {
   float* y; int ldy; float momentum, eps;
 };
 // blockIdx.y selects the job: one conv, or the two convs of sast_conv_bn_silu2 (same M, C)
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJob j1, int M, size_t n4, int C, int training, int iters) {
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJob j1, int M, size_t n4, int C, int training, int iters,
+                                                            unsigned c4_mul) {
   const BnFwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const double* __restrict__ sums = jb.sums;
   float* __restrict__ run_mean = jb.run_mean; float* __restrict__ run_var = jb.run_var; float* __restrict__ stats = jb.stats;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJo
   for (int it = 0; it < iters; ++it) {
     const size_t e = e0 + (size_t)it * 256;
     if (e >= n4) return;
-    const size_t m = e / c4; const int c = (int)(e % c4) * 4;
+    const size_t m = fast_div((int)e, c4, c4_mul); const int c = (int)(e - m * c4) * 4;   // n4 < 2^31 (launcher)
     const float4 v = ld4(x + m * C + c), g = ld4(gamma + c), b = ld4(beta + c);
     const float4 mu = *(const float4*)(bn_sm + c), rs = *(const float4*)(bn_sm + C + c);
     float4 z = make_float4((v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z,
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob 
 // Every block first folds the BN_STAT_COPIES copies of the two sums (written by bn_bwd_reduce_kernel into copy 0, or by the
 // consuming conv's dX epilogue into all of them) and the per-channel constants into LDS, then streams `iters` x 256 float4;
 // block 0 also publishes the affine gradients.
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob j1, size_t n4, int C, float invM, int training, int iters) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob j1, size_t n4, int C, float invM, int training, int iters,
+                                                           unsigned c4_mul) {
   const BnBwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const float* __restrict__ stats = jb.stats; const float* __restrict__ gamma = jb.gamma;
   const float* __restrict__ beta = jb.beta; const float* __restrict__ dy = jb.dy; const int lddy = jb.lddy;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
   for (int it = 0; it < iters; ++it) {
     const size_t e4 = e0 + (size_t)it * 256;
     if (e4 >= n4) return;
-    const size_t m = e4 / c4; const int c = (int)(e4 % c4) * 4;
+    const size_t m = fast_div((int)e4, c4, c4_mul); const int c = (int)(e4 - m * c4) * 4;   // n4 < 2^31 (launcher)
     const float4 v = ld4(x + m * C + c), d = bn_ld_dy(dy, jb.dy2, m * lddy + c);
     float out[4];
 #pragma unroll
@@ -316,7 +318,7 @@ void bn_bwd_apply_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int 
   int iters = (int)(n4 / (256 * 512));
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), njobs), dim3(256), sizeof(float) * 6 * C, st,
-                     j0, j1, n4, C, 1.0f / (float)M, training, iters);
+                     j0, j1, n4, C, 1.0f / (float)M, training, iters, div_mul_of((unsigned)(C / 4), n4));
 }
 
 inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad, int replicate, int ldx) {
@@ -355,6 +357,7 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
                      LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
   ConvDxClasses c;
   c.Hc = g.H / 2; c.Wc = g.W / 2; c.Mc = Mc;
+  c.mc_mul = div_mul_of((unsigned)c.Mc, 4ull * Mc); c.wc_mul = div_mul_of((unsigned)c.Wc, 4ull * Mc); c.hc_mul = div_mul_of((unsigned)c.Hc, 4ull * Mc);
   for (int cls = 0; cls < 4; ++cls) {
     const int py = (3 - cls) >> 1, px = (3 - cls) & 1;   // row order: heaviest class first (gemm.cuh: LdConvDxP)
     // taps that can be non-zero for this class: matching parity, plus (replicate padding) the border tap kk < pad that folds
@@ -421,6 +424,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const int k = a->ksize, pad = (k - 1) / 2;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
+  if ((unsigned long long)M * (C / 4) >= (1ull << 31)) return SAST_EINVAL;   // element indices of the BatchNorm passes are 31-bit
   double* sums = (double*)a->bn_ws;
   if (a->training && !a->bn_ws_zeroed) zero_fill(a->bn_ws, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
   int rc;
@@ -460,7 +464,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   {
     const BnFwdJob jb{a->conv_out, sums, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, a->momentum, a->eps};
     hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 1), dim3(256), sizeof(float) * 2 * C, st,
-                       jb, jb, M, n4, C, a->training, iters);
+                       jb, jb, M, n4, C, a->training, iters, div_mul_of((unsigned)(C / 4), n4));
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -549,7 +553,7 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
   const BnFwdJob j0{a->conv_out0, (const double*)a->bn_ws0, a->run_mean0, a->run_var0, a->stats0, a->bn_w0, a->bn_b0, a->y0, C, a->momentum0, a->eps0};
   const BnFwdJob j1{a->conv_out1, (const double*)a->bn_ws1, a->run_mean1, a->run_var1, a->stats1, a->bn_w1, a->bn_b1, a->y1, C, a->momentum1, a->eps1};
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 2), dim3(256), sizeof(float) * 2 * C, st, j0, j1,
-                     M, n4, C, 1, iters);
+                     M, n4, C, 1, iters, div_mul_of((unsigned)(C / 4), n4));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
