@@ -93,6 +93,13 @@ __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
+// exact n / d for n * d < 2^32 with mul = 2^32 / d + 1 (one v_mul_hi_u32 instead of the ~35-instruction integer division; the
+// weight-gradient im2col loader ran two of those per load inside its k-loop)
+__host__ __device__ inline unsigned div_mul_of(unsigned d, unsigned long long n_max) {
+  return (d > 1 && n_max * d < (1ull << 32)) ? (unsigned)((1ull << 32) / d + 1) : 0u;
+}
+__device__ __forceinline__ int fast_div(int n, int d, unsigned mul) { return mul ? (int)__umulhi((unsigned)n, mul) : n / d; }
+
 // ---- STP controls (SAST.py:109, :325-328): scale[b,c] = sum_j exp(Wc[c,j]) * (r[b,j] + 1e-6) and its weight gradient
 // dWc[c,j] += exp(Wc[c,j]) * sum_b dscale[b,c] * (r[b,j]+1e-6).  Tiny (B*C resp. C*J outputs): own kernels in k_rows.hip, or
 // side workgroups of the scoring GEMM launches (k_block.hip).  i = global element index.

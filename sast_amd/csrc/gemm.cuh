@@ -763,12 +763,7 @@ struct ConvGeom {
   int cin_shift, kw_mul;                                           // Cin == 1 << cin_shift (or -1); kw_mul = small_div_mul(KW)
   unsigned wo_mul, ho_mul;   // n / Wo == umulhi(n, wo_mul) for every row index n of the problem (0: use the division); same for Ho
 };
-// exact n / d for n * d < 2^32 with mul = 2^32 / d + 1 (one v_mul_hi_u32 instead of the ~35-instruction integer division the
-// weight-gradient im2col loader used to run twice per load inside its k-loop)
-__host__ __device__ inline unsigned div_mul_of(unsigned d, unsigned long long n_max) {
-  return (d > 1 && n_max * d < (1ull << 32)) ? (unsigned)((1ull << 32) / d + 1) : 0u;
-}
-__device__ __forceinline__ int fast_div(int n, int d, unsigned mul) { return mul ? (int)__umulhi((unsigned)n, mul) : n / d; }
+// (fast_div / div_mul_of: common.cuh)
 __device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, int shift, int r, int& kh, int& kw, int& c) {
   const int tap = shift >= 0 ? (r >> shift) : (r / chans);
   c = r - tap * chans;

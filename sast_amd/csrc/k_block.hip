@@ -115,10 +115,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
                                                                  const float* __restrict__ c1, const float* __restrict__ dh1,
                                                                  const float* __restrict__ dh1b, const float* __restrict__ dc1,
                                                                  float* __restrict__ dmix,
-                                                                 float* __restrict__ dc0, size_t n, int C) {
+                                                                 float* __restrict__ dc0, size_t n, int C, unsigned c_mul) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
-  const size_t m = e / C; const int j = (int)(e % C);
+  const size_t m = fast_div((int)e, C, c_mul); const int j = (int)(e - m * C);   // n < 2^31 (launcher)
   const float* gp = gates + m * 4 * C + j;
   const float f = gp[0], i = gp[C], o = gp[2 * C], g = gp[3 * C];
   const float tc = tanhf(c1[e]);
@@ -396,8 +396,9 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   const int M = a->B * a->L, C = a->C;
   float* dmix = a->ws;
   const size_t n = (size_t)M * C;
+  if (n >= (1ull << 31)) return SAST_EINVAL;
   hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
-                     a->dh1b, a->dc1, dmix, a->dc0, n, C);
+                     a->dh1b, a->dc1, dmix, a->dc0, n, C, div_mul_of((unsigned)C, n));
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
   return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
                    LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);

@@ -137,30 +137,36 @@ int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int
 // ============================================================ NCHW (any dtype) -> NHWC fp32
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int H, int W, int Hp,
-                                                           int Wp) {
+                                                           int Wp, unsigned c_mul) {
   extern __shared__ float tile[];  // [64][C+1]
   const int b = blockIdx.y, p0 = blockIdx.x * 64, HWp = Hp * Wp;
   const int ldt = C + 1;
+  // the 64 pixels of the block start at (py0, px0) and wrap at most once per row of the map (no division per element)
+  const int py0 = p0 / Wp, px0 = p0 - py0 * Wp;
   for (int e = threadIdx.x; e < 64 * C; e += 256) {
-    const int c = e >> 6, p = p0 + (e & 63);
+    const int c = e >> 6, i = e & 63, p = p0 + i;
     if (p < HWp) {
-      const int py = p / Wp, px = p - py * Wp;      // output pixel of the (zero-padded) map
-      tile[(e & 63) * ldt + c] = (py < H && px < W) ? (float)x[(((size_t)b * C + c) * H + py) * W + px] : 0.f;
+      int py = py0, px = px0 + i;               // output pixel of the (zero-padded) map
+      while (px >= Wp) { px -= Wp; ++py; }
+      tile[i * ldt + c] = (py < H && px < W) ? (float)x[(((size_t)b * C + c) * H + py) * W + px] : 0.f;
     }
   }
   __syncthreads();
   const int np = min(64, HWp - p0);
   float* o = y + ((size_t)b * HWp + p0) * C;
-  for (int e = threadIdx.x; e < np * C; e += 256) o[e] = tile[(e / C) * ldt + (e % C)];
+  for (int e = threadIdx.x; e < np * C; e += 256) {
+    const int q = fast_div(e, C, c_mul);
+    o[e] = tile[q * ldt + (e - q * C)];
+  }
 }
 
 int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   dim3 grid((Hp * Wp + 63) / 64, B);
   const size_t sh = sizeof(float) * 64 * (C + 1);
   switch (dtype) {
-    case SAST_DT_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, H, W, Hp, Wp); break;
-    case SAST_DT_I32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, H, W, Hp, Wp); break;
-    case SAST_DT_U8:  hipLaunchKernelGGL((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, H, W, Hp, Wp); break;
+    case SAST_DT_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
+    case SAST_DT_I32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
+    case SAST_DT_U8:  hipLaunchKernelGGL((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
     default: return SAST_EINVAL;
   }
   SAST_CHECK_LAUNCH();
