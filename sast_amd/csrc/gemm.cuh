@@ -762,10 +762,11 @@ struct ConvGeom {
   int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad, replicate, ldx;  // ldx: channel stride of the input rows
   int cin_shift, kw_mul;                                           // Cin == 1 << cin_shift (or -1); kw_mul = small_div_mul(KW)
   unsigned wo_mul, ho_mul;   // n / Wo == umulhi(n, wo_mul) for every row index n of the problem (0: use the division); same for Ho
+  unsigned cin_mul;          // r / Cin for reduce indices r < KH*KW*Cin when Cin is not a power of two (the 20-channel stem)
 };
 // (fast_div / div_mul_of: common.cuh)
 __device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, int shift, int r, int& kh, int& kw, int& c) {
-  const int tap = shift >= 0 ? (r >> shift) : (r / chans);
+  const int tap = shift >= 0 ? (r >> shift) : (chans == g.Cin ? fast_div(r, chans, g.cin_mul) : r / chans);
   c = r - tap * chans;
   kh = (tap * g.kw_mul) >> 16;
   kw = tap - kh * g.KW;

@@ -331,6 +331,7 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   const unsigned long long rows = (unsigned long long)B * g.Ho * g.Wo;
   g.wo_mul = div_mul_of((unsigned)g.Wo, rows);
   g.ho_mul = div_mul_of((unsigned)g.Ho, rows);
+  g.cin_mul = div_mul_of((unsigned)Cin, (unsigned long long)k * k * Cin);
   return g;
 }
 
