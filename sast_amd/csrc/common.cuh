@@ -144,13 +144,15 @@ __device__ __forceinline__ void ls_finish_row(const LsFinish& p, int c, int lane
 // (reference: ops.py:189-220).  mode 0 = window, 1 = grid.
 struct PartMap {
   int H, W, ph, pw, mode;
+  int gw, gh, n_groups;          // groups per row / column, total (set by make_part_map)
+  unsigned pw_mul, gw_mul;       // fast_div multipliers for t / pw (t < ph*pw) and n / gw (n < N): the selection kernels decode
+                                 // (group, slot) -> token for every token they read, two divisions each before
   __host__ __device__ int T() const { return ph * pw; }
-  __host__ __device__ int N() const { return (H / ph) * (W / pw); }
+  __host__ __device__ int N() const { return n_groups; }
   // group n, slot t -> token index l = y*W + x
-  __host__ __device__ int token(int n, int t) const {
-    const int gw = W / pw, gh = H / ph;
-    const int a = t / pw, c = t % pw;
-    const int i = n / gw, j = n % gw;
+  __device__ __forceinline__ int token(int n, int t) const {
+    const int a = fast_div(t, pw, pw_mul), c = t - a * pw;
+    const int i = fast_div(n, gw, gw_mul), j = n - i * gw;
     int y, x;
     if (mode == 0) { y = i * ph + a; x = j * pw + c; }
     else           { y = a * gh + i; x = c * gw + j; }
@@ -159,10 +161,18 @@ struct PartMap {
   // token l -> (n, t)
   __host__ __device__ void group(int l, int& n, int& t) const {
     const int y = l / W, x = l % W;
-    const int gw = W / pw, gh = H / ph;
     if (mode == 0) { n = (y / ph) * gw + (x / pw); t = (y % ph) * pw + (x % pw); }
     else           { n = (y % gh) * gw + (x % gw); t = (y / gh) * pw + (x / gw); }
   }
 };
+
+inline PartMap make_part_map(int H, int W, int ph, int pw, int mode) {
+  PartMap pm{};
+  pm.H = H; pm.W = W; pm.ph = ph; pm.pw = pw; pm.mode = mode;
+  pm.gw = W / pw; pm.gh = H / ph; pm.n_groups = pm.gw * pm.gh;
+  pm.pw_mul = div_mul_of((unsigned)pw, (unsigned long long)ph * pw);
+  pm.gw_mul = div_mul_of((unsigned)pm.gw, (unsigned long long)pm.n_groups);
+  return pm;
+}
 
 }  // namespace sast

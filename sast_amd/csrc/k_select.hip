@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm,
 
 static int select_launch_n(const float* tok, int B, int H, int W_, int ph, int pw, float thr_win, float thr_tok, const SelPair& sp,
                            int nsel, hipStream_t st) {
-  PartMap pm{H, W_, ph, pw, 0};
+  PartMap pm = make_part_map(H, W_, ph, pw, 0);
   if (H % ph || W_ % pw || pm.T() > 128) return SAST_EINVAL;
   const int L = H * W_, N = pm.N(), W = B * N;
   const int chunks = (N + SEL_WAVES - 1) / SEL_WAVES;
