@@ -760,13 +760,15 @@ struct LdWeightNNS {
 // implicit-GEMM geometry of a 2D convolution on NHWC activations
 struct ConvGeom {
   int B, H, W, Cin, Ho, Wo, KH, KW, stride, pad, replicate, ldx;  // ldx: channel stride of the input rows
-  int cin_shift, kw_mul;                                           // Cin == 1 << cin_shift (or -1); kw_mul = small_div_mul(KW)
+  int stride_shift, kw_mul;                                        // stride == 1 << stride_shift; kw_mul = small_div_mul(KW)
   unsigned wo_mul, ho_mul;   // n / Wo == umulhi(n, wo_mul) for every row index n of the problem (0: use the division); same for Ho
-  unsigned cin_mul;          // r / Cin for reduce indices r < KH*KW*Cin when Cin is not a power of two (the 20-channel stem)
+  unsigned cin_mul;          // r / Cin == umulhi(r, cin_mul) for reduce indices r < KH*KW*Cin (never 0: geom_of checks)
 };
 // (fast_div / div_mul_of: common.cuh)
-__device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, int shift, int r, int& kh, int& kw, int& c) {
-  const int tap = shift >= 0 ? (r >> shift) : (chans == g.Cin ? fast_div(r, chans, g.cin_mul) : r / chans);
+// (tap, channel) of a reduce index.  The divisor is applied as a multiplier (div_mul_of) ALWAYS, powers of two included: a
+// `shift >= 0 ? r >> shift : r / chans` leaves a uniform branch and a division block per load inside the k-loop
+__device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, unsigned mul, int r, int& kh, int& kw, int& c) {
+  const int tap = (int)__umulhi((unsigned)r, mul);
   c = r - tap * chans;
   kh = (tap * g.kw_mul) >> 16;
   kw = tap - kh * g.KW;
@@ -784,7 +786,7 @@ struct LdIm2col {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     int kh, kw, ch;
-    split_tap(g, g.Cin, g.cin_shift, min(r, Reff - 4), kh, kw, ch);   // r and Reff are multiples of 4: the clamped float4 stays inside one pixel
+    split_tap(g, g.Cin, g.cin_mul, min(r, Reff - 4), kh, kw, ch);   // r and Reff are multiples of 4: the clamped float4 stays inside one pixel
     const int iy = c.iy0 + kh, ix = c.ix0 + kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
@@ -801,7 +803,7 @@ struct LdIm2colT {
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
     Ctx c;
     c.ok = j < NJ;
-    split_tap(g, g.Cin, g.cin_shift, c.ok ? j : 0, c.kh, c.kw, c.c);
+    split_tap(g, g.Cin, g.cin_mul, c.ok ? j : 0, c.kh, c.kw, c.c);
     return c;
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
@@ -819,7 +821,7 @@ struct LdIm2colT {
 // replicate padding: the clamped taps (kh < pad at iy == 0, same for x) fold onto output row/col 0.
 struct LdConvDx {
   static constexpr bool RC = true;
-  const float* dy; ConvGeom g; int Cout; int lddy; int cout_shift;
+  const float* dy; ConvGeom g; int Cout; int lddy; unsigned cout_mul;   // cout_mul = div_mul_of(Cout, reduce length), never 0
   struct Ctx { const float* img; int iy, ix; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
     const bool ok = i < Ieff;
@@ -830,15 +832,15 @@ struct LdConvDx {
   // source output coordinate of input coordinate i under tap k (returns validity; o is always in range)
   __device__ __forceinline__ bool src(int i, int k, int n_out, int& o) const {
     const int t = i + g.pad - k;
-    const int q = g.stride == 1 ? t : (g.stride == 2 ? (t >> 1) : (t / g.stride));
-    const bool hit = t >= 0 && q * g.stride == t && q < n_out;
+    const int q = t >> g.stride_shift;
+    const bool hit = t >= 0 && (q << g.stride_shift) == t && q < n_out;
     const bool rep = g.replicate && i == 0 && k < g.pad;
     o = hit ? q : 0;
     return hit || rep;
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     int kh, kw, co;
-    split_tap(g, Cout, cout_shift, min(r, Reff - 4), kh, kw, co);
+    split_tap(g, Cout, cout_mul, min(r, Reff - 4), kh, kw, co);
     int oy, ox;
     const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
     ok = c.ok && r < Reff && vy && vx;
@@ -850,12 +852,12 @@ struct LdConvDx {
 // IC: B[r = (tap,co)][j = ci] = w[co][tap][ci]   (weights stored channels-last: [Cout][KH][KW][Cin])
 struct LdWeightConvDx {
   static constexpr bool RC = false;
-  const float* w; int Cout, taps, Cin, cout_shift;
+  const float* w; int Cout, taps, Cin; unsigned cout_mul;
   struct Ctx { const float* col; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{w + (j < NJ ? j : 0), j < NJ}; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 1);
-    const int tap = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - tap * Cout;
+    const int tap = (int)__umulhi((unsigned)rr, cout_mul), co = rr - tap * Cout;
     ok = c.ok && r < Reff;
     v = ld4(c.col + ((size_t)co * taps + tap) * Cin);
     aux = 0.f;
@@ -866,12 +868,12 @@ struct LdWeightConvDx {
 // the same for two convs stacked along Cout (co < C1 -> w0, else w1): dX = [dy0 | dy1] * [w0; w1]
 struct LdWeightConvDx2 {
   static constexpr bool RC = false;
-  const float* w0; const float* w1; int Cout, C1, taps, Cin, cout_shift;   // Cout = total stacked output channels
+  const float* w0; const float* w1; int Cout, C1, taps, Cin; unsigned cout_mul;   // Cout = total stacked output channels
   struct Ctx { int j; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 1);
-    const int tap = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - tap * Cout;
+    const int tap = (int)__umulhi((unsigned)rr, cout_mul), co = rr - tap * Cout;
     ok = c.ok && r < Reff;
     const float* row = co < C1 ? w0 + ((size_t)co * taps + tap) * Cin : w1 + ((size_t)(co - C1) * taps + tap) * Cin;   // address select
     v = ld4(row + c.j);
@@ -900,7 +902,7 @@ struct ConvDxClasses {
 };
 struct LdConvDxP {
   static constexpr bool RC = true;
-  const float* dy; ConvGeom g; int Cout; int lddy; int cout_shift; ConvDxClasses k;
+  const float* dy; ConvGeom g; int Cout; int lddy; unsigned cout_mul; ConvDxClasses k;
   struct Ctx { const float* img; int iy, ix; unsigned kh, kw; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
     const bool ok = i < Ieff;
@@ -923,7 +925,7 @@ struct LdConvDxP {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 4);
-    const int slot = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - slot * Cout;
+    const int slot = (int)__umulhi((unsigned)rr, cout_mul), co = rr - slot * Cout;
     const int kh = (c.kh >> (4 * slot)) & 15, kw = (c.kw >> (4 * slot)) & 15;
     int oy, ox;
     const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
@@ -936,7 +938,7 @@ struct LdConvDxP {
 struct LdWeightConvDxP {
   static constexpr bool RC = false;
   static constexpr bool WANTS_M0 = true;
-  const float* w; int Cout, taps, Cin, cout_shift, KW; ConvDxClasses k;
+  const float* w; int Cout, taps, Cin; unsigned cout_mul; int KW; ConvDxClasses k;
   struct Ctx { const float* col; unsigned kh, kw; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ, int m0) const {
     Ctx c;
@@ -947,7 +949,7 @@ struct LdWeightConvDxP {
   __device__ __forceinline__ int reduce_len(int m0) const { return k.slots(m0 / k.Mc) * Cout; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 1);
-    const int slot = cout_shift >= 0 ? (rr >> cout_shift) : (rr / Cout), co = rr - slot * Cout;
+    const int slot = (int)__umulhi((unsigned)rr, cout_mul), co = rr - slot * Cout;
     const int kh = (c.kh >> (4 * slot)) & 15, kw = (c.kw >> (4 * slot)) & 15;
     const bool empty = kh == 15 || kw == 15;
     ok = c.ok && r < Reff && !empty;

@@ -326,7 +326,7 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.KH = k; g.KW = k; g.stride = stride; g.pad = pad; g.replicate = replicate; g.ldx = ldx;
   g.Ho = (H + 2 * pad - k) / stride + 1;
   g.Wo = (W + 2 * pad - k) / stride + 1;
-  g.cin_shift = pow2_shift(Cin);
+  g.stride_shift = pow2_shift(stride);     // strides are 1, 2 or 4
   g.kw_mul = small_div_mul(k);
   const unsigned long long rows = (unsigned long long)B * g.Ho * g.Wo;
   g.wo_mul = div_mul_of((unsigned)g.Wo, rows);
@@ -341,7 +341,9 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
 // dW (TN over the im2col rows) and dX of a k x k convolution in one launch
 int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cout, const float* w, float* dw, float* dx, int lddx,
                   hipStream_t st, const BnProducer* prod = nullptr) {
-  const int k = g.KH, shift = pow2_shift(Cout), K = k * k * g.Cin, M = g.B * g.Ho * g.Wo;
+  const int k = g.KH, K = k * k * g.Cin, M = g.B * g.Ho * g.Wo;
+  const unsigned shift = div_mul_of((unsigned)Cout, (unsigned long long)k * k * Cout);   // tap = umulhi(r, shift): multiplier, not a shift
+  if (!shift || !g.cin_mul || g.stride_shift < 0) return SAST_EINVAL;
   const LdRowsT ta{dconv, Cout};
   const LdIm2colT tb{x, g};
   if (!dx) return gemm_tn(ta, tb, dw, K, Cout, K, M, st);
@@ -588,7 +590,8 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
     const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx);
     const LdIm2colT tbc{a->x, g};
     if (!a->dx) return launch_gemm_split<TileSmallK2>(ta, tbc, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
-    const int shift = pow2_shift(2 * C);
+    const unsigned shift = div_mul_of((unsigned)(2 * C), 9ull * 2 * C);
+    if (!shift || !g.cin_mul) return SAST_EINVAL;
     const LdConvDx lac{dconv, g, 2 * C, 2 * C, shift};
     const LdWeightConvDx2 lbc{a->w0, a->w1, 2 * C, C, 9, a->Cin, shift};
     if (p1.x) {
