@@ -240,9 +240,31 @@ def _padding_index(index_token: Tensor, asy_index: Tensor) -> Tensor:
     return index_token[torch.isin(index_token, asy_index, assume_unique=True, invert=True)]
 
 
+def selection_diff(scores: Tensor, own, other, B: int, N: int, T: int, bounce: float) -> dict:
+    """test diagnostics for full-size runs (token decisions sit within 1 ulp of the threshold, so two
+    correct fp32 implementations with different summation orders may disagree on a handful of them): the window /
+    token decisions on which two index lists differ, with the relative threshold margin of each (from `scores`, this
+    side's own values).  Tokens of a window only one side kept are attributed to the window decision."""
+    mw, mt = selection_margins(scores, B, N, T, bounce)
+    mw, mt = mw.reshape(-1), mt.reshape(B * N, T)
+    iw_a, iw_b = own[0], other[0]
+    wa, wb = torch.zeros(B * N, dtype=torch.bool), torch.zeros(B * N, dtype=torch.bool)
+    wa[iw_a] = True
+    wb[iw_b] = True
+    wdiff = wa ^ wb
+    ta, tb = torch.zeros(B * N, T, dtype=torch.bool), torch.zeros(B * N, T, dtype=torch.bool)
+    ta.view(-1)[iw_a[torch.div(own[3], T, rounding_mode="floor")] * T + own[3] % T] = True
+    tb.view(-1)[iw_b[torch.div(other[3], T, rounding_mode="floor")] * T + other[3] % T] = True
+    tdiff = (ta ^ tb) & ~wdiff[:, None]
+    return {"win_diff": int(wdiff.sum()), "tok_diff": int(tdiff.sum()), "decisions": int(B * N + wa.sum() * T),
+            "max_margin": float(torch.cat([mw[wdiff], mt[tdiff], torch.zeros(1, dtype=mw.dtype)]).max())}
+
+
 def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnCfg,
-               index_list=None, first_block: bool = True, return_scores: bool = False):
-    """SAST.py:98-164.  x (B,H,W,C) NHWC, pe (1,H,W,C), r (B,20) -> (x, index_count, [list1,list2])."""
+               index_list=None, first_block: bool = True, return_scores: bool = False, forced_lists=None, diff_log=None):
+    """SAST.py:98-164.  x (B,H,W,C) NHWC, pe (1,H,W,C), r (B,20) -> (x, index_count, [list1,list2]).
+    forced_lists (test diagnostics, never the reference's behaviour): [list1, list2] to USE instead of this block's own
+    selection; the own selection is still computed and its disagreement with the forced one is appended to diff_log."""
     B, H, W, C = x.shape
     h, w = cfg.partition_size
     T = h * w
@@ -262,6 +284,10 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
         iw = select_windows(scores, B, N, T, cfg.bounce)
         it, asy, K = select_tokens(scores, iw, B, N, T, cfg.bounce)
         list1 = [iw, it, _padding_index(it, asy), asy, K]
+        if forced_lists is not None:
+            if diff_log is not None:
+                diff_log.append(dict(selection_diff(scores.detach(), list1, forced_lists[0], B, N, T, cfg.bounce), where=pre + "win"))
+            list1 = forced_lists[0]
     else:
         x = x.view(B * N, -1, C)
         list1, list2 = index_list
@@ -276,6 +302,10 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
         iw = select_windows(scores, B, N, T, cfg.bounce)
         it, asy, K = select_tokens(scores, iw, B, N, T, cfg.bounce)
         list2 = [iw, it, _padding_index(it, asy), asy, K]
+        if forced_lists is not None:
+            if diff_log is not None:
+                diff_log.append(dict(selection_diff(scores.detach(), list2, forced_lists[1], B, N, T, cfg.bounce), where=pre + "grid"))
+            list2 = forced_lists[1]
     x = grid_partition(x.view(B, H, W, C), (h, w)).view(B * N, -1, C)
     if len(list2[1]):
         x = ms_wsa(x, list2, B, p, pre + "grid_attn.", cfg)
@@ -303,7 +333,7 @@ def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: st
 
 # --------------------------------------------------------------------------- a11
 def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: BackboneCfg, stage_idx: int,
-                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None):
+                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None):
     """sast_rnn.py:265-287.  NCHW in -> (h NCHW, (h,c), P, index lists).  token_mask (B,H,W) bool: x[token_mask] = mask_token
     (:271-273, parameter `<pre>mask_token` of shape (1,1,1,C), only stage 0 has one when enable_masking is set)."""
     factor = cfg.patch_size if stage_idx == 0 else 2
@@ -319,7 +349,8 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
     all_lists = []
     for bi in range(cfg.num_blocks[stage_idx]):
         x, cnt, lists = sast_block(x, pe, r, p, f"{pre}att_blocks.{bi}.att.", cfg.attn,
-                                   index_list=lists, first_block=(bi == 0))
+                                   index_list=lists, first_block=(bi == 0),
+                                   forced_lists=forced_lists[bi] if (forced_lists is not None and bi == 0) else None, diff_log=diff_log)
         all_lists.append(lists)
         P += cnt
     x = x.permute(0, 3, 1, 2).contiguous()
@@ -328,8 +359,9 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
 
 
 def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "", return_lists: bool = False,
-             token_mask: Optional[Tensor] = None):
-    """sast_rnn.py:144-162.  x (B,20,H,W) -> ({1..4: h}, states, P)."""
+             token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None):
+    """sast_rnn.py:144-162.  x (B,20,H,W) -> ({1..4: h}, states, P).
+    forced_lists[stage][block] = [list1, list2] / diff_log: see sast_block (full-size parity diagnostics only)."""
     if prev_states is None:
         prev_states = [None] * 4
     r = non_zero_ratio(x)
@@ -337,7 +369,8 @@ def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "",
     out, states, P, lists = {}, [], [], []
     for s in range(4):
         x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s,
-                                        token_mask=token_mask if s == 0 else None)
+                                        token_mask=token_mask if s == 0 else None,
+                                        forced_lists=forced_lists[s] if forced_lists is not None else None, diff_log=diff_log)
         states.append(st)
         out[s + 1] = st[0]
         P.append(cnt)

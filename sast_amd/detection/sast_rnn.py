@@ -98,6 +98,7 @@ class RNNDetectorStage(nn.Module):
                                   cell_update_dropout=cfg_get(lstm_cfg, 'drop_cell_update', 0)) if enable_lstm else None
         self.pos_emb = PositionEmbeddingSine(stage_dim // 2, normalize=True, input_size=overload_size)
         self.mask_token = nn.Parameter(torch.zeros(1, 1, 1, stage_dim), requires_grad=True) if enable_token_masking else None
+        self.last_index_list = None
         if self.mask_token is not None:
             torch.nn.init.normal_(self.mask_token, std=.02)
 
@@ -118,6 +119,7 @@ class RNNDetectorStage(nn.Module):
                 x = SF.add_pos_embedding(x, table)                # every block adds the table (SAST.py:105)
             x, p_loss, index_list = blk.att.forward_posadded(x, r, index_list)
             P = P + p_loss
+        self.last_index_list = index_list        # the stage's [Selection, Selection] (device masks; parity tests read them)
         if self.lstm is not None:
             # h1 goes to the next stage and, through the state, to the FPN / the next time step: two aliases, one per consumer
             h1, h1b, c1 = self.lstm.forward_nhwc(x, h_and_c_previous, two_h=True)

@@ -1,0 +1,58 @@
+"""Per-kernel SQ counter summary of a `rocprofv3 --kernel-trace --pmc SQ_...` pass (rocpd SQLite).
+
+    python tools/rocpd_sq.py gpurun_out/r02_a/sq/sq_results.db --out profiles/r02_a_gemm_sq_counters.txt [--top 30]
+
+Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* / SQ_BUSY_CYCLES count quad-cycles summed over waves
+(resp. over SEs), SQ_VALU_MFMA_BUSY_CYCLES counts cycles.  The table reports ratios that do not depend on the unit:
+wait_any / wave, wait_inst / wave, lds_wait / wave, active / wave, and MFMA-pipe utilisation as
+MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel duration x clock) when --clock-ghz is given.
+"""
+import argparse
+import re
+import sqlite3
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::|sast::|void ", "", name)
+    return re.sub(r">\(.*$", ">", name) if name.startswith("gemm") else name.split("(")[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("db")
+    ap.add_argument("--out")
+    ap.add_argument("--top", type=int, default=30)
+    ap.add_argument("--clock-ghz", type=float, default=2.4)
+    a = ap.parse_args()
+    c = sqlite3.connect(a.db)
+    rows = c.execute("select name, counter_name, count(*), sum(counter_value), sum(duration) from pmc_events group by name, counter_name").fetchall()
+    k = defaultdict(dict)
+    for name, cn, n, s, d in rows:
+        e = k[short(name)]
+        e[cn] = s
+        e["_n"], e["_dur_ns"] = n, d
+    names = sorted({cn for e in k.values() for cn in e if not cn.startswith("_")})
+    ranked = sorted(k.items(), key=lambda kv: -kv[1]["_dur_ns"])
+    lines = [f"# per-kernel SQ counters of {a.db}; counters: {', '.join(names)}",
+             f"{'calls':>6} {'avg_us':>8} {'mfma_util':>9} {'wait_any':>8} {'wait_inst':>9} {'wait_lds':>8} {'active':>7} {'valu/wave_cyc':>13} {'lds_conf':>8}  kernel"]
+
+    def ratio(e, num, den):
+        return e[num] / e[den] if (num in e and den in e and e[den]) else float("nan")
+
+    for name, e in ranked[: a.top]:
+        dur_s = e["_dur_ns"] * 1e-9
+        mfma = e.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")) / (4 * 256 * dur_s * a.clock_ghz * 1e9) if dur_s else float("nan")
+        lines.append(f"{e['_n']:6d} {e['_dur_ns'] / e['_n'] / 1e3:8.2f} {mfma:9.3f} {ratio(e, 'SQ_WAIT_ANY', 'SQ_WAVE_CYCLES'):8.3f} "
+                     f"{ratio(e, 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES'):9.3f} {ratio(e, 'SQ_WAIT_INST_LDS', 'SQ_WAVE_CYCLES'):8.3f} "
+                     f"{ratio(e, 'SQ_ACTIVE_INST_ANY', 'SQ_WAVE_CYCLES'):7.3f} {ratio(e, 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES'):13.4f} "
+                     f"{ratio(e, 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'):8.3f}  {name[:200]}")
+    txt = "\n".join(lines)
+    print(txt)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
