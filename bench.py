@@ -91,6 +91,7 @@ class Trainer:
         self.fwd_only = fwd_only or infer     # --fwd-only: backbone forward, the reference's own benchmark.py protocol (BASELINE config C2)
         self.loss = None
         self.P = None
+        self.step0 = None
         self.graph = None
         self.use_graph = use_graph
         self._one = torch.ones((), device=dev)
@@ -131,8 +132,12 @@ class Trainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(2):
+            for it in range(2):
                 self.fwd_bwd()
+                if it == 0 and not self.fwd_only:
+                    # loss, kept-token counts and every gradient AT THE INITIAL WEIGHTS: the cpu_baseline leg runs the oracle on
+                    # the same weights and input and reports the disagreement in the JSON line (`parity`)
+                    self.step0 = {"loss": float(self.loss), "P": [int(p) for p in self.P], "grad": self.flat.grad.detach().cpu().clone()}
                 self.update()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -164,7 +169,38 @@ class Trainer:
             self.update()
 
 
-def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False):
+def parity_vs_oracle(tr, p, f, loss_cpu, P_cpu):
+    """the GPU leg's first step (initial weights, rank 0's input) against the oracle's first step on the same weights and input:
+    loss, kept-token counts, and the gradient of every parameter tensor (max-norm relative error; the two tensors behind the
+    scoring ReLU are reported separately, see tests/test_gpu_parity.py)."""
+    s0 = tr.step0
+    names = {}
+    for mod, pre in ((tr.net, "net."), (tr.fpn, "fpn.")):
+        for k, v in mod.named_parameters():
+            names.setdefault(id(v), pre + k)
+    worst, worst_kink, off, n = (0.0, None), (0.0, None), 0, 0
+    for prm in tr.flat.params:
+        k = prm.numel()
+        name = names[id(prm)]
+        from sast_amd.dist import _phys_view
+        g = _phys_view(s0["grad"][off:off + k], prm)
+        off += (k + 3) // 4 * 4
+        ref = (p if name.startswith("net.") else f)[name[4:]].grad
+        if ref is None:
+            continue
+        err = float((g - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+        n += 1
+        if "to_scores." in name:
+            worst_kink = max(worst_kink, (err, name))
+        else:
+            worst = max(worst, (err, name))
+    return {"loss_gpu": s0["loss"], "loss_cpu": loss_cpu, "loss_rel_err": abs(s0["loss"] - loss_cpu) / abs(loss_cpu),
+            "kept_tokens_equal": s0["P"] == [int(v) for v in P_cpu], "grad_tensors_compared": n,
+            "grad_max_rel_err": worst[0], "grad_max_rel_err_tensor": worst[1],
+            "grad_max_rel_err_behind_scoring_relu": worst_kink[0], "note": "first step at the initial weights, max-norm relative error per tensor"}
+
+
+def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False, tr=None):
     """the oracle (torch-CPU port of the reference path) timed on this box's host cores on a bounded sample,
     on the same initial weights and the same input as rank 0's GPU leg."""
     from oracle import sast_oracle as O
@@ -181,13 +217,16 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False):
             return
         for t in list(p.values()) + list(f.values()):
             t.grad = None
-        out, _s, _P = O.backbone(x, None, p, ocfg)
+        out, _s, P_cpu = O.backbone(x, None, p, ocfg)
         outs = O.pafpn(out, f, training=True)
-        O.proxy_loss(outs).backward()
+        loss = O.proxy_loss(outs)
+        loss.backward()
+        return float(loss), P_cpu
 
     # MKL/OpenMP over-subscription makes "all hardware threads" the slowest choice on big hosts: probe a few thread
     # counts with one step each and time the sample at the fastest (reported in `cores`)
-    one()
+    first = one()
+    parity = parity_vs_oracle(tr, p, f, *first) if (tr is not None and tr.step0 is not None and first is not None) else None
     best = (float("inf"), torch.get_num_threads())
     for nt in sorted({torch.get_num_threads(), 64, 32, 16, 8}):
         if nt > (os.cpu_count() or 1):
@@ -207,7 +246,7 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= (32 if fwd_only else 8):
             break
-    return {"value": BATCH * n / el, "unit": "frames/s", "cores": cores, "kind": "port",
+    return parity, {"value": BATCH * n / el, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": (f"{n} backbone forward passes of the same workload (B={BATCH}, {HW[0]}x{HW[1]}), " if fwd_only else
                        f"{n} fwd+bwd steps of the same workload (B={BATCH}, {HW[0]}x{HW[1]}, backbone+PAFPN, proxy loss), ") +
                       f"oracle/sast_oracle.py, torch {torch.__version__} CPU, {cores} threads, no optimizer step"}
@@ -285,10 +324,15 @@ def main():
     if rank == 0:
         kept = [int(p) for p in tr.P]
         L = [(HW[0] // s) * (HW[1] // s) for s in (4, 8, 16, 32)]
-        if args.res != "1mpx" or BATCH != 4:
-            pass  # (metric string stays BASELINE's; `config.workload` names what was actually run)
+        # BASELINE.json's metric string only for BASELINE's configuration (configs[2], and [3] for N > 1); any other run is labelled
+        baseline_cfg = args.res == "1mpx" and BATCH == 4 and args.seq_len == 1 and not (args.fwd_only or args.infer) and args.loss == "proxy"
+        metric = "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360" if baseline_cfg else (
+            f"frames/sec (B={BATCH}) SAST " + ("backbone+PAFPN+head inference" if args.infer else "backbone fwd" if args.fwd_only else
+                                               "backbone+PAFPN+YOLOX-loss fwd+bwd" if args.loss == "yolox" else "backbone fwd+bwd") +
+            (", 1Mpx 640x360" if args.res == "1mpx" else ", Gen1 304x240") + (f", {args.seq_len} timesteps BPTT" if args.seq_len > 1 else "") +
+            " [not the BASELINE.json metric configuration]")
         res = {
-            "metric": "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360",
+            "metric": metric, "baseline_metric": baseline_cfg,
             "value": BATCH * args.seq_len * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -307,7 +351,9 @@ def main():
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr)
         if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy":
-            res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only)
+            parity, res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only, tr=tr)
+            if parity is not None:
+                res["parity"] = parity
         print(json.dumps(res))
     if world > 1:
         dist.barrier()       # rank 0 may still be in its (rank-local) roofline leg: leave the group together

@@ -282,10 +282,13 @@ size_t sast_postprocess_ws_bytes(int B, int anchors_total);
 int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, int class_agnostic,
                      float* out, int32_t* n_out, void* ws, sast_stream_t stream);
 
-/* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441) */
+/* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441).  The betas are doubles and
+ * the bias corrections 1 - beta^step are evaluated in double, as torch does with its python scalars.  Every element is updated:
+ * a parameter that received no gradient counts as gradient 0 (torch skips grad=None parameters; identical when every parameter is
+ * on the loss path, as in this model). */
 int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,
                const float* lr_step /* device fp32[2]: learning rate, step count (already incremented) */,
-               float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+               double beta1, double beta2, float eps, float weight_decay, float grad_scale,
                float clip_value /* <=0: off; reference clips by value 1.0, train.py:156-157 */, sast_stream_t stream);
 
 /* measurement aid (bench.py roofline leg): HIP-event timing of every launch of the GEMM-template kernels, recorded on

@@ -343,7 +343,7 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
         x[token_mask] = p[pre + "mask_token"].to(x.dtype)
     B, H, W, C = x.shape
     if pe is None:
-        pe = position_embedding_sine(H, W, C)
+        pe = position_embedding_sine(H, W, C).to(x.dtype)
     P = 0
     lists = None
     all_lists = []
@@ -365,7 +365,10 @@ def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "",
     if prev_states is None:
         prev_states = [None] * 4
     r = non_zero_ratio(x)
-    x = x.float()
+    if x.dtype == torch.float64:       # fp64 arbiter run: same graph in double, parameters given in double
+        r = r.double()
+    else:
+        x = x.float()
     out, states, P, lists = {}, [], [], []
     for s in range(4):
         x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s,

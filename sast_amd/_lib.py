@@ -104,7 +104,7 @@ _SIGNATURES = {
     "sast_prof_enable": (C.c_int, [C.c_int]),
     "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),
-    "sast_adamw": (C.c_int, [P, P, P, P, C.c_size_t, P, F32, F32, F32, F32, F32, F32, P]),
+    "sast_adamw": (C.c_int, [P, P, P, P, C.c_size_t, P, C.c_double, C.c_double, F32, F32, F32, F32, P]),
 }
 
 _lib = None
@@ -130,6 +130,18 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+_tools = None
+
+
+def tools_lib():
+    """libsast_hip_tools.so: GEMM micro-benchmark / timeline entry points (csrc/k_test.hip) for tools/*.py -- not the product"""
+    global _tools
+    if _tools is None:
+        lib()      # the tools library links against the product library (same directory, rpath $ORIGIN)
+        _tools = C.CDLL(os.path.join(_HERE, "libsast_hip_tools.so"))
+    return _tools
 
 
 def check(rc: int, what: str):

@@ -1,4 +1,7 @@
-"""Build libsast_hip.so (gfx950) in-tree with hipcc.  `python -m sast_amd.build [--force]`."""
+"""Build libsast_hip.so (gfx950) in-tree with hipcc.  `python -m sast_amd.build [--force]`.
+
+Two libraries: libsast_hip.so (the product: every C-ABI entry point of include/sast_hip.h) and libsast_hip_tools.so (the
+GEMM micro-benchmark / timeline entry points of csrc/k_test.hip used by tools/*.py only; links against the product library)."""
 from __future__ import annotations
 
 import concurrent.futures as cf
@@ -11,8 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsast_hip.so")
+TOOLS_LIB = os.path.join(HERE, "libsast_hip_tools.so")
 ARCH = "gfx950"
-SOURCES = ["k_rows.hip", "k_select.hip", "k_attn.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_test.hip", "k_head.hip"]
+SOURCES = ["k_rows.hip", "k_select.hip", "k_attn.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_head.hip"]
+TOOLS_SOURCES = ["k_test.hip"]
 HEADERS = ["common.cuh", "gemm.cuh", "gemm_dispatch.cuh", "kernels.h", os.path.join("..", "..", "include", "sast_hip.h")]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SAST_EXTRA_FLAGS", "").split()
 
@@ -40,17 +45,24 @@ def _compile(src: str, force: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
-    with cf.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), SOURCES))
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+def _link(objs, out, force, extra=()):
+    if force or not os.path.exists(out) or os.path.getmtime(out) < _newest(objs):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", out, *extra]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr[-4000:]}")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = SOURCES + TOOLS_SOURCES
+    with cf.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    _link(objs[:len(SOURCES)], LIB, force)
+    _link(objs[len(SOURCES):], TOOLS_LIB, force or os.path.getmtime(TOOLS_LIB) < os.path.getmtime(LIB) if os.path.exists(TOOLS_LIB) else True,
+          extra=["-L" + HERE, "-lsast_hip", "-Wl,-rpath,$ORIGIN"])
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "and", TOOLS_LIB)
     return LIB
 
 

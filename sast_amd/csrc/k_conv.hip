@@ -282,12 +282,22 @@ int slice_copy(const float* src, int lds, int soff, float* dst, int ldd, int dof
 
 // ---------------------------------------------------------------- AdamW
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, size_t n4, const float* __restrict__ lr_step, float b1,
-                                                    float b2, float eps, float wd, float gscale, float clip) {
+                                                    float* __restrict__ v, size_t n4, const float* __restrict__ lr_step, double b1d,
+                                                    double b2d, float eps, float wd, float gscale, float clip) {
+  // bias corrections in DOUBLE from the double betas, once per workgroup: torch.optim.AdamW evaluates 1 - beta**step with python
+  // doubles; 1 - powf(0.999f, t) loses ~1e-5 relative at small t (cancellation, and 0.999f itself is off by 1.3e-8)
+  __shared__ float s_bc[2];
+  if (threadIdx.x == 0) {
+    const double step = (double)lr_step[1];
+    s_bc[0] = (float)(1.0 - pow(b1d, step));
+    s_bc[1] = (float)sqrt(1.0 - pow(b2d, step));
+  }
+  __syncthreads();
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n4) return;
-  const float lr = lr_step[0], step = lr_step[1];
-  const float bc1 = 1.f - powf(b1, step), bc2s = sqrtf(1.f - powf(b2, step));
+  const float lr = lr_step[0];
+  const float bc1 = s_bc[0], bc2s = s_bc[1];
+  const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
   float4 pv = ld4(p + e * 4), gv = ld4(g + e * 4), mv = ld4(m + e * 4), vv = ld4(v + e * 4);
   float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
 #pragma unroll
@@ -295,8 +305,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     float gr = gp[k] * gscale;
     if (clip > 0.f) gr = fminf(fmaxf(gr, -clip), clip);
     pp[k] *= 1.f - lr * wd;
-    mp[k] = b1 * mp[k] + (1.f - b1) * gr;
-    vp[k] = b2 * vp[k] + (1.f - b2) * gr * gr;
+    mp[k] = b1 * mp[k] + omb1 * gr;
+    vp[k] = b2 * vp[k] + omb2 * gr * gr;
     const float denom = sqrtf(vp[k]) / bc2s + eps;
     pp[k] -= (lr / bc1) * (mp[k] / denom);
   }
@@ -649,7 +659,7 @@ int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int
   return slice_copy(dout, C1 + C2, C1, db, C2, 0, C2, rows, st);
 }
 
-int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* lr_step, float beta1, float beta2, float eps,
+int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* lr_step, double beta1, double beta2, float eps,
                float weight_decay, float grad_scale, float clip_value, sast_stream_t stream) {
   if (n % 4) return SAST_EINVAL;
   const size_t n4 = n / 4;

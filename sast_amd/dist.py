@@ -54,10 +54,23 @@ class FlatParams:
         self.numel = n
 
     def zero_grad(self):
+        """the ONLY supported way to clear gradients: `module.zero_grad()` / `optimizer.zero_grad()` (set_to_none=True) or
+        `p.grad = None` would cut the views, the backward kernels would then accumulate into fresh tensors and the
+        all-reduce / optimizer would keep reading a stale flat buffer (check_views catches that)."""
         self.grad.zero_()
+
+    def check_views(self):
+        """every parameter's .grad must still be its view into the flat gradient buffer"""
+        base, end = self.grad.data_ptr(), self.grad.data_ptr() + 4 * self.numel
+        for p in self.params:
+            g = p.grad
+            if g is None or not (base <= g.data_ptr() < end):
+                raise RuntimeError("sast_amd.FlatParams: a parameter's .grad no longer points into the flat gradient buffer "
+                                   "(zero_grad(set_to_none=True) or `p.grad = None`?): use FlatParams.zero_grad() only")
 
     def all_reduce(self, group=None):
         """sum over ranks (the 1/world factor is applied by the optimizer's grad_scale)."""
+        self.check_views()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             host_side = self.grad.is_cuda and dist.get_backend(group) != "nccl"
             if host_side:
@@ -86,6 +99,7 @@ class FusedAdamW:
     def step(self, grad_scale: float = 1.0):
         self.lr_step += self._one
         fp = self.fp
+        fp.check_views()
         if fp.flat.is_cuda:
             from . import functional as SF
             SF.adamw_step(fp.flat, fp.grad, self.m, self.v, self.lr_step, self.betas[0], self.betas[1], self.eps, self.wd,

@@ -63,6 +63,17 @@ def _g(p):
     return g if g is not None else (_scratch_grad(p) if p is not None else None)
 
 
+def _consume(ctx, what: str):
+    """the backward kernels of these ops CONSUME scratch accumulators that the forward kernels cleared (BatchNorm-backward sums,
+    the LayerScale / fc2 / proj raw gradients, d(scale) of the STP controls): a second backward over the same forward
+    (retain_graph=True, or two losses back-propagated separately) would add into stale sums.  Refuse it loudly."""
+    if getattr(ctx, "_sast_consumed", False):
+        raise RuntimeError(f"sast_amd: {what}: backward was already run for this forward; a second backward over a retained graph "
+                           "is not supported (the fused backward consumes scratch accumulators cleared by the forward kernels). "
+                           "Sum the losses and call backward once, or re-run the forward.")
+    ctx._sast_consumed = True
+
+
 def is_channels_last_weight(w: torch.Tensor) -> bool:
     return w.dim() == 4 and w.permute(0, 2, 3, 1).is_contiguous()
 
@@ -283,6 +294,7 @@ class _ScoreSTP(torch.autograd.Function):
         B, Lt, Cc, amp = ctx.meta
         if dxw is None:
             return None, None, None, None, None, None
+        _consume(ctx, "score_stp")
         dxw = dxw.contiguous()
         dxp = torch.empty_like(xp)
         ws = torch.empty(B * Lt * Cc + B * Cc, device=xp.device)
@@ -527,6 +539,7 @@ class _MSWSA(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         xin, stats, big, raw = ctx.saved_tensors
+        _consume(ctx, "mswsa")
         sel, params, inner = ctx.sel, ctx.params, ctx.inner
         p = dict(zip(_MSWSA_PARAMS, params))
         Cc = xin.shape[-1]
@@ -680,6 +693,7 @@ class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, dy2=None):
         x, x2, conv_out, stats, bn_ws = ctx.saved_tensors
+        _consume(ctx, "conv_bn_silu")
         if dy is None:
             dy, dy2 = dy2, None
         if dy is None:
@@ -767,6 +781,7 @@ class _ConvBnSilu2(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy0, dy1):
         x, x2, co0, co1, st0, st1, ws0, ws1 = ctx.saved_tensors
+        _consume(ctx, "conv_bn_silu2")
         w0, bnw0, bnb0, w1, bnw1, bnb1 = ctx.params
         B, H, W, Cin, Cin1, Cout, mom0, eps0, mom1, eps1, M, ksize = ctx.meta
         dy0 = dy0.contiguous() if dy0 is not None else torch.zeros(B, H, W, Cout, device=x.device)
@@ -957,8 +972,8 @@ def cat2(a, b):
 def adamw_step(p, g, m, v, lr_step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, clip_value=0.0):
     """fused AdamW on flat fp32 buffers; lr_step = device tensor [lr, step]."""
     _need_gpu(p, g, m, v, lr_step)
-    L.check(L.lib().sast_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_step.data_ptr(), beta1, beta2, eps,
-                               weight_decay, grad_scale, clip_value, _stream()), "adamw")
+    L.check(L.lib().sast_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_step.data_ptr(), float(beta1), float(beta2),
+                               eps, weight_decay, grad_scale, clip_value, _stream()), "adamw")
 
 
 # ---------------------------------------------------------------------------------------------- YOLOX head (SURVEY §8f rank 1)

@@ -45,7 +45,10 @@ class PositiveLinear(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, input):
-        raise RuntimeError("PositiveLinear is evaluated inside the fused STP scoring kernel (SAST_block)")
+        """SAST.py:325-328: F.linear(input, exp(weight), bias).  Stand-alone use only (a (B,20) x (20,C) product, host-side
+        torch ops on whatever device the module lives on); inside SAST_block the same expression is evaluated by the fused
+        scoring launch (csrc/common.cuh:controls_fwd_elem), which this method is never called from."""
+        return nn.functional.linear(input, self.weight.exp(), self.bias)
 
 
 def get_score_index_2d21d(x: torch.Tensor, d: float, b: float) -> torch.Tensor:

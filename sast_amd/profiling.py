@@ -38,6 +38,27 @@ def _norm_kernel(name: str) -> str:
     return re.sub(r"\s+", " ", name)
 
 
+def csrc_sha() -> str:
+    """content hash of the kernel sources: stamped into the PMC summary by tools/rocpd_pmc.py, compared by bench.py so that a
+    traffic figure measured on older kernels is flagged instead of silently reported"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".cuh", ".h")):
+            with open(os.path.join(d, fn), "rb") as f:
+                h.update(fn.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary_stamp():
+    try:
+        with open(_PMC_SUMMARY) as f:
+            return json.load(f).get("csrc_sha")
+    except (OSError, ValueError):
+        return None
+
+
 def pmc_traffic_bytes(kernel_name: str):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc summary (tools/rocpd_pmc.py: two separate
     passes FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note of MI355X_MICROARCH.md); None when not profiled."""
@@ -107,9 +128,10 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
     achieved = flops / (ms * 1e-3) / 1e12
     total_ms = sum(r[2] for r in rows)
     total_fl = sum(r[3] for r in rows)
+    stamp = pmc_summary_stamp()
     return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
-            "profiles/pmc_hbm_traffic_latest.json)", "kernel": name,
+            "profiles/pmc_hbm_traffic_latest.json)", "traffic_profile_csrc_sha": stamp, "traffic_stale": stamp != csrc_sha(), "kernel": name,
             "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
             "algorithmic_gflop_per_launch": flops / calls / 1e9,
             "all_gemm_kernels": {"ms_per_step": total_ms / n_steps, "gflop_per_step": total_fl / n_steps / 1e9,

@@ -3,7 +3,16 @@ golden fixtures captured from the reference.
 
 Bars (BASELINE.json north_star): token/window index masks bit-exact; floating point within
 FWD_ATOL = 3e-5 absolute on O(1) activations (fp32 everywhere, only the summation order differs
-from the CPU path), gradients within 2e-3 relative to the tensor's max-norm.
+from the CPU path), gradients within GRAD_RTOL = 3e-4 relative to the tensor's max-norm.
+
+The tolerances are ~10x the worst error MEASURED on the MI355X (round 2, gpurun_out/parity_errors.json written by
+conftest.record_error; summary in DESIGN.md section 4b): forward <= 1.2e-5 of the 3e-5 bar; gradients <= 3.3e-5 in every
+test below full size and <= 1.0e-4 at 1Mpx B=8 (batch-statistics BatchNorm backward of the PAFPN amplifies rounding noise;
+without the PAFPN the median tensor error is 6e-7).  One family is special: the gradients of `to_scores.{weight,bias}` sit
+behind a ReLU (SAST.py:110); a (token, channel) pre-activation within fp32 rounding of 0 is cut on one side and not on the
+other, which moves ONE row of dW / one element of db by that element's whole contribution (measured: max error 1e-3 of the
+max-norm in one row with an rms error of 2.5e-5; against an fp64 run of the oracle the affected row CHANGES, i.e. the
+reference itself has the same sensitivity).  Those two tensors are checked by rms (<= 3e-4) and a loose max (<= 2e-2).
 """
 import json
 import os
@@ -17,7 +26,7 @@ from oracle import sast_oracle as O
 pytestmark = pytest.mark.gpu
 
 FWD_ATOL = 3e-5
-GRAD_RTOL = 2e-3
+GRAD_RTOL = 3e-4
 LIST_NAMES = ("index_window", "index_token", "padding_index", "asy_index", "K")
 
 
@@ -54,6 +63,19 @@ def maxnorm_close(a, b, rtol, what=""):
     err = float((a - b).abs().max())
     record_error(_test_id(), what, err, scale, rtol)
     assert err <= rtol * scale + 1e-9, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rtol:.1e})"
+
+
+def grad_close(name, got, ref, rtol=None):
+    """gradient of parameter `name`: max-norm relative error, except for the tensors behind the scoring ReLU (see header)"""
+    if "to_scores." in name:
+        from conftest import record_error
+        a, b = got.detach().float().cpu(), ref.detach().float().cpu()
+        scale = float(b.abs().max()) + 1e-12
+        rms = float((a - b).pow(2).mean().sqrt())
+        record_error(_test_id(), name + " [rms]", rms, scale, GRAD_RTOL)
+        assert rms <= GRAD_RTOL * scale + 1e-9, f"{name}: rms err {rms:.3e} vs scale {scale:.3e}"
+        return maxnorm_close(got, ref, 2e-2, name + " [relu kink]")
+    return maxnorm_close(got, ref, GRAD_RTOL if rtol is None else rtol, name)
 
 
 def abs_close(a, b, atol, what=""):
@@ -123,7 +145,91 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     for k, v in blk.named_parameters():
         if "sub_layers" in k:
             continue
-        maxnorm_close(v.grad, torch.from_numpy(g["g_" + k]), GRAD_RTOL, k)
+        grad_close(k, v.grad, torch.from_numpy(g["g_" + k]))
+
+
+def test_stage_two_blocks_vs_golden(golden_dir, dev):
+    """a stage with num_blocks = 2: the second block has first_block=False and REUSES the first block's index lists
+    (SAST.py:124-128,149-150) -- reference outputs and kept-token counts of both blocks (fixture stage_two_blocks.npz), gradients
+    of both blocks against the oracle."""
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    g = _load(golden_dir, "stage_two_blocks")
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    B, H, W, C = x.shape
+    params = block_params(C, int(g["seed"]), nblocks=2)
+    amp = float(g["amp"])
+    b1 = SAST_block(C, attn_cfg((4, 5), amp), first_block=True).to(dev)
+    b2 = SAST_block(C, attn_cfg((4, 5), amp), first_block=False).to(dev)
+    load_params(b1, params, "att_blocks.0.att.")
+    load_params(b2, params, "att_blocks.1.att.")
+    pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    xd = x.to(dev).requires_grad_(True)
+    o1, c1, lists = b1(xd, pe, r.to(dev), None)
+    o2, c2, lists2 = b2(o1, pe, r.to(dev), lists)
+    assert (int(c1), int(c2)) == (int(g["count1"]), int(g["count2"]))
+    assert lists2[0] is lists[0] and lists2[1] is lists[1]
+    abs_close(o1, torch.from_numpy(g["out1"]), FWD_ATOL, "block 1 out")
+    abs_close(o2, torch.from_numpy(g["out2"]), FWD_ATOL, "block 2 out")
+    (o2 ** 2).mean().backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    cfg = O.AttnCfg(partition_size=(4, 5), amp=amp)
+    pe_o = O.position_embedding_sine(H, W, C)
+    a1, _c1, l1 = O.sast_block(xo, pe_o, r, po, "att_blocks.0.att.", cfg)
+    a2, _c2, _ = O.sast_block(a1, pe_o, r, po, "att_blocks.1.att.", cfg, index_list=l1, first_block=False)
+    (a2 ** 2).mean().backward()
+    maxnorm_close(xd.grad, xo.grad, GRAD_RTOL, "dx")
+    for blk, pre in ((b1, "att_blocks.0.att."), (b2, "att_blocks.1.att.")):
+        for k, v in blk.named_parameters():
+            if "sub_layers" not in k:
+                grad_close(pre + k, v.grad, po[pre + k].grad)
+
+
+def test_second_backward_is_refused(dev):
+    """the fused backward kernels consume scratch accumulators cleared by the forward kernels: a second backward
+    over a retained graph must raise instead of silently producing stale / doubled BatchNorm, LayerScale and controls gradients"""
+    from sast_amd.detection.network_blocks import BaseConv
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    torch.manual_seed(0)
+    conv = BaseConv(32, 32, 3, 1).to(dev).train()
+    y = conv.forward_nhwc(torch.randn(2, 8, 10, 32, device=dev, requires_grad=True))
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        y.sum().backward()
+    blk = SAST_block(32, attn_cfg((4, 5), 2e-2), first_block=True).to(dev)
+    pe = PositionEmbeddingSine(16, normalize=True, input_size=(1, 8, 10))
+    out, _c, _l = blk(torch.randn(2, 8, 10, 32, device=dev, requires_grad=True), pe, torch.rand(2, 20, device=dev) * 0.05, None)
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        out.sum().backward()
+
+
+def test_fused_adamw_matches_torch(dev):
+    """sast_adamw (bias corrections in double from double betas) against torch.optim.AdamW over 5 steps, with weight decay"""
+    from sast_amd.dist import FlatParams, FusedAdamW
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(64, 48).to(dev)
+    ref = torch.nn.Linear(64, 48).to(dev)
+    ref.load_state_dict(lin.state_dict())
+    flat = FlatParams([lin])
+    opt = FusedAdamW(flat, lr=1e-3, weight_decay=0.05)
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=0.05)
+    for step in range(5):
+        g = torch.Generator(device="cpu").manual_seed(step)
+        gw, gb = torch.randn(48, 64, generator=g).to(dev) * 1e-2, torch.randn(48, generator=g).to(dev) * 1e-2
+        flat.zero_grad()
+        lin.weight.grad += gw
+        lin.bias.grad += gb
+        ref.weight.grad, ref.bias.grad = gw.clone(), gb.clone()
+        opt.step()
+        topt.step()
+        abs_close(lin.weight, ref.weight, 2e-7, f"weight after step {step + 1}")     # updates are lr-sized (1e-3): 2e-4 of one update
+        abs_close(lin.bias, ref.bias, 2e-7, f"bias after step {step + 1}")
+    lin.zero_grad()                       # set_to_none=True: cuts the flat views -> must be caught, not silently ignored
+    with pytest.raises(RuntimeError, match="flat gradient buffer"):
+        opt.step()
 
 
 def test_ms_wsa_reference_signature(golden_dir, dev):
@@ -203,7 +309,7 @@ def test_backbone_tiny_vs_golden(golden_dir, dev, tag):
     for k, v in net.named_parameters():
         if "sub_layers" in k:
             continue
-        maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+        grad_close(k, v.grad, po[k].grad)
 
 
 @pytest.mark.parametrize("size,E,dh,depth,hw,part", [("large", 96, 32, 0.67, (128, 160), (4, 5)), ("small", 48, 24, 0.33, (128, 160), (4, 5)),
@@ -241,9 +347,9 @@ def test_backbone_other_sizes(dev, size, E, dh, depth, hw, part):
         maxnorm_close(a, b, 1e-4, f"pafpn out {i}")
     for k, v in net.named_parameters():
         if "sub_layers" not in k:
-            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+            grad_close(k, v.grad, po[k].grad)
     for k, v in fpn.named_parameters():
-        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
+        grad_close(k, v.grad, pf[k].grad)
 
 
 def test_yolox_head_eval_vs_golden(golden_dir, dev):
@@ -442,9 +548,9 @@ def test_detector_inference_end_to_end(dev):
     assert abs(float(losses_t["loss"]) - float(ref_t["loss"])) <= 1e-4 * abs(float(ref_t["loss"]))
     for k, v in det.backbone.named_parameters():
         if "sub_layers" not in k:
-            maxnorm_close(v.grad, po[k].grad, 5e-3, "backbone." + k)
+            maxnorm_close(v.grad, po[k].grad, 6e-4, "backbone." + k)    # measured worst 6.1e-5 (SimOTA loss: steeper than the proxy)
     for k, v in det.yolox_head.named_parameters():
-        maxnorm_close(v.grad, pho[k].grad, 5e-3, "head." + k)
+        maxnorm_close(v.grad, pho[k].grad, 6e-4, "head." + k)
 
 
 @pytest.mark.parametrize("B", [1, 3])
@@ -474,9 +580,9 @@ def test_backbone_odd_batches(dev, B):
         maxnorm_close(a, b, 1e-4, "pafpn out")
     for k, v in net.named_parameters():
         if "sub_layers" not in k:
-            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+            grad_close(k, v.grad, po[k].grad)
     for k, v in fpn.named_parameters():
-        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
+        grad_close(k, v.grad, pf[k].grad)
 
 
 def test_backbone_sequence_bptt(dev):
@@ -512,9 +618,9 @@ def test_backbone_sequence_bptt(dev):
     assert abs(float(loss) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
     for k, v in net.named_parameters():
         if "sub_layers" not in k:
-            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+            grad_close(k, v.grad, po[k].grad)
     for k, v in fpn.named_parameters():
-        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, k)
+        grad_close(k, v.grad, pf[k].grad)
 
 
 def test_pafpn_vs_golden(golden_dir, dev):
@@ -640,9 +746,9 @@ def test_full_size_train_parity(dev, B, amp, seed):
         maxnorm_close(a, b, 1e-4, f"pafpn out {i}")
     for k, v in net.named_parameters():
         if "sub_layers" not in k:
-            maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+            grad_close(k, v.grad, po[k].grad)
     for k, v in fpn.named_parameters():
-        maxnorm_close(v.grad, pf[k].grad, GRAD_RTOL, "fpn." + k)
+        grad_close("fpn." + k, v.grad, pf[k].grad)
 
 
 def test_selection_properties_full_size(dev):
@@ -711,58 +817,84 @@ def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
     for k, v in m.named_parameters():
         if "sub_layers" in k:
             continue
-        maxnorm_close(v.grad, po[k].grad, GRAD_RTOL, k)
+        grad_close(k, v.grad, po[k].grad)
+
+
+def _train_rig(dev, hw, part, E, chans, eps):
+    from sast_amd.config import backbone_config
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    from sast_amd.dist import FlatParams, FusedAdamW
+    torch.manual_seed(0)
+    net = RNNDetector(backbone_config(hw, part, embed_dim=E, AMP=2e-4, ls_init_value=0.5)).to(dev)   # dense: no selection flips
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev)
+    flat = FlatParams([net, fpn])
+    return net, fpn, flat, FusedAdamW(flat, lr=1e-3, eps=eps)
+
+
+def _train_step(x, net, fpn, flat, opt, update=True):
+    flat.zero_grad()
+    feats, _s, P = net.forward_nhwc(x)
+    outs = fpn.forward_nhwc(feats)
+    loss = sum((o * o).mean() for o in outs)
+    loss.backward()
+    if update:
+        opt.step()
+    return loss.detach(), P, outs          # P stays on the device (no sync: this runs under graph capture too)
+
+
+def test_same_state_twice_is_reproducible(dev):
+    """the same step twice from identical state: the forward is bit-identical (no atomics on the forward value path), the
+    kept-token counts are identical, and the gradients agree to fp32 rounding -- they are accumulated with float atomics
+    (split-R weight gradients, BatchNorm / LayerNorm reductions) whose order varies from run to run.  Measured on the MI355X:
+    1.2e-6 of the max-norm at 128x160 and 1.0e-6 at 1Mpx B=4 (tools/determinism_probe.py)."""
+    hw, part, E = (128, 160), (4, 5), 32
+    x = O.count_events(2, hw, seed=2, density=0.05).to(dev)
+    rig = _train_rig(dev, hw, part, E, (64, 128, 256), 1e-8)
+    runs = []
+    for _ in range(3):
+        l, P, outs = _train_step(x, *rig, update=False)
+        runs.append((float(l), [int(p) for p in P], [o.detach().clone() for o in outs], rig[2].grad.clone()))
+    for r in runs[1:]:
+        assert r[0] == runs[0][0] and r[1] == runs[0][1]
+        assert all(torch.equal(a, b) for a, b in zip(r[2], runs[0][2]))
+        maxnorm_close(r[3], runs[0][3], 1e-5, "flat gradient, same state twice")
 
 
 def test_graph_replay_matches_eager(dev):
     """a whole training step (zero grads, fwd, bwd, AdamW) captured in a hipGraph and replayed must reproduce the eager
-    steps: guards the scratch-buffer clears (hipMemsetAsync nodes were not re-executed on replay on ROCm 7.2)."""
-    from sast_amd.config import backbone_config
-    from sast_amd.detection import RNNDetector, YOLOPAFPN
-    from sast_amd.dist import FlatParams, FusedAdamW
+    steps: guards the scratch-buffer clears (hipMemsetAsync nodes were not re-executed on replay on ROCm 7.2).
+
+    How close two runs of a TRAINING LOOP can be (run to ground in round 2, tools/determinism_probe.py): one step from
+    identical state reproduces the gradient to 1e-6 (atomics order, test above).  AdamW with the default eps = 1e-8 turns that
+    into O(lr) parameter differences wherever a gradient element is itself rounding noise (the first update is
+    lr * g / (|g| + eps) = +-lr whatever |g| is), and the normalisation layers amplify from there: two EAGER loops differ by
+    8e-5 / 5e-4 / 9e-3 of the gradient max-norm after 1 / 2 / 3 updates (up to 0.2 on `to_scores` of stage 4, whose
+    gradient is 5e-4 of the largest) -- the "bimodal 3e-2" of round 1.  With eps = 1e-3 (>= the noise floor of the
+    gradients) the same two loops stay within 8e-6 / 6e-5 / 2e-4: that is what this test uses, with 10x margins, so a
+    buffer that is not cleared on replay (an O(1) error) cannot hide."""
     hw, part, E = (128, 160), (4, 5), 32
     x = O.count_events(2, hw, seed=2, density=0.05).to(dev)
-
-    def make():
-        torch.manual_seed(0)
-        net = RNNDetector(backbone_config(hw, part, embed_dim=E, AMP=2e-4, ls_init_value=0.5)).to(dev)   # dense: no selection flips
-        fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev)
-        flat = FlatParams([net, fpn])
-        return net, fpn, flat, FusedAdamW(flat, lr=1e-3)
-
-    def step(net, fpn, flat, opt):
-        flat.zero_grad()
-        feats, _s, _P = net.forward_nhwc(x)
-        loss = sum((o * o).mean() for o in fpn.forward_nhwc(feats))
-        loss.backward()
-        opt.step()
-        return loss.detach()
-
-    ea = make()
+    ea = _train_rig(dev, hw, part, E, (64, 128, 256), 1e-3)
     eager = []
     for _ in range(4):
-        l = step(*ea)
+        l, _P, _o = _train_step(x, *ea)
         eager.append((float(l), ea[2].grad.clone()))
-    gr = make()
+    gr = _train_rig(dev, hw, part, E, (64, 128, 256), 1e-3)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-        l0 = step(*gr)                                  # eager warm-up step == eager[0]
+        _train_step(x, *gr)                             # eager warm-up step == eager[0]
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        lg = step(*gr)
+        lg, _P, _o = _train_step(x, *gr)
     for k in range(1, 4):
         g.replay()
         torch.cuda.synchronize()
-        assert abs(float(lg) - eager[k][0]) <= 1e-4 * abs(eager[k][0]) + 1e-7, (k, float(lg), eager[k][0])
-        ref = eager[k][1]
-        err = float((gr[2].grad - ref).abs().max())
+        assert abs(float(lg) - eager[k][0]) <= 1e-5 * abs(eager[k][0]) + 1e-7, (k, float(lg), eager[k][0])
         assert torch.isfinite(gr[2].grad).all()
-        # atomics order + optimizer steps of drift: two EAGER runs of this loop differ by up to 3e-2 of the max-norm at the
-        # third / fourth step (measured, bimodal), a buffer that is not cleared on replay is an O(1) error
-        assert err <= (1e-2 if k == 1 else 8e-2) * float(ref.abs().max()) + 1e-7, (k, err)
+        maxnorm_close(gr[2].grad, eager[k][1], (1e-4, 1e-3, 3e-3)[k - 1], f"flat gradient after {k} updates, replay vs eager")
 
 
 # kept last: if this ever regresses the symptom is a GPU memory fault that aborts the process

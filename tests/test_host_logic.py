@@ -134,3 +134,13 @@ def test_flat_params_allreduce_adamw_gloo_world2(tmp_path):
                         "--master-port", "29731", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_positive_linear_forward_matches_reference_expression():
+    """SAST.py:325-328: F.linear(input, exp(weight), bias) -- the stand-alone module computes (inside SAST_block it is fused)"""
+    import torch
+    from sast_amd.layers.sast import PositiveLinear
+    torch.manual_seed(0)
+    m = PositiveLinear(20, 8, bias=True)
+    x = torch.rand(3, 20)
+    assert torch.equal(m(x), torch.nn.functional.linear(x, m.weight.exp(), m.bias))

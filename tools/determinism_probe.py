@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--full", action="store_true", help="1Mpx B=4 instead of the 128x160 B=2 test configuration")
     ap.add_argument("--amp", type=float, default=2e-4)
     ap.add_argument("--ls", type=float, default=0.5)
+    ap.add_argument("--eps", type=float, default=1e-8, help="AdamW eps (1e-8: an element whose gradient is rounding noise moves by +-lr)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     if args.full:
@@ -39,7 +40,7 @@ def main():
         for m, pre in ((net, "net."), (fpn, "fpn.")):
             for k, p in m.named_parameters():
                 names.setdefault(id(p), pre + k)
-        return net, fpn, flat, FusedAdamW(flat, lr=1e-3), [names[id(p)] for p in flat.params]
+        return net, fpn, flat, FusedAdamW(flat, lr=1e-3, eps=args.eps), [names[id(p)] for p in flat.params]
 
     def step(net, fpn, flat, opt, names, update):
         flat.zero_grad()

@@ -2,7 +2,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from sast_amd import _lib as L
-lib = L.lib(); fn = lib.sast_test_gemm_nt; fn.restype = C.c_int
+lib = L.tools_lib(); fn = lib.sast_test_gemm_nt; fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 for (M, N, K) in [(4096, 4096, 4096), (8192, 8192, 2048), (16384, 2048, 2048)]:

@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sast_amd import _lib as L
-lib = L.lib()
+lib = L.tools_lib()
 fn = lib.sast_test_gemm_nt
 fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]

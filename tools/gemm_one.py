@@ -2,7 +2,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sast_amd import _lib as L
-lib = L.lib(); fn = lib.sast_test_gemm_nt; fn.restype = C.c_int; fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
+lib = L.tools_lib(); fn = lib.sast_test_gemm_nt; fn.restype = C.c_int; fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
 M, N, K, t = [int(v) for v in sys.argv[1:5]]
 dev = torch.device("cuda:0")
 a = torch.randn(M, K, device=dev); w = torch.randn(N, K, device=dev); b = torch.randn(N, device=dev); c = torch.empty(M, N, device=dev)

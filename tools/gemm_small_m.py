@@ -2,7 +2,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
 from sast_amd import _lib as L
-lib = L.lib(); fn = lib.sast_test_gemm_nt; fn.restype = C.c_int
+lib = L.tools_lib(); fn = lib.sast_test_gemm_nt; fn.restype = C.c_int
 fn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
 shapes = [(960, 256, 2304), (960, 128, 1152), (960, 256, 512), (3840, 128, 1152), (3840, 64, 576), (15360, 64, 576), (15360, 128, 1152), (960, 1536, 512), (960, 512, 512), (960, 2688, 512), (960, 512, 1344), (960, 512, 1536), (960, 512, 2688), (3840, 768, 256), (3840, 256, 768), (3840, 256, 1344), (3840, 1344, 256), (960, 2048, 1024)]

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sast_amd import _lib as L
-lib = L.lib()
+lib = L.tools_lib()
 tn = lib.sast_test_gemm_tn; tn.restype = C.c_int; tn.argtypes = [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]
 tl = lib.sast_test_timeline; tl.restype = C.c_int; tl.argtypes = [C.c_void_p, C.c_int]
 tlr = lib.sast_test_timeline_reset; tlr.restype = C.c_int; tlr.argtypes = []

@@ -46,7 +46,10 @@ def main():
               f"{v['hbm_bytes_per_launch'] / (v['avg_us_profiled'] * 1e-6) / 1e12:6.2f} TB/s  {k[:150]}")
     if a.out:
         with open(a.out, "w") as fh:
-            json.dump({"correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-reports wide reads by 2x)",
+            import os, sys
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from sast_amd.profiling import csrc_sha
+            json.dump({"csrc_sha": csrc_sha(), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-reports wide reads by 2x)",
                        "total_bytes": tot, "kernels": dict(ranked)}, fh, indent=1)
 
 

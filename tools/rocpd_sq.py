@@ -24,29 +24,40 @@ def main():
     ap.add_argument("--out")
     ap.add_argument("--top", type=int, default=30)
     ap.add_argument("--clock-ghz", type=float, default=2.4)
+    ap.add_argument("--grbm-instances", type=int, default=8)
+    ap.add_argument("--raw", action="store_true", help="also print the raw counter sums per kernel")
     a = ap.parse_args()
     c = sqlite3.connect(a.db)
-    rows = c.execute("select name, counter_name, count(*), sum(counter_value), sum(duration) from pmc_events group by name, counter_name").fetchall()
+    # one row per (dispatch, counter, hardware instance: XCD x SE ...): counter values add up over the instances, the
+    # dispatch duration must be counted once
+    rows = c.execute("select name, counter_name, count(distinct dispatch_id), sum(counter_value) from pmc_events group by name, counter_name").fetchall()
+    durs = dict(c.execute("select name, sum(d) from (select name, dispatch_id, max(duration) as d from pmc_events group by name, dispatch_id) group by name").fetchall())
     k = defaultdict(dict)
-    for name, cn, n, s, d in rows:
+    for name, cn, n, s in rows:
         e = k[short(name)]
-        e[cn] = s
-        e["_n"], e["_dur_ns"] = n, d
+        e[cn] = e.get(cn, 0.0) + s
+        e["_n"] = n
+        e["_dur_ns"] = durs[name]
     names = sorted({cn for e in k.values() for cn in e if not cn.startswith("_")})
     ranked = sorted(k.items(), key=lambda kv: -kv[1]["_dur_ns"])
     lines = [f"# per-kernel SQ counters of {a.db}; counters: {', '.join(names)}",
-             f"{'calls':>6} {'avg_us':>8} {'mfma_util':>9} {'wait_any':>8} {'wait_inst':>9} {'wait_lds':>8} {'active':>7} {'valu/wave_cyc':>13} {'lds_conf':>8}  kernel"]
+             f"{'calls':>6} {'avg_us':>8} {'clk_ghz':>7} {'mfma_util':>9} {'wait_any':>8} {'wait_inst':>9} {'wait_lds':>8} {'active':>7} {'valu/wave_cyc':>13} {'lds_conf':>8}  kernel"]
 
     def ratio(e, num, den):
         return e[num] / e[den] if (num in e and den in e and e[den]) else float("nan")
 
     for name, e in ranked[: a.top]:
         dur_s = e["_dur_ns"] * 1e-9
-        mfma = e.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")) / (4 * 256 * dur_s * a.clock_ghz * 1e9) if dur_s else float("nan")
-        lines.append(f"{e['_n']:6d} {e['_dur_ns'] / e['_n'] / 1e3:8.2f} {mfma:9.3f} {ratio(e, 'SQ_WAIT_ANY', 'SQ_WAVE_CYCLES'):8.3f} "
+        # GRBM_GUI_ACTIVE: one instance per XCD (8) -> effective shader clock = cycles / 8 / kernel time
+        clk = e["GRBM_GUI_ACTIVE"] / a.grbm_instances / dur_s / 1e9 if ("GRBM_GUI_ACTIVE" in e and dur_s) else a.clock_ghz
+        mfma = e.get("SQ_VALU_MFMA_BUSY_CYCLES", float("nan")) / (4 * 256 * dur_s * clk * 1e9) if dur_s else float("nan")
+        lines.append(f"{e['_n']:6d} {e['_dur_ns'] / e['_n'] / 1e3:8.2f} {clk:7.2f} {mfma:9.3f} {ratio(e, 'SQ_WAIT_ANY', 'SQ_WAVE_CYCLES'):8.3f} "
                      f"{ratio(e, 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES'):9.3f} {ratio(e, 'SQ_WAIT_INST_LDS', 'SQ_WAVE_CYCLES'):8.3f} "
                      f"{ratio(e, 'SQ_ACTIVE_INST_ANY', 'SQ_WAVE_CYCLES'):7.3f} {ratio(e, 'SQ_INSTS_VALU', 'SQ_WAVE_CYCLES'):13.4f} "
                      f"{ratio(e, 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE'):8.3f}  {name[:200]}")
+    if a.raw:
+        for name, e in ranked[: a.top]:
+            lines.append("# " + name[:120] + "  " + "  ".join(f"{cn}={e[cn]:.4g}" for cn in names if cn in e))
     txt = "\n".join(lines)
     print(txt)
     if a.out:
