@@ -55,11 +55,12 @@ def synthetic_labels(B, hw, num_classes, max_labels=16, seed=0):
 
 
 class Trainer:
-    """minimal training step of the hot path (the reference's is Lightning's, modules/detection.py:113-221)."""
+    """bench harness around sast_amd.training.TrainStep (the reference's step is Lightning's, modules/detection.py:113-221)."""
 
-    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False, yolox_loss=False):
+    def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False, yolox_loss=False, segmented=None,
+                 label_every=0):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
-        from sast_amd.dist import FlatParams, FusedAdamW
+        from sast_amd.training import TrainStep
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
         self.net = RNNDetector(ref_cfg(HW, PART, amp))
         self.fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(128, 256, 512))
@@ -74,16 +75,24 @@ class Trainer:
             self.fpn.eval()
             fwd_only = True
         self.yolox_loss = yolox_loss   # --loss yolox: the real training objective (YOLOX head + SimOTA loss) instead of the proxy loss
+        rank = dist.get_rank() if world > 1 else 0
+        self.labels = self.indices = None
         if yolox_loss:
             from sast_amd.detection import YOLOXHead
             self.head = YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=(128, 256, 512)).to(dev).train()
-            self.labels = synthetic_labels(BATCH, HW, 3, max_labels=16, seed=(dist.get_rank() if world > 1 else 0)).to(dev)
+            # --label-every k (the reference's label-sparse step, modules/detection.py:161-177): timestep t carries labels for the
+            # samples b with (t + b) % k == 0, the last timestep for all; their features are gathered and batched for ONE head call
+            if label_every > 0:
+                self.indices = [[b for b in range(BATCH) if (t + b) % label_every == 0 or t == seq_len - 1] for t in range(seq_len)]
+            n_lab = sum(len(i) for i in self.indices) if self.indices is not None else BATCH
+            self.labels = synthetic_labels(n_lab, HW, 3, max_labels=16, seed=rank).to(dev)
         self.net.to(dev)
         self.fpn.to(dev)
-        self.flat = FlatParams([self.net, self.fpn] + ([self.head] if yolox_loss else []))
-        self.opt = FusedAdamW(self.flat, lr=2e-4, weight_decay=0.0, clip_value=1.0)
         self.world = world
-        rank = dist.get_rank() if world > 1 else 0
+        self.segmented = (world > 1) if segmented is None else bool(segmented)
+        self.ts = TrainStep(self.net, self.fpn, self.head if yolox_loss else None, lr=2e-4, weight_decay=0.0, clip_value=1.0, world=world,
+                            segmented=self.segmented)
+        self.flat, self.opt = self.ts.flat, self.ts.opt
         # seq_len > 1 (opt-in, --seq-len): the reference's BPTT step shape (modules/detection.py:141-177): L timesteps with the
         # recurrent states carried, PAFPN + loss on the last one, one backward through time.  Default 1 = BASELINE's metric.
         self.xs = [synthetic_events(BATCH, HW, seed=rank + 1000 * t).to(dev) for t in range(seq_len)]
@@ -94,64 +103,59 @@ class Trainer:
         self.step0 = None
         self.graph = None
         self.use_graph = use_graph
-        self._one = torch.ones((), device=dev)
+
+    def fwd_only_pass(self):
+        with torch.no_grad():
+            feats, _states, P = self.net.forward_nhwc(self.x)
+            if self.infer:
+                pred = self.head.forward_nhwc(self.fpn.forward_nhwc(feats))
+                self.loss = pred[..., 4].sum()
+            else:
+                self.loss = feats[4].sum()
+        self.P, self.feats = P, feats
 
     def fwd_bwd(self):
-        if self.infer:
-            with torch.no_grad():
-                feats, _states, P = self.net.forward_nhwc(self.x)
-                pred = self.head.forward_nhwc(self.fpn.forward_nhwc(feats))
-            self.loss, self.P, self.feats = pred[..., 4].sum(), P, feats
-            return
+        """forward + whole backward, no reduce / update (roofline leg, parity leg)"""
         if self.fwd_only:
-            with torch.no_grad():
-                feats, _states, P = self.net.forward_nhwc(self.x)
-            self.loss, self.P, self.feats = feats[4].sum(), P, feats
-            return
-        self.flat.zero_grad()
-        states = None
-        for x in self.xs:
-            feats, states, P = self.net.forward_nhwc(x, states)
-        outs = self.fpn.forward_nhwc(feats)
-        if self.yolox_loss:
-            _pred, losses = self.head.forward_train_nhwc(outs, self.labels)
-            loss = losses["loss"]
-        else:
-            from sast_amd import functional as SF
-            loss = SF.mean_squares(*outs)     # = sum((o * o).mean() for o in outs), one launch each way
-        loss.backward(gradient=self._one)     # a resident 1.0 instead of a ones_like fill launch per step
-        self.loss, self.P = loss.detach(), P
+            return self.fwd_only_pass()
+        self.ts.forward(self.xs, None, self.labels, self.indices)
+        for i in range(self.ts.n_segments()):
+            self.ts.backward_segment(i)
+        self.loss, self.P = self.ts.loss.detach(), self.ts.P
 
-    def update(self):
+    def eager_step(self):
         if self.fwd_only:
-            return
-        self.flat.all_reduce()
-        self.opt.step(grad_scale=1.0 / self.world)
+            return self.fwd_only_pass()
+        self.ts.step(self.xs, None, self.labels, self.indices)
+        self.loss, self.P = self.ts.loss.detach(), self.ts.P
 
     def capture(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for it in range(2):
-                self.fwd_bwd()
                 if it == 0 and not self.fwd_only:
                     # loss, kept-token counts and every gradient AT THE INITIAL WEIGHTS: the cpu_baseline leg runs the oracle on
                     # the same weights and input and reports the disagreement in the JSON line (`parity`)
+                    self.fwd_bwd()
                     self.step0 = {"loss": float(self.loss), "P": [int(p) for p in self.P], "grad": self.flat.grad.detach().cpu().clone()}
-                self.update()
+                self.eager_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.loss_first = float(self.loss)
         if not self.use_graph:
             return False
         try:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: calls made by other threads (the RCCL watchdog of torch.distributed) must not invalidate the capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.fwd_bwd()
-                if self.world == 1:
-                    self.update()
-            self.graph = g
+            if self.fwd_only:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.fwd_only_pass()
+                self.graph = g
+            else:
+                # thread_local: calls made by other threads (the RCCL watchdog of torch.distributed) must not invalidate the capture
+                self.ts.capture(self.xs, None, self.labels, self.indices)
+                self.graph = self.ts
+                self.loss, self.P = self.ts.loss, self.ts.P
             return True
         except Exception as e:  # noqa: BLE001
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
@@ -162,11 +166,8 @@ class Trainer:
     def step(self):
         if self.graph is not None:
             self.graph.replay()
-            if self.world > 1:
-                self.update()
         else:
-            self.fwd_bwd()
-            self.update()
+            self.eager_step()
 
 
 def parity_vs_oracle(tr, p, f, loss_cpu, P_cpu):
@@ -266,6 +267,11 @@ def main():
     ap.add_argument("--loss", choices=["proxy", "yolox"], default="proxy", help="proxy: sum mean(out^2) over the PAFPN outputs (BASELINE "
                     "metric); yolox: YOLOX head + SimOTA loss on synthetic boxes (the reference's real training objective)")
     ap.add_argument("--infer", action="store_true", help="backbone + PAFPN + YOLOX head, eval mode, forward only (decoded predictions)")
+    ap.add_argument("--segmented", dest="segmented", action="store_true", default=None, help="backward in 3 segments with bucketed all-reduce + "
+                    "AdamW on a side stream overlapping the remaining backward (default for N > 1; with N = 1 the same path, all-reduce a no-op)")
+    ap.add_argument("--no-segmented", dest="segmented", action="store_false")
+    ap.add_argument("--label-every", type=int, default=0, help="with --loss yolox and --seq-len L: labels on the samples b of timestep t with "
+                    "(t + b) %% k == 0 (and on all of the last timestep); their features are gathered into one head call (label-sparse step)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -299,7 +305,7 @@ def main():
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
     tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer,
-                 yolox_loss=args.loss == "yolox")
+                 yolox_loss=args.loss == "yolox", segmented=args.segmented, label_every=args.label_every)
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -343,6 +349,7 @@ def main():
                                     if args.loss == "yolox" else " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
+                       "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
                        "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},

@@ -282,6 +282,27 @@ size_t sast_postprocess_ws_bytes(int B, int anchors_total);
 int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, int class_agnostic,
                      float* out, int32_t* n_out, void* ws, sast_stream_t stream);
 
+/* (f)2  label-sparse feature gather -- BackboneFeatureSelector, modules/utils/detection.py:24-47 (used by the training step,
+ * modules/detection.py:161-177): out = cat over the sequence's timesteps t of feat_t[selected_t], samples being contiguous chunks
+ * of `sample_floats` floats (one NHWC feature map of one sample).  Output sample j comes from src[t_of[j]] sample b_of[j].
+ * sast_gather_samples copies; sast_gather_samples_bwd writes the gradient of EVERY sample of every timestep tensor (dsrc[t], B samples
+ * each): the matching rows of `out` (= d out) or zeros.  n_src <= 32 timesteps, n_out <= 256 selected samples, B <= 256. */
+#define SAST_GATHER_MAX_SRC 32
+#define SAST_GATHER_MAX_OUT 256
+typedef struct {
+  int32_t n_src, n_out, B, _pad;
+  size_t sample_floats;                  /* multiple of 4 */
+  const float* src[SAST_GATHER_MAX_SRC]; /* forward: the timestep tensors */
+  float* dsrc[SAST_GATHER_MAX_SRC];      /* backward: their gradients (all written) */
+  float* out;                            /* forward: [n_out, sample_floats]; backward: the gradient of it (read) */
+  uint8_t t_of[SAST_GATHER_MAX_OUT], b_of[SAST_GATHER_MAX_OUT];
+} SastSampleGather;
+int sast_gather_samples(const SastSampleGather* a, sast_stream_t stream);
+int sast_gather_samples_bwd(const SastSampleGather* a, sast_stream_t stream);
+/* RNNStates.reset, modules/utils/detection.py:96-130: x[b] = 0 for the samples with sel[b] != 0, in place (x: [B, sample_floats]) */
+typedef struct { uint8_t sel[256]; } SastSampleMask;
+int sast_zero_samples(float* x, int B, size_t sample_floats, const SastSampleMask* sel, sast_stream_t stream);
+
 /* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441).  The betas are doubles and
  * the bias corrections 1 - beta^step are evaluated in double, as torch does with its python scalars.  Every element is updated:
  * a parameter that received no gradient counts as gradient 0 (torch skips grad=None parameters; identical when every parameter is
@@ -290,6 +311,14 @@ int sast_adamw(float* p, const float* g, float* m, float* v, size_t n,
                const float* lr_step /* device fp32[2]: learning rate, step count (already incremented) */,
                double beta1, double beta2, float eps, float weight_decay, float grad_scale,
                float clip_value /* <=0: off; reference clips by value 1.0, train.py:156-157 */, sast_stream_t stream);
+/* the same with the learning rate of torch.optim.lr_scheduler.OneCycleLR(anneal_strategy='linear', cycle_momentum=False, two phases)
+ * as configured at modules/detection.py:418-431, evaluated ON THE DEVICE from the step counter lr_step[1] (lr_step[0] is ignored):
+ * optimizer step t (1-based) uses the scheduler's lr at step_num = t - 1, i.e.
+ * phase 1 (step_num <= end1): initial_lr -> max_lr, phase 2: max_lr -> min_lr at end2 = total_steps - 1; end1 = pct_start*total_steps - 1.
+ * No host interaction per step: a hipGraph replay advances the schedule by itself. */
+int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, float* lr_step, double beta1, double beta2, float eps,
+                        float weight_decay, float grad_scale, float clip_value, double initial_lr, double max_lr, double min_lr,
+                        double end1, double end2, sast_stream_t stream);
 
 /* measurement aid (bench.py roofline leg): HIP-event timing of every launch of the GEMM-template kernels, recorded on
  * the launch stream; the report lists per kernel instantiation: calls, total ms, total algorithmic FLOPs (2*M*N*K with

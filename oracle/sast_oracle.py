@@ -768,6 +768,54 @@ def init_pafpn_params(in_channels=(128, 256, 512), depth: float = 0.67, seed: in
     return p
 
 
+# --------------------------------------------------------------------------- (f)2 sequence bookkeeping
+def select_backbone_features(feature_seq: Sequence[Dict[int, Tensor]], indices_seq: Sequence[Optional[Sequence[int]]]) -> Optional[Dict[int, Tensor]]:
+    """BackboneFeatureSelector (modules/utils/detection.py:24-47) as the training step drives it (modules/detection.py:161-171):
+    per timestep the features of the samples that carry labels, v[selected_indices], concatenated over the timesteps.
+    indices_seq[t] = None / [] : the timestep contributes nothing (the reference only calls add_backbone_features when
+    len(current_labels) > 0)."""
+    feats: Dict[int, List[Tensor]] = {}
+    for f, idx in zip(feature_seq, indices_seq):
+        if idx is None or len(idx) == 0:
+            continue
+        for k, v in f.items():
+            feats.setdefault(k, []).append(v[list(idx)])
+    if not feats:
+        return None
+    return {k: torch.cat(v, dim=0) for k, v in feats.items()}
+
+
+def rnn_states_reset(states, indices_or_bool=None):
+    """RNNStates.recursive_reset (modules/utils/detection.py:96-116) on detached states [(h, c)] per stage: zero the selected samples."""
+    out = []
+    for h, c in states:
+        h, c = h.detach().clone(), c.detach().clone()
+        for t in (h, c):
+            if indices_or_bool is None:
+                t[:] = 0
+            else:
+                t[indices_or_bool] = 0
+        out.append((h, c))
+    return out
+
+
+def sequence_train_step(x_seq: Sequence[Tensor], indices_seq, labels: Tensor, bp: Params, fp: Params, hp: Params, cfg: BackboneCfg,
+                        prev_states=None, num_classes: int = 3, strides=(8, 16, 32), depth: float = 0.67):
+    """the model part of Module.training_step (modules/detection.py:139-177): L timesteps through the backbone with the recurrent
+    states carried (not detached inside the sequence), the features of the labelled (timestep, sample) pairs gathered, ONE
+    PAFPN + head + SimOTA loss call on the batched features.  labels: (sum_t len(indices_seq[t]), max_labels, 5) yolox format in
+    gather order.  -> (losses dict, final states, P list per timestep)."""
+    states, feats_seq, Ps = prev_states, [], []
+    for x in x_seq:
+        out, states, P = backbone(x, states, bp, cfg)
+        feats_seq.append(out)
+        Ps.append(P)
+    sel = select_backbone_features(feats_seq, indices_seq)
+    fpn_out = pafpn({k: sel[k] for k in (2, 3, 4)}, fp, depth=depth, training=True)
+    losses = yolox_head_train(fpn_out, labels, hp, strides, num_classes=num_classes)
+    return losses, states, Ps
+
+
 def proxy_loss(outs: Sequence[Tensor]) -> Tensor:
     """sum_k mean(out_k^2)."""
     return sum((o.float() ** 2).mean() for o in outs)

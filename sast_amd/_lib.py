@@ -61,6 +61,12 @@ SastConvBnArgs = _struct("SastConvBnArgs", [
         "p_conv_out p_stats p_bn_w p_bn_b p_bn_ws p2_conv_out p2_stats p2_bn_w p2_bn_b p2_bn_ws dy2"),
 ])
 
+SastSampleGather = _struct("SastSampleGather", [
+    (I32, "n_src n_out B _pad"), (C.c_size_t, "sample_floats"), (P * 32, "src"), (P * 32, "dsrc"), (P, "out"),
+    (C.c_uint8 * 256, "t_of"), (C.c_uint8 * 256, "b_of"),
+])
+SastSampleMask = _struct("SastSampleMask", [(C.c_uint8 * 256, "sel")])
+
 _SIGNATURES = {
     "sast_version": (C.c_int, []),
     "sast_nzratio": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
@@ -101,6 +107,11 @@ _SIGNATURES = {
     "sast_upsample_cat_bwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]),
     "sast_cat2_fwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_cat2_bwd": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
+    "sast_gather_samples": (C.c_int, [C.POINTER(SastSampleGather), P]),
+    "sast_gather_samples_bwd": (C.c_int, [C.POINTER(SastSampleGather), P]),
+    "sast_zero_samples": (C.c_int, [P, C.c_int, C.c_size_t, C.POINTER(SastSampleMask), P]),
+    "sast_adamw_onecycle": (C.c_int, [P, P, P, P, C.c_size_t, P, C.c_double, C.c_double, F32, F32, F32, F32, C.c_double, C.c_double, C.c_double,
+                                      C.c_double, C.c_double, P]),
     "sast_prof_enable": (C.c_int, [C.c_int]),
     "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),

@@ -180,6 +180,22 @@ int sast_mask_token_fwd(float* x, const uint8_t* mask, const float* token, const
   if (!x || !mask || !token || C % 4 || L < 1) return SAST_EINVAL;
   return mask_token_fwd_launch(x, mask, token, pos_emb, rows, C, L, (hipStream_t)stream);
 }
+int sast_gather_samples(const SastSampleGather* a, sast_stream_t stream) {
+  if (!a || !a->out || a->n_src < 1 || a->n_src > SAST_GATHER_MAX_SRC || a->n_out < 0 || a->n_out > SAST_GATHER_MAX_OUT || a->sample_floats % 4) return SAST_EINVAL;
+  for (int j = 0; j < a->n_out; ++j) if (a->t_of[j] >= a->n_src || a->b_of[j] >= a->B || !a->src[a->t_of[j]]) return SAST_EINVAL;
+  if (a->n_out == 0) return SAST_OK;
+  return sample_gather_launch(*a, false, (hipStream_t)stream);
+}
+int sast_gather_samples_bwd(const SastSampleGather* a, sast_stream_t stream) {
+  if (!a || a->n_src < 1 || a->n_src > SAST_GATHER_MAX_SRC || a->n_out < 0 || a->n_out > SAST_GATHER_MAX_OUT || a->B < 1 || a->B > 256 ||
+      a->sample_floats % 4 || (a->n_out && !a->out)) return SAST_EINVAL;
+  for (int t = 0; t < a->n_src; ++t) if (!a->dsrc[t]) return SAST_EINVAL;
+  return sample_gather_launch(*a, true, (hipStream_t)stream);
+}
+int sast_zero_samples(float* x, int B, size_t sample_floats, const SastSampleMask* sel, sast_stream_t stream) {
+  if (!x || !sel || B < 1 || B > 256 || sample_floats % 4) return SAST_EINVAL;
+  return zero_samples_launch(x, B, sample_floats, *sel, (hipStream_t)stream);
+}
 int sast_mask_token_bwd(const float* dy, const uint8_t* mask, float* dx, float* d_token, int rows, int C, sast_stream_t stream) {
   if (!dy || !mask || !dx || !d_token || C % 4) return SAST_EINVAL;
   return mask_token_bwd_launch(dy, mask, dx, d_token, rows, C, (hipStream_t)stream);

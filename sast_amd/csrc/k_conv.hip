@@ -281,21 +281,29 @@ int slice_copy(const float* src, int lds, int soff, float* dst, int ldd, int dof
 }
 
 // ---------------------------------------------------------------- AdamW
+struct OneCycle { int on; double initial_lr, max_lr, min_lr, end1, end2; };
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n4, const float* __restrict__ lr_step, double b1d,
-                                                    double b2d, float eps, float wd, float gscale, float clip) {
+                                                    double b2d, float eps, float wd, float gscale, float clip, OneCycle oc) {
   // bias corrections in DOUBLE from the double betas, once per workgroup: torch.optim.AdamW evaluates 1 - beta**step with python
   // doubles; 1 - powf(0.999f, t) loses ~1e-5 relative at small t (cancellation, and 0.999f itself is off by 1.3e-8)
-  __shared__ float s_bc[2];
+  __shared__ float s_bc[3];
   if (threadIdx.x == 0) {
     const double step = (double)lr_step[1];
     s_bc[0] = (float)(1.0 - pow(b1d, step));
     s_bc[1] = (float)sqrt(1.0 - pow(b2d, step));
+    double lr = (double)lr_step[0];
+    if (oc.on) {   // OneCycleLR, linear anneal, two phases (torch.optim.lr_scheduler.OneCycleLR.get_lr)
+      const double sn = step - 1.0;
+      if (sn <= oc.end1) lr = oc.initial_lr + (oc.max_lr - oc.initial_lr) * (oc.end1 > 0.0 ? sn / oc.end1 : 1.0);
+      else lr = oc.max_lr + (oc.min_lr - oc.max_lr) * ((sn - oc.end1) / (oc.end2 - oc.end1));
+    }
+    s_bc[2] = (float)lr;
   }
   __syncthreads();
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n4) return;
-  const float lr = lr_step[0];
+  const float lr = s_bc[2];
   const float bc1 = s_bc[0], bc2s = s_bc[1];
   const float b1 = (float)b1d, b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
   float4 pv = ld4(p + e * 4), gv = ld4(g + e * 4), mv = ld4(m + e * 4), vv = ld4(v + e * 4);
@@ -664,7 +672,18 @@ int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const flo
   if (n % 4) return SAST_EINVAL;
   const size_t n4 = n / 4;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
-                     beta2, eps, weight_decay, grad_scale, clip_value);
+                     beta2, eps, weight_decay, grad_scale, clip_value, OneCycle{0, 0, 0, 0, 0, 0});
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, float* lr_step, double beta1, double beta2, float eps,
+                        float weight_decay, float grad_scale, float clip_value, double initial_lr, double max_lr, double min_lr,
+                        double end1, double end2, sast_stream_t stream) {
+  if (n % 4 || !(end2 > end1)) return SAST_EINVAL;
+  const size_t n4 = n / 4;
+  const OneCycle oc{1, initial_lr, max_lr, min_lr, end1, end2};
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
+                     beta2, eps, weight_decay, grad_scale, clip_value, oc);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -762,6 +762,56 @@ int mean_square_launch(const float* const* x, float* const* dx, const size_t* n,
   return SAST_OK;
 }
 
+// ============================================================ label-sparse sample gather (modules/utils/detection.py:24-47)
+// BackboneFeatureSelector: over the T timesteps of a sequence only the samples that carry labels are kept,
+// out = cat_t( feat_t[selected_t] ).  One launch copies every selected sample of one feature map (chunk = one sample's H*W*C
+// floats); the backward writes EVERY sample gradient of every timestep (the gathered gradient or zeros) in one launch.
+// Source / destination pointers travel by value (kernel arguments), so a captured launch keeps pointing into the graph's pool.
+__global__ __launch_bounds__(256) void gather_samples_kernel(SastSampleGather a) {
+  const int j = blockIdx.y;
+  const float* __restrict__ src = a.src[a.t_of[j]] + (size_t)a.b_of[j] * a.sample_floats;
+  float* __restrict__ dst = a.out + (size_t)j * a.sample_floats;
+  const size_t n4 = a.sample_floats / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4(dst + 4 * i, ld4(src + 4 * i));
+}
+__global__ __launch_bounds__(256) void scatter_samples_kernel(SastSampleGather a) {
+  const int t = blockIdx.y / a.B, b = blockIdx.y % a.B;
+  int j = -1;
+  for (int k = 0; k < a.n_out; ++k) if (a.t_of[k] == t && a.b_of[k] == b) j = k;      // block-uniform scan (n_out <= 256)
+  float* __restrict__ dst = a.dsrc[t] + (size_t)b * a.sample_floats;
+  const size_t n4 = a.sample_floats / 4;
+  if (j < 0) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4(dst + 4 * i, zero4());
+  } else {
+    const float* __restrict__ src = a.out + (size_t)j * a.sample_floats;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4(dst + 4 * i, ld4(src + 4 * i));
+  }
+}
+int sample_gather_launch(const SastSampleGather& a, bool backward, hipStream_t st) {
+  const size_t n4 = a.sample_floats / 4;
+  int bx = (int)((n4 + 256 * 8 - 1) / (256 * 8));
+  bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+  if (!backward) hipLaunchKernelGGL(gather_samples_kernel, dim3(bx, a.n_out), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(scatter_samples_kernel, dim3(bx, a.n_src * a.B), dim3(256), 0, st, a);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+// RNNStates.reset (modules/utils/detection.py:96-130): state[selected samples] = 0, in place
+__global__ __launch_bounds__(256) void zero_samples_kernel(float* __restrict__ x, size_t sample_floats, SastSampleMask m) {
+  if (!m.sel[blockIdx.y]) return;
+  float* __restrict__ dst = x + (size_t)blockIdx.y * sample_floats;
+  const size_t n4 = sample_floats / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) st4(dst + 4 * i, zero4());
+}
+int zero_samples_launch(float* x, int B, size_t sample_floats, const SastSampleMask& m, hipStream_t st) {
+  const size_t n4 = sample_floats / 4;
+  int bx = (int)((n4 + 256 * 8 - 1) / (256 * 8));
+  bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+  hipLaunchKernelGGL(zero_samples_kernel, dim3(bx, B), dim3(256), 0, st, x, sample_floats, m);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
 // ============================================================ Context Broadcasting (SAST.py:240-246)
 //   x_cb = 0.5 * m + 0.5 * mean_over_all_L_tokens_of_the_sample(m placed at the kept tokens, zero elsewhere)
 // Compact rows are in ascending (sample-major) group order by construction (k_select.hip / selection_from_index_lists), so a

@@ -48,6 +48,9 @@ int cb_apply_fwd_launch(const float* m, const float* y, const float* gamma, cons
 int cb_apply_bwd_launch(const float* dout, const float* gsum, const int* row_tok, const int* nrows_dev, int rows_max, int tps, int C,
                         float* dz, hipStream_t st);
 
+int sample_gather_launch(const SastSampleGather& a, bool backward, hipStream_t st);
+int zero_samples_launch(float* x, int B, size_t sample_floats, const SastSampleMask& m, hipStream_t st);
+
 // k_select.hip
 int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mode, float thr_win, float thr_tok,
                   int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,

@@ -968,6 +968,85 @@ def cat2(a, b):
     return _Cat2.apply(a, b)
 
 
+# ---------------------------------------------------------------------------------------------- (f)2 label-sparse gather
+class _GatherSamples(torch.autograd.Function):
+    """out = cat_t(x_t[idx_t]) over the timesteps of a sequence (BackboneFeatureSelector, modules/utils/detection.py:24-47)."""
+
+    @staticmethod
+    def forward(ctx, table, *xs):
+        _need_gpu(*xs)
+        xs = tuple(x.contiguous() for x in xs)
+        B = xs[0].shape[0]
+        sample = xs[0][0].numel()
+        if any(x.shape != xs[0].shape or x.dtype != torch.float32 for x in xs):
+            raise RuntimeError("sast_amd: gather_samples needs fp32 tensors of one shape (one feature map over the timesteps)")
+        if len(xs) > 32 or len(table) > 256 or B > 256 or sample % 4:
+            raise RuntimeError("sast_amd: gather_samples supports <= 32 timesteps, <= 256 selected samples, batch <= 256")
+        out = torch.empty((len(table),) + tuple(xs[0].shape[1:]), device=xs[0].device)
+        a = L.SastSampleGather()
+        a.n_src, a.n_out, a.B, a.sample_floats, a.out = len(xs), len(table), B, sample, out.data_ptr()
+        for t, x in enumerate(xs):
+            a.src[t] = x.data_ptr()
+        for j, (t, b) in enumerate(table):
+            a.t_of[j], a.b_of[j] = t, b
+        L.check(L.lib().sast_gather_samples(C.byref(a), _stream()), "gather_samples")
+        ctx.table, ctx.meta = table, (len(xs), B, sample, tuple(xs[0].shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_src, B, sample, shape = ctx.meta
+        dout = dout.contiguous()
+        dxs = tuple(torch.empty(shape, device=dout.device) for _ in range(n_src))
+        a = L.SastSampleGather()
+        a.n_src, a.n_out, a.B, a.sample_floats, a.out = n_src, len(ctx.table), B, sample, dout.data_ptr()
+        for t, d in enumerate(dxs):
+            a.dsrc[t] = d.data_ptr()
+        for j, (t, b) in enumerate(ctx.table):
+            a.t_of[j], a.b_of[j] = t, b
+        L.check(L.lib().sast_gather_samples_bwd(C.byref(a), _stream()), "gather_samples_bwd")
+        return (None,) + dxs
+
+
+def gather_samples(xs, indices) -> torch.Tensor:
+    """xs: the feature map of T timesteps, each (B, ...) fp32; indices: per timestep the list of selected batch indices (unique
+    within a timestep, may be empty) -> (sum_t len(indices[t]), ...) = torch.cat([x[idx] for x, idx in zip(xs, indices) if idx])."""
+    table = tuple((t, int(b)) for t, idx in enumerate(indices) for b in idx)
+    for t, idx in enumerate(indices):
+        if len(set(int(b) for b in idx)) != len(idx):
+            raise RuntimeError("sast_amd: gather_samples needs unique batch indices per timestep")
+    return _GatherSamples.apply(table, *xs)
+
+
+@torch.no_grad()
+def zero_samples(x: torch.Tensor, indices_or_bool=None) -> torch.Tensor:
+    """RNNStates.recursive_reset (modules/utils/detection.py:96-116): x[indices_or_bool] = 0 in place (all samples when None)."""
+    _need_gpu(x)
+    if x.dtype != torch.float32 or not (x.is_contiguous() or x.permute(0, 2, 3, 1).is_contiguous()):
+        raise RuntimeError("sast_amd: zero_samples needs a dense fp32 tensor with the batch as its outermost dimension")
+    B = x.shape[0]
+    m = L.SastSampleMask()
+    if indices_or_bool is None:
+        sel = range(B)
+    else:
+        t = torch.as_tensor(indices_or_bool).cpu()
+        sel = torch.nonzero(t).view(-1).tolist() if t.dtype == torch.bool else [int(v) % B for v in t.view(-1).tolist()]
+    for b in sel:
+        m.sel[b] = 1
+    L.check(L.lib().sast_zero_samples(x.data_ptr(), B, x[0].numel(), C.byref(m), _stream()), "zero_samples")
+    return x
+
+
+@torch.no_grad()
+def adamw_onecycle_step(p, g, m, v, lr_step, sched, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, clip_value=0.0):
+    """fused AdamW with the OneCycleLR learning rate evaluated on the device from the step counter lr_step[1]
+    (sched: dist.OneCycleLR; modules/detection.py:418-431)."""
+    _need_gpu(p, g, m, v, lr_step)
+    L.check(L.lib().sast_adamw_onecycle(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr_step.data_ptr(), float(beta1),
+                                        float(beta2), eps, weight_decay, grad_scale, clip_value, sched.initial_lr, sched.max_lr, sched.min_lr,
+                                        sched.end1, sched.end2, _stream()), "adamw_onecycle")
+
+
 @torch.no_grad()
 def adamw_step(p, g, m, v, lr_step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, clip_value=0.0):
     """fused AdamW on flat fp32 buffers; lr_step = device tensor [lr, step]."""

@@ -1,0 +1,191 @@
+"""The training step of the hot path: forward, backward in SEGMENTS, bucketed gradient all-reduce overlapped with the
+remaining backward, fused AdamW per bucket.
+
+Reference: Lightning's DDP step around Module.training_step (modules/detection.py:113-221), `DDPStrategy(gradient_as_bucket_view=
+True)` (train.py:96-98) -- DDP all-reduces gradient buckets while the backward pass is still running.  Here the same overlap is
+explicit and hipGraph-friendly:
+
+  bucket 0  PAFPN (+ YOLOX head)      final after segment A  (loss -> FPN inputs)
+  bucket 1  backbone stage 4          final after segment B  (stage-4 backward)
+  bucket 2  backbone stages 3, 2, 1   final after segment C
+
+The parameters / gradients of a bucket are one contiguous slice of the flat buffers (dist.FlatParams).  After each segment the
+main stream records an event; a side stream waits for it, all-reduces that bucket over RCCL (torch.distributed "nccl") and runs
+the AdamW update of the bucket, while the main stream continues with the next segment (the later segments never read the
+parameters of an earlier bucket again).  The next step's forward waits for the side stream.  Each segment can be a captured
+hipGraph (three graphs sharing one memory pool); the collectives stay OUTSIDE the graphs, so no RCCL call is ever captured.
+With world == 1 the all-reduce is a no-op and everything else is identical, so a single-GPU run exercises the same path.
+
+For sequences (seq_len > 1, BPTT) the backbone gradients only become final at the end of the backward: segments B and C merge.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import functional as SF
+from .dist import FlatParams, FusedAdamW, OneCycleLR
+
+
+class TrainStep:
+    def __init__(self, net, fpn, head=None, *, lr: float = 2e-4, weight_decay: float = 0.0, clip_value: float = 0.0, eps: float = 1e-8,
+                 schedule: Optional[OneCycleLR] = None, world: int = 1, group=None, segmented: bool = True):
+        self.net, self.fpn, self.head = net, fpn, head
+        self.world, self.group, self.segmented = world, group, segmented
+        stages = list(net.stages)
+        buckets = [[fpn] + ([head] if head is not None else []), [stages[3]], [stages[2], stages[1], stages[0]]]
+        self.flat = FlatParams([], buckets=buckets)
+        self.opt = FusedAdamW(self.flat, lr=lr, weight_decay=weight_decay, clip_value=clip_value, eps=eps, schedule=schedule)
+        dev = self.flat.flat.device
+        self._one = torch.ones((), device=dev)
+        self.side = torch.cuda.Stream() if dev.type == "cuda" else None
+        self.loss = self.P = self.losses = None
+        self._graphs = None
+        self._seg_state = None
+
+    # ---------------------------------------------------------------- forward + backward segments
+    def forward(self, xs: Sequence[torch.Tensor], states=None, labels=None, indices=None, token_masks=None):
+        """xs: the event tensors of the sequence (one timestep = BASELINE's metric).  labels None: proxy objective
+        sum_k mean(out_k^2) on the PAFPN outputs of the last timestep; else the YOLOX / SimOTA loss on `labels`, with
+        `indices` (per timestep the batch indices that carry labels, modules/detection.py:161-171) or on the last timestep."""
+        self.flat.zero_grad()
+        single = len(xs) == 1 and self.segmented
+        feats_seq, Ps = [], []
+        for t, x in enumerate(xs):
+            feats, states, P = self.net.forward_nhwc(x, states, token_masks[t] if token_masks is not None else None,
+                                                     cut_before_stage=3 if single else None)
+            feats_seq.append(feats)
+            Ps.append(P)
+        cut = self.net.last_cut if single else None
+        if indices is not None:
+            from .detection.sequence import BackboneFeatureSelector
+            sel = BackboneFeatureSelector()
+            for f, idx in zip(feats_seq, indices):
+                if idx is not None and len(idx) > 0:
+                    sel.add_backbone_features({k: f[k] for k in self.fpn.in_features}, idx)
+            fpn_in = sel.get_batched_backbone_features()
+        else:
+            fpn_in = {k: feats_seq[-1][k] for k in self.fpn.in_features}
+        leaves = None
+        if self.segmented:      # FPN inputs as detached leaves: segment A ends there
+            leaves = {k: v.detach().requires_grad_(True) for k, v in fpn_in.items()}
+        outs = self.fpn.forward_nhwc(leaves if leaves is not None else fpn_in)
+        if labels is not None:
+            _pred, self.losses = self.head.forward_train_nhwc(outs, labels)
+            loss = self.losses["loss"]
+        else:
+            loss = SF.mean_squares(*outs)
+        self.loss, self.P, self.states = loss, Ps[-1], states
+        self._seg_state = (loss, fpn_in, leaves, cut)
+        return loss
+
+    def n_segments(self) -> int:
+        if not self.segmented:
+            return 1
+        return 3 if self._seg_state[3] is not None else 2
+
+    def backward_segment(self, i: int):
+        loss, fpn_in, leaves, cut = self._seg_state
+        if i == 0:
+            loss.backward(gradient=self._one)            # a resident 1.0 instead of a ones_like fill launch per step
+            return
+        keys = list(fpn_in.keys())
+        if cut is None:                                  # one backbone segment (sequences, or stage input without a graph)
+            torch.autograd.backward([fpn_in[k] for k in keys], [leaves[k].grad for k in keys])
+            return
+        top = keys[-1]                                   # the stage-4 feature map
+        if i == 1:
+            torch.autograd.backward([fpn_in[top]], [leaves[top].grad])
+        else:
+            rest = keys[:-1]
+            torch.autograd.backward([cut[0]] + [fpn_in[k] for k in rest], [cut[1].grad] + [leaves[k].grad for k in rest])
+
+    def bucket_of_segment(self, i: int) -> List[int]:
+        n = self.n_segments()
+        if n == 1:
+            return [0, 1, 2]
+        if n == 2:
+            return [[0], [1, 2]][i]
+        return [i]
+
+    # ---------------------------------------------------------------- reduce + update
+    def _reduce_update(self, buckets: List[int]):
+        for b in buckets:
+            self.flat.all_reduce(self.group, bucket=b)
+            self.opt.update(grad_scale=1.0 / self.world, bucket=b)
+
+    def _after_segment(self, i: int, first: bool):
+        """all-reduce + AdamW of the buckets that segment i completed; on the side stream when the step is segmented"""
+        if self.side is None or not self.segmented:
+            if first:
+                self.opt.begin_step()
+            self._reduce_update(self.bucket_of_segment(i))
+            return
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            if first:
+                self.opt.begin_step()
+            self._reduce_update(self.bucket_of_segment(i))
+
+    def finish(self):
+        if self.side is not None and self.segmented:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    # ---------------------------------------------------------------- eager step
+    def step(self, xs, states=None, labels=None, indices=None, token_masks=None):
+        self.flat.check_views()
+        self.forward(xs, states, labels, indices, token_masks)
+        for i in range(self.n_segments()):
+            self.backward_segment(i)
+            self._after_segment(i, first=(i == 0))
+        self.finish()
+        return self.loss
+
+    # ---------------------------------------------------------------- hipGraph: one graph per segment, collectives outside
+    def capture(self, xs, states=None, labels=None, indices=None, token_masks=None):
+        """capture the step as hipGraphs (the inputs must be static tensors); `replay()` then runs a whole step.
+        segmented: forward + segment A, segment B, segment C as graphs sharing one memory pool, reduce + update between them
+        (never captured).  not segmented and world == 1: ONE graph including the optimizer update; not segmented and
+        world > 1: one graph for forward + backward, all-reduce + update behind it."""
+        self.flat.check_views()
+        if not self.segmented:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.forward(xs, states, labels, indices, token_masks)
+                self.backward_segment(0)
+                if self.world == 1:
+                    self._after_segment(0, first=True)
+            self._graphs = [g]
+            self.loss = self.loss.detach()
+            return
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            self.forward(xs, states, labels, indices, token_masks)
+            self.backward_segment(0)
+        graphs.append(g)
+        for i in range(1, self.n_segments()):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                self.backward_segment(i)
+            graphs.append(g)
+        self._graphs = graphs
+        self.loss = self.loss.detach()
+
+    def replay(self):
+        if not self.segmented:
+            self._graphs[0].replay()
+            if self.world > 1:
+                self._after_segment(0, first=True)
+            return self.loss
+        for i, g in enumerate(self._graphs):
+            g.replay()
+            self._after_segment(i, first=(i == 0))
+        self.finish()
+        return self.loss

@@ -379,8 +379,56 @@ def gen_head_train(ref):
           "fg per image", [int(a[0].sum()) for a in mine["assign"]])
 
 
+def gen_sequence_gather(ref):
+    """(f)2: BackboneFeatureSelector / RNNStates of modules/utils/detection.py driven as modules/detection.py:161-171 does."""
+    if RI.REF_ROOT not in sys.path:
+        sys.path.insert(0, RI.REF_ROOT)
+    from modules.utils.detection import BackboneFeatureSelector, RNNStates
+    g = torch.Generator().manual_seed(17)
+    T, B = 4, 3
+    shapes = {1: (8, 6, 10), 2: (16, 3, 5), 3: (32, 2, 3), 4: (64, 1, 2)}       # (C, H, W)
+    idx_seq = [[0, 2], [], [1], [2, 0, 1]]
+    sel = BackboneFeatureSelector()
+    d = {"idx_json": np.array(json.dumps(idx_seq))}
+    feats_seq = []
+    for t in range(T):
+        f = {k: torch.randn(B, *shp, generator=g) for k, shp in shapes.items()}
+        feats_seq.append(f)
+        for k, v in f.items():
+            d[f"f{t}_{k}"] = np_(v)
+        if len(idx_seq[t]) > 0:
+            sel.add_backbone_features(backbone_features=f, selected_indices=idx_seq[t])
+    out = sel.get_batched_backbone_features()
+    mine = O.select_backbone_features(feats_seq, idx_seq)
+    for k, v in out.items():
+        assert torch.equal(v, mine[k])
+        d[f"out_{k}"] = np_(v)
+    # RNNStates: save + detach, reset of samples {0, 2} by bool tensor and of sample 1 by index list
+    st = RNNStates()
+    states = [(torch.randn(B, c, h, w, generator=g), torch.randn(B, c, h, w, generator=g)) for c, h, w in shapes.values()]
+    for i, (h, c) in enumerate(states):
+        d[f"h_{i}"], d[f"c_{i}"] = np_(h), np_(c)
+    st.save_states_and_detach(worker_id=0, states=[(h.clone().requires_grad_(True) * 1.0, c.clone()) for h, c in states])
+    assert all(not h.requires_grad for h, _ in st.get_states(0))
+    st.reset(worker_id=0, indices_or_bool_tensor=torch.tensor([True, False, True]))
+    mine = O.rnn_states_reset(states, torch.tensor([True, False, True]))
+    for i, (h, c) in enumerate(st.get_states(0)):
+        assert torch.equal(h, mine[i][0]) and torch.equal(c, mine[i][1])
+        d[f"reset_bool_h_{i}"], d[f"reset_bool_c_{i}"] = np_(h).copy(), np_(c).copy()      # (the next reset works in place)
+    st.reset(worker_id=0, indices_or_bool_tensor=[1])
+    for i, (h, c) in enumerate(st.get_states(0)):
+        d[f"reset_idx_h_{i}"] = np_(h)
+        assert float(h.abs().max()) == 0.0
+    assert st.get_states(5) is None
+    np.savez_compressed(os.path.join(HERE, "sequence_gather.npz"), **d)
+    print("sequence_gather ok")
+
+
 def main():
     ref = RI.import_reference()
+    if "--sequence-only" in sys.argv:
+        gen_sequence_gather(ref)
+        return
     if "--mask-only" in sys.argv:
         gen_masked_backbone(ref)
         return
@@ -407,6 +455,7 @@ def main():
     gen_head_train(ref)
     gen_masked_backbone(ref)
     gen_full_stats(ref)
+    gen_sequence_gather(ref)
 
 
 if __name__ == "__main__":

@@ -820,6 +820,151 @@ def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
         grad_close(k, v.grad, po[k].grad)
 
 
+def test_sequence_gather_vs_golden(golden_dir, dev):
+    """(f)2 BackboneFeatureSelector / RNNStates (modules/utils/detection.py:24-47,76-130) through sast_gather_samples /
+    sast_zero_samples: outputs against the imported reference's (fixture sequence_gather.npz, bit-exact: pure data movement), the
+    backward against torch autograd of the oracle expression, NCHW-view and NHWC inputs alike."""
+    import json as _json
+    from sast_amd.detection.sequence import BackboneFeatureSelector, RNNStates
+    g = _load(golden_dir, "sequence_gather")
+    idx_seq = _json.loads(str(g["idx_json"]))
+    feats_cpu = [{k: torch.from_numpy(g[f"f{t}_{k}"]) for k in (1, 2, 3, 4)} for t in range(len(idx_seq))]
+    for layout in ("nchw_contiguous", "channels_last"):
+        sel = BackboneFeatureSelector()
+        leaves = []
+        for f, idx in zip(feats_cpu, idx_seq):
+            fd = {}
+            for k, v in f.items():
+                t = v.to(dev)
+                if layout == "channels_last":
+                    t = t.contiguous(memory_format=torch.channels_last)
+                fd[k] = t.requires_grad_(True)
+            leaves.append(fd)
+            if len(idx) > 0:
+                sel.add_backbone_features(backbone_features=fd, selected_indices=idx)
+        out = sel.get_batched_backbone_features()
+        for k in (1, 2, 3, 4):
+            assert torch.equal(out[k].cpu(), torch.from_numpy(g[f"out_{k}"])), (layout, k)
+        w = {k: torch.randn(out[k].shape, generator=torch.Generator().manual_seed(k)) for k in out}
+        sum((out[k] * w[k].to(dev)).sum() for k in out).backward()
+        ref_leaves = [{k: v.clone().requires_grad_(True) for k, v in f.items()} for f in feats_cpu]
+        ref = O.select_backbone_features(ref_leaves, idx_seq)
+        sum((ref[k] * w[k]).sum() for k in ref).backward()
+        for t in range(len(idx_seq)):
+            for k in (1, 2, 3, 4):
+                rg, gg = ref_leaves[t][k].grad, leaves[t][k].grad
+                assert (rg is None) == (gg is None), (layout, t, k)          # a timestep without labels takes no part
+                if rg is not None:
+                    assert torch.equal(gg.cpu(), rg), (layout, t, k)
+    assert BackboneFeatureSelector().get_batched_backbone_features() is None
+    # RNNStates: detach on save, per-sample reset by bool tensor and by index list, unknown worker -> None
+    st = RNNStates()
+    states = [(torch.from_numpy(g[f"h_{i}"]).to(dev).requires_grad_(True) * 1.0, torch.from_numpy(g[f"c_{i}"]).to(dev)) for i in range(4)]
+    st.save_states_and_detach(worker_id=0, states=states)
+    assert all(not h.requires_grad for h, _ in st.get_states(0)) and st.get_states(5) is None
+    st.reset(worker_id=0, indices_or_bool_tensor=torch.tensor([True, False, True]))
+    for i, (h, c) in enumerate(st.get_states(0)):
+        assert torch.equal(h.cpu(), torch.from_numpy(g[f"reset_bool_h_{i}"])) and torch.equal(c.cpu(), torch.from_numpy(g[f"reset_bool_c_{i}"]))
+    st.reset(worker_id=0, indices_or_bool_tensor=[1])
+    assert all(float(h.abs().max()) == 0.0 for h, _ in st.get_states(0))
+
+
+def test_label_sparse_sequence_step(dev):
+    """the model part of the reference's training step (modules/detection.py:139-177): L = 3 timesteps with carried states, labels
+    on a subset of the (timestep, sample) pairs, the labelled features gathered into ONE PAFPN + head + SimOTA call, BPTT through
+    everything -- losses, kept-token counts and every gradient against the oracle run the same way; then a second sequence that
+    starts from the saved (detached) states with sample 1 reset."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN, YOLOXHead
+    from sast_amd.detection.sequence import RNNStates
+    from sast_amd.training import TrainStep
+    hw, part, E, L, B, nc = (128, 160), (4, 5), 32, 3, 3, 2
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    bp = O.init_backbone_params(ocfg, seed=61, ls_init=0.5)
+    fp = O.init_pafpn_params((64, 128, 256), seed=62)
+    hp = O.init_head_params((64, 128, 256), num_classes=nc, seed=63)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev).train()
+    head = YOLOXHead(num_classes=nc, strides=(8, 16, 32), in_channels=(64, 128, 256)).to(dev).train()
+    load_params(net, bp)
+    load_params(fpn, fp)
+    load_params(head, hp)
+    ts = TrainStep(net, fpn, head, lr=0.0, segmented=True)          # lr 0: the parameters stay put, gradients are what is compared
+    xs = [O.count_events(B, hw, seed=70 + t, density=0.05) for t in range(L)]
+    indices = [[0, 2], [], [1, 2, 0]]
+    labels = O.synthetic_labels(5, hw, nc, max_labels=5, seed=64)
+    ts.step([x.to(dev) for x in xs], None, labels.to(dev), indices)
+    po = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
+    pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fp.items()}
+    ph = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in hp.items()}
+    ref, ref_states, Ps = O.sequence_train_step(xs, indices, labels, po, pf, ph, ocfg, num_classes=nc)
+    ref["loss"].backward()
+    assert [int(p) for p in ts.P] == [int(p) for p in Ps[-1]]
+    assert abs(float(ts.losses["loss"]) - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"]))
+    for k, v in net.named_parameters():
+        if "sub_layers" not in k:
+            grad_close(k, v.grad, po[k].grad, 6e-4)
+    for k, v in fpn.named_parameters():
+        grad_close("fpn." + k, v.grad, pf[k].grad, 6e-4)
+    for k, v in head.named_parameters():
+        grad_close("head." + k, v.grad, ph[k].grad, 6e-4)
+    # next sequence of the same worker: saved states are detached, sample 1 starts a new recording (is_first_sample)
+    rs = RNNStates()
+    rs.save_states_and_detach(worker_id=0, states=ts.states)
+    rs.reset(worker_id=0, indices_or_bool_tensor=torch.tensor([False, True, False]))
+    prev = rs.get_states(0)
+    ts.step([x.to(dev) for x in xs[:2]], prev, labels[:3].to(dev), [[1], [0, 2]])
+    oprev = O.rnn_states_reset([(h.detach(), c.detach()) for h, c in ref_states], torch.tensor([False, True, False]))
+    ref2, _s, Ps2 = O.sequence_train_step(xs[:2], [[1], [0, 2]], labels[:3], bp, fp, hp, ocfg, prev_states=oprev, num_classes=nc)
+    assert [int(p) for p in ts.P] == [int(p) for p in Ps2[-1]]
+    assert abs(float(ts.losses["loss"]) - float(ref2["loss"])) <= 1e-4 * abs(float(ref2["loss"]))
+
+
+def test_segmented_step_matches_monolithic(dev):
+    """training.TrainStep: backward in three segments with per-bucket (all-reduce +) AdamW on a side stream == the monolithic step,
+    eager and as hipGraphs (three graphs sharing a pool, reduce + update between them); OneCycleLR evaluated on the device."""
+    from sast_amd.config import backbone_config
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    from sast_amd.dist import OneCycleLR
+    from sast_amd.training import TrainStep
+    hw, part, E = (128, 160), (4, 5), 32
+    x = O.count_events(2, hw, seed=2, density=0.05).to(dev)
+
+    def rig(segmented):
+        torch.manual_seed(0)
+        net = RNNDetector(backbone_config(hw, part, embed_dim=E, AMP=2e-4, ls_init_value=0.5)).to(dev)
+        fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev)
+        return TrainStep(net, fpn, lr=1e-3, eps=1e-3, clip_value=1.0, schedule=OneCycleLR(1e-3, total_steps=20, pct_start=0.25), segmented=segmented)
+
+    mono, seg, segg = rig(False), rig(True), rig(True)
+    assert seg.flat.bucket_ranges[0][1] > 0 and seg.flat.bucket_ranges[2][1] == seg.flat.numel
+    ref = []
+    for _ in range(4):
+        mono.step([x])
+        ref.append((float(mono.loss), mono.flat.grad.clone(), mono.flat.flat.clone()))
+    for k in range(4):
+        seg.step([x])
+        assert seg.n_segments() == 3
+        torch.cuda.synchronize()
+        assert abs(float(seg.loss) - ref[k][0]) <= 1e-5 * abs(ref[k][0])
+        maxnorm_close(seg.flat.grad, ref[k][1], (1e-5, 1e-4, 1e-3, 3e-3)[k], f"segmented eager, gradient of step {k}")
+    maxnorm_close(seg.flat.flat, ref[3][2], 1e-4, "segmented eager, parameters after 4 updates")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        segg.step([x])                                   # eager warm-up == step 0
+        torch.cuda.synchronize()
+        segg.capture([x])
+        for k in range(1, 4):
+            segg.replay()
+            torch.cuda.synchronize()
+            assert abs(float(segg.loss) - ref[k][0]) <= 1e-5 * abs(ref[k][0]), (k, float(segg.loss), ref[k][0])
+            maxnorm_close(segg.flat.grad, ref[k][1], (1e-4, 1e-3, 3e-3)[k - 1], f"segmented graphs, gradient of step {k}")
+    torch.cuda.current_stream().wait_stream(s)
+    maxnorm_close(segg.flat.flat, ref[3][2], 1e-4, "segmented graphs, parameters after 4 updates")
+    # the device-side schedule advanced with the replays: same step count, and the host closed form agrees with torch (CPU test)
+    assert float(segg.opt.lr_step[1]) == 4.0
+
+
 def _train_rig(dev, hw, part, E, chans, eps):
     from sast_amd.config import backbone_config
     from sast_amd.detection import RNNDetector, YOLOPAFPN

@@ -144,3 +144,120 @@ def test_positive_linear_forward_matches_reference_expression():
     m = PositiveLinear(20, 8, bias=True)
     x = torch.rand(3, 20)
     assert torch.equal(m(x), torch.nn.functional.linear(x, m.weight.exp(), m.bias))
+
+
+def test_onecycle_lr_matches_torch():
+    """dist.OneCycleLR (the closed form the fused AdamW kernel evaluates on the device) == torch.optim.lr_scheduler.OneCycleLR as
+    the reference configures it (modules/detection.py:418-431), every step of a short and of the shipped 400k-step schedule"""
+    import torch
+    from sast_amd.dist import OneCycleLR
+    for total, pct in ((400000, 0.005), (50, 0.3)):
+        lin = torch.nn.Linear(2, 2)
+        opt = torch.optim.AdamW(lin.parameters(), lr=2e-4)
+        sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=2e-4, div_factor=25, final_div_factor=10000 / 25, total_steps=total, pct_start=pct,
+                                                  cycle_momentum=False, anneal_strategy='linear')
+        mine = OneCycleLR(2e-4, total, pct, 25, 10000)
+        for k in range(min(total, 2500)):
+            assert abs(opt.param_groups[0]['lr'] - mine.lr_at(k)) <= 1e-12 * 2e-4, k
+            opt.step()
+            if k < total - 1:
+                sch.step()
+
+
+_DDP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import sast_oracle as O              # test infrastructure: produces the per-rank gradients that are injected
+from sast_amd.config import backbone_config
+from sast_amd.detection import RNNDetector, YOLOPAFPN
+from sast_amd.dist import FlatParams, FusedAdamW, OneCycleLR
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+hw, part, E, Bl = (128, 160), (4, 5), 32, 2
+ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+params = O.init_backbone_params(ocfg, seed=3, ls_init=0.5)
+fparams = O.init_pafpn_params((64, 128, 256), seed=4)
+net = RNNDetector(backbone_config(hw, part, embed_dim=E, AMP=2e-2, ls_init_value=0.5))          # the REAL modules (CPU parameters only:
+fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256))                      # their forward needs the MI355X)
+def load(module, p):
+    sd = module.state_dict(); new = {}
+    for k in sd:
+        kk = k
+        for a, b in (("sub_layers.0.", "ls1."), ("sub_layers.2.", "norm2."), ("sub_layers.3.", "mlp."), ("sub_layers.4.", "ls2.")):
+            kk = kk.replace(a, b)
+        new[k] = sd[k] if kk.endswith("num_batches_tracked") else p[kk]
+    module.load_state_dict(new, strict=True)
+load(net, params); load(fpn, fparams)
+stages = list(net.stages)
+flat = FlatParams([], buckets=[[fpn], [stages[3]], [stages[2], stages[1], stages[0]]])       # the bucket layout of training.TrainStep
+sched = OneCycleLR(1e-3, total_steps=10, pct_start=0.3)
+opt = FusedAdamW(flat, lr=1e-3, schedule=sched, clip_value=1.0)
+names = {}
+for mod, pre in ((net, "net."), (fpn, "fpn.")):
+    for k, v in mod.named_parameters():
+        names.setdefault(id(v), pre + k)
+
+def oracle_grads(x, P, F):
+    po = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+    pf = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in F.items()}
+    out, _s, _P = O.backbone(x, None, po, ocfg)
+    O.proxy_loss(O.pafpn({k: out[k] for k in (2, 3, 4)}, pf, training=True)).backward()      # BatchNorm batch statistics of THIS shard only
+    return po, pf
+
+def current(mod, pre):
+    return {k: v.detach().clone() for k, v in mod.state_dict().items() if "sub_layers" not in k}
+
+xs = [O.count_events(Bl, hw, seed=10 + r, density=0.05) for r in range(world)]
+# single-process reference: "world independent replicas + averaged gradients" (SURVEY 8e), torch.optim.AdamW + OneCycleLR + clip by value
+ref_p = {("net." + k): v.clone().requires_grad_(True) for k, v in current(net, "net.").items()}
+ref_f = {("fpn." + k): (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in current(fpn, "fpn.").items()}
+ref_all = {**ref_p, **{k: v for k, v in ref_f.items() if v.requires_grad}}
+ropt = torch.optim.AdamW(list(ref_all.values()), lr=1e-3, weight_decay=0.0)
+rsch = torch.optim.lr_scheduler.OneCycleLR(ropt, max_lr=1e-3, div_factor=25, final_div_factor=10000 / 25, total_steps=10, pct_start=0.3,
+                                           cycle_momentum=False, anneal_strategy='linear')
+for step in range(3):
+    # ---- this rank: gradients of its shard, injected into the flat views (what the HIP backward does in place)
+    po, pf = oracle_grads(xs[rank], current(net, "net."), current(fpn, "fpn."))
+    flat.zero_grad()
+    for prm in flat.params:
+        n = names[id(prm)]
+        g = (po if n.startswith("net.") else pf)[n[4:]].grad
+        prm.grad.add_(g)
+    opt.begin_step()
+    for b in (0, 1, 2):                       # bucket order of the segmented backward
+        flat.all_reduce(bucket=b)
+        opt.update(grad_scale=1.0 / world, bucket=b)
+    # ---- reference
+    ropt.zero_grad()
+    acc = {k: torch.zeros_like(v) for k, v in ref_all.items()}
+    for r in range(world):
+        P = {k[4:]: v.detach() for k, v in ref_p.items()}
+        F = {k[4:]: v.detach() for k, v in ref_f.items()}
+        qo, qf = oracle_grads(xs[r], P, F)
+        for k in acc:
+            acc[k] += (qo if k.startswith("net.") else qf)[k[4:]].grad / world
+    for k, v in ref_all.items():
+        v.grad = acc[k].clamp(-1.0, 1.0)
+    ropt.step(); rsch.step()
+worst = 0.0
+for prm in flat.params:
+    n = names[id(prm)]
+    worst = max(worst, float((prm.detach() - ref_all[n].detach()).abs().max()))
+assert worst <= 1e-5, worst      # updates are lr-sized (up to 1e-3 per step): <= 1 % of one update after 3 steps (measured 2.6e-6)
+dist.destroy_process_group()
+print("rank", rank, "ok", worst)
+'''
+
+
+def test_two_replicas_bucketed_allreduce_equals_averaged_single_process_gloo(tmp_path):
+    """SURVEY 8(e) parity for the data-parallel path, on CPU: 2 ranks (gloo), the REAL modules' parameters re-homed into the bucketed
+    flat buffers of training.TrainStep, per-rank gradients (oracle, rank-local BatchNorm statistics) injected into the flat views,
+    per-bucket all-reduce + fused AdamW (OneCycleLR, clip by value)  ==  one process that evaluates both shards as independent replicas,
+    averages the gradients and steps torch.optim.AdamW + torch OneCycleLR.  Three optimizer steps."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2

@@ -225,3 +225,19 @@ def test_oracle_equals_reference_live():
     assert Pa == Pb
     for k in (1, 2, 3, 4):
         assert torch.equal(a[k], b[k])
+
+
+def test_sequence_gather_and_rnn_states(golden_dir):
+    """(f)2: oracle restatement of BackboneFeatureSelector / RNNStates.reset against the imported reference's outputs"""
+    import json
+    g = _load(golden_dir, "sequence_gather")
+    idx_seq = json.loads(str(g["idx_json"]))
+    feats_seq = [{k: torch.from_numpy(g[f"f{t}_{k}"]) for k in (1, 2, 3, 4)} for t in range(len(idx_seq))]
+    out = O.select_backbone_features(feats_seq, idx_seq)
+    for k in (1, 2, 3, 4):
+        assert torch.equal(out[k], torch.from_numpy(g[f"out_{k}"]))
+    states = [(torch.from_numpy(g[f"h_{i}"]), torch.from_numpy(g[f"c_{i}"])) for i in range(4)]
+    rs = O.rnn_states_reset(states, torch.tensor([True, False, True]))
+    for i in range(4):
+        assert torch.equal(rs[i][0], torch.from_numpy(g[f"reset_bool_h_{i}"])) and torch.equal(rs[i][1], torch.from_numpy(g[f"reset_bool_c_{i}"]))
+    assert O.select_backbone_features(feats_seq, [[], None, [], []]) is None
