@@ -12,6 +12,7 @@ namespace sast {
 
 struct ProfLaunch { hipEvent_t e0, e1; double flops; std::string tag; };
 static bool g_on = false;
+static bool g_shapes = false;   // sast_prof_enable(2): one report row per (instantiation, problem shape)
 static std::vector<ProfLaunch> g_launches;
 static std::vector<hipEvent_t> g_pending;
 
@@ -55,6 +56,7 @@ void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int*
   if (dR) { int v; hipMemcpyAsync(&v, dR, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < r) r = v; }
   l.flops = 2.0 * (double)m * (double)NJ * (double)G * (double)r;
   l.tag = tag;
+  if (g_shapes) { char sh[96]; snprintf(sh, sizeof sh, " |M=%d N=%d R=%d", m, NJ * G, r); l.tag += sh; }
   g_launches.push_back(l);
   *e0 = l.e0;
   *e1 = l.e1;
@@ -76,6 +78,12 @@ void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, i
   l.flops = flops_static + 2.0 * (double)dev_min(M1, dM1, st) * NJ1 * G1 * (double)dev_min(R1, dR1, st) +
             2.0 * (double)dev_min(M2, dM2, st) * NJ2 * G2 * (double)dev_min(R2, dR2, st);
   l.tag = tag;
+  if (g_shapes) {
+    char sh[160];
+    snprintf(sh, sizeof sh, " |M=%d N=%d R=%d + M=%d N=%d R=%d", dev_min(M1, dM1, st), NJ1 * G1, dev_min(R1, dR1, st), dev_min(M2, dM2, st), NJ2 * G2,
+             dev_min(R2, dR2, st));
+    l.tag += sh;
+  }
   g_launches.push_back(l);
   *e0 = l.e0;
   *e1 = l.e1;
@@ -113,6 +121,7 @@ float sast_prof_calibrate(sast_stream_t stream, int n) {
 
 int sast_prof_enable(int on) {
   sast::g_on = on != 0;
+  sast::g_shapes = on == 2;
   if (on) {
     for (auto& l : sast::g_launches) { hipEventDestroy(l.e0); hipEventDestroy(l.e1); }
     sast::g_launches.clear();

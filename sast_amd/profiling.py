@@ -91,11 +91,12 @@ def _short(tag: str) -> str:
     return f"gemm_kernel<{names[0]}, {names[1]}, {names[2]}, {names[3]}{', split' if m.group(1) else ''}>"
 
 
-def gemm_report(run_steps, n_steps: int = 3):
-    """run_steps(n): executes n eager steps.  Returns [(name, calls, total_ms, total_flops)] sorted by time."""
+def gemm_report(run_steps, n_steps: int = 3, per_shape: bool = False):
+    """run_steps(n): executes n eager steps.  Returns [(name, calls, total_ms, total_flops)] sorted by time; per_shape: one row
+    per (instantiation, problem shape), the shape appended to the name after " |"."""
     lib = L.lib()
     torch.cuda.synchronize()
-    lib.sast_prof_enable(1)
+    lib.sast_prof_enable(2 if per_shape else 1)
     try:
         run_steps(n_steps)
         torch.cuda.synchronize()
@@ -107,7 +108,8 @@ def gemm_report(run_steps, n_steps: int = 3):
     rows = []
     for line in buf.value.decode().splitlines():
         tag, n, ms, fl = line.rsplit("\t", 3)
-        rows.append((_short(tag), int(n), float(ms), float(fl)))
+        tag, _, shape = tag.partition(" |")
+        rows.append((_short(tag) + (" |" + shape if shape else ""), int(n), float(ms), float(fl)))
     rows.sort(key=lambda r: -r[2])
     return rows
 
