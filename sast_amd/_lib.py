@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsast_hip.so")
+LIB_PATH = os.environ.get("SAST_LIB_PATH") or os.path.join(_HERE, "libsast_hip.so")   # SAST_LIB_PATH: A/B builds (tools only)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sast_hip.h")
 
 P = C.c_void_p

@@ -33,12 +33,13 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
-def _compile(src: str, force: bool) -> str:
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src: str, force: bool, flags=None, obj_dir=None) -> str:
+    obj_dir = obj_dir or OBJ
+    obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= _newest(deps):
         return obj
-    cmd = [_hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [_hipcc(), *(FLAGS + list(flags or [])), "-c", os.path.join(CSRC, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr[-6000:]}")
@@ -66,5 +67,22 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_variant(out: str, flags) -> str:
+    """an A/B build of the product library with extra compile flags (e.g. -DSAST_SINGLE_TILE_ACCS=1) next to the in-tree one;
+    run with SAST_LIB_PATH=<out> (tools only: A/B measurements inside one gpurun call)."""
+    out = os.path.abspath(out)
+    obj_dir = out + ".obj"
+    os.makedirs(obj_dir, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, True, flags, obj_dir), SOURCES))
+    _link(objs, out, True)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--out" in sys.argv:
+        o = sys.argv[sys.argv.index("--out") + 1]
+        fl = sys.argv[sys.argv.index("--flags") + 1].split() if "--flags" in sys.argv else []
+        print("built", build_variant(o, fl))
+    else:
+        build(force="--force" in sys.argv, verbose=True)

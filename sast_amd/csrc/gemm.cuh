@@ -35,8 +35,23 @@
 
 // per-block phase timestamps for the micro-benchmarks (k_test.hip defines SAST_TL before including this header; the
 // product translation units compile it away)
+// -DSAST_TL_ENABLE (variant builds only, `python -m sast_amd.build --out ab/libsast_hip_tl.so --flags -DSAST_TL_ENABLE`): the same
+// stamps inside the PRODUCT kernels of a translation unit, read back through sast_tl_read / sast_tl_reset (k_conv.hip)
+#if defined(SAST_TL_ENABLE) && !defined(SAST_TL)
+static __device__ unsigned long long sast_tl_buf[8 * 8192];
+#define SAST_TL(k)                                                                                          \
+  do {                                                                                                      \
+    const unsigned bid_ = blockIdx.x;                                                                       \
+    if (threadIdx.x == 0 && bid_ < 8192) sast_tl_buf[bid_ * 8 + (k)] = wall_clock64();                      \
+    if (threadIdx.x == 0 && bid_ < 8192 && (k) == 0) sast_tl_buf[bid_ * 8 + 7] = __smid();                 \
+  } while (0)
+#define SAST_TL_JOB(j) do { if (threadIdx.x == 0 && blockIdx.x < 8192) sast_tl_buf[blockIdx.x * 8 + 6] = (j); } while (0)
+#endif
 #ifndef SAST_TL
 #define SAST_TL(k)
+#endif
+#ifndef SAST_TL_JOB
+#define SAST_TL_JOB(j)
 #endif
 
 namespace sast {
@@ -47,6 +62,10 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // MFMA work is ~0.2-0.4 us: see tools/gemm_timeline.py).  Must be even (LDS is double-buffered).
 #ifndef SAST_PF_DEFAULT
 #define SAST_PF_DEFAULT 2
+#endif
+// independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
+#ifndef SAST_SINGLE_TILE_ACCS
+#define SAST_SINGLE_TILE_ACCS 1
 #endif
 // OCC: blocks per CU the register allocation must leave room for (0 = no constraint beyond the block size).
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16, int KS_ = 1, int PF_ = SAST_PF_DEFAULT, int OCC_ = 0>
@@ -84,6 +103,8 @@ template <class EP> struct EpHasSide<EP, std::void_t<decltype(EP::SIDE)>> : std:
 template <class EP> inline int ep_side_blocks(const EP& ep) {
   if constexpr (EpHasSide<EP>::value) return ep.side_blocks; else return 0;
 }
+template <class L, class = void> struct LoaderUniformTile : std::false_type {};
+template <class L> struct LoaderUniformTile<L, std::void_t<decltype(L::UNIFORM_TILE)>> : std::bool_constant<L::UNIFORM_TILE> {};
 template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
@@ -113,7 +134,8 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
   static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
   static_assert(KS * GROUP_FLOATS == GemmSmem<T, LA, LB>::FLOATS, "GemmSmem");
-  const int kg = threadIdx.x / NT;          // k-group of this wave (wave-uniform)
+  const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // k-group of this wave: wave-uniform, kept in an SGPR so that
+                                                                      // everything derived from the k-tile index stays on the scalar unit
   float* As = smem + kg * GROUP_FLOATS;
   float* Bs = As + 2 * A_STAGE;
 
@@ -204,14 +226,22 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
   }
 
+  // a loader with UNIFORM_TILE gets the k-tile base r0 (wave-uniform) and the lane's offset inside the tile separately: whatever it
+  // decodes from r0 alone (the tap of an implicit-GEMM convolution whose channel count is a multiple of BK) runs on the scalar unit
   auto gload = [&](int kt, int set) {
     const int r0 = kt * BK;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) la.load(ca[it], r0 + ra_off[it], Rl, ra[set][it], aa[set][it], oa[set][it]);
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
+        if constexpr (LoaderUniformTile<LA>::value) la.load_u(ca[it], r0, ra_off[it], Rl, BK, ra[set][it], aa[set][it], oa[set][it]);
+        else la.load(ca[it], r0 + ra_off[it], Rl, ra[set][it], aa[set][it], oa[set][it]);
+      }
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
-      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) lb.load(cb[it], r0 + rb_off[it], Rl, rb[set][it], ab[set][it], ob[set][it]);
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
+        if constexpr (LoaderUniformTile<LB>::value) lb.load_u(cb[it], r0, rb_off[it], Rl, BK, rb[set][it], ab[set][it], ob[set][it]);
+        else lb.load(cb[it], r0 + rb_off[it], Rl, rb[set][it], ab[set][it], ob[set][it]);
+      }
   };
 
   auto lstore = [&](int buf, int set) {
@@ -234,13 +264,22 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   constexpr bool EARLY_AUX = T::TM * T::TJ == 1;
   typename EP::Aux eaux[EARLY_AUX ? 16 : 1];
 
-  f32x16 acc[T::TM][T::TN];
+  // a wave with ONE 32x32 accumulator tile issues a chain of MFMAs that each depend on the previous one.  Hypothesis tested in
+  // round 2: whatever the compiler schedules between two of them delays the chain, so two accumulators for the even / odd k-steps
+  // (dependency distance two) should help.  Measured: they do NOT (step 5.83 vs 5.715 ms, the weight-gradient micro-benchmark 2-5 %
+  // slower): back-to-back dependent v_mfma_f32_32x32x2_f32 issue at full rate on gfx950 and the extra 16 VGPRs cost more than the
+  // slack buys.  Kept as a compile-time knob (-DSAST_SINGLE_TILE_ACCS=2).
+  constexpr int NACC = (T::TM * T::TN == 1) ? SAST_SINGLE_TILE_ACCS : 1;
+  f32x16 accs[NACC][T::TM][T::TN];
 #pragma unroll
-  for (int a = 0; a < T::TM; ++a)
+  for (int c = 0; c < NACC; ++c)
 #pragma unroll
-    for (int b = 0; b < T::TN; ++b)
+    for (int a = 0; a < T::TM; ++a)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+      for (int b = 0; b < T::TN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accs[c][a][b][e] = 0.f;
+  f32x16 (&acc)[T::TM][T::TN] = accs[0];
   float csum[T::TM];
 #pragma unroll
   for (int a = 0; a < T::TM; ++a) csum[a] = 0.f;
@@ -285,7 +324,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
         for (int tb = 0; tb < T::TN; ++tb)
-          acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][ks], b[tb][ks], acc[ta][tb], 0, 0, 0);
+          accs[ks % NACC][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][ks], b[tb][ks], accs[ks % NACC][ta][tb], 0, 0, 0);
   };
 
   // software pipeline: this k-group owns tiles kt0 + kg + KS*i.  At phase p the LDS buffer p%2 holds tile p, register set
@@ -327,6 +366,12 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
   }
 
+  if constexpr (NACC > 1) {
+#pragma unroll
+    for (int c = 1; c < NACC; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) accs[0][0][0][e] += accs[c][0][0][e];
+  }
   SAST_TL(2);
   if constexpr (KS > 1) {   // fold the k-groups' partial accumulators into group 0 through LDS
     float* red = smem + kg * GROUP_FLOATS + (wave * T::TM * T::TN) * 16 * 64 + lane;
@@ -449,6 +494,7 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
   constexpr int F2 = GemmSmem<typename J2::T, typename J2::LA, typename J2::LB>::FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
   if ((int)blockIdx.x < n1) {
+    SAST_TL_JOB(1);
     if (threadIdx.x >= J1::T::NT) return;   // surplus waves of the larger workgroup shape (block-uniform per wave)
     gemm_body<typename J1::T, typename J1::LA, typename J1::LB, typename J1::EP, J1::SPLIT>(
         a.la, a.lb, a.ep, a.M, a.NJ, a.R, a.dM, a.dR, a.colsum, a.nsplit, a.xcd_remap, blockIdx.x, n1, smem);
@@ -458,6 +504,7 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
       n2 -= b.ep.side_blocks;
       if ((int)blockIdx.x >= n1 + n2) { b.ep.side(blockIdx.x - n1 - n2); return; }
     }
+    SAST_TL_JOB(2);
     if (threadIdx.x >= J2::T::NT) return;
     gemm_body<typename J2::T, typename J2::LA, typename J2::LB, typename J2::EP, J2::SPLIT>(
         b.la, b.lb, b.ep, b.M, b.NJ, b.R, b.dM, b.dR, b.colsum, b.nsplit, b.xcd_remap, blockIdx.x - n1, n2, smem);
@@ -763,6 +810,7 @@ struct ConvGeom {
   int stride_shift, kw_mul;                                        // stride == 1 << stride_shift; kw_mul = small_div_mul(KW)
   unsigned wo_mul, ho_mul;   // n / Wo == umulhi(n, wo_mul) for every row index n of the problem (0: use the division); same for Ho
   unsigned cin_mul;          // r / Cin == umulhi(r, cin_mul) for reduce indices r < KH*KW*Cin (never 0: geom_of checks)
+  unsigned w_mul, h_mul;     // the same for INPUT pixel indices n < B*H*W: n / W, (n / W) / H  (0: plain division)
 };
 // (fast_div / div_mul_of: common.cuh)
 // (tap, channel) of a reduce index.  The divisor is applied as a multiplier (div_mul_of) ALWAYS, powers of two included: a
@@ -781,7 +829,7 @@ struct LdIm2col {
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
     const bool ok = i < Ieff;
     const int ii = ok ? i : 0;
-    const int ox = ii % g.Wo, t = ii / g.Wo, oy = t % g.Ho, b = t / g.Ho;
+    const int t = fast_div(ii, g.Wo, g.wo_mul), ox = ii - t * g.Wo, b = fast_div(t, g.Ho, g.ho_mul), oy = t - b * g.Ho;
     return Ctx{x + (size_t)b * g.H * g.W * g.ldx, oy * g.stride - g.pad, ox * g.stride - g.pad, ok};
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
@@ -794,6 +842,23 @@ struct LdIm2col {
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
+};
+// the same when the channel count is a multiple of the k-tile (every conv of the path except the stem, Cin = 20): a k-tile then lies
+// inside ONE tap, which is decoded from the wave-uniform tile base on the scalar unit -- per lane only the pixel clamp and the
+// address remain (the generic form spends ~35 VALU instructions per float4 on the decode; with the conv loaders of two jobs
+// sharing a SIMD the VALU port, not the MFMA pipe, bounded the paired conv kernels: tools/conv_timeline.py)
+struct LdIm2colU : LdIm2col {
+  static constexpr bool UNIFORM_TILE = true;
+  __device__ __forceinline__ void load_u(const Ctx& c, int r0, int off, int Reff, int bk, float4& v, float& aux, bool& ok) const {
+    const int rc = min(r0, Reff - bk);           // uniform; Reff and r0 are multiples of bk
+    int kh, kw, ch0;
+    split_tap(g, g.Cin, g.cin_mul, rc, kh, kw, ch0);
+    const int iy = c.iy0 + kh, ix = c.ix0 + kw;
+    const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+    ok = c.ok && r0 < Reff && (g.replicate || (cy == iy && cx == ix));
+    v = ld4(c.img + ((size_t)cy * g.W + cx) * g.ldx + ch0 + off);
+    aux = 0.f;
+  }
 };
 // IC: B(t)[r = (b,oy,ox)][j = (kh,kw,c)]   (weight gradient)
 struct LdIm2colT {
@@ -826,7 +891,7 @@ struct LdConvDx {
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
     const bool ok = i < Ieff;
     const int ii = ok ? i : 0;
-    const int ix = ii % g.W, t = ii / g.W, iy = t % g.H, b = t / g.H;
+    const int t = fast_div(ii, g.W, g.w_mul), ix = ii - t * g.W, b = fast_div(t, g.H, g.h_mul), iy = t - b * g.H;
     return Ctx{dy + (size_t)b * g.Ho * g.Wo * lddy, iy, ix, ok};
   }
   // source output coordinate of input coordinate i under tap k (returns validity; o is always in range)
@@ -849,6 +914,19 @@ struct LdConvDx {
   }
   SAST_DEFAULT_FINISH
 };
+struct LdConvDxU : LdConvDx {   // Cout a multiple of the k-tile: uniform tap, see LdIm2colU
+  static constexpr bool UNIFORM_TILE = true;
+  __device__ __forceinline__ void load_u(const Ctx& c, int r0, int off, int Reff, int bk, float4& v, float& aux, bool& ok) const {
+    const int rc = min(r0, Reff - bk);
+    int kh, kw, co0;
+    split_tap(g, Cout, cout_mul, rc, kh, kw, co0);
+    int oy, ox;
+    const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
+    ok = c.ok && r0 < Reff && vy && vx;
+    v = ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co0 + off);
+    aux = 0.f;
+  }
+};
 // IC: B[r = (tap,co)][j = ci] = w[co][tap][ci]   (weights stored channels-last: [Cout][KH][KW][Cin])
 struct LdWeightConvDx {
   static constexpr bool RC = false;
@@ -865,6 +943,16 @@ struct LdWeightConvDx {
   SAST_DEFAULT_FINISH
 };
 
+struct LdWeightConvDxU : LdWeightConvDx {   // Cout a multiple of the k-tile: the tap of the tile comes from the uniform base
+  static constexpr bool UNIFORM_TILE = true;
+  __device__ __forceinline__ void load_u(const Ctx& c, int r0, int off, int Reff, int bk, float4& v, float& aux, bool& ok) const {
+    const int rc = min(r0, Reff - bk);
+    const int tap = (int)__umulhi((unsigned)rc, cout_mul), co0 = rc - tap * Cout;
+    ok = c.ok && r0 < Reff;
+    v = ld4(c.col + ((size_t)co0 * taps + tap) * Cin + (size_t)off * (taps * Cin));
+    aux = 0.f;
+  }
+};
 // the same for two convs stacked along Cout (co < C1 -> w0, else w1): dX = [dy0 | dy1] * [w0; w1]
 struct LdWeightConvDx2 {
   static constexpr bool RC = false;

@@ -350,7 +350,16 @@ inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad
   g.wo_mul = div_mul_of((unsigned)g.Wo, rows);
   g.ho_mul = div_mul_of((unsigned)g.Ho, rows);
   g.cin_mul = div_mul_of((unsigned)Cin, (unsigned long long)k * k * Cin);
+  g.w_mul = div_mul_of((unsigned)W, (unsigned long long)B * H * W);
+  g.h_mul = div_mul_of((unsigned)H, (unsigned long long)B * H * W);
   return g;
+}
+
+// forward implicit GEMM of a k x k convolution: the uniform-tap loader whenever a 16-wide k-tile lies inside one tap (gemm.cuh: LdIm2colU)
+template <class LB, class EP>
+int conv_gemm(const float* x, const ConvGeom& g, const LB& lb, const EP& ep, int M, int NJ, int K, hipStream_t st) {
+  if (g.Cin % 16 == 0) return gemm_auto(LdIm2colU{{x, g}}, lb, ep, M, NJ, K, st);
+  return gemm_auto(LdIm2col{x, g}, lb, ep, M, NJ, K, st);
 }
 
 // backward of a k x k convolution.  Stride 2 with a 3x3 kernel (downsample convs of stages 2-4, the two bottom-up PAFPN convs)
@@ -370,12 +379,19 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
   const int Mc = g.B * (g.H / 2) * (g.W / 2);
   if (prod && prod->x) {   // stride-1 convs only (the caller checks): dX epilogue also reduces the producer's BatchNorm backward sums
     if (g.stride != 1 || lddx != g.Cin || prod->C != g.Cin) return SAST_EINVAL;
+    if (Cout % 16 == 0)
+      return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDxU{{dconv, g, Cout, Cout, shift}},
+                       LdWeightConvDxU{{w, Cout, k * k, g.Cin, shift}}, EpStoreBnRed{dx, lddx, *prod}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
     return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
                      LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStoreBnRed{dx, lddx, *prod}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
   }
-  if (!(parity && g.stride == 2 && k == 3 && g.pad == 1 && g.H % 2 == 0 && g.W % 2 == 0 && Mc % 64 == 0))
+  if (!(parity && g.stride == 2 && k == 3 && g.pad == 1 && g.H % 2 == 0 && g.W % 2 == 0 && Mc % 64 == 0)) {
+    if (Cout % 16 == 0)
+      return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDxU{{dconv, g, Cout, Cout, shift}},
+                       LdWeightConvDxU{{w, Cout, k * k, g.Cin, shift}}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
     return gemm_pair(ta, tb, dw, K, Cout, K, M, nullptr, nullptr, LdConvDx{dconv, g, Cout, Cout, shift},
                      LdWeightConvDx{w, Cout, k * k, g.Cin, shift}, EpStore{dx, lddx, nullptr}, g.B * g.H * g.W, g.Cin, k * k * Cout, nullptr, st, pair_tn_blocks_conv());
+  }
   ConvDxClasses c;
   c.Hc = g.H / 2; c.Wc = g.W / 2; c.Mc = Mc;
   c.mc_mul = div_mul_of((unsigned)c.Mc, 4ull * Mc); c.wc_mul = div_mul_of((unsigned)c.Wc, 4ull * Mc); c.hc_mul = div_mul_of((unsigned)c.Hc, 4ull * Mc);
@@ -418,7 +434,7 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
   const int k = 2 * a->factor - 1;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
-  int rc = gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
+  int rc = conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
   if (rc) return rc;
   return ln_fwd_launch(a->conv_out, a->y, a->ln_w, a->ln_b, a->pe, g.Ho * g.Wo, a->mean, a->rstd, M, a->Cout, 1e-5f, st);
 }
@@ -459,18 +475,18 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
     const EpBnSilu ep{a->y, a->ldy, a->run_mean, a->run_var, a->bn_w, a->bn_b, a->eps};
     return one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
                         : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
-               : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+               : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
     rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
                       : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
-             : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+             : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   } else {
     const EpStore ep{a->conv_out, C, nullptr};
     rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
                       : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
-             : gemm_auto(LdIm2col{a->x, g}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+             : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (rc) return rc;
   if (a->training && sep) {
@@ -551,7 +567,7 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
     if (a->ksize == 3) {
       if (a->Cin1 != a->Cin) return SAST_EINVAL;
       const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx);
-      return gemm_auto(LdIm2col{a->x, g}, LdWeightNT2{a->w0, a->w1, 9 * a->Cin, C}, ep, M, 2 * C, 9 * a->Cin, st);
+      return conv_gemm(a->x, g, LdWeightNT2{a->w0, a->w1, 9 * a->Cin, C}, ep, M, 2 * C, 9 * a->Cin, st);
     }
     return gemm_auto(LdRows2{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2}, LdWeightNT2{a->w0, a->w1, a->Cin, C}, ep, M,
                      2 * C, a->Cin, st);
@@ -564,7 +580,7 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
   }
   const LdRows2 la{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2};
   const EpStoreStats2 ep{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1};
-  int rc = a->ksize == 3 ? gemm_auto(LdIm2col{a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx)}, LdWeightNT2{a->w0, a->w1, K, C}, ep, M,
+  int rc = a->ksize == 3 ? conv_gemm(a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx), LdWeightNT2{a->w0, a->w1, K, C}, ep, M,
                                      2 * C, K, st)
                          : gemm_auto(la, LdWeightNT2{a->w0, a->w1, K, C}, ep, M, 2 * C, K, st);
   if (rc) return rc;
@@ -687,5 +703,17 @@ int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, 
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
+
+#ifdef SAST_TL_ENABLE
+// variant builds only: per-block phase stamps of the LAST GEMM launch of this translation unit (conv / FPN kernels)
+int sast_tl_reset(void) {
+  static unsigned long long zeros[8 * 8192];
+  return hipMemcpyToSymbol(HIP_SYMBOL(sast_tl_buf), zeros, sizeof(zeros)) == hipSuccess ? 0 : -5;
+}
+int sast_tl_read(unsigned long long* host_out, int nblocks) {
+  if (nblocks > 8192) nblocks = 8192;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sast_tl_buf), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -5;
+}
+#endif
 
 }  // extern "C"

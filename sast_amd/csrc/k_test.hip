@@ -77,6 +77,20 @@ struct EpAtomicT {  // same as EpAtomic, distinct type (instrumented instantiati
   }
 };
 
+// diagnostic loaders: no memory access at all (what is left is LDS traffic + barriers + MFMA), and loads without the LDS/MFMA part
+struct LdNullT {
+  static constexpr bool RC = false;
+  struct Ctx { int i; bool ok; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return Ctx{i, i < Ieff}; }
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j, j < NJ}; }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v = make_float4((float)(r & 7), 1.f, (float)(c.i & 3), 0.5f);
+    aux = 0.f;
+  }
+  SAST_DEFAULT_FINISH
+};
+
 extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, float* colsum, int Mo, int NJ, int R, int tile, int splits,
                                  int null_ep, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
@@ -91,6 +105,13 @@ extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, fl
     }
   }
   const EpAtomicT ep{out, NJ};
+  if (tile == 40) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 32, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // BK = 32
+  if (tile == 41) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 32, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+  if (tile == 42) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 64, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // BK = 64
+  if (tile == 43) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 64, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+  if (tile == 100) return launch_gemm_split<TileSmallK2>(LdNullT{}, LdNullT{}, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // no global loads
+  if (tile == 101) return launch_gemm_split<TileSmall>(LdNullT{}, LdNullT{}, ep, Mo, NJ, R, nullptr, splits, colsum, st);
+  if (tile == 102) return launch_gemm_split<TileSmallK2>(la, LdNullT{}, ep, Mo, NJ, R, nullptr, splits, colsum, st);          // A only
   switch (tile) {
     case 0: return launch_gemm_split<TileSmall>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     case 1: return launch_gemm_split<TileSmallK2>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
@@ -118,4 +139,48 @@ extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, fl
     case 8: return launch_gemm_split<Tile<128, 64, 2, 2, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
     default: return SAST_EINVAL;
   }
+}
+
+
+// ---- MFMA issue-rate calibration (tools/mfma_peak.py): what a wave / a SIMD sustains on v_mfma_f32_32x32x2_f32 with the loop
+// structure of gemm_body (dependent chain on one accumulator, LDS operand reads, a workgroup barrier per 8 MFMAs)
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  __shared__ float lds[64 * 68 * 2];
+  for (int i = threadIdx.x; i < 64 * 68 * 2; i += 256) lds[i] = (float)(i & 7) * 0.001f;
+  __syncthreads();
+  f32x16 acc0, acc1;
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  const int lane = threadIdx.x & 63, l31 = lane & 31, hf = lane >> 5;
+  float a[8], b[8];
+  for (int k = 0; k < 8; ++k) { a[k] = lds[(hf * 8 + k) * 68 + l31]; b[k] = lds[64 * 68 + (hf * 8 + k) * 68 + l31]; }
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 2 || MODE == 4) {   // operands re-read from LDS every k-tile (ds_read_b32, [k][row] layout)
+      const int o = (it & 1) * 4;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { a[k] = lds[(hf * 8 + k) * 68 + l31 + o]; b[k] = lds[64 * 68 + (hf * 8 + k) * 68 + l31 + o]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (MODE == 1 && (k & 1)) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], b[k], acc0, 0, 0, 0);
+    }
+    if (MODE == 3 || MODE == 4) __syncthreads();
+  }
+  float s = 0.f;
+  for (int e = 0; e < 16; ++e) s += acc0[e] + acc1[e];
+  if (s == 123.456f) out[0] = s;
+}
+extern "C" int sast_test_mfma_peak(float* out, int mode, int blocks, int iters, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 3: hipLaunchKernelGGL(mfma_peak_kernel<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    default: return SAST_EINVAL;
+  }
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
 }

@@ -9,7 +9,8 @@ tn = lib.sast_test_gemm_tn; tn.restype = C.c_int; tn.argtypes = [C.c_void_p] * 4
 tl = lib.sast_test_timeline; tl.restype = C.c_int; tl.argtypes = [C.c_void_p, C.c_int]
 tlr = lib.sast_test_timeline_reset; tlr.restype = C.c_int; tlr.argtypes = []
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
-VAR = {1: "64x64 K2", 0: "64x64 K1", 24: "64x64 pf4", 30: "128x64", 32: "64x128", 33: "128x128", 34: "192x64"}
+VAR = {1: "K2 bk16", 40: "K2 bk32", 43: "K2 bk64", 0: "K1 bk16", 41: "K1 bk32", 42: "K1 bk64", 100: "K2 noload", 33: "128x128"}
+TSZ_EXTRA = {33: (128, 128)}
 TSZ = {30: (128, 64), 35: (128, 64), 36: (128, 64), 32: (64, 128), 33: (128, 128), 34: (192, 64)}
 def span(nblocks):
     buf = np.zeros((nblocks, 8), dtype=np.uint64)
@@ -17,17 +18,17 @@ def span(nblocks):
     t = buf[:, :5].astype(np.int64)
     t = t[t[:, 4] > 0]
     return (t[:, 4].max() - t[:, 0].min()) / 100.0
-shapes = [(192, 64, 61440), (64, 64, 61440), (320, 64, 61440), (64, 160, 61440), (384, 128, 15360), (640, 128, 15360), (128, 320, 15360), (768, 256, 3840), (1344, 256, 3840), (256, 672, 3840), (1536, 512, 960), (2688, 512, 960), (512, 1344, 960), (512, 512, 960)]
+shapes = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or [(192, 64, 61440), (64, 64, 61440), (320, 64, 61440), (64, 160, 61440), (384, 128, 15360), (640, 128, 15360), (128, 320, 15360), (768, 256, 3840), (1344, 256, 3840), (256, 672, 3840), (1536, 512, 960), (2688, 512, 960), (512, 1344, 960), (512, 512, 960)]
 print("shape".ljust(18) + "blocks " + " ".join(v.rjust(10) for v in VAR.values()))
 for (Mo, NJ, R) in shapes:
     dy = torch.randn(R, Mo, device=dev); x = torch.randn(R, NJ, device=dev); out = torch.zeros(Mo, NJ, device=dev); cs = torch.zeros(Mo, device=dev)
     ref = dy.t() @ x
-    for total in (256, 384, 512, 768):
+    for total in (152, 256, 512, 768):
         line = f"{Mo}x{NJ}x{R}".ljust(18) + f"{total:5d}  "
         for t in VAR:
             bm, bn = TSZ.get(t, (64, 64))
             nb = ((Mo + bm - 1) // bm) * ((NJ + bn - 1) // bn)
-            splits = max(1, min((total + nb - 1) // nb, (R + 255) // 256))
+            splits = max(1, min((total + nb - 1) // nb, (R + 127) // 128))
             best = 1e9
             rc = 0
             for rep in range(4):
@@ -40,7 +41,8 @@ for (Mo, NJ, R) in shapes:
             if rc:
                 line += f"   rc={rc:4d}"
                 continue
-            err = float((out - ref).abs().max() / ref.abs().max())
-            assert err < 1e-4, (t, err)
+            if t < 100:
+                err = float((out - ref).abs().max() / ref.abs().max())
+                assert err < 1e-4, (t, err)
             line += f" {best:8.1f}us"
         print(line)
