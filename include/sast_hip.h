@@ -39,6 +39,14 @@ int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t
 int sast_nzratio_padded(const void* x, int dtype, int B, int Cin, int H, int W, int Hp, int Wp, int32_t* cnt_ws, float* r,
                         sast_stream_t stream);
 
+/* the whole input side in ONE launch (modules/detection.py:143-144 pad + cast, sast_rnn.py:45-60 non_zero_ratio,
+ * sast_rnn.py:153 / ops.py:19-24 float + NCHW->NHWC): x (B,C,H,W) of `dtype`, possibly smaller than the padded size (Hp,Wp) it stands
+ * for (zeros at the bottom / right), is read ONCE -> r fp32 (B,4,C) and y fp32 (B,Hp,Wp,C).  H,W multiples of 4; Hp,Wp multiples of
+ * 32 with (Hp/32)*(Wp/32) even; C = 20 (the stacked-histogram representation: 2 polarities x 10 time bins).  ws: int32[B*4*C + 1], ZERO on entry and left zero on exit (the last
+ * workgroup finishes the ratios and clears it), so a caller allocates and clears it once. */
+int sast_input_prep(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, float* y,
+                    sast_stream_t stream);
+
 /* layout changes at the NCHW API boundary (reference: ops.py:19-30 nChw_2_nhwC / nhwC_2_nChw, x.float() sast_rnn.py:153) */
 int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream);
 /* cast + layout change + zero padding to Hp x Wp in one pass: y[B, Hp, Wp, C] */

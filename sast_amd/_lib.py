@@ -74,6 +74,7 @@ _SIGNATURES = {
     "sast_nzratio_padded": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
     "sast_nchw_to_nhwc_padded": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_nhwc_to_nchw": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    "sast_input_prep": (C.c_int, [P] + [C.c_int] * 7 + [P, P, P, P]),
     "sast_add_rows": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_mean_square_fwd": (C.c_int, [P, P, C.c_int, P, P]),
     "sast_mean_square_bwd": (C.c_int, [P, P, C.c_int, P, C.c_int, P, P]),

@@ -134,6 +134,138 @@ int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int
   }
 }
 
+// ============================================================ input side in ONE launch
+// non_zero_ratio + x.float() + zero padding + NCHW -> NHWC of the event tensor: x (uint8 / int32 / fp32, NCHW, possibly unpadded) is
+// read exactly once.  One wave = one 32 x 32 pixel tile, lane = one 4 x 4 pixel cell (cy = lane / 8, cx = lane % 8).  For each of the
+// cell's four rows the wave reads 8 image rows x 32 px of every channel (coalesced 128-byte row segments), keeps the running cell
+// maximum per channel in registers and transposes the values through a wave-private LDS tile [8 rows][32 px][C], from which whole
+// NHWC row segments (32 px x C floats, contiguous) are written back -- a first version that stored 16-byte (pixel, channel-quad)
+// pieces straight from registers took 170 us on 1Mpx B=4 (64 cache lines per store instruction) against 67 us for the separate
+// kernels.  The four pooling levels of non_zero_ratio (max-pool 4 / 8 / 16 / 32 != 0, sast_rnn.py:45-60) are xor-shuffle maxima over
+// the lanes of the wave.  Counts: wave -> LDS -> one atomic per (level, channel) and workgroup; the LAST workgroup (ticket) turns the
+// counts into ratios and clears counters and ticket again, so the scratch stays zero between calls.
+constexpr int PREP_WAVES = 2;
+template <typename T, int C>
+__global__ __launch_bounds__(64 * PREP_WAVES) void input_prep_kernel(const T* __restrict__ x, float* __restrict__ y, int* __restrict__ ws,
+                                                                     float* __restrict__ r, int B, int H, int W, int Hp, int Wp,
+                                                                     float s0, float s1, float s2, float s3) {
+  __shared__ __attribute__((aligned(16))) float tile_s[PREP_WAVES][8 * 32 * C];
+  __shared__ int cnt_s[4 * C];
+  __shared__ int last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 4 * C; i += 64 * PREP_WAVES) cnt_s[i] = 0;
+  const int tiles_x = Wp / 32, tiles_y = Hp / 32;
+  const int tile = blockIdx.x * PREP_WAVES + wave;        // over B * tiles_y * tiles_x
+  const bool live = tile < B * tiles_y * tiles_x;
+  const int tt = live ? tile : 0;
+  const int tx = tt % tiles_x, ty = (tt / tiles_x) % tiles_y, b = tt / (tiles_x * tiles_y);
+  const int cy = lane >> 3, cx = lane & 7;
+  const int y0 = ty * 32 + cy * 4, x0 = tx * 32 + cx * 4;
+  const bool inside = live && y0 < H && x0 < W;  // H, W are multiples of 4: a cell is inside or in the zero padding as a whole
+  struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
+  float* tl = tile_s[wave];
+  float m[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) m[c] = -INFINITY;
+  // all C row segments of a row set are requested before any is used (C x 1 KB in flight per wave), and the next row set is
+  // requested before the current one is written out: with < 4 waves per CU the kernel is otherwise bound by load latency
+  Vec4 q[C];
+  auto request = [&](int rr) {
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+      q[c] = *reinterpret_cast<const Vec4*>(x + (((size_t)b * C + c) * H + (inside ? y0 + rr : 0)) * W + (inside ? x0 : 0));
+  };
+  request(0);
+  for (int rr = 0; rr < 4; ++rr) {
+    __syncthreads();                             // the previous row set has been written out
+#pragma unroll
+    for (int c0 = 0; c0 < C; c0 += 4) {
+      float v[4][4];
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          v[ch][px] = inside ? (float)q[c0 + ch].v[px] : 0.f;
+          m[c0 + ch] = fmaxf(m[c0 + ch], v[ch][px]);
+        }
+#pragma unroll
+      for (int px = 0; px < 4; ++px) st4(tl + ((cy * 32 + cx * 4 + px) * C + c0), make_float4(v[0][px], v[1][px], v[2][px], v[3][px]));
+    }
+    if (rr < 3) request(rr + 1);
+    __syncthreads();
+    if (live) {
+      constexpr int ROW4 = 32 * C / 4;           // float4 per 32-pixel row segment
+      for (int i = lane; i < 8 * ROW4; i += 64) {
+        const int row = i / ROW4, off = i - row * ROW4;
+        st4(y + (((size_t)b * Hp + ty * 32 + row * 4 + rr) * Wp + tx * 32) * C + 4 * off, ld4(tl + row * 32 * C + 4 * off));
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float mc = m[c];
+    // level 1: this cell; levels 2..4: max over the 2x2 / 4x4 / 8x8 cell neighbourhoods (lane bits 0,3 / 1,4 / 2,5)
+    const unsigned long long b1 = __ballot(inside && mc != 0.f);
+    float m2 = fmaxf(mc, __shfl_xor(mc, 1, 64));  m2 = fmaxf(m2, __shfl_xor(m2, 8, 64));
+    float m3 = fmaxf(m2, __shfl_xor(m2, 2, 64)); m3 = fmaxf(m3, __shfl_xor(m3, 16, 64));
+    float m4 = fmaxf(m3, __shfl_xor(m3, 4, 64)); m4 = fmaxf(m4, __shfl_xor(m4, 32, 64));
+    // a pooled cell counts once (its top-left lane); cells in the zero padding have maximum 0
+    const unsigned long long b2 = __ballot(!(lane & 9) && inside && m2 != 0.f);
+    const unsigned long long b3 = __ballot(!(lane & 27) && inside && m3 != 0.f);
+    const unsigned long long b4 = __ballot(lane == 0 && inside && m4 != 0.f);
+    if (lane == 0) {
+      if (b1) atomicAdd(&cnt_s[0 * C + c], __popcll(b1));
+      if (b2) atomicAdd(&cnt_s[1 * C + c], __popcll(b2));
+      if (b3) atomicAdd(&cnt_s[2 * C + c], __popcll(b3));
+      if (b4) atomicAdd(&cnt_s[3 * C + c], __popcll(b4));
+    }
+  }
+  __syncthreads();
+  const int b_blk = (blockIdx.x * PREP_WAVES) / (tiles_x * tiles_y);   // the tiles of a workgroup belong to one sample (host check)
+  int* cnt = ws;                                                      // [B][4][C]
+  if (b_blk < B)
+    for (int i = threadIdx.x; i < 4 * C; i += 64 * PREP_WAVES) if (cnt_s[i]) atomicAdd(cnt + (size_t)b_blk * 4 * C + i, cnt_s[i]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(ws + B * 4 * C, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (last) {
+    __threadfence();
+    for (int i = threadIdx.x; i < B * 4 * C; i += 64 * PREP_WAVES) {
+      const int lvl = (i / C) & 3;
+      const int n = __hip_atomic_load(cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r[i] = (lvl == 0 ? s0 : lvl == 1 ? s1 : lvl == 2 ? s2 : s3) * (float)n;   // fp32(B/numel) * fp32(count), as the reference's scalar*tensor
+      cnt[i] = 0;
+    }
+    if (threadIdx.x == 0) ws[B * 4 * C] = 0;
+  }
+}
+
+template <typename T>
+int input_prep_launch(const void* x, float* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
+  if (C != 20) return SAST_EINVAL;               // the stacked-histogram representation of the path: 2 polarities x 10 bins
+  const int tiles = B * (Hp / 32) * (Wp / 32);
+  float s[4];
+  int f = 4;
+  for (int l = 0; l < 4; ++l) {
+    const double numel = (double)B * C * (Hp / f) * (Wp / f);
+    s[l] = (float)((double)B / numel);
+    f *= 2;
+  }
+  hipLaunchKernelGGL((input_prep_kernel<T, 20>), dim3((tiles + PREP_WAVES - 1) / PREP_WAVES), dim3(64 * PREP_WAVES), 0, st, (const T*)x, y, ws, r,
+                     B, H, W, Hp, Wp, s[0], s[1], s[2], s[3]);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+int input_prep_dispatch(const void* x, int dtype, float* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
+  switch (dtype) {
+    case SAST_DT_F32: return input_prep_launch<float>(x, y, ws, r, B, C, H, W, Hp, Wp, st);
+    case SAST_DT_I32: return input_prep_launch<int>(x, y, ws, r, B, C, H, W, Hp, Wp, st);
+    case SAST_DT_U8:  return input_prep_launch<unsigned char>(x, y, ws, r, B, C, H, W, Hp, Wp, st);
+    default: return SAST_EINVAL;
+  }
+}
+
 // ============================================================ NCHW (any dtype) -> NHWC fp32
 template <typename T>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int H, int W, int Hp,

@@ -117,6 +117,33 @@ def nchw_to_nhwc_float(x: torch.Tensor, pad_hw=None) -> torch.Tensor:
     return y
 
 
+_PREP_WS = {}
+
+
+@torch.no_grad()
+def input_prep(x: torch.Tensor, pad_hw=None):
+    """non_zero_ratio (sast_rnn.py:45-60) + x.float() + zero padding to pad_hw (utils/padding.py:29-53) + NCHW->NHWC (ops.py:19-24)
+    in ONE launch that reads the event tensor once -> (r (B,4,C) fp32, x_nhwc (B,Hp,Wp,C) fp32).  Falls back to the two separate
+    launches for shapes the fused kernel does not cover (padded sizes that are not multiples of 32, channel counts other than 20)."""
+    _need_gpu(x)
+    if x.dtype not in _DT:
+        x = x.float()
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    Hp, Wp = (int(pad_hw[0]), int(pad_hw[1])) if pad_hw is not None else (H, W)
+    if H % 4 or W % 4 or Hp % 32 or Wp % 32 or Cc != 20 or ((Hp // 32) * (Wp // 32)) % 2 or Hp < H or Wp < W:
+        pad = (Hp, Wp) if (Hp, Wp) != (H, W) else None
+        return non_zero_ratio(x, pad), nchw_to_nhwc_float(x, pad)
+    key = (x.device, B, Cc)
+    ws = _PREP_WS.get(key)
+    if ws is None:      # zero on entry, zero on exit: cleared once, the kernel's last workgroup leaves it clean
+        ws = _PREP_WS[key] = torch.zeros(B * 4 * Cc + 1, device=x.device, dtype=torch.int32)
+    r = torch.empty(B, 4, Cc, device=x.device, dtype=torch.float32)
+    y = torch.empty(B, Hp, Wp, Cc, device=x.device, dtype=torch.float32)
+    L.check(L.lib().sast_input_prep(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, Hp, Wp, ws.data_ptr(), r.data_ptr(), y.data_ptr(), _stream()), "input_prep")
+    return r, y
+
+
 def as_nhwc(x: torch.Tensor) -> torch.Tensor:
     """(B,C,H,W) logical NCHW -> (B,H,W,C) contiguous; zero-copy when x is already channels-last in memory."""
     v = x.permute(0, 2, 3, 1)

@@ -116,6 +116,35 @@ def test_non_zero_ratio(golden_dir, dev):
         assert torch.equal(SF.non_zero_ratio(xx.to(dev)).cpu(), ref)
 
 
+def test_input_prep_one_launch(golden_dir, dev):
+    """sast_input_prep: non_zero_ratio + cast + zero padding + NCHW->NHWC in one launch == the separate ops == the oracle, for the
+    three input dtypes, padded and unpadded, count-valued and binary events, negative floats (max-pool semantics), twice in a
+    row (the self-cleaning scratch) -- ratios and layout bit-exact."""
+    from sast_amd import functional as SF
+    cases = [(O.count_events(2, (384, 640), seed=5, density=0.01), None),
+             (O.count_events(3, (360, 640), seed=6, density=0.02), (384, 640)),          # 1Mpx as stored (unpadded) -> padded
+             (O.synthetic_events(4, (256, 320), seed=7, sparsity=0.97), None),
+             (O.count_events(2, (240, 304), seed=8, density=0.03), (256, 320))]          # Gen1 as stored
+    for x, pad in cases:
+        xp = x if pad is None else torch.nn.functional.pad(x, (0, pad[1] - x.shape[-1], 0, pad[0] - x.shape[-2]))
+        ref_r = O.non_zero_ratio(xp)
+        ref_y = xp.float().permute(0, 2, 3, 1).contiguous()
+        variants = [x, x.int(), x.float()]
+        if pad is None:
+            neg = x.float()
+            neg[:, ::2] *= -1.0                      # negative values: a window of negatives and zeros pools to 0 only with a zero in it
+            variants.append(neg)
+        for xx in variants:
+            xq = xx if pad is None else torch.nn.functional.pad(xx, (0, pad[1] - xx.shape[-1], 0, pad[0] - xx.shape[-2]))
+            want_r, want_y = O.non_zero_ratio(xq), xq.float().permute(0, 2, 3, 1).contiguous()
+            for _rep in range(2):
+                r, y = SF.input_prep(xx.to(dev), pad)
+                assert torch.equal(r.cpu(), want_r), (xx.dtype, pad)
+                assert torch.equal(y.cpu(), want_y), (xx.dtype, pad)
+            assert torch.equal(SF.non_zero_ratio(xx.to(dev), pad).cpu(), want_r)
+    assert ref_r.shape[1:] == (4, 20) and ref_y.shape[-1] == 20
+
+
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
                                   "block_large_c96"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
