@@ -349,6 +349,8 @@ def main():
                                     if args.loss == "yolox" else " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
+                       "gemm_arithmetic": ("fp32 products on the bf16 MFMA pipe: exact 3-way bf16 operand split, 6 MFMAs per product tile, fp32 accumulate"
+                                           if __import__("sast_amd._lib", fromlist=["lib"]).lib().sast_mfma_split3() else "v_mfma_f32_32x32x2_f32"),
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),

@@ -30,6 +30,9 @@ typedef void* sast_stream_t; /* hipStream_t */
 enum { SAST_DT_F32 = 0, SAST_DT_I32 = 1, SAST_DT_U8 = 2 };
 
 int sast_version(void);
+/* 1: the GEMM template evaluates fp32 products as six bf16 MFMAs on an exact three-way operand split (default build);
+ * 0: v_mfma_f32_32x32x2_f32 (-DSAST_MFMA_SPLIT3=0) */
+int sast_mfma_split3(void);
 
 /* a1  non_zero_ratio -- models/detection/recurrent_backbone/sast_rnn.py:45-60.
  * x: (B,Cin,H,W) NCHW of `dtype`; cnt_ws: int32[B*4*Cin] scratch; r: fp32 (B,4,Cin). H,W multiples of 32. */

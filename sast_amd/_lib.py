@@ -69,6 +69,7 @@ SastSampleMask = _struct("SastSampleMask", [(C.c_uint8 * 256, "sel")])
 
 _SIGNATURES = {
     "sast_version": (C.c_int, []),
+    "sast_mfma_split3": (C.c_int, []),
     "sast_nzratio": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
     "sast_nchw_to_nhwc": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_nzratio_padded": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),

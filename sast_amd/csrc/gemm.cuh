@@ -1,9 +1,11 @@
-// fp32 tiled GEMM on the CDNA4 f32-input matrix cores (v_mfma_f32_32x32x2_f32).
+// fp32 tiled GEMM on the CDNA4 matrix cores.
 //
 //   D[m][j,g] = sum_r A(m, r) * B(j, g, r)          m < M, j < NJ, g < G, r < R
 //
-// * exact fp32 (the MFMA is bit-identical to an fmaf chain) -- required because the
-//   block output feeds the next stage's index-exact token selection.
+// * fp32 in, fp32 out, fp32-accurate products -- required because the block output feeds the next stage's index-exact
+//   token selection.  Default (SAST_MFMA_SPLIT3=1): every operand is split exactly into three bf16 terms and a
+//   product is six v_mfma_f32_32x32x16_bf16 with fp32 accumulation (error <= 2^-23 |x||y| per product, one fp32 rounding; 2.7x
+//   the MFMA rate of the f32-input instruction); -DSAST_MFMA_SPLIT3=0 selects v_mfma_f32_32x32x2_f32 (bit-identical to an fmaf chain).
 // * operands come through LOADER functors, so the same kernel serves linear layers,
 //   implicit-GEMM convolutions (im2col / backward-data gathers on NHWC), row gathers
 //   of the compacted token list, dual-source rows ([x|h] of the ConvLSTM) and the
@@ -57,11 +59,40 @@ static __device__ unsigned long long sast_tl_buf[8 * 8192];
 namespace sast {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// exact three-way bf16 split of 8 fp32 values (one lane's k-values of a k-tile): x = h + m + l with every term a bf16 (the top 8,
+// middle 8 and bottom 8 significand bits; truncation, so the residuals are exact), packed as the 8-element operands of
+// v_mfma_f32_32x32x16_bf16 (element j in bits [16j, 16j+16))
+struct Split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = __float_as_uint(x[i]) & 0xffff0000u;
+    const float r1 = x[i] - __uint_as_float(h[i]);
+    m[i] = __float_as_uint(r1) & 0xffff0000u;
+    l[i] = __float_as_uint(r1 - __uint_as_float(m[i]));      // <= 8 significant bits left: its high half IS the bf16
+  }
+  u32x4 ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {      // (hi16 of element 2i+1) << 16 | hi16 of element 2i
+    ph[i] = __builtin_amdgcn_perm(h[2 * i + 1], h[2 * i], 0x07060302u);
+    pm[i] = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], 0x07060302u);
+    pl[i] = __builtin_amdgcn_perm(l[2 * i + 1], l[2 * i], 0x07060302u);
+  }
+  return Split3{__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl)};
+}
 
 // PF: k-tiles kept in flight in registers per k-group (global-load latency under load is ~2-3 us on MI355X, one k-tile of
 // MFMA work is ~0.2-0.4 us: see tools/gemm_timeline.py).  Must be even (LDS is double-buffered).
 #ifndef SAST_PF_DEFAULT
 #define SAST_PF_DEFAULT 2
+#endif
+// 1: fp32 products on the bf16 matrix pipe through an exact three-way operand split (gemm_body::compute); 0: v_mfma_f32_32x32x2_f32
+#ifndef SAST_MFMA_SPLIT3
+#define SAST_MFMA_SPLIT3 1
 #endif
 // independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
 #ifndef SAST_SINGLE_TILE_ACCS
@@ -318,13 +349,40 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
         for (int ks = 0; ks < HK; ++ks) csum[t] += a[t][ks];
     }
+    if constexpr (SAST_MFMA_SPLIT3 && HK == 8) {
+      // fp32 x fp32 on the bf16 matrix pipe: every operand is split EXACTLY into three bf16 terms, x = h + m + l (8 + 8 + 8
+      // significand bits by truncation; the residuals x - h and x - h - m are exact in fp32), and the product is evaluated as the six
+      // terms hh + hm + mh + mm + hl + lh with fp32 accumulation; the dropped terms ml + lm + ll are <= 2^-23 |x||y|, the size of one
+      // fp32 rounding of the product.  A lane's 8 k-values of a k-tile are exactly one v_mfma_f32_32x32x16_bf16 operand (k = 8 *
+      // (lane / 32) + j), so the loaders, the LDS layouts and the operand reads are those of the fp32 path; 6 MFMAs of 32 cycles
+      // replace 8 of 64 per 32 x 32 x 16 tile step, at the price of ~90 VALU operations per lane for the split.
+      Split3 sa[T::TM], sb[T::TN];
 #pragma unroll
-    for (int ks = 0; ks < HK; ++ks)
+      for (int t = 0; t < T::TM; ++t) sa[t] = split3(a[t]);
+#pragma unroll
+      for (int t = 0; t < T::TN; ++t) sb[t] = split3(b[t]);
 #pragma unroll
       for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
-        for (int tb = 0; tb < T::TN; ++tb)
-          accs[ks % NACC][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][ks], b[tb][ks], accs[ks % NACC][ta][tb], 0, 0, 0);
+        for (int tb = 0; tb < T::TN; ++tb) {
+          f32x16 c = accs[0][ta][tb];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].l, sb[tb].h, c, 0, 0, 0);     // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].h, sb[tb].l, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].m, sb[tb].m, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].m, sb[tb].h, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].h, sb[tb].m, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].h, sb[tb].h, c, 0, 0, 0);
+          accs[0][ta][tb] = c;
+        }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < HK; ++ks)
+#pragma unroll
+        for (int ta = 0; ta < T::TM; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < T::TN; ++tb)
+            accs[ks % NACC][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta][ks], b[tb][ks], accs[ks % NACC][ta][tb], 0, 0, 0);
+    }
   };
 
   // software pipeline: this k-group owns tiles kt0 + kg + KS*i.  At phase p the LDS buffer p%2 holds tile p, register set

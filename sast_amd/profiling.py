@@ -15,7 +15,9 @@ import os
 
 from . import _lib as L
 
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3          # 256 CUs x 4 SIMDs x 64 flop/cycle x 2.4 GHz (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2516.6        # 256 CUs x 4 SIMDs x 1024 flop/cycle x 2.4 GHz (v_mfma_f32_32x32x16_bf16), dense
+SPLIT3_PRODUCTS = 6                   # bf16 MFMAs per fp32 product tile in the default build (gemm.cuh: split3)
 _PMC_SUMMARY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_hbm_traffic_latest.json")
 
 
@@ -131,7 +133,16 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
     total_ms = sum(r[2] for r in rows)
     total_fl = sum(r[3] for r in rows)
     stamp = pmc_summary_stamp()
-    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+    split3 = bool(L.lib().sast_mfma_split3())
+    pipe = {}
+    if split3:
+        # the default build executes an fp32 product tile as 6 bf16 MFMAs on an exact 3-way operand split: the contract's `peak`
+        # stays the dense MFMA peak of the dtype the path computes in (f32: 157.3), the bound of the pipe actually used is given too
+        eff = PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS
+        pipe = {"executed_as": "fp32 operands split exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate "
+                               "(error <= 2^-23 |x||y| per product); SAST_MFMA_SPLIT3=0 builds the v_mfma_f32_32x32x2_f32 form",
+                "peak_of_executed_pipe": eff, "frac_of_executed_pipe": achieved / eff}
+    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", **pipe,
             "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
             "profiles/pmc_hbm_traffic_latest.json)", "traffic_profile_csrc_sha": stamp, "traffic_stale": stamp != csrc_sha(), "kernel": name,
             "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,

@@ -10,8 +10,8 @@ FAM = [("GEMM template (all linears, convs, dW/dX pairs)", r"gemm_kernel|gemm_du
        ("LayerNorm / STP / gather rows", r"ln_|ln1_|stp_"),
        ("selection (scores -> keep masks -> compaction)", r"select_"),
        ("ConvLSTM pointwise backward", r"lstm_"),
-       ("input: non_zero_ratio, NCHW->NHWC", r"nzr_|nchw_"),
-       ("upsample+concat, slices", r"upsample|slice_copy"),
+       ("input: non_zero_ratio + cast + pad + NCHW->NHWC", r"nzr_|nchw_|input_prep"),
+       ("upsample+concat, slices, sample gather", r"upsample|slice_copy|gather_samples|scatter_samples|zero_samples"),
        ("AdamW + gradient clear", r"adamw|FillFunctor"),
        ("objective + remaining ATen", r"mean_square|at::|reduce_kernel|multi_tensor|zero_fill")]
 t = collections.OrderedDict((n, [0, 0.0, 0.0]) for n, _ in FAM)

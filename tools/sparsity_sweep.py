@@ -4,7 +4,7 @@ One bench line per AMP, plus (--pmc) the whole-step HBM traffic from two rocprof
 import glob, json, os, sqlite3, subprocess, sys
 
 PEAK_TF, PEAK_HBM = 157.3, 8000.0
-PMC_STEPS, PMC_WARM = 3, 1          # eager steps under the counters; + 2 un-graphed steps bench.py runs before timing
+PMC_STEPS, PMC_WARM = 3, 1          # eager steps under the counters; + 3 un-graphed fwd+bwd passes bench.py runs before timing
 amps = (2e-4, 2e-3, 2e-2, 0.2, 1.0, 5.0)
 do_pmc = "--pmc" in sys.argv
 os.makedirs("gpurun_out/sweep", exist_ok=True)
@@ -46,7 +46,7 @@ for amp in amps:
     if do_pmc:
         f, w = pmc_total_kb(amp, "FETCH_SIZE"), pmc_total_kb(amp, "WRITE_SIZE")
         if f is not None and w is not None:
-            steps = PMC_STEPS + PMC_WARM + 2
+            steps = PMC_STEPS + PMC_WARM + 3
             hbm = (2.0 * f + w) * 1024.0 / steps
             d["sweep"].update({"hbm_bytes_per_step": hbm, "hbm_gbps": hbm / (d["ms_per_step"] * 1e-3) / 1e9,
                                "hbm_frac_of_8TBps": hbm / (d["ms_per_step"] * 1e-3) / 1e9 / PEAK_HBM,
