@@ -59,7 +59,7 @@ inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
 // weight-gradient form: out[Mo, NJ] += A^T B over R rows (dR: device-side count), optional column sums of A (bias gradient)
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
-  return launch_gemm_split<TileSmallK2>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, tn_splits(Mo, NJ, R), colsum, st);
+  return launch_gemm_split<TileSplitR>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, tn_splits(Mo, NJ, R), colsum, st);
 }
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, hipStream_t st) {
@@ -84,19 +84,19 @@ int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1
   const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
   const int splits = tn_splits(Mo, NJ1, R1, gemm_pair_enabled() ? (tn_target > 0 ? tn_target : pair_tn_blocks_paired()) : 0);
   if (!gemm_pair_enabled() || Mo <= 0 || NJ1 <= 0 || R1 <= 0 || M2 <= 0 || NJ2 <= 0 || R2 <= 0) {
-    int rc = launch_gemm_split<TileSmallK2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);
+    int rc = launch_gemm_split<TileSplitR>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);
     if (rc) return rc;
     if (thin) return launch_gemm<TileThinK4>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
     if (k2) return launch_gemm<TileSmallK2>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
     return launch_gemm<TileSmall>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
   }
   if (thin)
-    return launch_gemm_dual<TileSmallK2, LA1, LB1, EP1, TileThinK4, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+    return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileThinK4, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                       ep2, M2, NJ2, R2, dM2, st);
   if (k2)
-    return launch_gemm_dual<TileSmallK2, LA1, LB1, EP1, TileSmallK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+    return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileSmallK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                        ep2, M2, NJ2, R2, dM2, st);
-  return launch_gemm_dual<TileSmallK2, LA1, LB1, EP1, TileSmall, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
+  return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileSmall, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
                                                                                    M2, NJ2, R2, dM2, st);
 }
 

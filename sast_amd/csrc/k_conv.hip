@@ -623,7 +623,7 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
   if (a->ksize == 3) {   // two 3x3 stride-1 convs (the first convs of the two YOLOX head towers)
     const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx);
     const LdIm2colT tbc{a->x, g};
-    if (!a->dx) return launch_gemm_split<TileSmallK2>(ta, tbc, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
+    if (!a->dx) return launch_gemm_split<TileSplitR>(ta, tbc, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
     const unsigned shift = div_mul_of((unsigned)(2 * C), 9ull * 2 * C);
     if (!shift || !g.cin_mul) return SAST_EINVAL;
     const LdConvDx lac{dconv, g, 2 * C, 2 * C, shift};
@@ -637,7 +637,7 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
                         pair_tn_blocks_conv());
   }
   const LdRowsT2 tb{a->x, a->ldx, a->Cin1, C2 > 0 ? a->x2 : nullptr, a->ldx2};
-  if (!a->dx) return launch_gemm_split<TileSmallK2>(ta, tb, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
+  if (!a->dx) return launch_gemm_split<TileSplitR>(ta, tb, ep1, 2 * C, K, M, nullptr, tn_splits(2 * C, K, M), nullptr, st);
   if (C2 > 0 && !a->dx2) return SAST_EINVAL;
   const LdRows la{dconv, 2 * C, nullptr};
   const LdWeightNN2 lb{a->w0, a->w1, K, C};

@@ -105,6 +105,11 @@ extern "C" int sast_test_gemm_tn(const float* dy, const float* x, float* out, fl
     }
   }
   const EpAtomicT ep{out, NJ};
+  if (tile == 50) return launch_gemm_split<Tile<64, 64, 2, 1, 1, 16, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // wave tile 32x64, 2 k-groups, 4 waves
+  if (tile == 51) return launch_gemm_split<Tile<64, 64, 2, 1, 1, 16, 4>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // wave tile 32x64, 4 k-groups, 8 waves
+  if (tile == 52) return launch_gemm_split<Tile<64, 64, 1, 2, 1, 16, 4>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // wave tile 64x32, 4 k-groups
+  if (tile == 53) return launch_gemm_split<Tile<64, 64, 1, 1, 1, 16, 4>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // wave tile 64x64, 4 k-groups, 4 waves
+  if (tile == 54) return launch_gemm_split<Tile<64, 64, 1, 1, 1, 16, 8>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // wave tile 64x64, 8 k-groups, 8 waves
   if (tile == 40) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 32, 2>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // BK = 32
   if (tile == 41) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 32, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);
   if (tile == 42) return launch_gemm_split<Tile<64, 64, 2, 2, 1, 64, 1>>(la, lb, ep, Mo, NJ, R, nullptr, splits, colsum, st);   // BK = 64

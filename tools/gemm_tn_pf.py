@@ -9,7 +9,7 @@ tn = lib.sast_test_gemm_tn; tn.restype = C.c_int; tn.argtypes = [C.c_void_p] * 4
 tl = lib.sast_test_timeline; tl.restype = C.c_int; tl.argtypes = [C.c_void_p, C.c_int]
 tlr = lib.sast_test_timeline_reset; tlr.restype = C.c_int; tlr.argtypes = []
 dev = torch.device("cuda:0"); st = torch.cuda.current_stream().cuda_stream
-VAR = {1: "K2 bk16", 40: "K2 bk32", 43: "K2 bk64", 0: "K1 bk16", 41: "K1 bk32", 42: "K1 bk64", 100: "K2 noload", 33: "128x128"}
+VAR = {1: "K2 2x2w", 0: "K1 2x2w", 50: "K2 32x64w", 51: "K4 32x64w", 52: "K4 64x32w", 53: "K4 64x64w", 54: "K8 64x64w", 30: "128x64"}
 TSZ_EXTRA = {33: (128, 128)}
 TSZ = {30: (128, 64), 35: (128, 64), 36: (128, 64), 32: (64, 128), 33: (128, 128), 34: (192, 64)}
 def span(nblocks):
