@@ -272,11 +272,16 @@ def main():
     ap.add_argument("--no-segmented", dest="segmented", action="store_false")
     ap.add_argument("--label-every", type=int, default=0, help="with --loss yolox and --seq-len L: labels on the samples b of timestep t with "
                     "(t + b) %% k == 0 (and on all of the last timestep); their features are gathered into one head call (label-sparse step)")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32", help="f32: the product path (BASELINE metric).  bf16: the separately "
+                    "built reduced-precision library (GEMM operands rounded to bf16, fp32 accumulate; the arithmetic class of the reference's AMP-16 "
+                    "experiments) -- reported as a different metric, index decisions differ from the fp32 reference's")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     BATCH = args.batch
+    if args.precision == "bf16":       # before anything imports sast_amd._lib
+        os.environ["SAST_LIB_PATH"] = os.path.join(ROOT, "sast_amd", "libsast_hip_bf16.so")
     if args.res == "gen1":
         HW, PART = (256, 320), (8, 10)
 
@@ -331,17 +336,19 @@ def main():
         kept = [int(p) for p in tr.P]
         L = [(HW[0] // s) * (HW[1] // s) for s in (4, 8, 16, 32)]
         # BASELINE.json's metric string only for BASELINE's configuration (configs[2], and [3] for N > 1); any other run is labelled
-        baseline_cfg = args.res == "1mpx" and BATCH == 4 and args.seq_len == 1 and not (args.fwd_only or args.infer) and args.loss == "proxy"
+        baseline_cfg = (args.res == "1mpx" and BATCH == 4 and args.seq_len == 1 and not (args.fwd_only or args.infer) and args.loss == "proxy"
+                        and args.precision == "f32")
         metric = "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360" if baseline_cfg else (
             f"frames/sec (B={BATCH}) SAST " + ("backbone+PAFPN+head inference" if args.infer else "backbone fwd" if args.fwd_only else
                                                "backbone+PAFPN+YOLOX-loss fwd+bwd" if args.loss == "yolox" else "backbone fwd+bwd") +
             (", 1Mpx 640x360" if args.res == "1mpx" else ", Gen1 304x240") + (f", {args.seq_len} timesteps BPTT" if args.seq_len > 1 else "") +
+            (", bf16 GEMM operands (reduced-precision library)" if args.precision == "bf16" else "") +
             " [not the BASELINE.json metric configuration]")
         res = {
             "metric": metric, "baseline_metric": baseline_cfg,
             "value": BATCH * args.seq_len * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 operands / f32 accumulate", "data": "synthetic",
             "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
                                    (" full SAST backbone + PAFPN + YOLOX head (3 classes), eval forward -> decoded predictions, " if args.infer else
                                     " full SAST backbone, forward only (benchmark.py protocol), " if args.fwd_only else
@@ -349,8 +356,9 @@ def main():
                                     if args.loss == "yolox" else " full SAST backbone + PAFPN, fwd+bwd + AdamW, ") +
                                    f"B={BATCH}/GPU, binary events (rand>{SPARSITY}), random-init, AMP={args.amp}",
                        "global_batch": BATCH * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "hipgraph": bool(graphed),
-                       "gemm_arithmetic": ("fp32 products on the bf16 MFMA pipe: exact 3-way bf16 operand split, 6 MFMAs per product tile, fp32 accumulate"
-                                           if __import__("sast_amd._lib", fromlist=["lib"]).lib().sast_mfma_split3() else "v_mfma_f32_32x32x2_f32"),
+                       "gemm_arithmetic": {1: "fp32 products on the bf16 MFMA pipe: exact 3-way bf16 operand split, 6 MFMAs per product tile, fp32 accumulate",
+                                           0: "v_mfma_f32_32x32x2_f32", 2: "operands rounded to bf16, one bf16 MFMA per tile step, fp32 accumulate (reduced precision)"}[
+                                               __import__("sast_amd._lib", fromlist=["lib"]).lib().sast_mfma_split3()],
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
@@ -359,7 +367,7 @@ def main():
         if not args.no_roofline:
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr)
-        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy":
+        if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy" and args.precision == "f32":
             parity, res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only, tr=tr)
             if parity is not None:
                 res["parity"] = parity

@@ -31,7 +31,8 @@ enum { SAST_DT_F32 = 0, SAST_DT_I32 = 1, SAST_DT_U8 = 2 };
 
 int sast_version(void);
 /* 1: the GEMM template evaluates fp32 products as six bf16 MFMAs on an exact three-way operand split (default build);
- * 0: v_mfma_f32_32x32x2_f32 (-DSAST_MFMA_SPLIT3=0) */
+ * 0: v_mfma_f32_32x32x2_f32 (-DSAST_MFMA_SPLIT3=0); 2: the reduced-precision library libsast_hip_bf16.so (-DSAST_MFMA_BF16=1: operands
+ * rounded to bf16, one MFMA per tile step, fp32 accumulate -- `bench.py --precision bf16`, never part of an fp32 parity claim) */
 int sast_mfma_split3(void);
 
 /* a1  non_zero_ratio -- models/detection/recurrent_backbone/sast_rnn.py:45-60.

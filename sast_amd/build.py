@@ -15,6 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libsast_hip.so")
 TOOLS_LIB = os.path.join(HERE, "libsast_hip_tools.so")
+BF16_LIB = os.path.join(HERE, "libsast_hip_bf16.so")
 ARCH = "gfx950"
 SOURCES = ["k_rows.hip", "k_select.hip", "k_attn.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_head.hip"]
 TOOLS_SOURCES = ["k_test.hip"]
@@ -62,16 +63,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
     _link(objs[:len(SOURCES)], LIB, force)
     _link(objs[len(SOURCES):], TOOLS_LIB, force or os.path.getmtime(TOOLS_LIB) < os.path.getmtime(LIB) if os.path.exists(TOOLS_LIB) else True,
           extra=["-L" + HERE, "-lsast_hip", "-Wl,-rpath,$ORIGIN"])
+    # the reduced-precision variant of the product library (bf16 GEMM operands, `bench.py --precision bf16`): same sources, one flag
+    if os.environ.get("SAST_BUILD_BF16", "1") != "0":
+        stale = force or not os.path.exists(BF16_LIB) or os.path.getmtime(BF16_LIB) < os.path.getmtime(LIB)
+        if stale:
+            build_variant(BF16_LIB, ["-DSAST_MFMA_BF16=1"], obj_dir=os.path.join(OBJ, "bf16"))
     if verbose:
         print("built", LIB, "and", TOOLS_LIB)
     return LIB
 
 
-def build_variant(out: str, flags) -> str:
+def build_variant(out: str, flags, obj_dir=None) -> str:
     """an A/B build of the product library with extra compile flags (e.g. -DSAST_SINGLE_TILE_ACCS=1) next to the in-tree one;
     run with SAST_LIB_PATH=<out> (tools only: A/B measurements inside one gpurun call)."""
     out = os.path.abspath(out)
-    obj_dir = out + ".obj"
+    obj_dir = obj_dir or out + ".obj"
     os.makedirs(obj_dir, exist_ok=True)
     with cf.ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
         objs = list(ex.map(lambda s: _compile(s, True, flags, obj_dir), SOURCES))

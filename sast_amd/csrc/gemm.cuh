@@ -94,6 +94,10 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
 #ifndef SAST_MFMA_SPLIT3
 #define SAST_MFMA_SPLIT3 1
 #endif
+// 1: bf16 operands (RNE), one MFMA per tile step -- the separately built reduced-precision library, never the default
+#ifndef SAST_MFMA_BF16
+#define SAST_MFMA_BF16 0
+#endif
 // independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
 #ifndef SAST_SINGLE_TILE_ACCS
 #define SAST_SINGLE_TILE_ACCS 1
@@ -349,7 +353,22 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
         for (int ks = 0; ks < HK; ++ks) csum[t] += a[t][ks];
     }
-    if constexpr (SAST_MFMA_SPLIT3 && HK == 8) {
+    if constexpr (SAST_MFMA_BF16 && HK == 8) {
+      // reduced-precision build (libsast_hip_bf16.so, `bench.py --precision bf16`): operands rounded to bf16 (RNE), ONE MFMA per tile
+      // step, fp32 accumulation -- the arithmetic class of the reference's AMP-16 experiments (config/experiment/gen4/default.yaml:6);
+      // NOT used by any parity claim of the fp32 path: kept-token decisions differ from the fp32 reference's, as they do there.
+      using f32x8 = __attribute__((ext_vector_type(8))) float;
+      bf16x8 ha[T::TM], hb[T::TN];
+#pragma unroll
+      for (int t = 0; t < T::TM; ++t) { f32x8 v; for (int i = 0; i < 8; ++i) v[i] = a[t][i]; ha[t] = __builtin_convertvector(v, bf16x8); }
+#pragma unroll
+      for (int t = 0; t < T::TN; ++t) { f32x8 v; for (int i = 0; i < 8; ++i) v[i] = b[t][i]; hb[t] = __builtin_convertvector(v, bf16x8); }
+#pragma unroll
+      for (int ta = 0; ta < T::TM; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < T::TN; ++tb)
+          accs[0][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ta], hb[tb], accs[0][ta][tb], 0, 0, 0);
+    } else if constexpr (SAST_MFMA_SPLIT3 && HK == 8) {
       // fp32 x fp32 on the bf16 matrix pipe: every operand is split EXACTLY into three bf16 terms, x = h + m + l (8 + 8 + 8
       // significand bits by truncation; the residuals x - h and x - h - m are exact in fp32), and the product is evaluated as the six
       // terms hh + hm + mh + mm + hl + lh with fp32 accumulation; the dropped terms ml + lm + ll are <= 2^-23 |x||y|, the size of one

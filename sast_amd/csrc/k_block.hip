@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
 extern "C" {
 
 int sast_version(void) { return 100; }
-int sast_mfma_split3(void) { return SAST_MFMA_SPLIT3; }
+int sast_mfma_split3(void) { return SAST_MFMA_BF16 ? 2 : SAST_MFMA_SPLIT3; }
 
 int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream) {
   if (!x || !cnt_ws || !r || H % 32 || W % 32) return SAST_EINVAL;

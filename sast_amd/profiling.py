@@ -133,7 +133,7 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3):
     total_ms = sum(r[2] for r in rows)
     total_fl = sum(r[3] for r in rows)
     stamp = pmc_summary_stamp()
-    split3 = bool(L.lib().sast_mfma_split3())
+    split3 = L.lib().sast_mfma_split3() == 1
     pipe = {}
     if split3:
         # the default build executes an fp32 product tile as 6 bf16 MFMAs on an exact 3-way operand split: the contract's `peak`
