@@ -133,6 +133,10 @@ def declared_symbols():
 def lib():
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64.so: it must be in the process BEFORE this library is loaded, otherwise the dynamic
+        # linker binds libsast_hip.so to the system copy under /opt/rocm and the process ends up with two HIP runtimes -- torch's
+        # owns the device, ours reports "no ROCm-capable device" at the first launch (seen when build() loaded the library first)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m sast_amd.build` (needs hipcc, gfx950). "

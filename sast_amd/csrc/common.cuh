@@ -3,15 +3,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
+#include <cstdlib>
 
 #define SAST_OK 0
 #define SAST_EINVAL (-22)
 #define SAST_ELAUNCH (-5)
 
-#define SAST_CHECK_LAUNCH()                               \
-  do {                                                    \
-    hipError_t e__ = hipGetLastError();                   \
-    if (e__ != hipSuccess) return SAST_ELAUNCH;           \
+// every launch goes through these: a stale error left on this thread by somebody else's HIP call (PyTorch polls events, probes
+// host pointers, ...) is cleared first, so what SAST_CHECK_LAUNCH reads belongs to the launch (SAST_DEBUG_LAUNCH=1 prints it)
+#define SAST_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+#define SAST_EXT_LAUNCH(...) do { (void)hipGetLastError(); hipExtLaunchKernelGGL(__VA_ARGS__); } while (0)
+// hipErrorNotReady is not a launch failure: it is the sticky result of somebody else's hipEventQuery / hipStreamQuery on this thread
+// (PyTorch's caching allocator polls events after H2D copies) and would otherwise fail the first launch after such a poll
+#define SAST_CHECK_LAUNCH()                                                                                          \
+  do {                                                                                                               \
+    hipError_t e__ = hipGetLastError();                                                                              \
+    if (e__ != hipSuccess && e__ != hipErrorNotReady) {                                                              \
+      if (getenv("SAST_DEBUG_LAUNCH")) fprintf(stderr, "[sast] %s:%d launch error %d: %s\n", __FILE__, __LINE__, (int)e__, hipGetErrorString(e__)); \
+      return SAST_ELAUNCH;                                                                                           \
+    }                                                                                                                \
   } while (0)
 
 namespace sast {

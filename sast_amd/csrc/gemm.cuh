@@ -614,10 +614,10 @@ inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, 
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ,
+    SAST_EXT_LAUNCH((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ,
                           R, dM, dR, (float*)nullptr, 1, remap);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
+    SAST_LAUNCH((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R, dM, dR,
                        (float*)nullptr, 1, remap);
   }
   SAST_CHECK_LAUNCH();
@@ -637,10 +637,10 @@ inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, in
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R,
+    SAST_EXT_LAUNCH((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R,
                           (const int*)nullptr, dR, colsum, splits, remap);
   } else {
-    hipLaunchKernelGGL((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
+    SAST_LAUNCH((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, la, lb, ep, M, NJ, R,
                        (const int*)nullptr, dR, colsum, splits, remap);
   }
   SAST_CHECK_LAUNCH();
@@ -676,9 +676,9 @@ inline int launch_gemm_dual(const LA1& la1, const LB1& lb1, const EP1& ep1, int 
   if (prof_enabled()) {
     hipEvent_t e0, e1;
     prof_kernel_events2(__PRETTY_FUNCTION__, 0.0, TS::G, M1, NJ1, R1, nullptr, dR1, TP::G, M2, NJ2, R2, dM2, nullptr, st, &e0, &e1);
-    hipExtLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
+    SAST_EXT_LAUNCH((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
   } else {
-    hipLaunchKernelGGL((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, a, b, n1);
+    SAST_LAUNCH((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, a, b, n1);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;

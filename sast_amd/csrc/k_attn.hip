@@ -171,8 +171,8 @@ template <int DH>
 static int fwd_launch_dh(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, hipStream_t st) {
   const int heads = C / DH;
   const float scale = 1.0f / sqrtf((float)DH);
-  if (T <= 64) hipLaunchKernelGGL((attn_fwd_kernel<64, DH>), dim3(W, heads), dim3(64), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
-  else if (T <= 128) hipLaunchKernelGGL((attn_fwd_kernel<128, DH>), dim3(W, heads), dim3(128), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
+  if (T <= 64) SAST_LAUNCH((attn_fwd_kernel<64, DH>), dim3(W, heads), dim3(64), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
+  else if (T <= 128) SAST_LAUNCH((attn_fwd_kernel<128, DH>), dim3(W, heads), dim3(128), sizeof(float) * 2 * T * DH, st, qkv, o, lse, row_off, Kw, C, heads, scale, T);
   else return SAST_EINVAL;
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -182,8 +182,8 @@ static int bwd_launch_dh(const float* qkv, const float* o, const float* dout, co
                          const int* Kw, int W, int T, int C, hipStream_t st) {
   const int heads = C / DH;
   const float scale = 1.0f / sqrtf((float)DH);
-  if (T <= 64) hipLaunchKernelGGL((attn_bwd_kernel<64, DH>), dim3(W, heads), dim3(64), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
-  else if (T <= 128) hipLaunchKernelGGL((attn_bwd_kernel<128, DH>), dim3(W, heads), dim3(128), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
+  if (T <= 64) SAST_LAUNCH((attn_bwd_kernel<64, DH>), dim3(W, heads), dim3(64), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
+  else if (T <= 128) SAST_LAUNCH((attn_bwd_kernel<128, DH>), dim3(W, heads), dim3(128), sizeof(float) * (4 * T * DH + 2 * T), st, qkv, o, dout, lse, dqkv, row_off, Kw, C, heads, scale, T);
   else return SAST_EINVAL;
   SAST_CHECK_LAUNCH();
   return SAST_OK;

@@ -333,9 +333,9 @@ int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_
   const float scale = 1.0f / sqrtf((float)dh);
   // the LDS tiles are sized by the number of 32-token tiles a partition can need: 3 for the Gen1 partitions (T = 80) keeps
   // two workgroups per CU where the 4-tile variant fits one
-  if (T <= 64) hipLaunchKernelGGL((attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
-  else if (T <= 96) hipLaunchKernelGGL((attn_fwd_mfma_kernel<3>), dim3(W, heads), dim3(192), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
-  else hipLaunchKernelGGL((attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  if (T <= 64) SAST_LAUNCH((attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else if (T <= 96) SAST_LAUNCH((attn_fwd_mfma_kernel<3>), dim3(W, heads), dim3(192), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else SAST_LAUNCH((attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -349,11 +349,11 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
   const LsFinish& a1 = f1 ? *f1 : z;
   if (!f0 || !f1) fC = 0;
   const int wpb = T <= 64 ? 2 : (T <= 96 ? 3 : 4), side = (2 * fC + wpb - 1) / wpb;
-  if (T <= 60) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 60>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 64) hipLaunchKernelGGL((attn_bwd_mfma_kernel<2, 64>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 80) hipLaunchKernelGGL((attn_bwd_mfma_kernel<3, 80>), dim3(W + side, heads), dim3(192), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 96) hipLaunchKernelGGL((attn_bwd_mfma_kernel<3, 96>), dim3(W + side, heads), dim3(192), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else hipLaunchKernelGGL((attn_bwd_mfma_kernel<4, 128>), dim3(W + side, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  if (T <= 60) SAST_LAUNCH((attn_bwd_mfma_kernel<2, 60>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else if (T <= 64) SAST_LAUNCH((attn_bwd_mfma_kernel<2, 64>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else if (T <= 80) SAST_LAUNCH((attn_bwd_mfma_kernel<3, 80>), dim3(W + side, heads), dim3(192), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else if (T <= 96) SAST_LAUNCH((attn_bwd_mfma_kernel<3, 96>), dim3(W + side, heads), dim3(192), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else SAST_LAUNCH((attn_bwd_mfma_kernel<4, 128>), dim3(W + side, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -418,7 +418,7 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   float* dmix = a->ws;
   const size_t n = (size_t)M * C;
   if (n >= (1ull << 31)) return SAST_EINVAL;
-  hipLaunchKernelGGL(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
+  SAST_LAUNCH(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
                      a->dh1b, a->dc1, dmix, a->dc0, n, C, div_mul_of((unsigned)C, n));
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
   return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void slice_copy_kernel(const float* __restrict
 int slice_copy(const float* src, int lds, int soff, float* dst, int ldd, int doff, int Cs, size_t rows, hipStream_t st) {
   const size_t n4 = rows * (Cs / 4);
   if (!n4) return SAST_OK;
-  hipLaunchKernelGGL(slice_copy_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, lds, soff, dst, ldd, doff, Cs, n4);
+  SAST_LAUNCH(slice_copy_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, lds, soff, dst, ldd, doff, Cs, n4);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -328,14 +328,14 @@ void bn_bwd_reduce_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int
   int rpb = (M + target - 1) / target;
   rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
   const int c4n = C / 4, RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb, njobs), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, j0, j1, M, C,
+  SAST_LAUNCH(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb, njobs), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, j0, j1, M, C,
                      rpb);
 }
 void bn_bwd_apply_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int M, int C, int training, hipStream_t st) {
   const size_t n4 = (size_t)M * (C / 4);
   int iters = (int)(n4 / (256 * 512));
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), njobs), dim3(256), sizeof(float) * 6 * C, st,
+  SAST_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), njobs), dim3(256), sizeof(float) * 6 * C, st,
                      j0, j1, n4, C, 1.0f / (float)M, training, iters, div_mul_of((unsigned)(C / 4), n4));
 }
 
@@ -493,14 +493,14 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
     int rpb = (M + sep - 1) / sep;
     rpb = rpb < 8 ? 8 : rpb;
     const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(double) * 2 * RP * C, st, a->conv_out, M, C, sums, rpb);
+    SAST_LAUNCH(bn_stats_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(double) * 2 * RP * C, st, a->conv_out, M, C, sums, rpb);
   }
   const size_t n4 = (size_t)M * (C / 4);
   int iters = (int)(n4 / (256 * 512));     // >= 512 blocks while the image allows it; the per-block statistics prologue is 2C*COPIES loads
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
   {
     const BnFwdJob jb{a->conv_out, sums, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, a->momentum, a->eps};
-    hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 1), dim3(256), sizeof(float) * 2 * C, st,
+    SAST_LAUNCH(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 1), dim3(256), sizeof(float) * 2 * C, st,
                        jb, jb, M, n4, C, a->training, iters, div_mul_of((unsigned)(C / 4), n4));
   }
   SAST_CHECK_LAUNCH();
@@ -589,7 +589,7 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
   const BnFwdJob j0{a->conv_out0, (const double*)a->bn_ws0, a->run_mean0, a->run_var0, a->stats0, a->bn_w0, a->bn_b0, a->y0, C, a->momentum0, a->eps0};
   const BnFwdJob j1{a->conv_out1, (const double*)a->bn_ws1, a->run_mean1, a->run_var1, a->stats1, a->bn_w1, a->bn_b1, a->y1, C, a->momentum1, a->eps1};
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 2), dim3(256), sizeof(float) * 2 * C, st, j0, j1,
+  SAST_LAUNCH(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 2), dim3(256), sizeof(float) * 2 * C, st, j0, j1,
                      M, n4, C, 1, iters, div_mul_of((unsigned)(C / 4), n4));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -656,7 +656,7 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
 int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream) {
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   const size_t n4 = (size_t)B * 4 * H * W * ((C1 + C2) / 4);
-  hipLaunchKernelGGL(upsample_cat_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
+  SAST_LAUNCH(upsample_cat_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -664,7 +664,7 @@ int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H,
   hipStream_t st = (hipStream_t)stream;
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   const size_t n4 = (size_t)B * H * W * (C1 / 4), n4b = (size_t)B * 4 * H * W * (C2 / 4);
-  hipLaunchKernelGGL(upsample_cat_bwd_kernel, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, st, dout, da, db, H, W, C1, C1 + C2, n4,
+  SAST_LAUNCH(upsample_cat_bwd_kernel, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, st, dout, da, db, H, W, C1, C1 + C2, n4,
                      n4b);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -687,7 +687,7 @@ int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const flo
                float weight_decay, float grad_scale, float clip_value, sast_stream_t stream) {
   if (n % 4) return SAST_EINVAL;
   const size_t n4 = n / 4;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
+  SAST_LAUNCH(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
                      beta2, eps, weight_decay, grad_scale, clip_value, OneCycle{0, 0, 0, 0, 0, 0});
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -698,7 +698,7 @@ int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, 
   if (n % 4 || !(end2 > end1)) return SAST_EINVAL;
   const size_t n4 = n / 4;
   const OneCycle oc{1, initial_lr, max_lr, min_lr, end1, end2};
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
+  SAST_LAUNCH(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
                      beta2, eps, weight_decay, grad_scale, clip_value, oc);
   SAST_CHECK_LAUNCH();
   return SAST_OK;

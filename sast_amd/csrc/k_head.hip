@@ -590,7 +590,7 @@ int sast_head_pred_fwd(const float* reg_feat, const float* cls_feat, const float
       anchor_offset + H * W > anchors_total)
     return SAST_EINVAL;
   const size_t n = (size_t)B * H * W * (5 + num_classes);
-  hipLaunchKernelGGL(head_pred_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reg_feat, cls_feat, w_reg, b_reg,
+  SAST_LAUNCH(head_pred_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, reg_feat, cls_feat, w_reg, b_reg,
                      w_obj, b_obj, w_cls, b_cls, pred, train, B, H, W, hidden, num_classes, stride, anchor_offset, anchors_total, decode);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -604,9 +604,9 @@ int sast_head_pred_bwd(const float* draw, const float* reg_feat, const float* cl
   if (!draw || hidden % 4 || num_classes < 1 || num_classes > HEAD_MAX_CLASSES) return SAST_EINVAL;
   const int HW = H * W;
   const size_t n = (size_t)B * HW * (hidden / 4);
-  hipLaunchKernelGGL(head_pred_bwd_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, draw, w_reg, w_obj, w_cls, d_reg_feat,
+  SAST_LAUNCH(head_pred_bwd_feat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, draw, w_reg, w_obj, w_cls, d_reg_feat,
                      d_cls_feat, B, HW, hidden, num_classes, anchor_offset, anchors_total);
-  hipLaunchKernelGGL(head_pred_bwd_w_kernel, dim3((unsigned)(((size_t)B * HW + 63) / 64), (5 + num_classes + 7) / 8), dim3(256),
+  SAST_LAUNCH(head_pred_bwd_w_kernel, dim3((unsigned)(((size_t)B * HW + 63) / 64), (5 + num_classes + 7) / 8), dim3(256),
                      sizeof(float) * 8 * hidden, st, draw, reg_feat, cls_feat, dw_reg, db_reg, dw_obj, db_obj, dw_cls, db_cls, B, HW, hidden,
                      num_classes, anchor_offset, anchors_total);
   SAST_CHECK_LAUNCH();
@@ -640,14 +640,14 @@ int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadG
   if (A > MATCH_THREADS * MATCH_PER) return SAST_EINVAL;
   // pick counters, nlabel, num_fg and the loss accumulators are contiguous: one clear
   zero_fill(cnt, sizeof(int) * ((size_t)2 * B * A + 2 * B) + sizeof(float) * 8, st);
-  hipLaunchKernelGGL(head_count_labels_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, B, G, nlabel);
-  hipLaunchKernelGGL(simota_cost_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, nlabel, lv, G, num_classes, cost, iou);
-  hipLaunchKernelGGL(simota_match_kernel, dim3(G, B), dim3(MATCH_THREADS), 0, st, cost, iou, nlabel, A, G, cnt);
-  hipLaunchKernelGGL(simota_resolve_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, cost, iou, nlabel, A, G, cnt, fg_mask, matched_gt,
+  SAST_LAUNCH(head_count_labels_kernel, dim3((B + 63) / 64), dim3(64), 0, st, labels, B, G, nlabel);
+  SAST_LAUNCH(simota_cost_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, nlabel, lv, G, num_classes, cost, iou);
+  SAST_LAUNCH(simota_match_kernel, dim3(G, B), dim3(MATCH_THREADS), 0, st, cost, iou, nlabel, A, G, cnt);
+  SAST_LAUNCH(simota_resolve_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, cost, iou, nlabel, A, G, cnt, fg_mask, matched_gt,
                      matched_iou, num_fg);
-  hipLaunchKernelGGL(yolox_loss_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, fg_mask, matched_gt, matched_iou, num_fg, lv,
+  SAST_LAUNCH(yolox_loss_kernel, dim3((A + 255) / 256, B), dim3(256), 0, st, train_out, labels, fg_mask, matched_gt, matched_iou, num_fg, lv,
                      B, G, num_classes, use_l1, draw, acc);
-  hipLaunchKernelGGL(yolox_loss_finish_kernel, dim3(1), dim3(64), 0, st, acc, num_fg, nlabel, B, losses);
+  SAST_LAUNCH(yolox_loss_finish_kernel, dim3(1), dim3(64), 0, st, acc, num_fg, nlabel, B, losses);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -666,9 +666,9 @@ int sast_postprocess(const float* prediction, int B, int anchors_total, int num_
   unsigned long long* mask = (unsigned long long*)(det + (size_t)B * A * 8);
   int* ncand = (int*)(mask + (size_t)B * A * words);
   zero_fill(mask, sizeof(unsigned long long) * (size_t)B * A * words, st);
-  hipLaunchKernelGGL(nms_candidates_kernel, dim3(B), dim3(1024), 0, st, prediction, A, num_classes, conf_thre, det, ncand);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, A, nms_thre, mask, words, class_agnostic);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, det, ncand, A, mask, words, out, n_out);
+  SAST_LAUNCH(nms_candidates_kernel, dim3(B), dim3(1024), 0, st, prediction, A, num_classes, conf_thre, det, ncand);
+  SAST_LAUNCH(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, A, nms_thre, mask, words, class_agnostic);
+  SAST_LAUNCH(nms_scan_kernel, dim3(B), dim3(64), 0, st, det, ncand, A, mask, words, out, n_out);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, s
 int zero_fill(void* p, size_t bytes, hipStream_t st) {
   const size_t n = (bytes + 3) / 4;
   if (!n) return SAST_OK;
-  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float*)p, n);
+  SAST_LAUNCH(zero_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (float*)p, n);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -111,7 +111,7 @@ template <typename T>
 int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   zero_fill(cnt, sizeof(int) * B * 4 * C, st);
   dim3 grid(1, (H + 31) / 32, B * C);
-  hipLaunchKernelGGL((nzr_count_kernel<T>), grid, dim3(256), 0, st, (const T*)x, cnt, C, H, W);
+  SAST_LAUNCH((nzr_count_kernel<T>), grid, dim3(256), 0, st, (const T*)x, cnt, C, H, W);
   float s[4];
   int f = 4;
   for (int l = 0; l < 4; ++l) {
@@ -120,7 +120,7 @@ int nzr_launch(const void* x, int* cnt, float* r, int B, int C, int H, int W, in
     f *= 2;
   }
   const int n = B * 4 * C;
-  hipLaunchKernelGGL(nzr_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cnt, r, n, C, s[0], s[1], s[2], s[3]);
+  SAST_LAUNCH(nzr_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, st, cnt, r, n, C, s[0], s[1], s[2], s[3]);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -252,7 +252,7 @@ int input_prep_launch(const void* x, float* y, int* ws, float* r, int B, int C, 
     s[l] = (float)((double)B / numel);
     f *= 2;
   }
-  hipLaunchKernelGGL((input_prep_kernel<T, 20>), dim3((tiles + PREP_WAVES - 1) / PREP_WAVES), dim3(64 * PREP_WAVES), 0, st, (const T*)x, y, ws, r,
+  SAST_LAUNCH((input_prep_kernel<T, 20>), dim3((tiles + PREP_WAVES - 1) / PREP_WAVES), dim3(64 * PREP_WAVES), 0, st, (const T*)x, y, ws, r,
                      B, H, W, Hp, Wp, s[0], s[1], s[2], s[3]);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -296,9 +296,9 @@ int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int 
   dim3 grid((Hp * Wp + 63) / 64, B);
   const size_t sh = sizeof(float) * 64 * (C + 1);
   switch (dtype) {
-    case SAST_DT_F32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
-    case SAST_DT_I32: hipLaunchKernelGGL((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
-    case SAST_DT_U8:  hipLaunchKernelGGL((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
+    case SAST_DT_F32: SAST_LAUNCH((nchw_to_nhwc_kernel<float>), grid, dim3(256), sh, st, (const float*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
+    case SAST_DT_I32: SAST_LAUNCH((nchw_to_nhwc_kernel<int>), grid, dim3(256), sh, st, (const int*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
+    case SAST_DT_U8:  SAST_LAUNCH((nchw_to_nhwc_kernel<unsigned char>), grid, dim3(256), sh, st, (const unsigned char*)x, y, C, H, W, Hp, Wp, div_mul_of((unsigned)C, 64ull * C)); break;
     default: return SAST_EINVAL;
   }
   SAST_CHECK_LAUNCH();
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 int nhwc_to_nchw_launch(const float* x, float* y, int B, int C, int HW, hipStream_t st) {
   dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, x, y, C, HW);
+  SAST_LAUNCH(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, x, y, C, HW);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -496,7 +496,7 @@ static inline int bwd_grid(int rows, int rpb) {
 int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* beta, const float* add, int add_rows,
                   float* mean, float* rstd, int rows, int C, float eps, hipStream_t st) {
   if (rows <= 0) return SAST_OK;
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0, st,
+  SAST_DISPATCH_C(C, SAST_LAUNCH((ln_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0, st,
                                         x, y, gamma, beta, add, add_rows, mean, rstd, rows, eps));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -505,7 +505,7 @@ int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* bet
 int ln_bwd_launch(const float* x, const float* dy, const float* gamma, const float* mean, const float* rstd, float* dx,
                   float* dgamma, float* dbeta, int rows, int C, hipStream_t st) {
   if (rows <= 0) return SAST_OK;
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, ROWB / GL)), dim3(ROWB),
+  SAST_DISPATCH_C(C, SAST_LAUNCH((ln_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, ROWB / GL)), dim3(ROWB),
                                         sizeof(float) * (ROWB / GL) * C, st, x, dy, gamma, mean, rstd, dx, dgamma, dbeta, rows));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(ROWB) void ln1_gather_bwd_kernel(const float* __res
 int ln1_gather_fwd_launch(const float* xin, float* out, float* sc, const int* tok_slot, const float* g1, const float* b1,
                           const float* g2, const float* b2, float* mean1, float* rstd1, float* mean2, float* rstd2,
                           int rows, int C, float eps, float* zero_ptr, size_t zero_floats, hipStream_t st) {
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0,
+  SAST_DISPATCH_C(C, SAST_LAUNCH((ln1_gather_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0,
                                         st, xin, out, sc, tok_slot, g1, b1, g2, b2, mean1, rstd1, mean2, rstd2, rows, eps, zero_ptr,
                                         zero_ptr ? zero_floats / 4 : (size_t)0));
   SAST_CHECK_LAUNCH();
@@ -604,7 +604,7 @@ int ln1_gather_bwd_launch(const float* xin, const float* dout, const float* dsc,
                           const float* b1, const float* g2, const float* mean1, const float* rstd1, const float* mean2,
                           const float* rstd2, float* dxin, float* dg1, float* db1, float* dg2, float* db2, int rows, int C,
                           hipStream_t st) {
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((ln1_gather_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, ROWB / GL)), dim3(ROWB),
+  SAST_DISPATCH_C(C, SAST_LAUNCH((ln1_gather_bwd_kernel<GL, VPL>), dim3(bwd_grid(rows, ROWB / GL)), dim3(ROWB),
                                         sizeof(float) * (ROWB / GL) * C, st, xin, dout, dsc, tok_slot, g1, b1, g2, mean1, rstd1,
                                         mean2, rstd2, dxin, dg1, db1, dg2, db2, rows));
   SAST_CHECK_LAUNCH();
@@ -703,20 +703,20 @@ __global__ __launch_bounds__(ROWB) void stp_bwd_kernel(const float* __restrict__
 
 int controls_fwd_launch(const float* wc, const float* r, int r_stride, float* scale, int B, int C, int J, float* zero_bc,
                         hipStream_t st) {
-  hipLaunchKernelGGL(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ControlsJob{wc, r, r_stride, scale, zero_bc, nullptr, nullptr, B, C, J});
+  SAST_LAUNCH(controls_fwd_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, ControlsJob{wc, r, r_stride, scale, zero_bc, nullptr, nullptr, B, C, J});
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int controls_bwd_launch(const float* wc, const float* r, int r_stride, const float* dscale, float* dwc, int B, int C, int J,
                         hipStream_t st) {
-  hipLaunchKernelGGL(controls_bwd_kernel, dim3((C * J + 255) / 256), dim3(256), 0, st, ControlsJob{wc, r, r_stride, nullptr, nullptr, dscale, dwc, B, C, J});
+  SAST_LAUNCH(controls_bwd_kernel, dim3((C * J + 255) / 256), dim3(256), 0, st, ControlsJob{wc, r, r_stride, nullptr, nullptr, dscale, dwc, B, C, J});
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int stp_fwd_launch(const float* xp, const float* s, const float* scale, float amp, float* xw, float* tok, int B, int L, int C,
                    hipStream_t st) {
   const int rows = B * L;
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0, st, xp,
+  SAST_DISPATCH_C(C, SAST_LAUNCH((stp_fwd_kernel<GL, VPL>), dim3((rows + 256 / GL - 1) / (256 / GL)), dim3(256), 0, st, xp,
                                         s, scale, amp, xw, tok, rows, L));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -725,7 +725,7 @@ int stp_bwd_launch(const float* xp, const float* s, const float* scale, const fl
                    float* dscale, int B, int L, int C, hipStream_t st) {
   // dscale must be zeroed by the caller
   const int rpb = L >= 8192 ? 128 : (L >= 1024 ? 64 : 32);   // >= ~120 blocks per sample at every stage
-  SAST_DISPATCH_C(C, hipLaunchKernelGGL((stp_bwd_kernel<GL, VPL>), dim3((L + rpb - 1) / rpb, B), dim3(ROWB),
+  SAST_DISPATCH_C(C, SAST_LAUNCH((stp_bwd_kernel<GL, VPL>), dim3((L + rpb - 1) / rpb, B), dim3(ROWB),
                                         sizeof(float) * (ROWB / GL) * C, st, xp, s, scale, g, direct, dz, dscale, L, rpb));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__
 }
 int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, int table_rows, hipStream_t st) {
   const size_t n4 = (size_t)rows * (C / 4);
-  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, t, y, n4, C / 4, table_rows);
+  SAST_LAUNCH(add_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, t, y, n4, C / 4, table_rows);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -777,13 +777,13 @@ __global__ __launch_bounds__(256) void mask_token_bwd_kernel(const float* __rest
 }
 int mask_token_fwd_launch(float* x, const unsigned char* mask, const float* token, const float* pe, int rows, int C, int L, hipStream_t st) {
   const size_t n4 = (size_t)rows * (C / 4);
-  hipLaunchKernelGGL(mask_token_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, mask, token, pe, n4, C / 4, L);
+  SAST_LAUNCH(mask_token_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, mask, token, pe, n4, C / 4, L);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int mask_token_bwd_launch(const float* dy, const unsigned char* mask, float* dx, float* dtoken, int rows, int C, hipStream_t st) {
   const int rpb = 256;
-  hipLaunchKernelGGL(mask_token_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dy, mask, dx, dtoken, rows, C, rpb);
+  SAST_LAUNCH(mask_token_bwd_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dy, mask, dx, dtoken, rows, C, rpb);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -818,7 +818,7 @@ int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* d
   if (rows <= 0) return SAST_OK;
   const int rpb = 256;
   dim3 grid((C / 4 + 63) / 64, (rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, st, x, ld, idx, rows, drows, C, out, rpb);
+  SAST_LAUNCH(colsum_kernel, grid, dim3(256), 0, st, x, ld, idx, rows, drows, C, out, rpb);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(64) void ls_linear_finish_kernel(LsFinish p0, LsFin
 int ls_linear_finish_launch(const float* w, const float* b, const float* gamma, const float* raw, const float* s, float* dw,
                             float* db, float* dgamma, int C, int K, hipStream_t st) {
   const LsFinish p{w, b, gamma, raw, s, dw, db, dgamma, K};
-  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3(C, 1), dim3(64), 0, st, p, p, C);
+  SAST_LAUNCH(ls_linear_finish_kernel, dim3(C, 1), dim3(64), 0, st, p, p, C);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -845,7 +845,7 @@ int ls_linear_finish2_launch(const float* w0, const float* b0, const float* g0, 
                              float* dg0, int K0, const float* w1, const float* b1, const float* g1, const float* raw1, const float* s1,
                              float* dw1, float* db1, float* dg1, int K1, int C, hipStream_t st) {
   const LsFinish p0{w0, b0, g0, raw0, s0, dw0, db0, dg0, K0}, p1{w1, b1, g1, raw1, s1, dw1, db1, dg1, K1};
-  hipLaunchKernelGGL(ls_linear_finish_kernel, dim3(C, 2), dim3(64), 0, st, p0, p1, C);
+  SAST_LAUNCH(ls_linear_finish_kernel, dim3(C, 2), dim3(64), 0, st, p0, p1, C);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -888,8 +888,8 @@ int mean_square_launch(const float* const* x, float* const* dx, const size_t* n,
                        const float* g, int g_stride, hipStream_t st) {
   MsqJob j{};
   for (int t = 0; t < count; ++t) { j.x[t] = x[t]; j.dx[t] = dx ? dx[t] : nullptr; j.n[t] = n[t]; }
-  if (!dx) hipLaunchKernelGGL(mean_square_fwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, partials);
-  else hipLaunchKernelGGL(mean_square_bwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, g, g_stride);
+  if (!dx) SAST_LAUNCH(mean_square_fwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, partials);
+  else SAST_LAUNCH(mean_square_bwd_kernel, dim3(blocks, count), dim3(1024), 0, st, j, g, g_stride);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -923,8 +923,8 @@ int sample_gather_launch(const SastSampleGather& a, bool backward, hipStream_t s
   const size_t n4 = a.sample_floats / 4;
   int bx = (int)((n4 + 256 * 8 - 1) / (256 * 8));
   bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
-  if (!backward) hipLaunchKernelGGL(gather_samples_kernel, dim3(bx, a.n_out), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(scatter_samples_kernel, dim3(bx, a.n_src * a.B), dim3(256), 0, st, a);
+  if (!backward) SAST_LAUNCH(gather_samples_kernel, dim3(bx, a.n_out), dim3(256), 0, st, a);
+  else SAST_LAUNCH(scatter_samples_kernel, dim3(bx, a.n_src * a.B), dim3(256), 0, st, a);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -939,7 +939,7 @@ int zero_samples_launch(float* x, int B, size_t sample_floats, const SastSampleM
   const size_t n4 = sample_floats / 4;
   int bx = (int)((n4 + 256 * 8 - 1) / (256 * 8));
   bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
-  hipLaunchKernelGGL(zero_samples_kernel, dim3(bx, B), dim3(256), 0, st, x, sample_floats, m);
+  SAST_LAUNCH(zero_samples_kernel, dim3(bx, B), dim3(256), 0, st, x, sample_floats, m);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -1010,7 +1010,7 @@ int cb_sample_sum_launch(const float* src, int ld, bool gather, const int* row_t
   int rc = zero_fill(out, sizeof(float) * (size_t)n_samples * C, st);
   if (rc || rows_max <= 0) return rc;
   const int strip = 256;
-  hipLaunchKernelGGL(cb_sample_sum_kernel, dim3((rows_max + strip - 1) / strip, n_samples), dim3(256), 0, st, src, ld,
+  SAST_LAUNCH(cb_sample_sum_kernel, dim3((rows_max + strip - 1) / strip, n_samples), dim3(256), 0, st, src, ld,
                      gather ? row_tok : nullptr, row_tok, nrows_dev, tps, C, strip, out);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -1019,7 +1019,7 @@ int cb_apply_fwd_launch(const float* m, const float* y, const float* gamma, cons
                         const int* nrows_dev, int rows_max, int tps, int C, float* out, hipStream_t st) {
   if (rows_max <= 0) return SAST_OK;
   const size_t n = (size_t)rows_max * (C / 4);
-  hipLaunchKernelGGL(cb_apply_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, y, gamma, sum, row_tok, nrows_dev,
+  SAST_LAUNCH(cb_apply_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, y, gamma, sum, row_tok, nrows_dev,
                      tps, C, out);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -1028,7 +1028,7 @@ int cb_apply_bwd_launch(const float* dout, const float* gsum, const int* row_tok
                         float* dz, hipStream_t st) {
   if (rows_max <= 0) return SAST_OK;
   const size_t n = (size_t)rows_max * (C / 4);
-  hipLaunchKernelGGL(cb_apply_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, nullptr, nullptr, gsum, row_tok,
+  SAST_LAUNCH(cb_apply_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, nullptr, nullptr, gsum, row_tok,
                      nrows_dev, tps, C, dz);
   SAST_CHECK_LAUNCH();
   return SAST_OK;

@@ -145,9 +145,9 @@ static int select_launch_n(const float* tok, int B, int H, int W_, int ph, int p
   if (H % ph || W_ % pw || pm.T() > 128) return SAST_EINVAL;
   const int L = H * W_, N = pm.N(), W = B * N;
   const int chunks = (N + SEL_WAVES - 1) / SEL_WAVES;
-  hipLaunchKernelGGL(select_mask_kernel, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win,
+  SAST_LAUNCH(select_mask_kernel, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win,
                      thr_tok, sp);
-  hipLaunchKernelGGL(select_fill_kernel, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, sp);
+  SAST_LAUNCH(select_fill_kernel, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, sp);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

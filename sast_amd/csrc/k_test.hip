@@ -179,11 +179,11 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
 extern "C" int sast_test_mfma_peak(float* out, int mode, int blocks, int iters, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   switch (mode) {
-    case 0: hipLaunchKernelGGL(mfma_peak_kernel<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 3: hipLaunchKernelGGL(mfma_peak_kernel<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
-    case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 0: SAST_LAUNCH(mfma_peak_kernel<0>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 1: SAST_LAUNCH(mfma_peak_kernel<1>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 2: SAST_LAUNCH(mfma_peak_kernel<2>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 3: SAST_LAUNCH(mfma_peak_kernel<3>, dim3(blocks), dim3(256), 0, st, out, iters); break;
+    case 4: SAST_LAUNCH(mfma_peak_kernel<4>, dim3(blocks), dim3(256), 0, st, out, iters); break;
     default: return SAST_EINVAL;
   }
   SAST_CHECK_LAUNCH();
