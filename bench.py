@@ -5,7 +5,7 @@ SAST backbone (4 stages: conv-downsample+LN, STP scoring/selection, 2x MS-WSA, C
 forward + backward of the proxy loss sum_k mean(out_k^2) + gradient all-reduce (N>1) + AdamW update.
 One "step" = one such pass over one synthetic batch (benchmark.py:52-64 input protocol).
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 300 --warmup 50        (the defaults: the reference's benchmark.py protocol)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0.
@@ -257,8 +257,8 @@ def main():
     global BATCH, HW, PART
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default = the reference's benchmark.py protocol: 300 timed iterations, benchmark.py:52-64)")
+    ap.add_argument("--warmup", type=int, default=50, help="untimed warm-up steps (reference protocol: 50)")
     ap.add_argument("--amp", type=float, default=2e-4, help="attention_cfg.AMP (controls the kept-token fraction)")
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (BASELINE config: 4; sparsity sweep C5: 8)")
     ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
