@@ -690,14 +690,16 @@ using TileMid   = Tile<64, 128, 2, 2, 1>;   // wave tile 32x64
 using TileSmall = Tile<64, 64, 2, 2, 1>;    // wave tile 32x32
 using TileSmallK2 = Tile<64, 64, 2, 2, 1, 16, 2>;   // + 2-way intra-block k split (8 waves)
 using TileSmallK4 = Tile<64, 64, 2, 2, 1, 16, 4>;   // + 4-way intra-block k split (16 waves)
-// the split-R (weight-gradient) job.  Under the bf16x3 operand split a wave tile of 32x64 (Tile<64, 64, 2, 1, 1, 16, 4>: an operand's
-// split and its LDS reads serve two MFMA tiles) is 7-12 % faster than the 2x2-wave K2 form in the stand-alone micro-benchmark
-// (tools/gemm_tn_pf.py) but 4 % slower in the step: its 70 KB of LDS (4 k-groups) costs the paired launches their co-residency
-// with the activation-gradient job.  -DSAST_SPLITR_32X64 selects it.
-#ifdef SAST_SPLITR_32X64
+// the split-R (weight-gradient) job: 64x64 block, wave tile 32x64 (two accumulator tiles per wave: an operand's bf16x3 split and its
+// LDS reads serve two MFMA tiles), 2 k-groups of 2 waves.  Measured under the operand split, A/B in one call: -2.0 % of the step against
+// the 2x2-wave K2 form (8 waves) with 192 workgroups in the paired launches; the 4-k-group form of the same wave tile (8 waves, 70 KB
+// of LDS) is faster alone but 4 % slower in the step -- it costs the paired launches their co-residency with the dX job.
+#ifdef SAST_SPLITR_32X64_K4
 using TileSplitR = Tile<64, 64, 2, 1, 1, 16, 4>;
-#else
+#elif defined(SAST_SPLITR_2X2)
 using TileSplitR = Tile<64, 64, 2, 2, 1, 16, 2>;
+#else
+using TileSplitR = Tile<64, 64, 2, 1, 1, 16, 2>;
 #endif
 using TileThinK4  = Tile<32, 64, 1, 2, 1, 16, 4>;   // 32x64 block, 4 k-groups of 2 waves: for grids of < ~1.5 64x64-tiles per CU
 using TileTinyK8 = Tile<32, 32, 1, 1, 1, 16, 8>;   // 32x32 block, 8 single-wave k-groups: grids of < ~half a 32x64-tile per CU with a long reduction

@@ -16,7 +16,7 @@ inline int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 inline bool gemm_pair_enabled() { static int v = env_int("SAST_GEMM_PAIR", 1); return v != 0; }
-inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 512); return v; }
+inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 768); return v; }
 inline int pair_ks_min_r() { static int v = env_int("SAST_KS_MINR", 256); return v; }
 inline int pair_thin_nb() { static int v = env_int("SAST_THIN_NB", 384); return v; }
 inline int pair_ks_nb() { static int v = env_int("SAST_KS_NB", 1000000); return v; }
@@ -38,13 +38,13 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hi
   return gemm_auto(la, lb, ep, M, NJ, R, nullptr, st);
 }
 
-// inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (152 measured best, re-swept after the parity-class dX job stopped multiplying its empty tap slots; a target
+// inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (round 2, 4-wave split-R tile under the operand split: 192 measured best of 128 ... 512; round 1, 8-wave tile: 152; a target
 // that adapts to the dX job's grid size was not better)
 // the same for the k x k conv pairs (im2col / backward-data jobs)
-inline int pair_tn_blocks_conv() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_CONV", 152); return v; }
+inline int pair_tn_blocks_conv() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_CONV", 192); return v; }
 // and for the 1x1 conv pairs of the FPN / head (k_conv.hip)
-inline int pair_tn_blocks_1x1() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_1X1", 152); return v; }
-inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 152); return v; }
+inline int pair_tn_blocks_1x1() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_1X1", 192); return v; }
+inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 192); return v; }
 
 // target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)
 inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
