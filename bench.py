@@ -89,7 +89,7 @@ class Trainer:
         self.net.to(dev)
         self.fpn.to(dev)
         self.world = world
-        self.segmented = (world > 1) if segmented is None else bool(segmented)
+        self.segmented = ((world > 1) and os.environ.get("SAST_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
         self.ts = TrainStep(self.net, self.fpn, self.head if yolox_loss else None, lr=2e-4, weight_decay=0.0, clip_value=1.0, world=world,
                             segmented=self.segmented)
         self.flat, self.opt = self.ts.flat, self.ts.opt
@@ -161,6 +161,20 @@ class Trainer:
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             self.graph = None
             torch.cuda.synchronize()
+            if self.segmented and not self.fwd_only:
+                # the segmented step (three graphs + side-stream bucket updates) could not be captured: fall back to the plain step
+                # (one graph for forward + backward, all-reduce + AdamW behind it) rather than to eager launches
+                try:
+                    self.ts.segmented = self.segmented = False
+                    self.ts.capture(self.xs, None, self.labels, self.indices)
+                    self.graph = self.ts
+                    self.loss, self.P = self.ts.loss, self.ts.P
+                    print("[bench] captured the unsegmented step instead", file=sys.stderr)
+                    return True
+                except Exception as e2:  # noqa: BLE001
+                    print(f"[bench] unsegmented capture failed too ({type(e2).__name__}: {e2})", file=sys.stderr)
+                    self.graph = None
+                    torch.cuda.synchronize()
             return False
 
     def step(self):

@@ -11,6 +11,20 @@
 
 namespace sast {
 
+// the plain-GEMM tiles gemm_auto / the dX job of a paired launch choose from (overridable for A/B builds)
+#ifndef SAST_TILE_THIN
+#define SAST_TILE_THIN TileThinK4
+#endif
+#ifndef SAST_TILE_K2
+#define SAST_TILE_K2 TileSmallK2
+#endif
+#ifndef SAST_TILE_K1
+#define SAST_TILE_K1 TileSmall
+#endif
+using TileAutoThin = SAST_TILE_THIN;
+using TileAutoK2 = SAST_TILE_K2;
+using TileAutoK1 = SAST_TILE_K1;
+
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -29,9 +43,9 @@ template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dM, hipStream_t st) {
   const long nb = (long)((M + 63) / 64) * ((NJ + 63) / 64);
   if (!dM && use_tiny(M, NJ, R)) return launch_gemm<TileTinyK8>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-  if (nb <= pair_thin_nb() && R >= pair_ks_min_r()) return launch_gemm<TileThinK4>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-  if (nb <= pair_ks_nb() && R >= pair_ks_min_r()) return launch_gemm<TileSmallK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
-  return launch_gemm<TileSmall>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  if (nb <= pair_thin_nb() && R >= pair_ks_min_r()) return launch_gemm<TileAutoThin>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  if (nb <= pair_ks_nb() && R >= pair_ks_min_r()) return launch_gemm<TileAutoK2>(la, lb, ep, M, NJ, R, dM, nullptr, st);
+  return launch_gemm<TileAutoK1>(la, lb, ep, M, NJ, R, dM, nullptr, st);
 }
 template <class LA, class LB, class EP>
 int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hipStream_t st) {
@@ -86,17 +100,17 @@ int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1
   if (!gemm_pair_enabled() || Mo <= 0 || NJ1 <= 0 || R1 <= 0 || M2 <= 0 || NJ2 <= 0 || R2 <= 0) {
     int rc = launch_gemm_split<TileSplitR>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);
     if (rc) return rc;
-    if (thin) return launch_gemm<TileThinK4>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
-    if (k2) return launch_gemm<TileSmallK2>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
-    return launch_gemm<TileSmall>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
+    if (thin) return launch_gemm<TileAutoThin>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
+    if (k2) return launch_gemm<TileAutoK2>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
+    return launch_gemm<TileAutoK1>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
   }
   if (thin)
-    return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileThinK4, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+    return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileAutoThin, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                       ep2, M2, NJ2, R2, dM2, st);
   if (k2)
-    return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileSmallK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
+    return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileAutoK2, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                        ep2, M2, NJ2, R2, dM2, st);
-  return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileSmall, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
+  return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileAutoK1, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2, ep2,
                                                                                    M2, NJ2, R2, dM2, st);
 }
 
