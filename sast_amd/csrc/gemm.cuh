@@ -85,10 +85,31 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
   return Split3{__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl)};
 }
 
+// the same split for the 4 consecutive k-values a thread stores to LDS: three 8-byte pieces, one per plane (plane stride in floats)
+__device__ __forceinline__ void store_split3(float* dst, int plane_floats, float4 v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = __float_as_uint(x[i]) & 0xffff0000u;
+    const float r1 = x[i] - __uint_as_float(h[i]);
+    m[i] = __float_as_uint(r1) & 0xffff0000u;
+    l[i] = __float_as_uint(r1 - __uint_as_float(m[i]));
+  }
+  using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+  *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+  *reinterpret_cast<u32x2*>(dst + plane_floats) = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+  *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+
 // PF: k-tiles kept in flight in registers per k-group (global-load latency under load is ~2-3 us on MI355X, one k-tile of
 // MFMA work is ~0.2-0.4 us: see tools/gemm_timeline.py).  Must be even (LDS is double-buffered).
 #ifndef SAST_PF_DEFAULT
 #define SAST_PF_DEFAULT 2
+#endif
+// 1: reduce-contiguous operands are split into their bf16 planes once, at the LDS store (see OperandPresplit)
+#ifndef SAST_PRESPLIT_RC
+#define SAST_PRESPLIT_RC 1
 #endif
 // 1: fp32 products on the bf16 matrix pipe through an exact three-way operand split (gemm_body::compute); 0: v_mfma_f32_32x32x2_f32
 #ifndef SAST_MFMA_SPLIT3
@@ -97,6 +118,9 @@ __device__ __forceinline__ Split3 split3(const float (&x)[8]) {
 // 1: bf16 operands (RNE), one MFMA per tile step -- the separately built reduced-precision library, never the default
 #ifndef SAST_MFMA_BF16
 #define SAST_MFMA_BF16 0
+#endif
+#ifndef SAST_BF16_MFMA_REPEAT
+#define SAST_BF16_MFMA_REPEAT 1
 #endif
 // independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
 #ifndef SAST_SINGLE_TILE_ACCS
@@ -144,10 +168,26 @@ template <class EP, class = void> struct EpHasStats : std::false_type {};
 template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> : std::bool_constant<EP::COLSTATS> {};
 
 // LDS floats one workgroup of an instantiation needs
+// PRESPLIT (bf16x3 build): a reduce-contiguous (RC) operand is split into its three bf16 planes ONCE, by the thread that stores it to
+// LDS, instead of by every wave that reads it (in a 2x2-wave tile each element is read by two waves: the split VALU work of such an
+// operand halves; measured, the split is 0.7 ms of the 5.3 ms step).  Plane layout [row][BK + 8] bf16 (48-byte rows: ds_write_b64 of a
+// thread's 4 k-values, one conflict-free ds_read_b128 per plane = a lane's 8 k-values as one MFMA operand).  Index-contiguous (IC)
+// operands keep the fp32 [k][row] layout and are split after the read.  Not for 8-way k-split tiles, nor where the planes (36 instead of
+// 20 floats per row) would push a workgroup beyond 80 KB of LDS, nor for the 4-gate LSTM tiles (one wave reads all 128 B rows there: nothing
+// is shared, and the larger planes made the stage-1/2 LSTM GEMMs 25 % slower).
+template <class T, class L>
+struct OperandPresplitWanted { static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_RC && L::RC && T::BK == 16 && T::KS <= 4 && T::G < 4; };
+constexpr int PS_ROW_FLOATS = 3 * (16 + 8) / 2;   // 3 planes x 24 bf16 per row, in floats (36)
+constexpr int PS_MAX_FLOATS = 20480;              // a workgroup's LDS with presplit operands must leave room for two per CU (80 KB)
 template <class T, class LA, class LB>
 struct GemmSmem {
   static constexpr int LDK = T::BK + 4;
-  static constexpr int A_STAGE = LA::RC ? T::BM * LDK : T::BK * (T::BM + 4), B_STAGE = LB::RC ? T::BN * LDK : T::BK * (T::BN + 4);
+  static constexpr int A_PLAIN = LA::RC ? T::BM * LDK : T::BK * (T::BM + 4), B_PLAIN = LB::RC ? T::BN * LDK : T::BK * (T::BN + 4);
+  static constexpr int A_PS = OperandPresplitWanted<T, LA>::value ? T::BM * PS_ROW_FLOATS : A_PLAIN;
+  static constexpr int B_PS = OperandPresplitWanted<T, LB>::value ? T::BN * PS_ROW_FLOATS : B_PLAIN;
+  static constexpr bool PS_FITS = T::KS * 2 * (A_PS + B_PS) <= PS_MAX_FLOATS;
+  static constexpr bool PSA = PS_FITS && OperandPresplitWanted<T, LA>::value, PSB = PS_FITS && OperandPresplitWanted<T, LB>::value;
+  static constexpr int A_STAGE = PSA ? A_PS : A_PLAIN, B_STAGE = PSB ? B_PS : B_PLAIN;
   static constexpr int FLOATS = T::KS * 2 * (A_STAGE + B_STAGE);
 };
 
@@ -165,7 +205,8 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   constexpr int LDK = BK + 4, HK = BK / 2;
   constexpr int LDA = LA::RC ? LDK : BM + 4;
   constexpr int LDB = LB::RC ? LDK : BN + 4;
-  constexpr int A_STAGE = LA::RC ? BM * LDK : BK * LDA, B_STAGE = LB::RC ? BN * LDK : BK * LDB;
+  constexpr bool PSA = GemmSmem<T, LA, LB>::PSA, PSB = GemmSmem<T, LA, LB>::PSB;
+  constexpr int A_STAGE = GemmSmem<T, LA, LB>::A_STAGE, B_STAGE = GemmSmem<T, LA, LB>::B_STAGE;
   constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
   static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
   static_assert(KS * GROUP_FLOATS == GemmSmem<T, LA, LB>::FLOATS, "GemmSmem");
@@ -234,7 +275,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       const int row = s / (BK / 4), kq = s % (BK / 4);
       ca[it] = la.prep(m0 + row, Meff);
       ra_off[it] = kq * 4;
-      la_off[it] = row * LDK + kq * 4;
+      la_off[it] = PSA ? row * 12 + kq * 2 : row * LDK + kq * 4;     // presplit: float index inside ONE plane (48-byte rows, 8 bytes per slot)
     } else {
       const int iq = s % (BM / 4), kk = s / (BM / 4);
       ca[it] = la.prep(m0 + iq * 4, Meff);
@@ -251,7 +292,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jl, g, NJ, m0);
       else cb[it] = lb.prep(j0 + jl, g, NJ);
       rb_off[it] = kq * 4;
-      lb_off[it] = nnmap(jl, g) * LDK + kq * 4;
+      lb_off[it] = PSB ? nnmap(jl, g) * 12 + kq * 2 : nnmap(jl, g) * LDK + kq * 4;
     } else {
       const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
       if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jq * 4, g, NJ, m0);
@@ -284,10 +325,16 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     float* bs = Bs + buf * B_STAGE;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) st4(as + la_off[it], la.finish(ra[set][it], aa[set][it], oa[set][it]));
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
+        if constexpr (PSA) store_split3(as + la_off[it], BM * 12, la.finish(ra[set][it], aa[set][it], oa[set][it]));
+        else st4(as + la_off[it], la.finish(ra[set][it], aa[set][it], oa[set][it]));
+      }
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
-      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+      if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
+        if constexpr (PSB) store_split3(bs + lb_off[it], BN * 12, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+        else st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+      }
   };
 
   // epilogue operands are requested EARLY: the per-column constants (bias, LayerScale gamma ...) before the reduction loop,
@@ -325,9 +372,13 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     const float* bs = Bs + buf * B_STAGE;
     const int l31 = lane & 31, hf = lane >> 5;
     float a[T::TM][HK], b[T::TN][HK];
+    Split3 sa[T::TM], sb[T::TN];
 #pragma unroll
     for (int t = 0; t < T::TM; ++t) {
-      if constexpr (LA::RC) {
+      if constexpr (PSA) {
+        const float* p = as + (wm * T::WTM + t * 32 + l31) * 12 + hf * 4;       // 16 bytes = this lane's 8 k-values of one plane
+        sa[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BM * 12)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BM * 12))};
+      } else if constexpr (LA::RC) {
         const float* p = as + (wm * T::WTM + t * 32 + l31) * LDK + hf * HK;
 #pragma unroll
         for (int q = 0; q < HK / 4; ++q) { const float4 v = ld4(p + 4 * q); a[t][4 * q] = v.x; a[t][4 * q + 1] = v.y; a[t][4 * q + 2] = v.z; a[t][4 * q + 3] = v.w; }
@@ -338,7 +389,10 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
 #pragma unroll
     for (int t = 0; t < T::TN; ++t) {
-      if constexpr (LB::RC) {
+      if constexpr (PSB) {
+        const float* p = bs + (wn * T::WTN + t * 32 + l31) * 12 + hf * 4;
+        sb[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BN * 12)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BN * 12))};
+      } else if constexpr (LB::RC) {
         const float* p = bs + (wn * T::WTN + t * 32 + l31) * LDK + hf * HK;
 #pragma unroll
         for (int q = 0; q < HK / 4; ++q) { const float4 v = ld4(p + 4 * q); b[t][4 * q] = v.x; b[t][4 * q + 1] = v.y; b[t][4 * q + 2] = v.z; b[t][4 * q + 3] = v.w; }
@@ -348,6 +402,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       }
     }
     if (SPLIT && do_colsum) {
+      static_assert(!(SPLIT && PSA), "column sums read the fp32 A operand: split-R jobs take an index-contiguous A");
 #pragma unroll
       for (int t = 0; t < T::TM; ++t)
 #pragma unroll
@@ -367,7 +422,8 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
         for (int tb = 0; tb < T::TN; ++tb)
-          accs[0][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ta], hb[tb], accs[0][ta][tb], 0, 0, 0);
+          for (int rep = 0; rep < SAST_BF16_MFMA_REPEAT; ++rep)     // (experiments: > 1 isolates the cost of the MFMAs from the cost of the split)
+            accs[0][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ta], hb[tb], accs[0][ta][tb], 0, 0, 0);
     } else if constexpr (SAST_MFMA_SPLIT3 && HK == 8) {
       // fp32 x fp32 on the bf16 matrix pipe: every operand is split EXACTLY into three bf16 terms, x = h + m + l (8 + 8 + 8
       // significand bits by truncation; the residuals x - h and x - h - m are exact in fp32), and the product is evaluated as the six
@@ -375,11 +431,14 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       // fp32 rounding of the product.  A lane's 8 k-values of a k-tile are exactly one v_mfma_f32_32x32x16_bf16 operand (k = 8 *
       // (lane / 32) + j), so the loaders, the LDS layouts and the operand reads are those of the fp32 path; 6 MFMAs of 32 cycles
       // replace 8 of 64 per 32 x 32 x 16 tile step, at the price of ~90 VALU operations per lane for the split.
-      Split3 sa[T::TM], sb[T::TN];
+      if constexpr (!PSA) {
 #pragma unroll
-      for (int t = 0; t < T::TM; ++t) sa[t] = split3(a[t]);
+        for (int t = 0; t < T::TM; ++t) sa[t] = split3(a[t]);
+      }
+      if constexpr (!PSB) {
 #pragma unroll
-      for (int t = 0; t < T::TN; ++t) sb[t] = split3(b[t]);
+        for (int t = 0; t < T::TN; ++t) sb[t] = split3(b[t]);
+      }
 #pragma unroll
       for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
