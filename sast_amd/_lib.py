@@ -66,6 +66,7 @@ SastSampleGather = _struct("SastSampleGather", [
     (C.c_uint8 * 256, "t_of"), (C.c_uint8 * 256, "b_of"),
 ])
 SastSampleMask = _struct("SastSampleMask", [(C.c_uint8 * 256, "sel")])
+SastShadowTensor = _struct("SastShadowTensor", [(C.c_longlong, "offset"), (I32, "rows cols")])
 
 _SIGNATURES = {
     "sast_version": (C.c_int, []),
@@ -114,6 +115,9 @@ _SIGNATURES = {
     "sast_zero_samples": (C.c_int, [P, C.c_int, C.c_size_t, C.POINTER(SastSampleMask), P]),
     "sast_adamw_onecycle": (C.c_int, [P, P, P, P, C.c_size_t, P, C.c_double, C.c_double, F32, F32, F32, F32, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, P]),
+    "sast_weight_shadow_register": (C.c_int, [P, C.c_longlong, P, P, C.POINTER(SastShadowTensor), C.c_int]),
+    "sast_weight_shadow_refresh": (C.c_int, [C.c_longlong, C.c_longlong, P]),
+    "sast_weight_shadow_active": (C.c_int, []),
     "sast_prof_enable": (C.c_int, [C.c_int]),
     "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -157,7 +161,7 @@ def tools_lib():
     global _tools
     if _tools is None:
         lib()      # the tools library links against the product library (same directory, rpath $ORIGIN)
-        _tools = C.CDLL(os.path.join(_HERE, "libsast_hip_tools.so"))
+        _tools = C.CDLL(os.environ.get("SAST_TOOLS_LIB_PATH") or os.path.join(_HERE, "libsast_hip_tools.so"))   # (variant builds: A/B of k_test.hip)
     return _tools
 
 

@@ -55,6 +55,13 @@ static __device__ unsigned long long sast_tl_buf[8 * 8192];
 #ifndef SAST_TL_JOB
 #define SAST_TL_JOB(j)
 #endif
+#ifndef SAST_TLF
+#define SAST_TLF_DECL
+#define SAST_TLF(k)
+#define SAST_TLF_COUNT()
+#define SAST_TLF_FLUSH()
+#define SAST_TLF_WAIT_OLDER(n)
+#endif
 
 namespace sast {
 
@@ -102,6 +109,27 @@ __device__ __forceinline__ void store_split3(float* dst, int plane_floats, float
   *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
 }
 
+// a lane's MFMA operand (8 consecutive k of index c0 + lane % 32, k = 8 * (lane / 32) + j) from the three [k][W] bf16 planes of an
+// index-contiguous presplit operand (OperandPresplitIC): per plane two transposing reads of a 4(k) x 16(index) block each
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+template <int W>
+__device__ __forceinline__ Split3 psi_read(const float* planes, int c0, int lane) {
+  using lds_bf16x4 = __attribute__((address_space(3))) bf16x4;
+  const int i = lane & 15;
+  const int k = 8 * (lane >> 5) + (i >> 2);                               // row this lane ADDRESSES (rows k and k + 4: same swizzle)
+  const int gran = ((c0 >> 2) + 4 * ((lane >> 4) & 1) + (i & 3)) ^ (W == 64 ? ((k >> 1) & 1) << 3 : W == 128 ? (k & 3) << 3 : 0);
+  const char* base = reinterpret_cast<const char*>(planes) + k * (2 * W) + gran * 8;
+  bf16x8 r[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const char* q = base + p * (32 * W);                                   // plane = 16 rows x 2W bytes
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q + 4 * (2 * W)));
+    r[p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  return Split3{r[0], r[1], r[2]};
+}
+
 // PF: k-tiles kept in flight in registers per k-group (global-load latency under load is ~2-3 us on MI355X, one k-tile of
 // MFMA work is ~0.2-0.4 us: see tools/gemm_timeline.py).  Must be even (LDS is double-buffered).
 #ifndef SAST_PF_DEFAULT
@@ -110,6 +138,11 @@ __device__ __forceinline__ void store_split3(float* dst, int plane_floats, float
 // 1: reduce-contiguous operands are split into their bf16 planes once, at the LDS store (see OperandPresplit)
 #ifndef SAST_PRESPLIT_RC
 #define SAST_PRESPLIT_RC 1
+#endif
+// 1: index-contiguous operands too: split at the LDS store into [k][index] bf16 planes, read back through the transposing LDS read
+// (ds_read_b64_tr_b16) straight into MFMA operand order (see OperandPresplitIC)
+#ifndef SAST_PRESPLIT_IC
+#define SAST_PRESPLIT_IC 1
 #endif
 // 1: fp32 products on the bf16 matrix pipe through an exact three-way operand split (gemm_body::compute); 0: v_mfma_f32_32x32x2_f32
 #ifndef SAST_MFMA_SPLIT3
@@ -122,9 +155,24 @@ __device__ __forceinline__ void store_split3(float* dst, int plane_floats, float
 #ifndef SAST_BF16_MFMA_REPEAT
 #define SAST_BF16_MFMA_REPEAT 1
 #endif
+// the loads of a phase are ISSUED before anything else of the phase: without the fence hipcc moves the validity selects / bf16 splits of the
+// register sets loaded in earlier phases (lstore) to the top of the phase, in front of the new loads, and waits for them there with
+// s_waitcnt vmcnt(0) -- no load is then in flight for longer than one phase (seen in the ISA; the k-loops ran at one global-load latency,
+// ~0.65 us, per k-tile whatever the tile shape: tools/gemm_timeline.py)
+#ifndef SAST_SCHED_FENCE
+#define SAST_SCHED_FENCE 1
+#endif
+#if SAST_SCHED_FENCE
+#define SAST_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SAST_PHASE_FENCE()
+#endif
+#ifndef SAST_WAVE_GROUPS_FREE
+#define SAST_WAVE_GROUPS_FREE 1
+#endif
 // independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
 #ifndef SAST_SINGLE_TILE_ACCS
-#define SAST_SINGLE_TILE_ACCS 1
+#define SAST_SINGLE_TILE_ACCS (SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 ? 2 : 1)
 #endif
 // OCC: blocks per CU the register allocation must leave room for (0 = no constraint beyond the block size).
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16, int KS_ = 1, int PF_ = SAST_PF_DEFAULT, int OCC_ = 0>
@@ -170,26 +218,59 @@ template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> :
 // LDS floats one workgroup of an instantiation needs
 // PRESPLIT (bf16x3 build): a reduce-contiguous (RC) operand is split into its three bf16 planes ONCE, by the thread that stores it to
 // LDS, instead of by every wave that reads it (in a 2x2-wave tile each element is read by two waves: the split VALU work of such an
-// operand halves; measured, the split is 0.7 ms of the 5.3 ms step).  Plane layout [row][BK + 8] bf16 (48-byte rows: ds_write_b64 of a
+// operand halves; measured, the split is 0.7 ms of the 5.3 ms step).  Plane layout [row][BK] bf16 (32-byte rows with a chunk swizzle, ps_chunk_swizzle: ds_write_b64 of a
 // thread's 4 k-values, one conflict-free ds_read_b128 per plane = a lane's 8 k-values as one MFMA operand).  Index-contiguous (IC)
-// operands keep the fp32 [k][row] layout and are split after the read.  Not for 8-way k-split tiles, nor where the planes (36 instead of
+// operands keep the fp32 [k][row] layout and are split after the read.  Not for 8-way k-split tiles, nor where the planes (24 instead of
 // 20 floats per row) would push a workgroup beyond 80 KB of LDS, nor for the 4-gate LSTM tiles (one wave reads all 128 B rows there: nothing
 // is shared, and the larger planes made the stage-1/2 LSTM GEMMs 25 % slower).
 template <class T, class L>
 struct OperandPresplitWanted { static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_RC && L::RC && T::BK == 16 && T::KS <= 4 && T::G < 4; };
-constexpr int PS_ROW_FLOATS = 3 * (16 + 8) / 2;   // 3 planes x 24 bf16 per row, in floats (36)
+constexpr int PS_ROW_FLOATS = 3 * 16 / 2;         // 3 planes x 16 bf16 per row, in floats (24)
+// unpadded 32-byte plane rows: the 16-byte chunk (k 0-7 | k 8-15) of a row is XOR-ed with bit 3 of the row index.  ds_read_b128 serves
+// the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}: with the swizzle their 16 chunks are 16 different 16-byte bank groups
+// (without it rows r and r+24 / r+8 of a group collide); a ds_write_b64 group (4 rows x 4 slots) covers 128 contiguous bytes either way
+__device__ __forceinline__ constexpr int ps_chunk_swizzle(int row) { return (row >> 3) & 1; }
 constexpr int PS_MAX_FLOATS = 20480;              // a workgroup's LDS with presplit operands must leave room for two per CU (80 KB)
+// PRESPLIT of an index-contiguous (IC) operand (both operands of every weight gradient, the weights of the dX GEMMs): the storing thread
+// holds 4 consecutive INDEX values of one k, the MFMA operand of a lane is 8 consecutive k of one index.  The planes are kept [k][index]
+// (bf16, row = W index values = 2W bytes, one ds_write_b64 per plane and slot) and read with ds_read_b64_tr_b16: the 16 lanes of a
+// group address the 4 x 16 block (lane i: row i / 4, 8-byte granule i % 4) and receive it transposed (lane i: column i, 4 rows), two
+// reads per plane = a lane's 8 k-values.  A 32-lane half reads 4 rows x 64 bytes per access; rows of 64 (128) values alias in the 64
+// banks, so the granule index is XOR-ed with a function of k that moves the 4 rows of a block to 4 different 64-byte bank groups.
+template <class T, class L, int W>
+struct OperandPresplitIC {
+  static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_IC && !L::RC && T::BK == 16 && T::KS <= 4 && T::G < 4 &&
+                                (W == 32 || W == 64 || W == 128);
+};
+// granule (8 bytes = 4 index values) XOR of row k for a plane row of W values
+template <int W> __device__ __forceinline__ constexpr int psi_swizzle(int k) { return W == 64 ? ((k >> 1) & 1) << 3 : W == 128 ? (k & 3) << 3 : 0; }
+// a B-side loader may read an operand that is ALREADY split (SPLIT_SOURCE: the bf16 planes of the weights kept next to the fp32 master
+// copy, LdWeightPre): its raw registers are the three plane pieces of a slot (Raw3) and the LDS store is a plain copy into the presplit
+// planes.  Tiles without presplit planes (8-way k-split, 4-gate, LDS budget) fall back to the loader's fp32 form (L::Plain, plain()).
+struct Raw3 { uint2 h, m, l; };
+template <class L, class = void> struct LoaderSplitSource : std::false_type {};
+template <class L> struct LoaderSplitSource<L, std::void_t<decltype(L::SPLIT_SOURCE)>> : std::bool_constant<L::SPLIT_SOURCE> {};
+template <class L, class = void> struct LoaderRaw { using type = float4; };
+template <class L> struct LoaderRaw<L, std::void_t<typename L::Raw>> { using type = typename L::Raw; };
 template <class T, class LA, class LB>
-struct GemmSmem {
+struct GemmSmemOf {
   static constexpr int LDK = T::BK + 4;
   static constexpr int A_PLAIN = LA::RC ? T::BM * LDK : T::BK * (T::BM + 4), B_PLAIN = LB::RC ? T::BN * LDK : T::BK * (T::BN + 4);
-  static constexpr int A_PS = OperandPresplitWanted<T, LA>::value ? T::BM * PS_ROW_FLOATS : A_PLAIN;
-  static constexpr int B_PS = OperandPresplitWanted<T, LB>::value ? T::BN * PS_ROW_FLOATS : B_PLAIN;
+  static constexpr bool A_WANT = OperandPresplitWanted<T, LA>::value || OperandPresplitIC<T, LA, T::BM>::value;
+  static constexpr bool B_WANT = OperandPresplitWanted<T, LB>::value || OperandPresplitIC<T, LB, T::BN>::value;
+  static constexpr int A_PS = !A_WANT ? A_PLAIN : LA::RC ? T::BM * PS_ROW_FLOATS : 24 * T::BM;   // IC: 3 planes x 16 rows x W bf16
+  static constexpr int B_PS = !B_WANT ? B_PLAIN : LB::RC ? T::BN * PS_ROW_FLOATS : 24 * T::BN;
   static constexpr bool PS_FITS = T::KS * 2 * (A_PS + B_PS) <= PS_MAX_FLOATS;
-  static constexpr bool PSA = PS_FITS && OperandPresplitWanted<T, LA>::value, PSB = PS_FITS && OperandPresplitWanted<T, LB>::value;
+  static constexpr bool PSA = PS_FITS && A_WANT, PSB = PS_FITS && B_WANT;
   static constexpr int A_STAGE = PSA ? A_PS : A_PLAIN, B_STAGE = PSB ? B_PS : B_PLAIN;
   static constexpr int FLOATS = T::KS * 2 * (A_STAGE + B_STAGE);
 };
+// the B loader a tile actually runs with: a split-source loader only where the tile keeps presplit B planes
+template <class T, class LA, class LB, bool SS = LoaderSplitSource<LB>::value> struct ResolveB { using type = LB; };
+template <class T, class LA, class LB> struct ResolveB<T, LA, LB, true> {
+  using type = std::conditional_t<GemmSmemOf<T, LA, LB>::PSB, LB, typename LB::Plain>;
+};
+template <class T, class LA, class LB> using GemmSmem = GemmSmemOf<T, LA, typename ResolveB<T, LA, LB>::type>;
 
 // the whole GEMM of one workgroup.  `block` / `nblocks` are the workgroup's index and the grid size of ITS problem (a
 // launch may carry two problems, see gemm_dual_kernel), `smem` its LDS (GemmSmem<...>::FLOATS floats, 16-byte aligned).
@@ -198,6 +279,10 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
                                           const int* __restrict__ dM, const int* __restrict__ dR,
                                           float* __restrict__ colsum, int nsplit, int xcd_remap, int block, int nblocks,
                                           float* __restrict__ smem) {
+  if constexpr (!std::is_same_v<typename ResolveB<T, LA, LB>::type, LB>) {   // no presplit B planes in this tile: the loader's fp32 form
+    gemm_body<T, LA, typename LB::Plain, EP, SPLIT>(la, lb.plain(), ep, M, NJ, R, dM, dR, colsum, nsplit, xcd_remap, block, nblocks, smem);
+    return;
+  } else {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NTG, G = T::G, BJ = T::BJ, KS = T::KS;
   // LDS tile layouts: a reduce-contiguous (RC) operand keeps its natural [row][k] order (row stride LDK = BK + 4 floats):
   // one ds_write_b128 per global float4 and BK/8 ds_read_b128 per lane per k-tile, both conflict-free; an index-contiguous
@@ -251,7 +336,8 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   // LayerScale multiply are deferred to `finish`), so hipcc keeps the loads outstanding behind counted s_waitcnt vmcnt(N)
   // instead of draining them right after issue.
   constexpr int PF = T::PF;
-  float4 ra[PF][A_PER], rb[PF][B_PER];
+  typename LoaderRaw<LA>::type ra[PF][A_PER];
+  typename LoaderRaw<LB>::type rb[PF][B_PER];
   float aa[PF][A_PER], ab[PF][B_PER];
   bool oa[PF][A_PER], ob[PF][B_PER];
   // rows at or beyond the end of this block's reduction range read as zeros: the pipeline below never branches on tile
@@ -275,12 +361,12 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       const int row = s / (BK / 4), kq = s % (BK / 4);
       ca[it] = la.prep(m0 + row, Meff);
       ra_off[it] = kq * 4;
-      la_off[it] = PSA ? row * 12 + kq * 2 : row * LDK + kq * 4;     // presplit: float index inside ONE plane (48-byte rows, 8 bytes per slot)
+      la_off[it] = PSA ? row * 8 + (kq ^ (2 * ps_chunk_swizzle(row))) * 2 : row * LDK + kq * 4;   // presplit: float index inside ONE plane (32-byte rows, 8 bytes per slot)
     } else {
       const int iq = s % (BM / 4), kk = s / (BM / 4);
       ca[it] = la.prep(m0 + iq * 4, Meff);
       ra_off[it] = kk;
-      la_off[it] = kk * LDA + iq * 4;
+      la_off[it] = PSA ? kk * (BM / 2) + (iq ^ psi_swizzle<BM>(kk)) * 2 : kk * LDA + iq * 4;     // presplit: float index inside ONE [k][m] bf16 plane
     }
   }
 #pragma unroll
@@ -292,13 +378,13 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jl, g, NJ, m0);
       else cb[it] = lb.prep(j0 + jl, g, NJ);
       rb_off[it] = kq * 4;
-      lb_off[it] = PSB ? nnmap(jl, g) * 12 + kq * 2 : nnmap(jl, g) * LDK + kq * 4;
+      lb_off[it] = PSB ? nnmap(jl, g) * 8 + (kq ^ (2 * ps_chunk_swizzle(nnmap(jl, g)))) * 2 : nnmap(jl, g) * LDK + kq * 4;
     } else {
       const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
       if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jq * 4, g, NJ, m0);
       else cb[it] = lb.prep(j0 + jq * 4, g, NJ);
       rb_off[it] = kk;
-      lb_off[it] = kk * LDB + nnmap(jq * 4, g);
+      lb_off[it] = PSB ? kk * (BN / 2) + ((nnmap(jq * 4, g) >> 2) ^ psi_swizzle<BN>(kk)) * 2 : kk * LDB + nnmap(jq * 4, g);
     }
   }
 
@@ -320,19 +406,36 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       }
   };
 
+  // bias gradient of a split-R job = column sums of its A operand.  An index-contiguous A is summed by the thread that stores it to LDS
+  // (4 adds per slot, before the bf16 split), a reduce-contiguous one by the waves that read it (csum, below)
+  const bool do_colsum = SPLIT && colsum != nullptr && bj == 0 && (!LA::RC || wn == 0);
+  float4 csacc[A_PER];
+#pragma unroll
+  for (int it = 0; it < A_PER; ++it) csacc[it] = zero4();
+
   auto lstore = [&](int buf, int set) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
       if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
-        if constexpr (PSA) store_split3(as + la_off[it], BM * 12, la.finish(ra[set][it], aa[set][it], oa[set][it]));
-        else st4(as + la_off[it], la.finish(ra[set][it], aa[set][it], oa[set][it]));
+        const float4 v = la.finish(ra[set][it], aa[set][it], oa[set][it]);
+        if constexpr (SPLIT && !LA::RC) {
+          if (do_colsum) { csacc[it].x += v.x; csacc[it].y += v.y; csacc[it].z += v.z; csacc[it].w += v.w; }
+        }
+        if constexpr (PSA) store_split3(as + la_off[it], BM * 8, v);
+        else st4(as + la_off[it], v);
       }
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
       if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
-        if constexpr (PSB) store_split3(bs + lb_off[it], BN * 12, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+        if constexpr (LoaderSplitSource<LB>::value) {
+          static_assert(PSB && LB::RC, "a split-source loader stores into reduce-contiguous presplit planes");
+          const Raw3 v = lb.finish(rb[set][it], ab[set][it], ob[set][it]);
+          *reinterpret_cast<uint2*>(bs + lb_off[it]) = v.h;
+          *reinterpret_cast<uint2*>(bs + lb_off[it] + BN * 8) = v.m;
+          *reinterpret_cast<uint2*>(bs + lb_off[it] + 2 * BN * 8) = v.l;
+        } else if constexpr (PSB) store_split3(bs + lb_off[it], BN * 8, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
         else st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
       }
   };
@@ -365,7 +468,6 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   float csum[T::TM];
 #pragma unroll
   for (int a = 0; a < T::TM; ++a) csum[a] = 0.f;
-  const bool do_colsum = SPLIT && colsum != nullptr && bj == 0 && wn == 0;
 
   auto compute = [&](int buf) {
     const float* as = As + buf * A_STAGE;
@@ -375,9 +477,11 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     Split3 sa[T::TM], sb[T::TN];
 #pragma unroll
     for (int t = 0; t < T::TM; ++t) {
-      if constexpr (PSA) {
-        const float* p = as + (wm * T::WTM + t * 32 + l31) * 12 + hf * 4;       // 16 bytes = this lane's 8 k-values of one plane
-        sa[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BM * 12)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BM * 12))};
+      if constexpr (PSA && !LA::RC) {
+        sa[t] = psi_read<BM>(as, wm * T::WTM + t * 32, lane);
+      } else if constexpr (PSA) {
+        const float* p = as + (wm * T::WTM + t * 32 + l31) * 8 + (hf ^ ps_chunk_swizzle(l31)) * 4;       // 16 bytes = this lane's 8 k-values of one plane
+        sa[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BM * 8)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BM * 8))};
       } else if constexpr (LA::RC) {
         const float* p = as + (wm * T::WTM + t * 32 + l31) * LDK + hf * HK;
 #pragma unroll
@@ -389,9 +493,11 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
 #pragma unroll
     for (int t = 0; t < T::TN; ++t) {
-      if constexpr (PSB) {
-        const float* p = bs + (wn * T::WTN + t * 32 + l31) * 12 + hf * 4;
-        sb[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BN * 12)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BN * 12))};
+      if constexpr (PSB && !LB::RC) {
+        sb[t] = psi_read<BN>(bs, wn * T::WTN + t * 32, lane);
+      } else if constexpr (PSB) {
+        const float* p = bs + (wn * T::WTN + t * 32 + l31) * 8 + (hf ^ ps_chunk_swizzle(l31)) * 4;
+        sb[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BN * 8)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BN * 8))};
       } else if constexpr (LB::RC) {
         const float* p = bs + (wn * T::WTN + t * 32 + l31) * LDK + hf * HK;
 #pragma unroll
@@ -401,8 +507,8 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
         for (int ks = 0; ks < HK; ++ks) b[t][ks] = bs[(hf * HK + ks) * LDB + wn * T::WTN + t * 32 + l31];
       }
     }
-    if (SPLIT && do_colsum) {
-      static_assert(!(SPLIT && PSA), "column sums read the fp32 A operand: split-R jobs take an index-contiguous A");
+    if (SPLIT && LA::RC && do_colsum) {
+      static_assert(!(SPLIT && PSA && LA::RC), "read-side column sums need the fp32 A operand");
 #pragma unroll
       for (int t = 0; t < T::TM; ++t)
 #pragma unroll
@@ -439,19 +545,30 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
         for (int t = 0; t < T::TN; ++t) sb[t] = split3(b[t]);
       }
+      // a dependent v_mfma_f32_32x32x16_bf16 waits ~2.4 issue slots for its accumulator (measured: six chained MFMAs cost ~77 cycles each,
+      // tools/ab notes in DESIGN 3): a wave with ONE output tile runs two chains (the even and the odd terms, summed after the k-loop),
+      // a wave with several tiles issues term by term across its tiles, so that consecutive MFMAs never share an accumulator
+      if constexpr (NACC > 1) {
+        f32x16 c0 = accs[0][0][0], c1 = accs[1][0][0];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].l, sb[0].h, c0, 0, 0, 0);     // smallest terms first
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].h, sb[0].l, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].m, sb[0].m, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].m, sb[0].h, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].h, sb[0].m, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].h, sb[0].h, c1, 0, 0, 0);
+        accs[0][0][0] = c0; accs[1][0][0] = c1;
+      } else {
 #pragma unroll
-      for (int ta = 0; ta < T::TM; ++ta)
+        for (int term = 0; term < 6; ++term)
 #pragma unroll
-        for (int tb = 0; tb < T::TN; ++tb) {
-          f32x16 c = accs[0][ta][tb];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].l, sb[tb].h, c, 0, 0, 0);     // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].h, sb[tb].l, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].m, sb[tb].m, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].m, sb[tb].h, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].h, sb[tb].m, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[ta].h, sb[tb].h, c, 0, 0, 0);
-          accs[0][ta][tb] = c;
-        }
+          for (int ta = 0; ta < T::TM; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T::TN; ++tb) {
+              const bf16x8 x = term == 0 ? sa[ta].l : (term == 2 || term == 3) ? sa[ta].m : sa[ta].h;      // l.h, h.l, m.m, m.h, h.m, h.h
+              const bf16x8 y = term == 1 ? sb[tb].l : (term == 2 || term == 4) ? sb[tb].m : sb[tb].h;
+              accs[0][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, accs[0][ta][tb], 0, 0, 0);
+            }
+      }
     } else {
 #pragma unroll
       for (int ks = 0; ks < HK; ++ks)
@@ -470,21 +587,38 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   // under a validity branch it has to assume the not-taken path and drains everything.  n_it is block-uniform.
   const int n_it = (kt1 - kt0 + KS - 1) / KS;
   auto tile_of = [&](int i) { return kt0 + kg + KS * i; };
+  // the k-loop synchronises the waves that SHARE a stage.  A k-group of one wave shares nothing: its LDS traffic is ordered by the wave's
+  // own instruction order (the LDS queue of a wave is in order), so it runs the whole reduction without a workgroup barrier -- the
+  // barrier would only keep the k-groups of the workgroup in lockstep (every wave reading LDS, then every wave in its MFMA chain, then
+  // every wave in the split) instead of letting them overlap.  SAST_WAVE_GROUPS_FREE=0 restores the barrier.
+  auto group_sync = [&]() {
+    if constexpr (NT > 64 || !SAST_WAVE_GROUPS_FREE) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+  };
 #pragma unroll
   for (int u = 0; u < PF; ++u) gload(tile_of(u), u);
   lstore(0, 0);
-  __syncthreads();
+  group_sync();
   SAST_TL(1);
   int i = 0;
+  SAST_TLF_DECL
   for (; i + PF <= n_it; i += PF) {   // no exits inside the unrolled body: one straight-line block per PF phases
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       gload(tile_of(i + u + PF), u);
+      SAST_PHASE_FENCE();
+      SAST_TLF(0);
       compute(u & 1);
+      SAST_TLF(1);
+      SAST_TLF_WAIT_OLDER(A_PER + B_PER);      // (instrumented builds: the wait for the tile loaded a phase ago, apart from its split + store)
       lstore((u + 1) & 1, (u + 1) % PF);
-      __syncthreads();
+      SAST_TLF(2);
+      group_sync();
+      SAST_TLF(3);
+      SAST_TLF_COUNT();
     }
   }
+  SAST_TLF_FLUSH();
   if constexpr (EARLY_AUX) {
     const int jc = min(j0 + wn * 32 + (lane & 31), NJ - 1), mb = m0 + wm * T::WTM + 4 * (lane >> 5);
 #pragma unroll
@@ -497,7 +631,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       if (u < rem) {
         compute(u & 1);
         lstore((u + 1) & 1, (u + 1) % PF);
-        __syncthreads();
+        group_sync();
       }
     }
   }
@@ -509,6 +643,36 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       for (int e = 0; e < 16; ++e) accs[0][0][0][e] += accs[c][0][0][e];
   }
   SAST_TL(2);
+  if constexpr (SPLIT && !LA::RC) {
+    if (do_colsum) {
+      if constexpr (64 % (BM / 4) == 0 && A_SLOTS % NT == 0) {   // a thread's slots all belong to index quad lane % (BM/4): fold the slots, then the lanes that share the quad
+        float4 t = csacc[0];
+#pragma unroll
+        for (int it = 1; it < A_PER; ++it) { t.x += csacc[it].x; t.y += csacc[it].y; t.z += csacc[it].z; t.w += csacc[it].w; }
+#pragma unroll
+        for (int off = BM / 4; off < 64; off <<= 1) {
+          t.x += __shfl_xor(t.x, off, 64); t.y += __shfl_xor(t.y, off, 64); t.z += __shfl_xor(t.z, off, 64); t.w += __shfl_xor(t.w, off, 64);
+        }
+        const int m = m0 + 4 * lane;
+        if (lane < BM / 4) {
+          if (m < Meff) atomicAdd(colsum + m, t.x);
+          if (m + 1 < Meff) atomicAdd(colsum + m + 1, t.y);
+          if (m + 2 < Meff) atomicAdd(colsum + m + 2, t.z);
+          if (m + 3 < Meff) atomicAdd(colsum + m + 3, t.w);
+        }
+      } else {                                                    // odd tile heights (micro-benchmarks): every slot adds its own sums
+#pragma unroll
+        for (int it = 0; it < A_PER; ++it)
+          if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
+            const int m = m0 + 4 * ((tid + it * NT) % (BM / 4));
+            if (m < Meff) atomicAdd(colsum + m, csacc[it].x);
+            if (m + 1 < Meff) atomicAdd(colsum + m + 1, csacc[it].y);
+            if (m + 2 < Meff) atomicAdd(colsum + m + 2, csacc[it].z);
+            if (m + 3 < Meff) atomicAdd(colsum + m + 3, csacc[it].w);
+          }
+      }
+    }
+  }
   if constexpr (KS > 1) {   // fold the k-groups' partial accumulators into group 0 through LDS
     float* red = smem + kg * GROUP_FLOATS + (wave * T::TM * T::TN) * 16 * 64 + lane;
     if (kg > 0) {
@@ -521,7 +685,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
     __syncthreads();
     if (kg > 0) {
-      if (SPLIT && do_colsum) {
+      if (SPLIT && LA::RC && do_colsum) {
 #pragma unroll
         for (int t = 0; t < T::TM; ++t) {
           const float sv = csum[t] + __shfl_xor(csum[t], 32, 64);
@@ -543,7 +707,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
   }
 
-  if (SPLIT && do_colsum) {
+  if (SPLIT && LA::RC && do_colsum) {
 #pragma unroll
     for (int t = 0; t < T::TM; ++t) {
       const float s = csum[t] + __shfl_xor(csum[t], 32, 64);   // the two k-parities of the 32x32x2 A operand
@@ -599,6 +763,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
   }
   SAST_TL(4);
+  }
 }
 
 template <class T, class LA, class LB, class EP, bool SPLIT>
@@ -949,6 +1114,55 @@ struct LdWeightNNS {
   __device__ __forceinline__ float4 finish(float4 v, float aux, bool ok) const {
     return ok ? make_float4(v.x * aux, v.y * aux, v.z * aux, v.w * aux) : zero4();
   }
+};
+
+// RC rows scaled per reduce index: X[i][r] = p[row(i)*ld + r] * s[r]  (the LayerScale factor of a dX GEMM applied to dY instead of to
+// the weight rows, when the weights come pre-split: LdWeightPre)
+struct LdRowsS {
+  static constexpr bool RC = true;
+  const float* p; int ld; const int* idx; const float* s;
+  struct Ctx { const float* row; bool ok; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    return Ctx{p + (size_t)(idx ? idx[ii] : ii) * ld, ok};
+  }
+  struct Raw { float4 v, s; };
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, Raw& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    v.v = ld4(c.row + (ok ? r : 0));
+    v.s = ld4(s + (r < Reff ? r : 0));
+    aux = 0.f;
+  }
+  __device__ __forceinline__ float4 finish(const Raw& v, float, bool ok) const {
+    return ok ? make_float4(v.v.x * v.s.x, v.v.y * v.s.y, v.v.z * v.s.z, v.v.w * v.s.w) : zero4();
+  }
+};
+// weights that are ALREADY split into bf16 planes (the weight shadow, k_shadow.hip): 24-byte slots [h0..h3 | m0..m3 | l0..l3] per 4
+// consecutive reduce values, row stride `lds` slots.  Serves both forms: the NT shadow has the layout of the fp32 weights (row = output
+// channel, g*gs + j), the T shadow holds W^T (row = output column of a dX GEMM, reduce along the rows of W).  An invalid slot reads
+// the zero slot `z` (an address select: nothing touches the loaded registers before the LDS store).  PlainL: the fp32 loader of the
+// same operand, used by tiles that keep no presplit planes.
+template <class PlainL>
+struct LdWeightPre {
+  static constexpr bool RC = true;
+  static constexpr bool SPLIT_SOURCE = true;
+  using Raw = Raw3;
+  using Plain = PlainL;
+  PlainL p; const uint2* s; int lds; int gs; const uint2* z;
+  struct Ctx { const uint2* row; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int g, int NJ) const {
+    const bool ok = j < NJ;
+    return Ctx{s + (size_t)(g * gs + (ok ? j : 0)) * lds * 3, ok};
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, Raw3& v, float& aux, bool& ok) const {
+    ok = c.ok && r < Reff;
+    const uint2* q = ok ? c.row + (r >> 2) * 3 : z;
+    v.h = q[0]; v.m = q[1]; v.l = q[2];
+    aux = 0.f;
+  }
+  __device__ __forceinline__ Raw3 finish(const Raw3& v, float, bool) const { return v; }
+  __host__ __device__ __forceinline__ PlainL plain() const { return p; }
 };
 
 // implicit-GEMM geometry of a 2D convolution on NHWC activations

@@ -9,9 +9,30 @@ __device__ unsigned long long sast_tl_buf[8 * 8192];
     if (threadIdx.x == 0 && bid_ < 8192) sast_tl_buf[bid_ * 8 + (k)] = wall_clock64();                      \
     if (threadIdx.x == 0 && bid_ < 8192 && (k) == 0) sast_tl_buf[bid_ * 8 + 7] = __smid();                 \
   } while (0)
+// fine-grained attribution inside the k-loop (variant builds with -DSAST_TLF_ENABLE only: the clock reads perturb the schedule):
+// shader-clock cycles of wave 0 of every block spent in [0] issuing the global loads, [1] LDS operand reads + MFMA issue, [2] the wait
+// for the older tile + split + LDS store, [3] the barrier; [4] = phases counted
+#ifdef SAST_TLF_ENABLE
+__device__ unsigned long long sast_tlf_buf[8 * 8192];
+#define SAST_TLF_DECL long long tlf_acc_[6] = {0, 0, 0, 0, 0, 0}; long long tlf_prev_ = clock64();
+#define SAST_TLF(k) do { const long long t_ = clock64(); tlf_acc_[k] += t_ - tlf_prev_; tlf_prev_ = t_; } while (0)
+#define SAST_TLF_COUNT() do { tlf_acc_[4] += 1; } while (0)
+#define SAST_TLF_WAIT_OLDER(n) do { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); const long long t_ = clock64(); tlf_acc_[5] += t_ - tlf_prev_; tlf_prev_ = t_; } while (0)
+#define SAST_TLF_FLUSH()                                                                                    \
+  do {                                                                                                      \
+    const unsigned bid_ = blockIdx.y * gridDim.x + blockIdx.x;                                              \
+    if (threadIdx.x == 0 && bid_ < 8192) for (int q_ = 0; q_ < 6; ++q_) sast_tlf_buf[bid_ * 8 + q_] = tlf_acc_[q_]; \
+  } while (0)
+#endif
 #include "gemm.cuh"
 #include "kernels.h"
 using namespace sast;
+#ifdef SAST_TLF_ENABLE
+extern "C" int sast_test_tlf(unsigned long long* host_out, int nblocks) {
+  if (nblocks > 8192) nblocks = 8192;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sast_tlf_buf), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -5;
+}
+#endif
 
 extern "C" int sast_test_timeline_reset(void) {
   static unsigned long long zeros[8 * 8192];
@@ -53,6 +74,14 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     case 18: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 19: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    // wave-private tiles: one wave per k-group, no barrier in the k-loop
+    case 30: return launch_gemm<Tile<64, 64, 1, 1, 1, 16, 1>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 31: return launch_gemm<Tile<64, 64, 1, 1, 1, 16, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 32: return launch_gemm<Tile<64, 64, 1, 1, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 33: return launch_gemm<Tile<32, 64, 1, 1, 1, 16, 1>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 34: return launch_gemm<Tile<32, 64, 1, 1, 1, 16, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 35: return launch_gemm<Tile<32, 64, 1, 1, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 36: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     default: return SAST_EINVAL;
   }
 }

@@ -50,6 +50,6 @@ for spec in args.nt:
     for _ in range(3):
         nt(a.data_ptr(), w.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, tile, st)
     torch.cuda.synchronize()
-    bm = 32 if tile in (19, 18, 9) else 64
-    bn = 32 if tile in (18, 9) else 64
+    bm = 32 if tile in (19, 18, 17, 9, 33, 34, 35, 36) else 64
+    bn = 32 if tile in (18, 17, 9, 36) else 64
     report(f"NT {M}x{N}x{K} {TILE_NAMES.get(tile, tile)}", min(8192, ((M + bm - 1) // bm) * ((N + bn - 1) // bn) + 8))
