@@ -315,23 +315,6 @@ int sast_gather_samples_bwd(const SastSampleGather* a, sast_stream_t stream);
 typedef struct { uint8_t sel[256]; } SastSampleMask;
 int sast_zero_samples(float* x, int B, size_t sample_floats, const SastSampleMask* sel, sast_stream_t stream);
 
-/* Weight shadow (csrc/k_shadow.hip): the bf16 x 3 planes of the GEMM weights, maintained by the caller next to the fp32 master copy, so
- * that the forward and dX GEMMs read their weight operand ALREADY split (the operand split of fp32 weights is otherwise repeated by every
- * row-tile workgroup).  No counterpart in the reference (a property of this implementation's fp32-on-bf16-MFMA arithmetic); results are
- * bit-identical with and without it (same split arithmetic, same products).
- *   base / n_floats   the contiguous fp32 parameter buffer (sast_amd.dist.FlatParams.flat); every tensor 16-byte aligned inside it
- *   nt_planes         6 * n_floats bytes: slot e/4 = [h0..h3 | m0..m3 | l0..l3] (bf16) of floats e..e+3 -- forward GEMMs (y = x W^T)
- *   t_planes          same size, or NULL: for each listed 2-D tensor W[rows][cols] (rows % 4 == 0) its region holds W^T in the same slot
- *                     format -- dX GEMMs (dx = dy W).  Tensors not listed keep the fp32 path in their dX GEMM.
- * Registration is library-global (one parameter buffer per process); register(NULL, ...) clears it.  sast_weight_shadow_refresh
- * re-splits the floats [lo, hi) (hi <= 0: to the end; a range never cuts a listed tensor) -- call it after every parameter update, on
- * the stream that ordered the update.  Weights outside the registered buffer always take the fp32 loaders. */
-typedef struct { long long offset; int rows, cols; } SastShadowTensor;   /* offset: floats from base */
-int sast_weight_shadow_register(const float* base, long long n_floats, void* nt_planes, void* t_planes, const SastShadowTensor* tensors,
-                                int n_tensors);
-int sast_weight_shadow_refresh(long long lo, long long hi, sast_stream_t stream);
-int sast_weight_shadow_active(void);   /* 0: none registered, 1: NT planes, 2: NT + T planes */
-
 /* fused AdamW over a flat parameter buffer (torch.optim.AdamW semantics, modules/detection.py:409-441).  The betas are doubles and
  * the bias corrections 1 - beta^step are evaluated in double, as torch does with its python scalars.  Every element is updated:
  * a parameter that received no gradient counts as gradient 0 (torch skips grad=None parameters; identical when every parameter is

@@ -66,7 +66,6 @@ SastSampleGather = _struct("SastSampleGather", [
     (C.c_uint8 * 256, "t_of"), (C.c_uint8 * 256, "b_of"),
 ])
 SastSampleMask = _struct("SastSampleMask", [(C.c_uint8 * 256, "sel")])
-SastShadowTensor = _struct("SastShadowTensor", [(C.c_longlong, "offset"), (I32, "rows cols")])
 
 _SIGNATURES = {
     "sast_version": (C.c_int, []),
@@ -115,9 +114,6 @@ _SIGNATURES = {
     "sast_zero_samples": (C.c_int, [P, C.c_int, C.c_size_t, C.POINTER(SastSampleMask), P]),
     "sast_adamw_onecycle": (C.c_int, [P, P, P, P, C.c_size_t, P, C.c_double, C.c_double, F32, F32, F32, F32, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, P]),
-    "sast_weight_shadow_register": (C.c_int, [P, C.c_longlong, P, P, C.POINTER(SastShadowTensor), C.c_int]),
-    "sast_weight_shadow_refresh": (C.c_int, [C.c_longlong, C.c_longlong, P]),
-    "sast_weight_shadow_active": (C.c_int, []),
     "sast_prof_enable": (C.c_int, [C.c_int]),
     "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),

@@ -172,7 +172,7 @@ __device__ __forceinline__ Split3 psi_read(const float* planes, int c0, int lane
 #endif
 // independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
 #ifndef SAST_SINGLE_TILE_ACCS
-#define SAST_SINGLE_TILE_ACCS (SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 ? 2 : 1)
+#define SAST_SINGLE_TILE_ACCS 1
 #endif
 // OCC: blocks per CU the register allocation must leave room for (0 = no constraint beyond the block size).
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int G_, int BK_ = 16, int KS_ = 1, int PF_ = SAST_PF_DEFAULT, int OCC_ = 0>
@@ -244,16 +244,8 @@ struct OperandPresplitIC {
 };
 // granule (8 bytes = 4 index values) XOR of row k for a plane row of W values
 template <int W> __device__ __forceinline__ constexpr int psi_swizzle(int k) { return W == 64 ? ((k >> 1) & 1) << 3 : W == 128 ? (k & 3) << 3 : 0; }
-// a B-side loader may read an operand that is ALREADY split (SPLIT_SOURCE: the bf16 planes of the weights kept next to the fp32 master
-// copy, LdWeightPre): its raw registers are the three plane pieces of a slot (Raw3) and the LDS store is a plain copy into the presplit
-// planes.  Tiles without presplit planes (8-way k-split, 4-gate, LDS budget) fall back to the loader's fp32 form (L::Plain, plain()).
-struct Raw3 { uint2 h, m, l; };
-template <class L, class = void> struct LoaderSplitSource : std::false_type {};
-template <class L> struct LoaderSplitSource<L, std::void_t<decltype(L::SPLIT_SOURCE)>> : std::bool_constant<L::SPLIT_SOURCE> {};
-template <class L, class = void> struct LoaderRaw { using type = float4; };
-template <class L> struct LoaderRaw<L, std::void_t<typename L::Raw>> { using type = typename L::Raw; };
 template <class T, class LA, class LB>
-struct GemmSmemOf {
+struct GemmSmem {
   static constexpr int LDK = T::BK + 4;
   static constexpr int A_PLAIN = LA::RC ? T::BM * LDK : T::BK * (T::BM + 4), B_PLAIN = LB::RC ? T::BN * LDK : T::BK * (T::BN + 4);
   static constexpr bool A_WANT = OperandPresplitWanted<T, LA>::value || OperandPresplitIC<T, LA, T::BM>::value;
@@ -265,12 +257,6 @@ struct GemmSmemOf {
   static constexpr int A_STAGE = PSA ? A_PS : A_PLAIN, B_STAGE = PSB ? B_PS : B_PLAIN;
   static constexpr int FLOATS = T::KS * 2 * (A_STAGE + B_STAGE);
 };
-// the B loader a tile actually runs with: a split-source loader only where the tile keeps presplit B planes
-template <class T, class LA, class LB, bool SS = LoaderSplitSource<LB>::value> struct ResolveB { using type = LB; };
-template <class T, class LA, class LB> struct ResolveB<T, LA, LB, true> {
-  using type = std::conditional_t<GemmSmemOf<T, LA, LB>::PSB, LB, typename LB::Plain>;
-};
-template <class T, class LA, class LB> using GemmSmem = GemmSmemOf<T, LA, typename ResolveB<T, LA, LB>::type>;
 
 // the whole GEMM of one workgroup.  `block` / `nblocks` are the workgroup's index and the grid size of ITS problem (a
 // launch may carry two problems, see gemm_dual_kernel), `smem` its LDS (GemmSmem<...>::FLOATS floats, 16-byte aligned).
@@ -279,10 +265,6 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
                                           const int* __restrict__ dM, const int* __restrict__ dR,
                                           float* __restrict__ colsum, int nsplit, int xcd_remap, int block, int nblocks,
                                           float* __restrict__ smem) {
-  if constexpr (!std::is_same_v<typename ResolveB<T, LA, LB>::type, LB>) {   // no presplit B planes in this tile: the loader's fp32 form
-    gemm_body<T, LA, typename LB::Plain, EP, SPLIT>(la, lb.plain(), ep, M, NJ, R, dM, dR, colsum, nsplit, xcd_remap, block, nblocks, smem);
-    return;
-  } else {
   constexpr int BM = T::BM, BN = T::BN, BK = T::BK, NT = T::NTG, G = T::G, BJ = T::BJ, KS = T::KS;
   // LDS tile layouts: a reduce-contiguous (RC) operand keeps its natural [row][k] order (row stride LDK = BK + 4 floats):
   // one ds_write_b128 per global float4 and BK/8 ds_read_b128 per lane per k-tile, both conflict-free; an index-contiguous
@@ -336,8 +318,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   // LayerScale multiply are deferred to `finish`), so hipcc keeps the loads outstanding behind counted s_waitcnt vmcnt(N)
   // instead of draining them right after issue.
   constexpr int PF = T::PF;
-  typename LoaderRaw<LA>::type ra[PF][A_PER];
-  typename LoaderRaw<LB>::type rb[PF][B_PER];
+  float4 ra[PF][A_PER], rb[PF][B_PER];
   float aa[PF][A_PER], ab[PF][B_PER];
   bool oa[PF][A_PER], ob[PF][B_PER];
   // rows at or beyond the end of this block's reduction range read as zeros: the pipeline below never branches on tile
@@ -429,13 +410,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
       if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
-        if constexpr (LoaderSplitSource<LB>::value) {
-          static_assert(PSB && LB::RC, "a split-source loader stores into reduce-contiguous presplit planes");
-          const Raw3 v = lb.finish(rb[set][it], ab[set][it], ob[set][it]);
-          *reinterpret_cast<uint2*>(bs + lb_off[it]) = v.h;
-          *reinterpret_cast<uint2*>(bs + lb_off[it] + BN * 8) = v.m;
-          *reinterpret_cast<uint2*>(bs + lb_off[it] + 2 * BN * 8) = v.l;
-        } else if constexpr (PSB) store_split3(bs + lb_off[it], BN * 8, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+        if constexpr (PSB) store_split3(bs + lb_off[it], BN * 8, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
         else st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
       }
   };
@@ -545,9 +520,9 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
         for (int t = 0; t < T::TN; ++t) sb[t] = split3(b[t]);
       }
-      // a dependent v_mfma_f32_32x32x16_bf16 waits ~2.4 issue slots for its accumulator (measured: six chained MFMAs cost ~77 cycles each,
-      // tools/ab notes in DESIGN 3): a wave with ONE output tile runs two chains (the even and the odd terms, summed after the k-loop),
-      // a wave with several tiles issues term by term across its tiles, so that consecutive MFMAs never share an accumulator
+      // MFMA order: a wave with several output tiles issues term by term ACROSS its tiles, so that consecutive MFMAs do not share an
+      // accumulator.  For a wave with ONE tile two chains (even / odd terms, -DSAST_SINGLE_TILE_ACCS=2) were measured again under the bf16
+      // split: +-0 in the micro-benchmarks, +0.5 % on the step (16 more VGPRs) -- the chain is not what the k-loop waits for
       if constexpr (NACC > 1) {
         f32x16 c0 = accs[0][0][0], c1 = accs[1][0][0];
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa[0].l, sb[0].h, c0, 0, 0, 0);     // smallest terms first
@@ -763,7 +738,6 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     }
   }
   SAST_TL(4);
-  }
 }
 
 template <class T, class LA, class LB, class EP, bool SPLIT>
@@ -1114,55 +1088,6 @@ struct LdWeightNNS {
   __device__ __forceinline__ float4 finish(float4 v, float aux, bool ok) const {
     return ok ? make_float4(v.x * aux, v.y * aux, v.z * aux, v.w * aux) : zero4();
   }
-};
-
-// RC rows scaled per reduce index: X[i][r] = p[row(i)*ld + r] * s[r]  (the LayerScale factor of a dX GEMM applied to dY instead of to
-// the weight rows, when the weights come pre-split: LdWeightPre)
-struct LdRowsS {
-  static constexpr bool RC = true;
-  const float* p; int ld; const int* idx; const float* s;
-  struct Ctx { const float* row; bool ok; };
-  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
-    const bool ok = i < Ieff;
-    const int ii = ok ? i : 0;
-    return Ctx{p + (size_t)(idx ? idx[ii] : ii) * ld, ok};
-  }
-  struct Raw { float4 v, s; };
-  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, Raw& v, float& aux, bool& ok) const {
-    ok = c.ok && r < Reff;
-    v.v = ld4(c.row + (ok ? r : 0));
-    v.s = ld4(s + (r < Reff ? r : 0));
-    aux = 0.f;
-  }
-  __device__ __forceinline__ float4 finish(const Raw& v, float, bool ok) const {
-    return ok ? make_float4(v.v.x * v.s.x, v.v.y * v.s.y, v.v.z * v.s.z, v.v.w * v.s.w) : zero4();
-  }
-};
-// weights that are ALREADY split into bf16 planes (the weight shadow, k_shadow.hip): 24-byte slots [h0..h3 | m0..m3 | l0..l3] per 4
-// consecutive reduce values, row stride `lds` slots.  Serves both forms: the NT shadow has the layout of the fp32 weights (row = output
-// channel, g*gs + j), the T shadow holds W^T (row = output column of a dX GEMM, reduce along the rows of W).  An invalid slot reads
-// the zero slot `z` (an address select: nothing touches the loaded registers before the LDS store).  PlainL: the fp32 loader of the
-// same operand, used by tiles that keep no presplit planes.
-template <class PlainL>
-struct LdWeightPre {
-  static constexpr bool RC = true;
-  static constexpr bool SPLIT_SOURCE = true;
-  using Raw = Raw3;
-  using Plain = PlainL;
-  PlainL p; const uint2* s; int lds; int gs; const uint2* z;
-  struct Ctx { const uint2* row; bool ok; };
-  __device__ __forceinline__ Ctx prep(int j, int g, int NJ) const {
-    const bool ok = j < NJ;
-    return Ctx{s + (size_t)(g * gs + (ok ? j : 0)) * lds * 3, ok};
-  }
-  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, Raw3& v, float& aux, bool& ok) const {
-    ok = c.ok && r < Reff;
-    const uint2* q = ok ? c.row + (r >> 2) * 3 : z;
-    v.h = q[0]; v.m = q[1]; v.l = q[2];
-    aux = 0.f;
-  }
-  __device__ __forceinline__ Raw3 finish(const Raw3& v, float, bool) const { return v; }
-  __host__ __device__ __forceinline__ PlainL plain() const { return p; }
 };
 
 // implicit-GEMM geometry of a 2D convolution on NHWC activations

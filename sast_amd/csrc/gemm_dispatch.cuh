@@ -70,25 +70,6 @@ inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
   return splits < 1 ? 1 : splits;
 }
 
-// ---- weight shadow (k_shadow.hip): a weight operand that lies in the registered parameter buffer is read pre-split
-bool shadow_nt_of(const float* w, int ldw, const uint2** s, const uint2** z);
-bool shadow_t_of(const float* w, int rows, int cols, const uint2** s, const uint2** z);
-// forward form: f(loader) with the NT planes of w[(g*gs + j)][ldw] when registered, else with the fp32 loader
-template <class F>
-inline int with_weight_nt(const float* w, int ldw, int gs, F&& f) {
-  const uint2 *s, *z;
-  if (shadow_nt_of(w, ldw, &s, &z)) return f(LdWeightPre<LdWeightNT>{LdWeightNT{w, ldw, gs}, s, ldw / 4, gs, z});
-  return f(LdWeightNT{w, ldw, gs});
-}
-// dX form: B[r][j] = w[r*ldw + j] (* rscale[r]), R rows.  With T planes: f(scaled, loader) -- `scaled` false: the caller applies rscale to
-// its A operand (LdRowsS) instead; without: f(true, fp32 loader)
-template <class F>
-inline int with_weight_nn(const float* w, int ldw, int R, F&& f) {
-  const uint2 *s, *z;
-  if (shadow_t_of(w, R, ldw, &s, &z)) return f(LdWeightPre<LdWeightNN>{LdWeightNN{w, ldw}, s, R / 4, 0, z});
-  return f(LdWeightNN{w, ldw});
-}
-
 // weight-gradient form: out[Mo, NJ] += A^T B over R rows (dR: device-side count), optional column sums of A (bias gradient)
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {

@@ -238,7 +238,7 @@ int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   ep.c = a->s; ep.ldc = C; ep.bias = a->ws_b;
   ep.k = ControlsJob{a->wc, a->r, a->r_stride, a->scale, a->dscale_ws, nullptr, nullptr, a->B, C, 20};
   ep.side_blocks = (a->B * C + 255) / 256;
-  int rc = with_weight_nt(a->ws_w, C, 0, [&](auto lb) { return gemm_auto(LdRows{a->xp, C, nullptr}, lb, ep, M, C, C, nullptr, st); });
+  int rc = gemm_auto(LdRows{a->xp, C, nullptr}, LdWeightNT{a->ws_w, C, 0}, ep, M, C, C, nullptr, st);
   if (rc) return rc;
   return stp_fwd_launch(a->xp, a->s, a->scale, a->amp, a->xw, a->tok, a->B, a->L, C, st);
 }
@@ -257,10 +257,8 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
   ep.c = a->dxp; ep.ldc = C; ep.add = a->dxp; ep.ldadd = C;
   ep.k = ControlsJob{a->wc, a->r, a->r_stride, nullptr, nullptr, dscale, a->d_wc, a->B, C, 20};
   ep.side_blocks = (C * 20 + 255) / 256;
-  return with_weight_nn(a->ws_w, C, C, [&](auto lb) {
-    return gemm_pair(LdRowsT{dz, C}, LdRowsT{a->xp, C}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b,
-                     LdRows{dz, C, nullptr}, lb, ep, M, C, C, nullptr, st);
-  });
+  return gemm_pair(LdRowsT{dz, C}, LdRowsT{a->xp, C}, a->d_ws_w, C, C, C, M, nullptr, a->d_ws_b,
+                   LdRows{dz, C, nullptr}, LdWeightNN{a->ws_w, C}, ep, M, C, C, nullptr, st);
 }
 
 // ------------------------------------------------------------------ MS-WSA
@@ -282,28 +280,31 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   int rc = ln1_gather_fwd_launch(a->xin, a->out, a->S, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->ln2_b, a->mean1,
                                  a->rstd1, a->mean2, a->rstd2, R, C, a->eps, a->raw_ws, sast_mswsa_raw_ws_floats(C, inner), st);
   if (rc) return rc;
-  rc = with_weight_nt(a->qkv_w, C, 0, [&](auto lb) { return gemm_auto(LdRows{a->S, C, nullptr}, lb, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st); });
+  rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
   rc = T <= mfma_attn_max_t() ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st)
                               : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
-  rc = with_weight_nt(a->proj_w, C, 0, [&](auto lb) {
-    return gemm_auto(LdRows{a->O, C, nullptr}, lb, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
-  });
+  rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
   if (rc) return rc;
   {
     const LdRows la{a->Y, C, nullptr};
+    const LdWeightNT lb{a->fc1_w, C, inner};
     const EpGlu ep{a->UG, a->Hh, a->fc1_b, inner};
-    rc = with_weight_nt(a->fc1_w, C, inner, [&](auto lb) { return launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st); });
+    const long nb = (long)((R + 63) / 64) * ((inner + 63) / 64);
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("SAST_GLU_TILE"); mode = e ? atoi(e) : 0; }
+    if (mode && C >= 256 && nb <= 2 * pair_thin_nb()) rc = launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    else if (mode && C >= 256) rc = launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    else rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     if (rc) return rc;
   }
   if (a->cb_tps <= 0)
-    return with_weight_nt(a->fc2_w, inner, 0, [&](auto lb) {
-      return gemm_auto(LdRows{a->Hh, inner, nullptr}, lb, EpResidualLSScatter{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C}, R, C, inner, dR, st);
-    });
+    return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
+                     EpResidualLSScatter{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C}, R, C, inner, dR, st);
   // Context Broadcasting (SAST.py:240-246): the MLP output is mixed with its per-sample mean over ALL L tokens before LayerScale
   if (!a->cb_m || !a->cb_sum || R % a->cb_tps) return SAST_EINVAL;
-  rc = with_weight_nt(a->fc2_w, inner, 0, [&](auto lb) { return gemm_auto(LdRows{a->Hh, inner, nullptr}, lb, EpStore{a->cb_m, C, a->fc2_b}, R, C, inner, dR, st); });
+  rc = gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0}, EpStore{a->cb_m, C, a->fc2_b}, R, C, inner, dR, st);
   if (rc) return rc;
   rc = cb_sample_sum_launch(a->cb_m, C, false, a->sel.row_tok, dR, R, a->cb_tps, R / a->cb_tps, C, a->cb_sum, st);
   if (rc) return rc;
@@ -347,14 +348,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   // fc2: raw dW2 / db2 (LayerScale applied in the finish kernel) need dZ (= dout rows) and H;  dH = (gamma2 * dZ) W2 fused
   // with the GLU backward: dUG from the saved pre-activations
   if (dz_tok && a->ls2) {
-    // (with the weight shadow the LayerScale factor goes to the dZ operand, as in the reference's autograd order, and W2 is read pre-split)
-    const uint2 *sh, *zs;
-    if (shadow_t_of(a->fc2_w, C, inner, &sh, &zs))
-      rc = gemm_pair(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, LdRowsS{dz, C, dz_tok, a->ls2},
-                     LdWeightPre<LdWeightNN>{LdWeightNN{a->fc2_w, inner}, sh, C / 4, 0, zs}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
-    else
-      rc = gemm_pair(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2,
-                     LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
+    rc = gemm_pair(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2,
+                   LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
   } else {   // Context Broadcasting (compact dZ') or LayerScale disabled: the rarely used combinations stay two launches
     rc = dz_tok ? gemm_tn(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st)
                 : gemm_tn(LdRowsT{dz, C}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st);
@@ -364,20 +359,13 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   }
   if (rc) return rc;
   // fc1: dW1 / db1, and dY = dZ + dUG W1
-  rc = with_weight_nn(a->fc1_w, C, 2 * inner, [&](auto lb) {
-    return gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
-                     LdRows{dUG, 2 * inner, nullptr}, lb, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
-  });
+  rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
+                 LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
   if (rc) return rc;
   // proj: raw dWp / dbp, and dO = (gamma1 * dY) Wp
   if (a->ls1) {
-    const uint2 *sh, *zs;
-    if (shadow_t_of(a->proj_w, C, C, &sh, &zs))
-      rc = gemm_pair(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, LdRowsS{dY, C, nullptr, a->ls1},
-                     LdWeightPre<LdWeightNN>{LdWeightNN{a->proj_w, C}, sh, C / 4, 0, zs}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
-    else
-      rc = gemm_pair(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1,
-                     LdRows{dY, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+    rc = gemm_pair(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1,
+                   LdRows{dY, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   } else {
     rc = gemm_tn(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, st);
     if (rc) return rc;
@@ -398,10 +386,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv
-  rc = with_weight_nn(a->qkv_w, C, 3 * C, [&](auto lb) {
-    return gemm_pair(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b,
-                     LdRows{dQKV, 3 * C, nullptr}, lb, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
-  });
+  rc = gemm_pair(LdRowsT{dQKV, 3 * C}, LdRowsT{a->S, C}, a->d_qkv_w, C, 3 * C, C, R, dR, a->d_qkv_b,
+                 LdRows{dQKV, 3 * C, nullptr}, LdWeightNN{a->qkv_w, C}, EpStoreAdd{dS, C, dY, C}, R, C, 3 * C, dR, st);
   if (rc) return rc;
   // LN2 (kept rows) + LN1 (all tokens) backward
   return ln1_gather_bwd_launch(a->xin, a->dout, dS, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->mean1, a->rstd1, a->mean2,
@@ -435,10 +421,8 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
   SAST_LAUNCH(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
                      a->dh1b, a->dc1, dmix, a->dc0, n, C, div_mul_of((unsigned)C, n));
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
-  return with_weight_nn(a->w, 2 * C, 4 * C, [&](auto lb) {
-    return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
-                     LdRows{dmix, 4 * C, nullptr}, lb, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
-  });
+  return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
+                   LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);
 }
 
 }  // extern "C"

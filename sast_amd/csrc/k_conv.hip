@@ -434,7 +434,7 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
   const int k = 2 * a->factor - 1;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
-  int rc = with_weight_nt(a->w, K, 0, [&](auto lb) { return conv_gemm(a->x, g, lb, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st); });
+  int rc = conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
   if (rc) return rc;
   return ln_fwd_launch(a->conv_out, a->y, a->ln_w, a->ln_b, a->pe, g.Ho * g.Wo, a->mean, a->rstd, M, a->Cout, 1e-5f, st);
 }
@@ -473,23 +473,20 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   if (!a->training && !a->conv_out) {   // inference: one launch, nothing kept for a backward
     if (!a->run_mean || !a->run_var) return SAST_EINVAL;
     const EpBnSilu ep{a->y, a->ldy, a->run_mean, a->run_var, a->bn_w, a->bn_b, a->eps};
-    return with_weight_nt(a->w, K, 0, [&](auto lb) {
-      return one ? (a->x2 ? gemm_auto(la2, lb, ep, M, C, K, st) : gemm_auto(LdRows{a->x, a->ldx, nullptr}, lb, ep, M, C, K, st))
-                 : conv_gemm(a->x, g, lb, ep, M, C, K, st);
-    });
+    return one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                        : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+               : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
-    rc = with_weight_nt(a->w, K, 0, [&](auto lb) {
-      return one ? (a->x2 ? gemm_auto(la2, lb, ep, M, C, K, st) : gemm_auto(LdRows{a->x, a->ldx, nullptr}, lb, ep, M, C, K, st))
-                 : conv_gemm(a->x, g, lb, ep, M, C, K, st);
-    });
+    rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                      : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+             : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   } else {
     const EpStore ep{a->conv_out, C, nullptr};
-    rc = with_weight_nt(a->w, K, 0, [&](auto lb) {
-      return one ? (a->x2 ? gemm_auto(la2, lb, ep, M, C, K, st) : gemm_auto(LdRows{a->x, a->ldx, nullptr}, lb, ep, M, C, K, st))
-                 : conv_gemm(a->x, g, lb, ep, M, C, K, st);
-    });
+    rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                      : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+             : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (rc) return rc;
   if (a->training && sep) {
@@ -539,29 +536,21 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
     if (a->lddx != a->Cin1) return SAST_EINVAL;
     if (fold) {
       if ((p1.x && a->ldx != a->Cin1) || (p2.x && (a->ldx2 != C2 || !a->dx2))) return SAST_EINVAL;
-      return with_weight_nn(a->w, K, C, [&](auto lb) {
-        return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr}, lb,
-                         EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
-      });
+      return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K},
+                       EpSplit2BnRed{a->dx, a->dx2, a->Cin1, C2, p1, p2}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
     }
-    return with_weight_nn(a->w, K, C, [&](auto lb) {
-      return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr,
-                       LdRows{dconv, C, nullptr}, lb, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
-    });
+    return gemm_pair(LdRowsT{dconv, C}, tb, a->dw, K, C, K, M, nullptr, nullptr,
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpSplit2{a->dx, a->dx2, a->Cin1, C2}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
   }
   if (k == 1 && a->stride == 1) {
     if (!a->dx) return gemm_tn(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, st);
     if (fold) {
       if (a->lddx != a->Cin || a->ldx != a->Cin) return SAST_EINVAL;
-      return with_weight_nn(a->w, K, C, [&](auto lb) {
-        return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr},
-                         lb, EpStoreBnRed{a->dx, a->lddx, p1}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
-      });
+      return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr, LdRows{dconv, C, nullptr},
+                       LdWeightNN{a->w, K}, EpStoreBnRed{a->dx, a->lddx, p1}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
     }
-    return with_weight_nn(a->w, K, C, [&](auto lb) {
-      return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr,
-                       LdRows{dconv, C, nullptr}, lb, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
-    });
+    return gemm_pair(LdRowsT{dconv, C}, LdRowsT{a->x, a->ldx}, a->dw, K, C, K, M, nullptr, nullptr,
+                     LdRows{dconv, C, nullptr}, LdWeightNN{a->w, K}, EpStore{a->dx, a->lddx, nullptr}, M, a->Cin, C, nullptr, st, pair_tn_blocks_1x1());
   }
   return conv_bwd_pair(dconv, a->x, g, C, a->w, a->dw, a->dx, a->lddx, st, fold ? &p1 : nullptr);
 }

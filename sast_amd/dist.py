@@ -92,71 +92,6 @@ class FlatParams:
                 torch.cuda.synchronize()
 
 
-class WeightShadow:
-    """bf16 x 3 planes of the GEMM weights of a FlatParams buffer (include/sast_hip.h: sast_weight_shadow_*; csrc/k_shadow.hip).
-
-    While registered, every forward GEMM whose weight lies in the flat buffer reads it pre-split (NT planes), and the dX GEMMs of the
-    linear layers / 1x1 convolutions read W^T pre-split (T planes) -- bit-identical results, without the per-workgroup operand split
-    of the weights.  The owner must call `refresh` after EVERY change of the parameters (TrainStep does, per bucket, right behind the
-    AdamW update); `close()` unregisters (the registration is process-global: one parameter buffer at a time)."""
-
-    _current = None     # the instance whose buffers the library currently points at (weak reference)
-
-    def __init__(self, fp: "FlatParams", transposed: bool = True):
-        from . import _lib as L
-        import weakref
-        if not fp.flat.is_cuda:
-            raise RuntimeError("WeightShadow needs the parameters on the GPU")
-        self.fp = fp
-        n = fp.numel
-        self.nt = torch.zeros(n // 4 * 24, dtype=torch.uint8, device=fp.flat.device)
-        self.t = torch.zeros(n // 4 * 24, dtype=torch.uint8, device=fp.flat.device) if transposed else None
-        tensors = []
-        if transposed:
-            for p, off in zip(fp.params, fp.offsets):
-                two_d = p.dim() == 2 or (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1)
-                if two_d and p.shape[0] % 4 == 0 and (p.numel() // p.shape[0]) % 4 == 0:
-                    tensors.append((off, p.shape[0], p.numel() // p.shape[0]))
-        arr = (L.SastShadowTensor * max(1, len(tensors)))()
-        for i, (off, r, c) in enumerate(tensors):
-            arr[i].offset, arr[i].rows, arr[i].cols = off, r, c
-        self.n_transposed = len(tensors)
-        L.check(L.lib().sast_weight_shadow_register(fp.flat.data_ptr(), n, self.nt.data_ptr(), self.t.data_ptr() if transposed else None,
-                                                    arr, len(tensors)), "sast_weight_shadow_register")
-        prev = WeightShadow._current() if WeightShadow._current is not None else None
-        if prev is not None:
-            prev._open = False          # a newer registration replaced it: its owner's GEMMs are back on the fp32 weight loaders
-        WeightShadow._current = weakref.ref(self)
-        self._open = True
-        self.refresh()
-
-    @property
-    def active(self) -> bool:
-        return self._open
-
-    def refresh(self, bucket: Optional[int] = None):
-        """re-split the parameters (of one bucket) on the current stream"""
-        from . import _lib as L
-        if not self._open:
-            return
-        lo, hi = (0, self.fp.numel) if bucket is None else self.fp.bucket_ranges[bucket]
-        if hi > lo:
-            L.check(L.lib().sast_weight_shadow_refresh(lo, hi, torch.cuda.current_stream().cuda_stream), "sast_weight_shadow_refresh")
-
-    def close(self):
-        from . import _lib as L
-        if self._open:
-            L.lib().sast_weight_shadow_register(None, 0, None, None, None, 0)
-            self._open = False
-            WeightShadow._current = None
-
-    def __del__(self):      # the library must never keep pointers into freed buffers
-        try:
-            self.close()
-        except Exception:
-            pass
-
-
 class OneCycleLR:
     """torch.optim.lr_scheduler.OneCycleLR(anneal_strategy='linear', cycle_momentum=False, three_phase=False) as the reference
     configures it (modules/detection.py:418-431: final lr = max_lr / final_div_factor, i.e. torch's final_div_factor is

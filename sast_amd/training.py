@@ -26,15 +26,12 @@ import torch
 import torch.distributed as dist
 
 from . import functional as SF
-import os
-
-from .dist import FlatParams, FusedAdamW, OneCycleLR, WeightShadow
+from .dist import FlatParams, FusedAdamW, OneCycleLR
 
 
 class TrainStep:
     def __init__(self, net, fpn, head=None, *, lr: float = 2e-4, weight_decay: float = 0.0, clip_value: float = 0.0, eps: float = 1e-8,
-                 schedule: Optional[OneCycleLR] = None, world: int = 1, group=None, segmented: bool = True,
-                 weight_shadow: Optional[bool] = None):
+                 schedule: Optional[OneCycleLR] = None, world: int = 1, group=None, segmented: bool = True):
         self.net, self.fpn, self.head = net, fpn, head
         self.world, self.group, self.segmented = world, group, segmented
         stages = list(net.stages)
@@ -47,12 +44,6 @@ class TrainStep:
         self.loss = self.P = self.losses = None
         self._graphs = None
         self._seg_state = None
-        # bf16 x 3 planes of the weights, refreshed behind every AdamW update (dist.WeightShadow): the GEMMs read their weight operand
-        # pre-split.  OFF by default: measured on MI355X (1Mpx B=4 step, one box, kernel trace on/off) the dX GEMMs gain 50 us/step, the
-        # forward GEMMs LOSE 40 us/step (three loads per slot instead of one) and the two refresh kernels cost 65 us/step
-        if weight_shadow is None:
-            weight_shadow = os.environ.get("SAST_WEIGHT_SHADOW", "0") != "0"
-        self.shadow = WeightShadow(self.flat) if (weight_shadow and dev.type == "cuda") else None
 
     # ---------------------------------------------------------------- forward + backward segments
     def forward(self, xs: Sequence[torch.Tensor], states=None, labels=None, indices=None, token_masks=None):
@@ -124,8 +115,6 @@ class TrainStep:
         for b in buckets:
             self.flat.all_reduce(self.group, bucket=b)
             self.opt.update(grad_scale=1.0 / self.world, bucket=b)
-            if self.shadow is not None:
-                self.shadow.refresh(bucket=b)
 
     def _after_segment(self, i: int, first: bool):
         """all-reduce + AdamW of the buckets that segment i completed; on the side stream when the step is segmented"""
@@ -142,16 +131,6 @@ class TrainStep:
             if first:
                 self.opt.begin_step()
             self._reduce_update(self.bucket_of_segment(i))
-
-    def parameters_changed(self):
-        """call after writing the parameters by any other means than this step (load_state_dict, manual edits): re-splits the shadow"""
-        if self.shadow is not None:
-            self.shadow.refresh()
-
-    def close(self):
-        if self.shadow is not None:
-            self.shadow.close()
-            self.shadow = None
 
     def finish(self):
         if self.side is not None and self.segmented:

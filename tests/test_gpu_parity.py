@@ -994,65 +994,6 @@ def test_segmented_step_matches_monolithic(dev):
     assert float(segg.opt.lr_step[1]) == 4.0
 
 
-def test_weight_shadow_planes_and_step(dev):
-    """dist.WeightShadow / csrc/k_shadow.hip: (a) the NT planes hold h + m + l == w exactly for every parameter, the T planes the
-    transposed 2-D weights; (b) a TrainStep whose GEMMs read the weights pre-split follows the one that splits them in the kernels
-    (same products; the LayerScale factor of the fc2 / proj dX GEMMs moves from the weight rows to dY: rounding-level differences) and
-    the planes follow the parameters through the updates; (c) closing it puts every GEMM back on the fp32 loaders."""
-    from sast_amd import _lib
-    from sast_amd.config import backbone_config
-    from sast_amd.detection import RNNDetector, YOLOPAFPN
-    from sast_amd.training import TrainStep
-    hw, part, E = (128, 160), (4, 5), 32
-    x = O.count_events(2, hw, seed=2, density=0.05).to(dev)
-
-    def rig(shadow):
-        torch.manual_seed(0)
-        net = RNNDetector(backbone_config(hw, part, embed_dim=E, AMP=2e-4, ls_init_value=0.5)).to(dev)
-        fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev)
-        return TrainStep(net, fpn, lr=1e-3, eps=1e-3, clip_value=1.0, segmented=False, weight_shadow=shadow)
-
-    def planes(buf, n):      # (n/4 slots) x (3 planes) x (4 bf16) -> fp32 h, m, l per float
-        u = buf.view(torch.int16).view(n // 4, 3, 4).to(torch.int32) << 16
-        f = u.view(torch.float32)
-        return f[:, 0].reshape(-1), f[:, 1].reshape(-1), f[:, 2].reshape(-1)
-
-    plain = rig(False)
-    assert plain.shadow is None and _lib.lib().sast_weight_shadow_active() == 0
-    ref = []
-    for _ in range(3):
-        plain.step([x])
-        ref.append((float(plain.loss), plain.flat.grad.clone(), plain.flat.flat.clone()))
-    sh = rig(True)
-    assert sh.shadow is not None and sh.shadow.active and _lib.lib().sast_weight_shadow_active() == 2 and sh.shadow.n_transposed > 20
-    for k in range(3):
-        sh.step([x])
-        torch.cuda.synchronize()
-        assert abs(float(sh.loss) - ref[k][0]) <= 1e-5 * abs(ref[k][0]), (k, float(sh.loss), ref[k][0])
-        maxnorm_close(sh.flat.grad, ref[k][1], (1e-5, 1e-4, 1e-3)[k], f"weight shadow, gradient of step {k}")
-    maxnorm_close(sh.flat.flat, ref[2][2], 1e-4, "weight shadow, parameters after 3 updates")
-    # (a) after the updates the planes are those of the CURRENT parameters
-    n = sh.flat.numel
-    h, m, l = planes(sh.shadow.nt, n)
-    assert torch.equal((h + m) + l, sh.flat.flat), "NT planes: h + m + l != w"
-    assert torch.equal(h, (sh.flat.flat.view(torch.int32) & -65536).view(torch.float32)), "NT planes: h is not the truncated weight"
-    th, tm, tl = planes(sh.shadow.t, n)
-    checked = 0
-    for p, off in zip(sh.flat.params, sh.flat.offsets):
-        if p.dim() == 2 and p.shape[0] % 4 == 0 and p.shape[1] % 4 == 0:
-            r, c = p.shape
-            wt = ((th[off:off + r * c] + tm[off:off + r * c]) + tl[off:off + r * c]).view(c, r)
-            assert torch.equal(wt, sh.flat.flat[off:off + r * c].view(r, c).t()), f"T planes of a {r}x{c} weight"
-            checked += 1
-    assert checked > 10
-    # (c)
-    sh.close()
-    assert _lib.lib().sast_weight_shadow_active() == 0
-    sh.step([x])
-    torch.cuda.synchronize()
-    assert torch.isfinite(sh.loss)
-
-
 _BF16_WORKER = r'''
 import os, sys, json, torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
