@@ -224,7 +224,7 @@ template <class EP> struct EpHasStats<EP, std::void_t<decltype(EP::COLSTATS)>> :
 // 20 floats per row) would push a workgroup beyond 80 KB of LDS, nor for the 4-gate LSTM tiles (one wave reads all 128 B rows there: nothing
 // is shared, and the larger planes made the stage-1/2 LSTM GEMMs 25 % slower).
 template <class T, class L>
-struct OperandPresplitWanted { static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_RC && L::RC && T::BK == 16 && T::KS <= 4 && T::G < 4; };
+struct OperandPresplitWanted { static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_RC && L::RC && (T::BK == 16 || T::BK == 32) && T::KS <= 4 && T::G < 4; };
 constexpr int PS_ROW_FLOATS = 3 * 16 / 2;         // 3 planes x 16 bf16 per row, in floats (24)
 // unpadded 32-byte plane rows: the 16-byte chunk (k 0-7 | k 8-15) of a row is XOR-ed with bit 3 of the row index.  ds_read_b128 serves
 // the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31}: with the swizzle their 16 chunks are 16 different 16-byte bank groups
@@ -239,7 +239,7 @@ constexpr int PS_MAX_FLOATS = 20480;              // a workgroup's LDS with pres
 // banks, so the granule index is XOR-ed with a function of k that moves the 4 rows of a block to 4 different 64-byte bank groups.
 template <class T, class L, int W>
 struct OperandPresplitIC {
-  static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_IC && !L::RC && T::BK == 16 && T::KS <= 4 && T::G < 4 &&
+  static constexpr bool value = SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && SAST_PRESPLIT_IC && !L::RC && (T::BK == 16 || T::BK == 32) && T::KS <= 4 && T::G < 4 &&
                                 (W == 32 || W == 64 || W == 128);
 };
 // granule (8 bytes = 4 index values) XOR of row k for a plane row of W values
@@ -250,8 +250,9 @@ struct GemmSmem {
   static constexpr int A_PLAIN = LA::RC ? T::BM * LDK : T::BK * (T::BM + 4), B_PLAIN = LB::RC ? T::BN * LDK : T::BK * (T::BN + 4);
   static constexpr bool A_WANT = OperandPresplitWanted<T, LA>::value || OperandPresplitIC<T, LA, T::BM>::value;
   static constexpr bool B_WANT = OperandPresplitWanted<T, LB>::value || OperandPresplitIC<T, LB, T::BN>::value;
-  static constexpr int A_PS = !A_WANT ? A_PLAIN : LA::RC ? T::BM * PS_ROW_FLOATS : 24 * T::BM;   // IC: 3 planes x 16 rows x W bf16
-  static constexpr int B_PS = !B_WANT ? B_PLAIN : LB::RC ? T::BN * PS_ROW_FLOATS : 24 * T::BN;
+  // presplit stage = BK/16 sub-stages of one k16 step each: 3 planes x (rows x 16 bf16 | 16 x W bf16) = 24 floats per row / index
+  static constexpr int A_PS = !A_WANT ? A_PLAIN : T::BM * PS_ROW_FLOATS * (T::BK / 16);
+  static constexpr int B_PS = !B_WANT ? B_PLAIN : T::BN * PS_ROW_FLOATS * (T::BK / 16);
   static constexpr bool PS_FITS = T::KS * 2 * (A_PS + B_PS) <= PS_MAX_FLOATS;
   static constexpr bool PSA = PS_FITS && A_WANT, PSB = PS_FITS && B_WANT;
   static constexpr int A_STAGE = PSA ? A_PS : A_PLAIN, B_STAGE = PSB ? B_PS : B_PLAIN;
@@ -273,6 +274,9 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   constexpr int LDA = LA::RC ? LDK : BM + 4;
   constexpr int LDB = LB::RC ? LDK : BN + 4;
   constexpr bool PSA = GemmSmem<T, LA, LB>::PSA, PSB = GemmSmem<T, LA, LB>::PSB;
+  // BK = 32: two k16 steps per pipeline phase (half the barriers / waits per k), presplit operands only
+  static_assert(BK == 16 || !(PSA || PSB) || (PSA && PSB), "a 32-wide k-tile needs both operands presplit (or neither)");
+  constexpr int SUB_A = BM * PS_ROW_FLOATS, SUB_B = BN * PS_ROW_FLOATS;   // one k16 sub-stage of a presplit operand
   constexpr int A_STAGE = GemmSmem<T, LA, LB>::A_STAGE, B_STAGE = GemmSmem<T, LA, LB>::B_STAGE;
   constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
   static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
@@ -342,12 +346,12 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       const int row = s / (BK / 4), kq = s % (BK / 4);
       ca[it] = la.prep(m0 + row, Meff);
       ra_off[it] = kq * 4;
-      la_off[it] = PSA ? row * 8 + (kq ^ (2 * ps_chunk_swizzle(row))) * 2 : row * LDK + kq * 4;   // presplit: float index inside ONE plane (32-byte rows, 8 bytes per slot)
+      la_off[it] = PSA ? (kq >> 2) * SUB_A + row * 8 + ((kq & 3) ^ (2 * ps_chunk_swizzle(row))) * 2 : row * LDK + kq * 4;   // presplit: float index inside ONE plane (32-byte rows, 8 bytes per slot)
     } else {
       const int iq = s % (BM / 4), kk = s / (BM / 4);
       ca[it] = la.prep(m0 + iq * 4, Meff);
       ra_off[it] = kk;
-      la_off[it] = PSA ? kk * (BM / 2) + (iq ^ psi_swizzle<BM>(kk)) * 2 : kk * LDA + iq * 4;     // presplit: float index inside ONE [k][m] bf16 plane
+      la_off[it] = PSA ? (kk >> 4) * SUB_A + (kk & 15) * (BM / 2) + (iq ^ psi_swizzle<BM>(kk & 15)) * 2 : kk * LDA + iq * 4;     // presplit: float index inside ONE [k][m] bf16 plane
     }
   }
 #pragma unroll
@@ -359,13 +363,13 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jl, g, NJ, m0);
       else cb[it] = lb.prep(j0 + jl, g, NJ);
       rb_off[it] = kq * 4;
-      lb_off[it] = PSB ? nnmap(jl, g) * 8 + (kq ^ (2 * ps_chunk_swizzle(nnmap(jl, g)))) * 2 : nnmap(jl, g) * LDK + kq * 4;
+      lb_off[it] = PSB ? (kq >> 2) * SUB_B + nnmap(jl, g) * 8 + ((kq & 3) ^ (2 * ps_chunk_swizzle(nnmap(jl, g)))) * 2 : nnmap(jl, g) * LDK + kq * 4;
     } else {
       const int jq = s % (BJ / 4), g = (s / (BJ / 4)) % G, kk = s / (BJ / 4 * G);
       if constexpr (LoaderWantsM0<LB>::value) cb[it] = lb.prep(j0 + jq * 4, g, NJ, m0);
       else cb[it] = lb.prep(j0 + jq * 4, g, NJ);
       rb_off[it] = kk;
-      lb_off[it] = PSB ? kk * (BN / 2) + ((nnmap(jq * 4, g) >> 2) ^ psi_swizzle<BN>(kk)) * 2 : kk * LDB + nnmap(jq * 4, g);
+      lb_off[it] = PSB ? (kk >> 4) * SUB_B + (kk & 15) * (BN / 2) + ((nnmap(jq * 4, g) >> 2) ^ psi_swizzle<BN>(kk & 15)) * 2 : kk * LDB + nnmap(jq * 4, g);
     }
   }
 
@@ -448,6 +452,39 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
     const float* as = As + buf * A_STAGE;
     const float* bs = Bs + buf * B_STAGE;
     const int l31 = lane & 31, hf = lane >> 5;
+    if constexpr (SAST_MFMA_SPLIT3 && !SAST_MFMA_BF16 && PSA && PSB) {   // both operands presplit: BK/16 k16 steps straight from the planes
+#pragma unroll
+      for (int u = 0; u < BK / 16; ++u) {
+        Split3 sa[T::TM], sb[T::TN];
+#pragma unroll
+        for (int t = 0; t < T::TM; ++t) {
+          if constexpr (!LA::RC) sa[t] = psi_read<BM>(as + u * SUB_A, wm * T::WTM + t * 32, lane);
+          else {
+            const float* p = as + u * SUB_A + (wm * T::WTM + t * 32 + l31) * 8 + (hf ^ ps_chunk_swizzle(l31)) * 4;
+            sa[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BM * 8)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BM * 8))};
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < T::TN; ++t) {
+          if constexpr (!LB::RC) sb[t] = psi_read<BN>(bs + u * SUB_B, wn * T::WTN + t * 32, lane);
+          else {
+            const float* p = bs + u * SUB_B + (wn * T::WTN + t * 32 + l31) * 8 + (hf ^ ps_chunk_swizzle(l31)) * 4;
+            sb[t] = Split3{__builtin_bit_cast(bf16x8, ld4(p)), __builtin_bit_cast(bf16x8, ld4(p + BN * 8)), __builtin_bit_cast(bf16x8, ld4(p + 2 * BN * 8))};
+          }
+        }
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int ta = 0; ta < T::TM; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T::TN; ++tb) {
+              const bf16x8 x = term == 0 ? sa[ta].l : (term == 2 || term == 3) ? sa[ta].m : sa[ta].h;      // l.h, h.l, m.m, m.h, h.m, h.h: smallest terms first
+              const bf16x8 y = term == 1 ? sb[tb].l : (term == 2 || term == 4) ? sb[tb].m : sb[tb].h;
+              accs[0][ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, accs[0][ta][tb], 0, 0, 0);
+            }
+      }
+      return;
+    }
     float a[T::TM][HK], b[T::TN][HK];
     Split3 sa[T::TM], sb[T::TN];
 #pragma unroll

@@ -74,6 +74,12 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     case 18: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 19: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    // 32-wide k-tiles on presplit operands (two k16 steps per phase)
+    case 40: return launch_gemm<Tile<64, 64, 2, 2, 1, 32, 1>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 41: return launch_gemm<Tile<64, 64, 2, 2, 1, 32, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 42: return launch_gemm<Tile<32, 64, 1, 2, 1, 32, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 43: return launch_gemm<Tile<32, 64, 1, 2, 1, 32, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 44: return launch_gemm<Tile<64, 128, 2, 2, 1, 32, 1>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     // wave-private tiles: one wave per k-group, no barrier in the k-loop
     case 30: return launch_gemm<Tile<64, 64, 1, 1, 1, 16, 1>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 31: return launch_gemm<Tile<64, 64, 1, 1, 1, 16, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
