@@ -8,6 +8,8 @@ import ctypes as C
 import pytest
 import torch
 
+from conftest import record_error
+
 pytestmark = pytest.mark.gpu
 
 NT_TILES = [0, 1, 2, 3, 9, 10, 11, 13, 14, 17, 18, 19, 30, 31, 33, 35, 40, 41, 43, 44]
@@ -40,6 +42,7 @@ def test_nt_tiles_vs_fp64(tools, shape):
         assert tools.sast_test_gemm_nt(a.data_ptr(), w.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, tile, st) == 0, tile
         torch.cuda.synchronize()
         err = float((c.double() - ref).abs().max() / ref.abs().max())
+        record_error("test_nt_tiles_vs_fp64", f"tile {tile} shape {shape}", err, 1.0, 5e-6)
         assert err <= 5e-6, (tile, shape, err)
 
 
@@ -60,6 +63,7 @@ def test_tn_tiles_with_column_sums_vs_fp64(tools, shape):
             assert tools.sast_test_gemm_tn(dy.data_ptr(), x.data_ptr(), out.data_ptr(), cs.data_ptr(), Mo, NJ, R, tile, splits, 0, st) == 0, tile
             torch.cuda.synchronize()
             err = float((out.double() - ref).abs().max() / ref.abs().max())
+            record_error("test_tn_tiles_with_column_sums_vs_fp64", f"tile {tile} splits {splits} shape {shape}", err, 1.0, 5e-6)
             assert err <= 5e-6, (tile, splits, shape, err)
             err_cs = float((cs.double() - ref_cs).abs().max() / ref_cs.abs().max())
             assert err_cs <= 5e-6, ("column sums", tile, splits, shape, err_cs)
