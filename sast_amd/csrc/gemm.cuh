@@ -375,11 +375,19 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 
   // a loader with UNIFORM_TILE gets the k-tile base r0 (wave-uniform) and the lane's offset inside the tile separately: whatever it
   // decodes from r0 alone (the tap of an implicit-GEMM convolution whose channel count is a multiple of BK) runs on the scalar unit
+#ifdef SAST_EXP_A_REUSE   // timing experiment only (wrong results): the A operand is loaded / split / stored every N-th phase
+  int exp_g_ = 0, exp_s_ = 0;
+#define SAST_EXP_A_ON(ctr) (((ctr)++ % SAST_EXP_A_REUSE) == 0)
+#else
+#define SAST_EXP_A_ON(ctr) true
+  int exp_g_ = 0, exp_s_ = 0; (void)exp_g_; (void)exp_s_;
+#endif
   auto gload = [&](int kt, int set) {
     const int r0 = kt * BK;
+    const bool a_on = SAST_EXP_A_ON(exp_g_);
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
+      if ((A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) && a_on) {
         if constexpr (LoaderUniformTile<LA>::value) la.load_u(ca[it], r0, ra_off[it], Rl, BK, ra[set][it], aa[set][it], oa[set][it]);
         else la.load(ca[it], r0 + ra_off[it], Rl, ra[set][it], aa[set][it], oa[set][it]);
       }
@@ -401,9 +409,10 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   auto lstore = [&](int buf, int set) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
+    const bool a_on = SAST_EXP_A_ON(exp_s_);
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
+      if ((A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) && a_on) {
         const float4 v = la.finish(ra[set][it], aa[set][it], oa[set][it]);
         if constexpr (SPLIT && !LA::RC) {
           if (do_colsum) { csacc[it].x += v.x; csacc[it].y += v.y; csacc[it].z += v.z; csacc[it].w += v.w; }
