@@ -614,6 +614,41 @@ def test_backbone_odd_batches(dev, B):
         grad_close(k, v.grad, pf[k].grad)
 
 
+def test_backbone_empty_frames(dev):
+    """a sample WITHOUT a single event (r = 0: scale = 1e-6 * sum exp(Wc), the largest scale' = AMP / scale the model can see, every
+    token of the sample ties in the window / token softmaxes) next to a normal one, and a whole batch of empty frames: the reference's
+    edge case of a silent sensor (SAST.py:109-119: the +1e-6 keeps scale' finite; :117-118 would zero an infinite one)."""
+    from sast_amd.detection import RNNDetector
+    hw, part, E = (128, 160), (4, 5), 32
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=17, ls_init=0.5)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    load_params(net, params)
+    for case in ("one of two", "all"):
+        x = O.count_events(2, hw, seed=3, density=0.05)
+        if case == "one of two":
+            x[1].zero_()
+        else:
+            x.zero_()
+        net.zero_grad()
+        out, _st, P = net(x.to(dev))
+        loss = sum((out[k] ** 2).mean() for k in (1, 2, 3, 4))
+        assert torch.isfinite(loss), case
+        loss.backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        oo, _s, Po = O.backbone(x, None, po, ocfg)
+        loss_o = sum((oo[k] ** 2).mean() for k in (1, 2, 3, 4))
+        loss_o.backward()
+        assert [int(p) for p in P] == [int(p) for p in Po], (case, P, Po)
+        assert abs(float(loss) - float(loss_o)) <= 1e-5 * max(abs(float(loss_o)), 1e-6), (case, float(loss), float(loss_o))
+        for k in (1, 2, 3, 4):
+            abs_close(out[k].cpu(), oo[k], FWD_ATOL, f"empty frames ({case}): stage {k}")
+        for k, v in net.named_parameters():
+            if "sub_layers" not in k and po[k].grad is not None:
+                assert torch.isfinite(v.grad).all(), (case, k)
+                grad_close(k, v.grad, po[k].grad)
+
+
 def test_backbone_sequence_bptt(dev):
     """the training loop shape of modules/detection.py:141-177: L timesteps with the recurrent (h, c) states carried WITHOUT
     detaching, PAFPN on the last timestep's features, one backward through time; gradients against the oracle run the same way."""
