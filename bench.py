@@ -294,8 +294,10 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     BATCH = args.batch
-    if args.precision == "bf16":       # before anything imports sast_amd._lib
+    if args.precision == "bf16":       # before anything imports sast_amd._lib; opt-in build: `python -m sast_amd.build --bf16`
         os.environ["SAST_LIB_PATH"] = os.path.join(ROOT, "sast_amd", "libsast_hip_bf16.so")
+        if not os.path.exists(os.environ["SAST_LIB_PATH"]):
+            raise SystemExit("--precision bf16 needs the opt-in library: python -m sast_amd.build --bf16")
     if args.res == "gen1":
         HW, PART = (256, 320), (8, 10)
 
@@ -373,6 +375,8 @@ def main():
                        "gemm_arithmetic": {1: "fp32 products on the bf16 MFMA pipe: exact 3-way bf16 operand split, 6 MFMAs per product tile, fp32 accumulate",
                                            0: "v_mfma_f32_32x32x2_f32", 2: "operands rounded to bf16, one bf16 MFMA per tile step, fp32 accumulate (reduced precision)"}[
                                                __import__("sast_amd._lib", fromlist=["lib"]).lib().sast_mfma_split3()],
+                       "library": os.path.relpath(__import__("sast_amd._lib", fromlist=["lib"]).loaded_path(), ROOT),
+                       "product_library": __import__("sast_amd._lib", fromlist=["lib"]).is_product_library(),
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),

@@ -7,7 +7,11 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SAST_LIB_PATH") or os.path.join(_HERE, "libsast_hip.so")   # SAST_LIB_PATH: A/B builds (tools only)
+DEFAULT_LIB_PATH = os.path.join(_HERE, "libsast_hip.so")
+# SAST_LIB_PATH: an A/B or variant build instead of the in-tree product library (tools / measurement scripts only).  The override is
+# announced on stderr when the library is loaded and `loaded_path()` reports it (bench.py records it in its JSON line), so a stale
+# variable in a shell cannot silently put a parity or benchmark claim on another binary.
+LIB_PATH = os.environ.get("SAST_LIB_PATH") or DEFAULT_LIB_PATH
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "sast_hip.h")
 
 P = C.c_void_p
@@ -141,12 +145,24 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m sast_amd.build` (needs hipcc, gfx950). "
                 "sast_amd has no CPU/PyTorch fallback for the SAST hot path.")
+        if os.path.abspath(LIB_PATH) != os.path.abspath(DEFAULT_LIB_PATH):
+            import sys
+            print(f"[sast_amd] WARNING: SAST_LIB_PATH is set: loading {LIB_PATH} instead of the product library {DEFAULT_LIB_PATH}", file=sys.stderr)
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def loaded_path() -> str:
+    """the library file behind lib() (the in-tree product unless SAST_LIB_PATH overrides it)"""
+    return os.path.abspath(LIB_PATH)
+
+
+def is_product_library() -> bool:
+    return os.path.abspath(LIB_PATH) == os.path.abspath(DEFAULT_LIB_PATH)
 
 
 _tools = None

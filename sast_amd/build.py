@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libsast_hip.so")
 TOOLS_LIB = os.path.join(HERE, "libsast_hip_tools.so")
 BF16_LIB = os.path.join(HERE, "libsast_hip_bf16.so")
 ARCH = "gfx950"
-SOURCES = ["k_rows.hip", "k_select.hip", "k_attn.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_head.hip"]
+SOURCES = ["k_rows.hip", "k_select.hip", "k_attn_mfma.hip", "k_block.hip", "k_conv.hip", "k_prof.hip", "k_head.hip"]
 TOOLS_SOURCES = ["k_test.hip"]
 HEADERS = ["common.cuh", "gemm.cuh", "gemm_dispatch.cuh", "kernels.h", os.path.join("..", "..", "include", "sast_hip.h")]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SAST_EXTRA_FLAGS", "").split()
@@ -63,8 +63,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     _link(objs[:len(SOURCES)], LIB, force)
     _link(objs[len(SOURCES):], TOOLS_LIB, force or os.path.getmtime(TOOLS_LIB) < os.path.getmtime(LIB) if os.path.exists(TOOLS_LIB) else True,
           extra=["-L" + HERE, "-lsast_hip", "-Wl,-rpath,$ORIGIN"])
-    # the reduced-precision variant of the product library (bf16 GEMM operands, `bench.py --precision bf16`): same sources, one flag
-    if os.environ.get("SAST_BUILD_BF16", "1") != "0":
+    # the reduced-precision variant of the product library (bf16 GEMM operands, `bench.py --precision bf16`): same sources, one flag.
+    # OPT-IN (SAST_BUILD_BF16=1 or `python -m sast_amd.build --bf16`): not part of the product, a compile failure there must not fail build()
+    if os.environ.get("SAST_BUILD_BF16", "0") == "1":
         stale = force or not os.path.exists(BF16_LIB) or os.path.getmtime(BF16_LIB) < os.path.getmtime(LIB)
         if stale:
             build_variant(BF16_LIB, ["-DSAST_MFMA_BF16=1"], obj_dir=os.path.join(OBJ, "bf16"))
@@ -91,4 +92,6 @@ if __name__ == "__main__":
         fl = sys.argv[sys.argv.index("--flags") + 1].split() if "--flags" in sys.argv else []
         print("built", build_variant(o, fl))
     else:
+        if "--bf16" in sys.argv:
+            os.environ["SAST_BUILD_BF16"] = "1"
         build(force="--force" in sys.argv, verbose=True)

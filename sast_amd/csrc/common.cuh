@@ -10,20 +10,24 @@
 #define SAST_EINVAL (-22)
 #define SAST_ELAUNCH (-5)
 
-// every launch goes through these: a stale error left on this thread by somebody else's HIP call (PyTorch polls events, probes
-// host pointers, ...) is cleared first, so what SAST_CHECK_LAUNCH reads belongs to the launch (SAST_DEBUG_LAUNCH=1 prints it)
-#define SAST_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
-#define SAST_EXT_LAUNCH(...) do { (void)hipGetLastError(); hipExtLaunchKernelGGL(__VA_ARGS__); } while (0)
-// hipErrorNotReady is not a launch failure: it is the sticky result of somebody else's hipEventQuery / hipStreamQuery on this thread
-// (PyTorch's caching allocator polls events after H2D copies) and would otherwise fail the first launch after such a poll
-#define SAST_CHECK_LAUNCH()                                                                                          \
-  do {                                                                                                               \
-    hipError_t e__ = hipGetLastError();                                                                              \
-    if (e__ != hipSuccess && e__ != hipErrorNotReady) {                                                              \
-      if (getenv("SAST_DEBUG_LAUNCH")) fprintf(stderr, "[sast] %s:%d launch error %d: %s\n", __FILE__, __LINE__, (int)e__, hipGetErrorString(e__)); \
-      return SAST_ELAUNCH;                                                                                           \
-    }                                                                                                                \
-  } while (0)
+// Every launch goes through SAST_LAUNCH / SAST_EXT_LAUNCH.  A stale error left on this thread by somebody else's HIP call (PyTorch
+// polls events, probes host pointers, ...) is cleared first, the launch's own result is read right behind it and LATCHED per thread:
+// an entry point that enqueues several kernels and checks once at the end (SAST_CHECK_LAUNCH) reports a failure of ANY of them, not
+// only of the last one (SAST_DEBUG_LAUNCH=1 prints the failing launch site).  hipErrorNotReady is not a launch failure: it is the
+// sticky result of somebody else's hipEventQuery / hipStreamQuery on this thread (PyTorch's caching allocator polls events after H2D
+// copies).
+namespace sast {
+inline thread_local int g_launch_failed = 0;
+inline void launch_latch(hipError_t e, const char* file, int line) {
+  if (e == hipSuccess || e == hipErrorNotReady) return;
+  g_launch_failed = 1;
+  if (getenv("SAST_DEBUG_LAUNCH")) fprintf(stderr, "[sast] %s:%d launch error %d: %s\n", file, line, (int)e, hipGetErrorString(e));
+}
+inline bool launch_failed_take() { const bool f = g_launch_failed != 0; g_launch_failed = 0; return f; }
+}  // namespace sast
+#define SAST_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
+#define SAST_EXT_LAUNCH(...) do { (void)hipGetLastError(); hipExtLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
+#define SAST_CHECK_LAUNCH() do { if (sast::launch_failed_take()) return SAST_ELAUNCH; } while (0)
 
 namespace sast {
 

@@ -170,6 +170,10 @@ __device__ __forceinline__ Split3 psi_read(const float* planes, int c0, int lane
 #ifndef SAST_WAVE_GROUPS_FREE
 #define SAST_WAVE_GROUPS_FREE 1
 #endif
+// 1: the bias-gradient column sums of a weight-gradient job leave the workgroup as ONE atomic instruction per 64 columns (gemm_body)
+#ifndef SAST_COLSUM_LDS
+#define SAST_COLSUM_LDS 1
+#endif
 // independent accumulators of a wave that owns a single 32x32 output tile (1 = the round-1 kernel; see gemm_body)
 #ifndef SAST_SINGLE_TILE_ACCS
 #define SAST_SINGLE_TILE_ACCS 1
@@ -281,6 +285,10 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   constexpr int GROUP_FLOATS = 2 * (A_STAGE + B_STAGE);
   static_assert(KS == 1 || GROUP_FLOATS >= T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64, "k-split reduction must fit a group's LDS");
   static_assert(KS * GROUP_FLOATS == GemmSmem<T, LA, LB>::FLOATS, "GemmSmem");
+  // load_u() decodes ONE tap per k-tile: the hosts pick the uniform-tap loaders on `channels % 16 == 0` (k_conv.hip: conv_gemm,
+  // conv_bwd_pair), which is only the right predicate for 16-wide k-tiles -- a wider tile would straddle two taps silently
+  static_assert(!(LoaderUniformTile<LA>::value || LoaderUniformTile<LB>::value) || BK == 16,
+                "uniform-tap conv loaders need BK == 16 (or a host-side predicate on the tile's BK)");
   const int kg = __builtin_amdgcn_readfirstlane(threadIdx.x / NT);   // k-group of this wave: wave-uniform, kept in an SGPR so that
                                                                       // everything derived from the k-tile index stays on the scalar unit
   float* As = smem + kg * GROUP_FLOATS;
@@ -664,9 +672,18 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       for (int e = 0; e < 16; ++e) accs[0][0][0][e] += accs[c][0][0][e];
   }
   SAST_TL(2);
+  // Column sums of an index-contiguous A (the bias gradient of a weight-gradient job).  Every atomic INSTRUCTION aimed at the same
+  // 128-byte line costs ~25 ns, serialised chip-wide (measured, profiles/r03_a_tn_colsum_atomics.txt: 192 splits x 4 waves x 4
+  // instructions of 16 lanes on the two lines of a 64-float bias gradient = 79 us of a launch whose GEMM work is ~15 us).  So the
+  // waves of a workgroup fold their partial sums through LDS and ONE wave adds them with one instruction per 64 columns (CS_LDS);
+  // tiles whose k-group region has no room behind the k-split fold area keep the per-wave form.
+  constexpr int CS_OFF = KS > 1 ? T::WAVES_M * T::WAVES_N * T::TM * T::TN * 16 * 64 : 0;
+  constexpr int CS_WAVES = T::WAVES_M * T::WAVES_N;
+  constexpr bool CS_FAST = 64 % (BM / 4) == 0 && A_SLOTS % NT == 0;
+  constexpr bool CS_LDS = SAST_COLSUM_LDS && SPLIT && !LA::RC && CS_FAST && CS_OFF + CS_WAVES * BM <= GROUP_FLOATS;
   if constexpr (SPLIT && !LA::RC) {
     if (do_colsum) {
-      if constexpr (64 % (BM / 4) == 0 && A_SLOTS % NT == 0) {   // a thread's slots all belong to index quad lane % (BM/4): fold the slots, then the lanes that share the quad
+      if constexpr (CS_FAST) {   // a thread's slots all belong to index quad lane % (BM/4): fold the slots, then the lanes that share the quad
         float4 t = csacc[0];
 #pragma unroll
         for (int it = 1; it < A_PER; ++it) { t.x += csacc[it].x; t.y += csacc[it].y; t.z += csacc[it].z; t.w += csacc[it].w; }
@@ -674,12 +691,16 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
         for (int off = BM / 4; off < 64; off <<= 1) {
           t.x += __shfl_xor(t.x, off, 64); t.y += __shfl_xor(t.y, off, 64); t.z += __shfl_xor(t.z, off, 64); t.w += __shfl_xor(t.w, off, 64);
         }
-        const int m = m0 + 4 * lane;
-        if (lane < BM / 4) {
-          if (m < Meff) atomicAdd(colsum + m, t.x);
-          if (m + 1 < Meff) atomicAdd(colsum + m + 1, t.y);
-          if (m + 2 < Meff) atomicAdd(colsum + m + 2, t.z);
-          if (m + 3 < Meff) atomicAdd(colsum + m + 3, t.w);
+        if constexpr (CS_LDS) {
+          if (lane < BM / 4) st4(smem + kg * GROUP_FLOATS + CS_OFF + wave * BM + 4 * lane, t);   // this k-group's stages are dead (group_sync after the last compute)
+        } else {
+          const int m = m0 + 4 * lane;
+          if (lane < BM / 4) {
+            if (m < Meff) atomicAdd(colsum + m, t.x);
+            if (m + 1 < Meff) atomicAdd(colsum + m + 1, t.y);
+            if (m + 2 < Meff) atomicAdd(colsum + m + 2, t.z);
+            if (m + 3 < Meff) atomicAdd(colsum + m + 3, t.w);
+          }
         }
       } else {                                                    // odd tile heights (micro-benchmarks): every slot adds its own sums
 #pragma unroll
@@ -694,6 +715,27 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
       }
     }
   }
+  auto colsum_finish = [&]() {   // after a workgroup barrier behind the staging above: wave 0 of k-group 0 adds the folded sums
+    if constexpr (CS_LDS) {
+      if (do_colsum && threadIdx.x < 64) {
+#pragma unroll
+        for (int c0 = 0; c0 < BM; c0 += 64) {
+          const int c = c0 + lane;
+          float sum = 0.f;
+          if (BM % 64 == 0 || c < BM) {
+#pragma unroll
+            for (int g = 0; g < KS; ++g)
+#pragma unroll
+              for (int wv = 0; wv < CS_WAVES; ++wv) sum += smem[g * GROUP_FLOATS + CS_OFF + wv * BM + c];
+            if (m0 + c < Meff) atomicAdd(colsum + m0 + c, sum);
+          }
+        }
+      }
+    }
+  };
+  if constexpr (CS_LDS && KS == 1) {
+    if (do_colsum) { __syncthreads(); colsum_finish(); }   // block-uniform condition
+  }
   if constexpr (KS > 1) {   // fold the k-groups' partial accumulators into group 0 through LDS
     float* red = smem + kg * GROUP_FLOATS + (wave * T::TM * T::TN) * 16 * 64 + lane;
     if (kg > 0) {
@@ -705,6 +747,7 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
           for (int e = 0; e < 16; ++e) red[((a * T::TN + b) * 16 + e) * 64] = acc[a][b][e];
     }
     __syncthreads();
+    colsum_finish();
     if (kg > 0) {
       if (SPLIT && LA::RC && do_colsum) {
 #pragma unroll

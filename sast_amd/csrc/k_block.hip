@@ -9,13 +9,8 @@ using namespace sast;
 
 namespace {
 
-// partitions of up to this many tokens use the MFMA attention kernels (k_attn_mfma.hip); SAST_ATTN_MFMA_MAX_T=64 restores the
-// VALU kernel (k_attn.hip) for 64 < T <= 128
-inline int mfma_attn_max_t() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_ATTN_MFMA_MAX_T"); v = e ? atoi(e) : 128; }
-  return v;
-}
+// largest partition (tokens per window / grid group) the attention kernels of k_attn_mfma.hip are instantiated for
+constexpr int ATTN_MAX_T = 128;
 
 // ---------------------------------------------------------------- epilogues (protocol: col / pre / post, see gemm.cuh)
 struct EpBiasRelu {
@@ -276,14 +271,14 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   if (a->C % dh) return SAST_EINVAL;
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
+  if (T > ATTN_MAX_T) return SAST_EINVAL;
   const int* dR = a->sel.counts;  // device-side number of kept tokens
   int rc = ln1_gather_fwd_launch(a->xin, a->out, a->S, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->ln2_b, a->mean1,
                                  a->rstd1, a->mean2, a->rstd2, R, C, a->eps, a->raw_ws, sast_mswsa_raw_ws_floats(C, inner), st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
-  rc = T <= mfma_attn_max_t() ? attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st)
-                              : attn_fwd_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
+  rc = attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
   if (rc) return rc;
@@ -317,6 +312,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   const int dh = a->dim_head > 0 ? a->dim_head : 32;
+  if (T > ATTN_MAX_T) return SAST_EINVAL;
   const int* dR = a->sel.counts;
   const int* row_tok = a->sel.row_tok;
   float* dUG = a->ws;
@@ -372,17 +368,12 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
     rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   }
   if (rc) return rc;
-  // raw (gamma-free) fc2 and proj gradients -> parameter gradients incl. the LayerScale gammas, one launch for both
-  // (with the MFMA attention kernel they ride as side workgroups of the attention backward launch)
-  if (T <= mfma_attn_max_t()) {
+  // raw (gamma-free) fc2 and proj gradients -> parameter gradients incl. the LayerScale gammas: side workgroups of the attention
+  // backward launch
+  {
     const LsFinish f2{a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner};
     const LsFinish f1{a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C};
     rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C);
-  } else {
-    rc = ls_linear_finish2_launch(a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner,
-                                  a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C, C, st);
-    if (rc) return rc;
-    rc = attn_bwd_launch(a->QKV, a->O, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv

@@ -224,3 +224,16 @@ extern "C" int sast_test_mfma_peak(float* out, int mode, int blocks, int iters, 
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
+
+
+// ---- launch-error latching (common.cuh: SAST_LAUNCH / SAST_CHECK_LAUNCH): a failed launch followed by good ones inside one entry
+// point must still be reported by the single check at the end.  bad != 0: the first launch asks for 2048 threads per workgroup.
+__global__ void latch_probe_kernel(int* p) { if (p && threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }
+extern "C" int sast_test_launch_latch(int* scratch, int bad, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  SAST_LAUNCH(latch_probe_kernel, dim3(1), dim3(bad ? 2048 : 64), 0, st, scratch);
+  SAST_LAUNCH(latch_probe_kernel, dim3(1), dim3(64), 0, st, scratch);
+  SAST_LAUNCH(latch_probe_kernel, dim3(1), dim3(64), 0, st, scratch);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}

@@ -60,12 +60,6 @@ int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mod
 int select_pair_launch(const float* tok, int B, int H, int W, int ph, int pw, float thr_win, float thr_tok, const SastSel* win,
                        const SastSel* grid, hipStream_t st);
 
-// k_attn.hip
-int attn_fwd_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
-                    hipStream_t st);
-int attn_bwd_launch(const float* qkv, const float* o, const float* dout, const float* lse, float* dqkv, const int* row_off,
-                    const int* Kw, int W, int T, int C, int dh, hipStream_t st);
-
 // k_attn_mfma.hip (T <= 128)
 int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
                          hipStream_t st);

@@ -195,7 +195,9 @@ class RNNDetector(nn.Module):
         # an event tensor smaller than in_res_hw stands for its zero padding (the reference pads it first,
         # modules/detection.py:143-144 / utils/padding.py:29-53): ratios, cast, layout change and padding in two passes over x
         pad = self.in_res_hw if (x.shape[-2] < self.in_res_hw[0] or x.shape[-1] < self.in_res_hw[1]) else None
-        r, xin = SF.input_prep(x, pad)        # ratios, cast, padding and layout change in one launch that reads x once
+        if not hasattr(self, "_prep_ws"):
+            self._prep_ws = {}                # scratch of the input kernel, owned by this module (one per device and batch size)
+        r, xin = SF.input_prep(x, pad, self._prep_ws)   # ratios, cast, padding and layout change in one launch that reads x once
         states, output, P = [], {}, []
         for i, stage in enumerate(self.stages):
             if cut_before_stage is not None and i == cut_before_stage and torch.is_grad_enabled() and xin.requires_grad:

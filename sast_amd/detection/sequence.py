@@ -47,55 +47,51 @@ class BackboneFeatureSelector:
         return out
 
 
+def _map_leaves(tree, fn):
+    """fn applied to every tensor of a nested list / tuple / dict of tensors; the containers are rebuilt with their own types"""
+    if torch.is_tensor(tree):
+        return fn(tree)
+    if isinstance(tree, dict):
+        return {key: _map_leaves(val, fn) for key, val in tree.items()}
+    if isinstance(tree, (list, tuple)):
+        return type(tree)(_map_leaves(val, fn) for val in tree)
+    raise NotImplementedError(f"RNNStates: unsupported state container {type(tree).__name__}")
+
+
+def _zero_selected(which):
+    if which is not None and len(which) == 0:
+        raise AssertionError("RNNStates.reset: an empty selection (pass None to reset every sample)")
+
+    def zero(t: torch.Tensor) -> torch.Tensor:
+        if t.requires_grad:
+            raise AssertionError("RNNStates.reset: saved states are detached; got a tensor that requires grad")
+        return SF.zero_samples(t, which)       # in place, one launch per state tensor (sast_zero_samples)
+    return zero
+
+
 class RNNStates:
-    """modules/utils/detection.py:76-130: states[worker_id] = [(h, c)] per stage, detached when saved, zeroed per sample at
-    sequence starts."""
+    """Recurrent states per data-loader worker (the role of modules/utils/detection.py:76-130; same method names so that
+    modules/detection.py:141-177 can drive it): a table worker_id -> nested [(h, c) per stage], stored detached, selected
+    samples zeroed at sequence starts.  The tree walk is `_map_leaves`; the zeroing runs on the device."""
 
     def __init__(self):
         self.states = {}
 
-    def _has_states(self):
-        return len(self.states) > 0
-
     @classmethod
     def recursive_detach(cls, inp):
-        if isinstance(inp, torch.Tensor):
-            return inp.detach()
-        if isinstance(inp, list):
-            return [cls.recursive_detach(x) for x in inp]
-        if isinstance(inp, tuple):
-            return tuple(cls.recursive_detach(x) for x in inp)
-        if isinstance(inp, dict):
-            return {k: cls.recursive_detach(v) for k, v in inp.items()}
-        raise NotImplementedError
+        return _map_leaves(inp, torch.Tensor.detach)
 
     @classmethod
     def recursive_reset(cls, inp, indices_or_bool_tensor: Optional[Union[List[int], torch.Tensor]] = None):
-        if isinstance(inp, torch.Tensor):
-            assert inp.requires_grad is False, 'Not assumed here but should be the case.'
-            if indices_or_bool_tensor is not None:
-                assert len(indices_or_bool_tensor) > 0
-            return SF.zero_samples(inp, indices_or_bool_tensor)
-        if isinstance(inp, list):
-            return [cls.recursive_reset(x, indices_or_bool_tensor=indices_or_bool_tensor) for x in inp]
-        if isinstance(inp, tuple):
-            return tuple(cls.recursive_reset(x, indices_or_bool_tensor=indices_or_bool_tensor) for x in inp)
-        if isinstance(inp, dict):
-            return {k: cls.recursive_reset(v, indices_or_bool_tensor=indices_or_bool_tensor) for k, v in inp.items()}
-        raise NotImplementedError
+        return _map_leaves(inp, _zero_selected(indices_or_bool_tensor))
 
     def save_states_and_detach(self, worker_id: int, states) -> None:
         self.states[worker_id] = self.recursive_detach(states)
 
     def get_states(self, worker_id: int):
-        if not self._has_states():
-            return None
-        if worker_id not in self.states:
-            return None
-        return self.states[worker_id]
+        return self.states.get(worker_id)
 
     def reset(self, worker_id: int, indices_or_bool_tensor: Optional[Union[List[int], torch.Tensor]] = None):
-        if not self._has_states():
-            return
-        if worker_id in self.states:
-            self.states[worker_id] = self.recursive_reset(self.states[worker_id], indices_or_bool_tensor=indices_or_bool_tensor)
+        held = self.states.get(worker_id)
+        if held is not None:
+            self.states[worker_id] = self.recursive_reset(held, indices_or_bool_tensor)

@@ -121,7 +121,7 @@ _PREP_WS = {}
 
 
 @torch.no_grad()
-def input_prep(x: torch.Tensor, pad_hw=None):
+def input_prep(x: torch.Tensor, pad_hw=None, ws_cache: Optional[dict] = None):
     """non_zero_ratio (sast_rnn.py:45-60) + x.float() + zero padding to pad_hw (utils/padding.py:29-53) + NCHW->NHWC (ops.py:19-24)
     in ONE launch that reads the event tensor once -> (r (B,4,C) fp32, x_nhwc (B,Hp,Wp,C) fp32).  Falls back to the two separate
     launches for shapes the fused kernel does not cover (padded sizes that are not multiples of 32, channel counts other than 20)."""
@@ -134,13 +134,25 @@ def input_prep(x: torch.Tensor, pad_hw=None):
     if H % 4 or W % 4 or Hp % 32 or Wp % 32 or Cc != 20 or ((Hp // 32) * (Wp // 32)) % 2 or Hp < H or Wp < W:
         pad = (Hp, Wp) if (Hp, Wp) != (H, W) else None
         return non_zero_ratio(x, pad), nchw_to_nhwc_float(x, pad)
-    key = (x.device, B, Cc)
-    ws = _PREP_WS.get(key)
-    if ws is None:      # zero on entry, zero on exit: cleared once, the kernel's last workgroup leaves it clean
-        ws = _PREP_WS[key] = torch.zeros(B * 4 * Cc + 1, device=x.device, dtype=torch.int32)
+    # scratch (per-sample counters + the ticket of the "last workgroup"): zero on entry, zero on exit -- cleared when it is created,
+    # the kernel's last workgroup leaves it clean.  Owned by the caller (`ws_cache`: RNNDetector keeps one per module instance, whose
+    # calls are sequential) or, for bare calls, kept per (device, STREAM, B, C): two streams calling concurrently must not share
+    # counters.  It must not be born inside a stream capture (the zero fill would be captured and the buffer would belong to the
+    # graph's private pool): one un-captured warm-up call first, as torch's graph capture needs anyway.
+    cache = _PREP_WS if ws_cache is None else ws_cache
+    key = (x.device, B, Cc) if ws_cache is not None else (x.device, torch.cuda.current_stream().cuda_stream, B, Cc)
+    ws = cache.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sast_amd: input_prep needs one un-captured warm-up call (per model and batch size) before graph capture")
+        ws = cache[key] = torch.zeros(B * 4 * Cc + 1, device=x.device, dtype=torch.int32)
     r = torch.empty(B, 4, Cc, device=x.device, dtype=torch.float32)
     y = torch.empty(B, Hp, Wp, Cc, device=x.device, dtype=torch.float32)
-    L.check(L.lib().sast_input_prep(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, Hp, Wp, ws.data_ptr(), r.data_ptr(), y.data_ptr(), _stream()), "input_prep")
+    try:
+        L.check(L.lib().sast_input_prep(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, Hp, Wp, ws.data_ptr(), r.data_ptr(), y.data_ptr(), _stream()), "input_prep")
+    except Exception:
+        cache.pop(key, None)         # a failed launch may leave counters / the ticket non-zero: never reuse this buffer
+        raise
     return r, y
 
 

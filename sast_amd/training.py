@@ -33,9 +33,35 @@ class TrainStep:
     def __init__(self, net, fpn, head=None, *, lr: float = 2e-4, weight_decay: float = 0.0, clip_value: float = 0.0, eps: float = 1e-8,
                  schedule: Optional[OneCycleLR] = None, world: int = 1, group=None, segmented: bool = True):
         self.net, self.fpn, self.head = net, fpn, head
-        self.world, self.group, self.segmented = world, group, segmented
+        self.world, self.group = world, group
         stages = list(net.stages)
-        buckets = [[fpn] + ([head] if head is not None else []), [stages[3]], [stages[2], stages[1], stages[0]]]
+        first = [fpn] + ([head] if head is not None else [])
+        # The segmented backward is written for the topology of the shipped models: four backbone stages, the PAFPN reading stages up to
+        # the LAST one (its top feature map is the stage-4 state: segment B starts there), and no parameter shared between buckets --
+        # the side stream's AdamW rewrites a bucket's weights while the main stream still runs the backward of the later buckets, so a
+        # later segment must never read (or add gradient to) a parameter of an already-updated bucket.  Anything else runs unsegmented.
+        if segmented:
+            why = None
+            if len(stages) != 4:
+                why = f"{len(stages)} backbone stages (4 expected)"
+            elif list(fpn.in_features)[-1] != len(stages):
+                why = f"PAFPN in_stages {tuple(fpn.in_features)} do not end at the last backbone stage"
+            else:
+                owner = {}
+                for b, grp in enumerate([first, [stages[3]], stages[:3]]):
+                    for m in grp:
+                        for prm in m.parameters():
+                            if owner.setdefault(id(prm), b) != b:
+                                why = "a parameter is shared between gradient buckets"
+            if why is not None:
+                import warnings
+                warnings.warn(f"sast_amd.TrainStep: segmented backward disabled ({why}); running the monolithic step")
+                segmented = False
+        self.segmented = segmented
+        if len(stages) == 4:
+            buckets = [first, [stages[3]], [stages[2], stages[1], stages[0]]]
+        else:
+            buckets = [first, list(reversed(stages))]
         self.flat = FlatParams([], buckets=buckets)
         self.opt = FusedAdamW(self.flat, lr=lr, weight_decay=weight_decay, clip_value=clip_value, eps=eps, schedule=schedule)
         dev = self.flat.flat.device
@@ -105,7 +131,7 @@ class TrainStep:
     def bucket_of_segment(self, i: int) -> List[int]:
         n = self.n_segments()
         if n == 1:
-            return [0, 1, 2]
+            return list(range(len(self.flat.bucket_ranges)))
         if n == 2:
             return [[0], [1, 2]][i]
         return [i]

@@ -67,3 +67,19 @@ def test_tn_tiles_with_column_sums_vs_fp64(tools, shape):
             assert err <= 5e-6, (tile, splits, shape, err)
             err_cs = float((cs.double() - ref_cs).abs().max() / ref_cs.abs().max())
             assert err_cs <= 5e-6, ("column sums", tile, splits, shape, err_cs)
+
+
+def test_failed_launch_is_reported_by_the_trailing_check(tools):
+    """common.cuh: SAST_LAUNCH latches a launch failure per thread, so an entry point that enqueues several kernels and checks once
+    (sast_yolox_loss, sast_postprocess, the BatchNorm stats + apply pair ...) reports a failure of ANY launch, not only of the last.
+    The probe launches three kernels; with bad = 1 the FIRST asks for 2048 threads per workgroup and the other two are fine."""
+    tools.sast_test_launch_latch.restype = C.c_int
+    tools.sast_test_launch_latch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    dev = torch.device("cuda:0")
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert tools.sast_test_launch_latch(cnt.data_ptr(), 0, st) == 0
+    assert tools.sast_test_launch_latch(cnt.data_ptr(), 1, st) == -5          # SAST_ELAUNCH although the last two launches succeeded
+    assert tools.sast_test_launch_latch(cnt.data_ptr(), 0, st) == 0           # the latch is consumed by the check: no sticky state
+    torch.cuda.synchronize()
+    assert int(cnt) == 3 + 2 + 3
