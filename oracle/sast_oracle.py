@@ -261,10 +261,13 @@ def selection_diff(scores: Tensor, own, other, B: int, N: int, T: int, bounce: f
 
 
 def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnCfg,
-               index_list=None, first_block: bool = True, return_scores: bool = False, forced_lists=None, diff_log=None):
+               index_list=None, first_block: bool = True, return_scores: bool = False, forced_lists=None, diff_log=None,
+               kink_log: Optional[dict] = None):
     """SAST.py:98-164.  x (B,H,W,C) NHWC, pe (1,H,W,C), r (B,20) -> (x, index_count, [list1,list2]).
     forced_lists (test diagnostics, never the reference's behaviour): [list1, list2] to USE instead of this block's own
-    selection; the own selection is still computed and its disagreement with the forced one is appended to diff_log."""
+    selection; the own selection is still computed and its disagreement with the forced one is appended to diff_log.
+    kink_log (test diagnostics): kink_log[pre] = {"x": input of the scoring linear, "z": its pre-activation, "s": ReLU(z) with
+    retain_grad} -- what a kink-aware comparison of the `to_scores` gradients needs (tests/test_gpu_parity.py:scores_grads_close)."""
     B, H, W, C = x.shape
     h, w = cfg.partition_size
     T = h * w
@@ -275,7 +278,12 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
     scores = None
     if first_block:
         scale = F.linear(r + 1e-6, torch.exp(p[pre + "to_controls.weight"]))[:, None, None, :]
-        scores = F.relu(F.linear(x, p[pre + "to_scores.weight"], p[pre + "to_scores.bias"]))
+        z_pre = F.linear(x, p[pre + "to_scores.weight"], p[pre + "to_scores.bias"])
+        scores = F.relu(z_pre)
+        if kink_log is not None:
+            if scores.requires_grad:
+                scores.retain_grad()
+            kink_log.setdefault(pre, []).append({"x": x, "z": z_pre, "s": scores})
         weight = scale.sigmoid() * scores.sigmoid()
         x = (weight * x).view(B * N, -1, C)
         scale = cfg.amp / scale
@@ -333,7 +341,7 @@ def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: st
 
 # --------------------------------------------------------------------------- a11
 def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: BackboneCfg, stage_idx: int,
-                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None):
+                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None, kink_log=None):
     """sast_rnn.py:265-287.  NCHW in -> (h NCHW, (h,c), P, index lists).  token_mask (B,H,W) bool: x[token_mask] = mask_token
     (:271-273, parameter `<pre>mask_token` of shape (1,1,1,C), only stage 0 has one when enable_masking is set)."""
     factor = cfg.patch_size if stage_idx == 0 else 2
@@ -350,7 +358,8 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
     for bi in range(cfg.num_blocks[stage_idx]):
         x, cnt, lists = sast_block(x, pe, r, p, f"{pre}att_blocks.{bi}.att.", cfg.attn,
                                    index_list=lists, first_block=(bi == 0),
-                                   forced_lists=forced_lists[bi] if (forced_lists is not None and bi == 0) else None, diff_log=diff_log)
+                                   forced_lists=forced_lists[bi] if (forced_lists is not None and bi == 0) else None, diff_log=diff_log,
+                                   kink_log=kink_log)
         all_lists.append(lists)
         P += cnt
     x = x.permute(0, 3, 1, 2).contiguous()
@@ -359,7 +368,7 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
 
 
 def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "", return_lists: bool = False,
-             token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None):
+             token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None, kink_log=None):
     """sast_rnn.py:144-162.  x (B,20,H,W) -> ({1..4: h}, states, P).
     forced_lists[stage][block] = [list1, list2] / diff_log: see sast_block (full-size parity diagnostics only)."""
     if prev_states is None:
@@ -373,7 +382,8 @@ def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "",
     for s in range(4):
         x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s,
                                         token_mask=token_mask if s == 0 else None,
-                                        forced_lists=forced_lists[s] if forced_lists is not None else None, diff_log=diff_log)
+                                        forced_lists=forced_lists[s] if forced_lists is not None else None, diff_log=diff_log,
+                                        kink_log=kink_log)
         states.append(st)
         out[s + 1] = st[0]
         P.append(cnt)
@@ -800,14 +810,14 @@ def rnn_states_reset(states, indices_or_bool=None):
 
 
 def sequence_train_step(x_seq: Sequence[Tensor], indices_seq, labels: Tensor, bp: Params, fp: Params, hp: Params, cfg: BackboneCfg,
-                        prev_states=None, num_classes: int = 3, strides=(8, 16, 32), depth: float = 0.67):
+                        prev_states=None, num_classes: int = 3, strides=(8, 16, 32), depth: float = 0.67, kink_log=None):
     """the model part of Module.training_step (modules/detection.py:139-177): L timesteps through the backbone with the recurrent
     states carried (not detached inside the sequence), the features of the labelled (timestep, sample) pairs gathered, ONE
     PAFPN + head + SimOTA loss call on the batched features.  labels: (sum_t len(indices_seq[t]), max_labels, 5) yolox format in
     gather order.  -> (losses dict, final states, P list per timestep)."""
     states, feats_seq, Ps = prev_states, [], []
     for x in x_seq:
-        out, states, P = backbone(x, states, bp, cfg)
+        out, states, P = backbone(x, states, bp, cfg, kink_log=kink_log)
         feats_seq.append(out)
         Ps.append(P)
     sel = select_backbone_features(feats_seq, indices_seq)

@@ -8,11 +8,13 @@ from the CPU path), gradients within GRAD_RTOL = 3e-4 relative to the tensor's m
 The tolerances are ~10x the worst error MEASURED on the MI355X (round 2, gpurun_out/parity_errors.json written by
 conftest.record_error; summary in DESIGN.md section 4b): forward <= 1.2e-5 of the 3e-5 bar; gradients <= 3.3e-5 in every
 test below full size and <= 1.0e-4 at 1Mpx B=8 (batch-statistics BatchNorm backward of the PAFPN amplifies rounding noise;
-without the PAFPN the median tensor error is 6e-7).  One family is special: the gradients of `to_scores.{weight,bias}` sit
+without the PAFPN the median tensor error is 6e-7).  One family needs care: the gradients of `to_scores.{weight,bias}` sit
 behind a ReLU (SAST.py:110); a (token, channel) pre-activation within fp32 rounding of 0 is cut on one side and not on the
 other, which moves ONE row of dW / one element of db by that element's whole contribution (measured: max error 1e-3 of the
 max-norm in one row with an rms error of 2.5e-5; against an fp64 run of the oracle the affected row CHANGES, i.e. the
-reference itself has the same sensitivity).  Those two tensors are checked by rms (<= 3e-4) and a loose max (<= 2e-2).
+reference itself has the same sensitivity).  Round 3: those two tensors are compared KINK-AWARE at the ordinary GRAD_RTOL
+(parity_helpers.scores_grads_close): the elements whose pre-activation lies within 1e-5 of the kink are identified from the
+oracle's record of the layer and their contributions are taken out of the comparison on both sides; no tensor has a looser bar.
 """
 import json
 import os
@@ -26,7 +28,6 @@ from oracle import sast_oracle as O
 pytestmark = pytest.mark.gpu
 
 FWD_ATOL = 3e-5
-GRAD_RTOL = 3e-4
 LIST_NAMES = ("index_window", "index_token", "padding_index", "asy_index", "K")
 
 
@@ -52,30 +53,7 @@ def load_params(module, params, prefix=""):
     module.load_state_dict(new, strict=True)
 
 
-def _test_id():
-    return os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
-
-
-def maxnorm_close(a, b, rtol, what=""):
-    from conftest import record_error
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    scale = float(b.abs().max()) + 1e-12
-    err = float((a - b).abs().max())
-    record_error(_test_id(), what, err, scale, rtol)
-    assert err <= rtol * scale + 1e-9, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {rtol:.1e})"
-
-
-def grad_close(name, got, ref, rtol=None):
-    """gradient of parameter `name`: max-norm relative error, except for the tensors behind the scoring ReLU (see header)"""
-    if "to_scores." in name:
-        from conftest import record_error
-        a, b = got.detach().float().cpu(), ref.detach().float().cpu()
-        scale = float(b.abs().max()) + 1e-12
-        rms = float((a - b).pow(2).mean().sqrt())
-        record_error(_test_id(), name + " [rms]", rms, scale, GRAD_RTOL)
-        assert rms <= GRAD_RTOL * scale + 1e-9, f"{name}: rms err {rms:.3e} vs scale {scale:.3e}"
-        return maxnorm_close(got, ref, 2e-2, name + " [relu kink]")
-    return maxnorm_close(got, ref, GRAD_RTOL if rtol is None else rtol, name)
+from parity_helpers import GRAD_RTOL, KINK_BAND, _test_id, grad_close, maxnorm_close, net_grads_close, scores_grads_close  # noqa: E402,F401
 
 
 def abs_close(a, b, atol, what=""):
@@ -171,10 +149,14 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     abs_close(out.detach().cpu(), torch.from_numpy(g["out"]), FWD_ATOL, "")
     (out ** 2).mean().backward()
     maxnorm_close(xd.grad, torch.from_numpy(g["dx"]), GRAD_RTOL, "dx")
-    for k, v in blk.named_parameters():
-        if "sub_layers" in k:
-            continue
-        grad_close(k, v.grad, torch.from_numpy(g["g_" + k]))
+    # the fixture holds the REFERENCE's gradients; the oracle run only supplies the record of the scoring layer's near-zero
+    # pre-activations (x, z, dL/dscores) for the kink-aware comparison of d(to_scores)
+    kl = {}
+    po = {("att_blocks.0.att." + k): v.clone().requires_grad_(True) for k, v in {kk[len("att_blocks.0.att."):]: vv for kk, vv in params.items()}.items()}
+    oo, _c, _l = O.sast_block(x.clone(), O.position_embedding_sine(H, W, C), r, po, "att_blocks.0.att.",
+                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), enable_cb=cb, dim_head=dh), kink_log=kl)
+    (oo ** 2).mean().backward()
+    net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
 
 
 def test_stage_two_blocks_vs_golden(golden_dir, dev):
@@ -205,14 +187,13 @@ def test_stage_two_blocks_vs_golden(golden_dir, dev):
     xo = x.clone().requires_grad_(True)
     cfg = O.AttnCfg(partition_size=(4, 5), amp=amp)
     pe_o = O.position_embedding_sine(H, W, C)
-    a1, _c1, l1 = O.sast_block(xo, pe_o, r, po, "att_blocks.0.att.", cfg)
-    a2, _c2, _ = O.sast_block(a1, pe_o, r, po, "att_blocks.1.att.", cfg, index_list=l1, first_block=False)
+    kl = {}
+    a1, _c1, l1 = O.sast_block(xo, pe_o, r, po, "att_blocks.0.att.", cfg, kink_log=kl)
+    a2, _c2, _ = O.sast_block(a1, pe_o, r, po, "att_blocks.1.att.", cfg, index_list=l1, first_block=False, kink_log=kl)
     (a2 ** 2).mean().backward()
     maxnorm_close(xd.grad, xo.grad, GRAD_RTOL, "dx")
     for blk, pre in ((b1, "att_blocks.0.att."), (b2, "att_blocks.1.att.")):
-        for k, v in blk.named_parameters():
-            if "sub_layers" not in k:
-                grad_close(pre + k, v.grad, po[pre + k].grad)
+        net_grads_close(blk.named_parameters(), lambda k, pre=pre: po[pre + k].grad if (pre + k) in po else None, kl, prefix=pre, log_prefix=pre)
 
 
 def test_second_backward_is_refused(dev):
@@ -332,13 +313,11 @@ def test_backbone_tiny_vs_golden(golden_dir, dev, tag):
     loss.backward()
     # full oracle gradients on the host for every parameter
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    kl = {}
     o0, s0, _ = O.backbone(x0.cpu(), None, po, ocfg)
-    o1, _, _ = O.backbone(x1.cpu(), [(h.detach(), c.detach()) for h, c in s0], po, ocfg)
+    o1, _, _ = O.backbone(x1.cpu(), [(h.detach(), c.detach()) for h, c in s0], po, ocfg, kink_log=kl)
     sum((o1[k] ** 2).mean() for k in (1, 2, 3, 4)).backward()
-    for k, v in net.named_parameters():
-        if "sub_layers" in k:
-            continue
-        grad_close(k, v.grad, po[k].grad)
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
 
 
 @pytest.mark.parametrize("size,E,dh,depth,hw,part", [("large", 96, 32, 0.67, (128, 160), (4, 5)), ("small", 48, 24, 0.33, (128, 160), (4, 5)),
@@ -365,7 +344,8 @@ def test_backbone_other_sizes(dev, size, E, dh, depth, hw, part):
     loss.backward()
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
-    oo, _s, Po, lists = O.backbone(x, None, po, ocfg, return_lists=True)
+    kl = {}
+    oo, _s, Po, lists = O.backbone(x, None, po, ocfg, return_lists=True, kink_log=kl)
     oouts = O.pafpn({k: oo[k] for k in (2, 3, 4)}, pf, depth=depth, training=True)
     loss_o = sum((oo[k] ** 2).mean() for k in (1, 2, 3, 4)) + sum((o ** 2).mean() for o in oouts)
     loss_o.backward()
@@ -374,9 +354,7 @@ def test_backbone_other_sizes(dev, size, E, dh, depth, hw, part):
         abs_close(out[k].detach().cpu(), oo[k].detach(), FWD_ATOL, str(k))
     for i, (a, b) in enumerate(zip(outs, oouts)):   # reductions of up to 9*768 terms after batch-stat BN: relative tolerance
         maxnorm_close(a, b, 1e-4, f"pafpn out {i}")
-    for k, v in net.named_parameters():
-        if "sub_layers" not in k:
-            grad_close(k, v.grad, po[k].grad)
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
     for k, v in fpn.named_parameters():
         grad_close(k, v.grad, pf[k].grad)
 
@@ -601,15 +579,14 @@ def test_backbone_odd_batches(dev, B):
     sum((o ** 2).mean() for o in outs).backward()
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
-    oo, _s, Po = O.backbone(x, None, po, ocfg)
+    kl = {}
+    oo, _s, Po = O.backbone(x, None, po, ocfg, kink_log=kl)
     oouts = O.pafpn({k: oo[k] for k in (2, 3, 4)}, pf, training=True)
     sum((o ** 2).mean() for o in oouts).backward()
     assert [int(p) for p in P] == [int(p) for p in Po]
     for a, b in zip(outs, oouts):
         maxnorm_close(a, b, 1e-4, "pafpn out")
-    for k, v in net.named_parameters():
-        if "sub_layers" not in k:
-            grad_close(k, v.grad, po[k].grad)
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
     for k, v in fpn.named_parameters():
         grad_close(k, v.grad, pf[k].grad)
 
@@ -636,7 +613,8 @@ def test_backbone_empty_frames(dev):
         assert torch.isfinite(loss), case
         loss.backward()
         po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
-        oo, _s, Po = O.backbone(x, None, po, ocfg)
+        kl = {}
+        oo, _s, Po = O.backbone(x, None, po, ocfg, kink_log=kl)
         loss_o = sum((oo[k] ** 2).mean() for k in (1, 2, 3, 4))
         loss_o.backward()
         assert [int(p) for p in P] == [int(p) for p in Po], (case, P, Po)
@@ -646,7 +624,7 @@ def test_backbone_empty_frames(dev):
         for k, v in net.named_parameters():
             if "sub_layers" not in k and po[k].grad is not None:
                 assert torch.isfinite(v.grad).all(), (case, k)
-                grad_close(k, v.grad, po[k].grad)
+        net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
 
 
 def test_backbone_sequence_bptt(dev):
@@ -676,13 +654,12 @@ def test_backbone_sequence_bptt(dev):
     loss.backward()
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
-    loss_o, Ps_o = run(lambda x, st: O.backbone(x, st, po, ocfg), lambda f: O.pafpn(f, pf, training=True), lambda x: x)
+    kl = {}
+    loss_o, Ps_o = run(lambda x, st: O.backbone(x, st, po, ocfg, kink_log=kl), lambda f: O.pafpn(f, pf, training=True), lambda x: x)
     loss_o.backward()
     assert Ps == Ps_o
     assert abs(float(loss) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
-    for k, v in net.named_parameters():
-        if "sub_layers" not in k:
-            grad_close(k, v.grad, po[k].grad)
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
     for k, v in fpn.named_parameters():
         grad_close(k, v.grad, pf[k].grad)
 
@@ -788,8 +765,8 @@ def test_full_size_train_parity(dev, B, amp, seed):
     lists = _cpu_lists(net)
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fparams.items()}
-    log = []
-    oo, _s, Po = O.backbone(x, None, po, ocfg, forced_lists=lists, diff_log=log)
+    log, kl = [], {}
+    oo, _s, Po = O.backbone(x, None, po, ocfg, forced_lists=lists, diff_log=log, kink_log=kl)
     oouts = O.pafpn({k: oo[k] for k in (2, 3, 4)}, pf, training=True)
     loss_o = sum((o ** 2).mean() for o in oouts) + 0.25 * sum((oo[k] ** 2).mean() for k in (1, 2, 3, 4))
     loss_o.backward()
@@ -808,9 +785,7 @@ def test_full_size_train_parity(dev, B, amp, seed):
         abs_close(out[k], oo[k], FWD_ATOL, f"h{k}")
     for i, (a, b) in enumerate(zip(outs, oouts)):
         maxnorm_close(a, b, 1e-4, f"pafpn out {i}")
-    for k, v in net.named_parameters():
-        if "sub_layers" not in k:
-            grad_close(k, v.grad, po[k].grad)
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
     for k, v in fpn.named_parameters():
         grad_close("fpn." + k, v.grad, pf[k].grad)
 
@@ -960,13 +935,12 @@ def test_label_sparse_sequence_step(dev):
     po = {k: v.clone().requires_grad_(True) for k, v in bp.items()}
     pf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in fp.items()}
     ph = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in hp.items()}
-    ref, ref_states, Ps = O.sequence_train_step(xs, indices, labels, po, pf, ph, ocfg, num_classes=nc)
+    kl = {}
+    ref, ref_states, Ps = O.sequence_train_step(xs, indices, labels, po, pf, ph, ocfg, num_classes=nc, kink_log=kl)
     ref["loss"].backward()
     assert [int(p) for p in ts.P] == [int(p) for p in Ps[-1]]
     assert abs(float(ts.losses["loss"]) - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"]))
-    for k, v in net.named_parameters():
-        if "sub_layers" not in k:
-            grad_close(k, v.grad, po[k].grad, 6e-4)
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl, 6e-4)
     for k, v in fpn.named_parameters():
         grad_close("fpn." + k, v.grad, pf[k].grad, 6e-4)
     for k, v in head.named_parameters():

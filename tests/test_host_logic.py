@@ -261,3 +261,46 @@ def test_two_replicas_bucketed_allreduce_equals_averaged_single_process_gloo(tmp
                         "--master-port", "29741", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok") == 2
+
+
+def test_kink_aware_scores_gradient_comparison():
+    """parity_helpers.scores_grads_close on the CPU: a 'device' gradient that differs from the reference only by the ReLU decision of a
+    few pre-activations within rounding of zero passes at GRAD_RTOL; one that differs anywhere else (an O(1e-3) error in a row without
+    ambiguous elements, or a wrong contribution of an ambiguous one) fails."""
+    import pytest
+    from parity_helpers import scores_grads_close
+    g = torch.Generator().manual_seed(0)
+    n, C = 4000, 32
+    x = torch.randn(n, C, generator=g)
+    W = (torch.randn(C, C, generator=g) * 0.2).requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    # plant pre-activations within 1e-7 of the kink: solve for the bias-free hit by nudging the rows of x
+    z0 = torch.nn.functional.linear(x, W, b).detach()
+    planted = [(5, 3), (77, 3), (1234, 17), (3999, 30)]
+    for t, c in planted:
+        x[t] -= (z0[t, c] - 1e-7 * (1 if (t % 2) else -1)) * W[c].detach() / W[c].detach().pow(2).sum()
+    z = torch.nn.functional.linear(x, W, b)
+    s = torch.relu(z)
+    s.retain_grad()
+    w_out = torch.randn(n, C, generator=g)
+    (torch.sigmoid(s) * w_out).sum().backward()
+    rec = [{"x": x, "z": z, "s": s}]
+    rW, rb = W.grad.clone(), b.grad.clone()
+    for t, c in planted:
+        assert abs(float(z[t, c].detach())) < 1e-5 * float(z.detach().abs().max())
+    # the "device": every planted element decided the other way
+    dW, db = rW.clone(), rb.clone()
+    for t, c in planted:
+        sign = -1.0 if float(z[t, c]) > 0 else 1.0
+        dW[c] += sign * s.grad[t, c] * x[t]
+        db[c] += sign * s.grad[t, c]
+    scores_grads_close("blk.", dW, db, rW, rb, rec)
+    bad = dW.clone()
+    bad[9] += 2e-3 * float(rW.abs().max())                       # a row without ambiguous elements
+    with pytest.raises(AssertionError):
+        scores_grads_close("blk.", bad, db, rW, rb, rec)
+    bad = dW.clone()
+    bad[3] += 0.4 * s.grad[5, 3] * x[5]                          # a fractional (impossible) share of an ambiguous element
+    if float((0.4 * s.grad[5, 3] * x[5]).abs().max()) > 1e-3 * float(rW.abs().max()):
+        with pytest.raises(AssertionError):
+            scores_grads_close("blk.", bad, db, rW, rb, rec)
