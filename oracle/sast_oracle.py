@@ -260,14 +260,25 @@ def selection_diff(scores: Tensor, own, other, B: int, N: int, T: int, bounce: f
             "max_margin": float(torch.cat([mw[wdiff], mt[tdiff], torch.zeros(1, dtype=mw.dtype)]).max())}
 
 
+def _margin_entry(scores: Tensor, index_window: Tensor, B: int, N: int, T: int, bounce: float, where: str) -> dict:
+    mw, mt = selection_margins(scores, B, N, T, bounce)
+    flat = index_window if B > 1 else index_window      # (B == 1: ids are already 0..N-1)
+    mt = mt[flat]
+    allm = torch.cat([mw.reshape(-1), mt.reshape(-1)])
+    return {"where": where, "win_min": float(mw.min()), "tok_min": float(mt.min()),
+            "below": {k: int((allm < float(k)).sum()) for k in ("1e-7", "1e-6", "1e-5", "1e-4")}, "decisions": int(allm.numel())}
+
+
 def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnCfg,
                index_list=None, first_block: bool = True, return_scores: bool = False, forced_lists=None, diff_log=None,
-               kink_log: Optional[dict] = None):
+               kink_log: Optional[dict] = None, margin_log: Optional[list] = None):
     """SAST.py:98-164.  x (B,H,W,C) NHWC, pe (1,H,W,C), r (B,20) -> (x, index_count, [list1,list2]).
     forced_lists (test diagnostics, never the reference's behaviour): [list1, list2] to USE instead of this block's own
     selection; the own selection is still computed and its disagreement with the forced one is appended to diff_log.
     kink_log (test diagnostics): kink_log[pre] = {"x": input of the scoring linear, "z": its pre-activation, "s": ReLU(z) with
-    retain_grad} -- what a kink-aware comparison of the `to_scores` gradients needs (tests/test_gpu_parity.py:scores_grads_close)."""
+    retain_grad} -- what a kink-aware comparison of the `to_scores` gradients needs (tests/parity_helpers.py:scores_grads_close).
+    margin_log (fixture generation / diagnostics): per selection the relative distance of the DECIDED softmax values (all windows; the
+    tokens of the kept windows) to their thresholds: {"where", "win_min", "tok_min", "below": counts under 1e-7 / 1e-6 / 1e-5 / 1e-4}."""
     B, H, W, C = x.shape
     h, w = cfg.partition_size
     T = h * w
@@ -292,6 +303,8 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
         iw = select_windows(scores, B, N, T, cfg.bounce)
         it, asy, K = select_tokens(scores, iw, B, N, T, cfg.bounce)
         list1 = [iw, it, _padding_index(it, asy), asy, K]
+        if margin_log is not None:
+            margin_log.append(_margin_entry(scores.detach(), iw, B, N, T, cfg.bounce, pre + "win"))
         if forced_lists is not None:
             if diff_log is not None:
                 diff_log.append(dict(selection_diff(scores.detach(), list1, forced_lists[0], B, N, T, cfg.bounce), where=pre + "win"))
@@ -310,6 +323,8 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
         iw = select_windows(scores, B, N, T, cfg.bounce)
         it, asy, K = select_tokens(scores, iw, B, N, T, cfg.bounce)
         list2 = [iw, it, _padding_index(it, asy), asy, K]
+        if margin_log is not None:
+            margin_log.append(_margin_entry(scores.detach(), iw, B, N, T, cfg.bounce, pre + "grid"))
         if forced_lists is not None:
             if diff_log is not None:
                 diff_log.append(dict(selection_diff(scores.detach(), list2, forced_lists[1], B, N, T, cfg.bounce), where=pre + "grid"))
@@ -341,7 +356,8 @@ def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: st
 
 # --------------------------------------------------------------------------- a11
 def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: BackboneCfg, stage_idx: int,
-                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None, kink_log=None):
+                   pe: Optional[Tensor] = None, token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None, kink_log=None,
+                   margin_log=None):
     """sast_rnn.py:265-287.  NCHW in -> (h NCHW, (h,c), P, index lists).  token_mask (B,H,W) bool: x[token_mask] = mask_token
     (:271-273, parameter `<pre>mask_token` of shape (1,1,1,C), only stage 0 has one when enable_masking is set)."""
     factor = cfg.patch_size if stage_idx == 0 else 2
@@ -359,7 +375,7 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
         x, cnt, lists = sast_block(x, pe, r, p, f"{pre}att_blocks.{bi}.att.", cfg.attn,
                                    index_list=lists, first_block=(bi == 0),
                                    forced_lists=forced_lists[bi] if (forced_lists is not None and bi == 0) else None, diff_log=diff_log,
-                                   kink_log=kink_log)
+                                   kink_log=kink_log, margin_log=margin_log)
         all_lists.append(lists)
         P += cnt
     x = x.permute(0, 3, 1, 2).contiguous()
@@ -368,7 +384,7 @@ def backbone_stage(x: Tensor, state, r: Tensor, p: Params, pre: str, cfg: Backbo
 
 
 def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "", return_lists: bool = False,
-             token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None, kink_log=None):
+             token_mask: Optional[Tensor] = None, forced_lists=None, diff_log=None, kink_log=None, margin_log=None):
     """sast_rnn.py:144-162.  x (B,20,H,W) -> ({1..4: h}, states, P).
     forced_lists[stage][block] = [list1, list2] / diff_log: see sast_block (full-size parity diagnostics only)."""
     if prev_states is None:
@@ -383,7 +399,7 @@ def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "",
         x, st, cnt, ls = backbone_stage(x, prev_states[s], r[:, s], p, f"{pre}stages.{s}.", cfg, s,
                                         token_mask=token_mask if s == 0 else None,
                                         forced_lists=forced_lists[s] if forced_lists is not None else None, diff_log=diff_log,
-                                        kink_log=kink_log)
+                                        kink_log=kink_log, margin_log=margin_log)
         states.append(st)
         out[s + 1] = st[0]
         P.append(cnt)
