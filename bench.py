@@ -347,6 +347,19 @@ def main():
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    # N > 1: how much of the gradient exchange is NOT hidden behind the backward -- a few extra, un-timed steps on every rank with
+    # event pairs (main stream idle, side stream done); max over ranks
+    exposed_ms = None
+    if (world > 1 or tr.segmented) and not tr.fwd_only:
+        tr.ts.measure_exposed = True
+        for _ in range(20):
+            tr.step()
+        exposed_ms = tr.ts.exposed_ms()
+        tr.ts.measure_exposed = False
+        if world > 1:
+            t = torch.tensor([exposed_ms if exposed_ms is not None else -1.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exposed_ms = float(t.item()) if float(t.item()) >= 0 else None
 
     if rank == 0:
         kept = [int(p) for p in tr.P]
@@ -378,13 +391,16 @@ def main():
                        "library": os.path.relpath(__import__("sast_amd._lib", fromlist=["lib"]).loaded_path(), ROOT),
                        "product_library": __import__("sast_amd._lib", fromlist=["lib"]).is_product_library(),
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
+                       "collective_ranks": world, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "gradient_bytes_per_rank": 4 * int(tr.flat.numel),
+                       "allreduce_exposed_ms": exposed_ms,
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
                        "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},
         }
         if not args.no_roofline:
             from sast_amd.profiling import dominant_kernel_roofline
-            res["roofline"] = dominant_kernel_roofline(tr)
+            res["roofline"] = dominant_kernel_roofline(tr, ms_per_step=res["ms_per_step"] / max(args.seq_len, 1), hw=HW, batch=BATCH)
         if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy" and args.precision == "f32":
             parity, res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only, tr=tr)
             if parity is not None:

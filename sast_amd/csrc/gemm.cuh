@@ -882,6 +882,8 @@ void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, co
 // kernel-exact timing: events handed to hipExtLaunchKernelGGL are stamped at the kernel's own begin / end
 void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st,
                         hipEvent_t* e0, hipEvent_t* e1);
+void prof_kernel_events_ex(const char* tag, double flops, double bytes, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
+void prof_sum_k(const int* Kw, int W, hipStream_t st, double* sum_k, double* sum_k2);
 bool prof_enabled();
 bool xcd_remap_enabled();   // SAST_XCD_REMAP (default on)
 void prof_scope(const char* name, int c, int m, hipStream_t st, bool begin);

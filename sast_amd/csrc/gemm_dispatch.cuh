@@ -59,6 +59,10 @@ inline int pair_tn_blocks_conv() { static int v = env_int("SAST_TN_BLOCKS_PAIRED
 // and for the 1x1 conv pairs of the FPN / head (k_conv.hip)
 inline int pair_tn_blocks_1x1() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_1X1", 192); return v; }
 inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 192); return v; }
+// weight gradients of at most SAST_TN_SMALL_TILES output tiles (stage 1 / 2: 64x64 ... 128x128): every split adds its whole tile
+// atomically, a same-line chain of `splits` atomic instructions (~25 ns each) -- their own target (0 = the general one)
+inline int pair_tn_blocks_small() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_SMALL", 0); return v; }
+inline int pair_tn_small_tiles() { static int v = env_int("SAST_TN_SMALL_TILES", 4); return v; }
 
 // target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)
 inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
@@ -96,6 +100,8 @@ int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1
                  const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st, int tn_target) {
   const long nb2 = (long)((M2 + 63) / 64) * ((NJ2 + 63) / 64);
   const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
+  const int nb1 = ((Mo + 63) / 64) * ((NJ1 + 63) / 64);
+  if (gemm_pair_enabled() && pair_tn_blocks_small() > 0 && nb1 <= pair_tn_small_tiles()) tn_target = pair_tn_blocks_small();
   const int splits = tn_splits(Mo, NJ1, R1, gemm_pair_enabled() ? (tn_target > 0 ? tn_target : pair_tn_blocks_paired()) : 0);
   if (!gemm_pair_enabled() || Mo <= 0 || NJ1 <= 0 || R1 <= 0 || M2 <= 0 || NJ2 <= 0 || R2 <= 0) {
     int rc = launch_gemm_split<TileSplitR>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, st);

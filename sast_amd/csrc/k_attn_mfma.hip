@@ -1,33 +1,44 @@
-// MFMA version of the variable-length per-window attention (dim_head <= 32, multiple of 4; the reference ships dim_head
-// 32 and 24 (config/experiment/*/small.yaml); head dims below 32 are zero-padded in LDS).
+// Variable-length per-window attention on the bf16 matrix pipe with fp32-accurate products (dim_head <= 32, multiple of 4; the
+// reference ships dim_head 32 and 24 (config/experiment/*/small.yaml); head dims below 32 are zero-padded in LDS).
 //
-// One workgroup per (group, head): NTMAX waves, NTMAX = 2 for partitions of up to 64 tokens (1Mpx: T = 60) and 4 for up to
-// 128 tokens (Gen1: T = 80).  The K_m surviving tokens of the group are compact rows [row_off, row_off + K_m); they are
-// staged TRANSPOSED in LDS ([d][token], odd leading dimension 32*NTMAX+1) so that
-//   * operands whose reduce index is d   (S = Q K^T, dP = dO V^T)            are contiguous ds_read_b32, and
-//   * operands whose reduce index is a token (P V, P^T dO, dS^T Q, dS K)     are odd-stride reads,
-// both bank-conflict free.  QK^T / PV / all five backward products run on v_mfma_f32_32x32x2_f32 (exact fp32);
-// the softmax lives in the MFMA C layout (row = f(reg, lane>>5), col = lane&31) with half-wave shuffles.
-// Wave w owns query rows [32w, 32w+32) (forward; S, dP, dS, dQ in backward) and key rows [32w, 32w+32) for dK/dV.
-// The number of 32-token tiles NT = ceil(K_m / 32) is a template parameter of the body (block-uniform switch), so the
-// product loops carry no branches.  No padding work beyond rounding K_m up to 32; padded keys are masked to -inf,
-// padded queries are never stored.
+// One workgroup per (group, head): NTMAX waves, NTMAX = 2 for partitions of up to 64 tokens (1Mpx: T = 60), 3 for up to 96
+// (Gen1: T = 80), 4 for up to 128.  The K_m surviving tokens of the group are the compact rows [row_off, row_off + K_m).
+//
+// Round 3 form.  Every product is evaluated like the GEMM template's (gemm.cuh): fp32 operands split EXACTLY into three bf16
+// terms, six v_mfma_f32_32x32x16_bf16 per 32x32x16 tile step with fp32 accumulation (error <= 2^-23 |x||y| per product) --
+// 192 matrix-pipe cycles where the f32-input MFMA (the round-2 kernel) needed 512.
+//   * Q, K, V (and dO) are split ONCE, by the thread that stages them, into three bf16 planes [token][32 d] (64-byte rows; the
+//     16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3)).  The same image serves both operand roles conflict-free:
+//       reduce over d      (Q K^T, dO V^T):        a lane's 8 consecutive d of one token = one ds_read_b128 per plane;
+//       reduce over tokens (P V, P^T dO, dS^T Q, dS K): index = d, 8 consecutive tokens = two ds_read_b64_tr_b16 per plane (the
+//       transposing LDS read hands a lane column d of a 4 (token) x 16 (d) block).
+//   * The scores are produced TRANSPOSED, S^T = K Q^T: in the MFMA C layout a lane then owns ONE query (column) and 16 keys per
+//     tile (rows), so the softmax max / sum and the backward's D_i = sum_j P_ij dP_ij are in-register reductions plus ONE exchange
+//     with lane ^ 32 (v_permlane32_swap) instead of 5-step half-wave all-reduces per row.
+//   * P (and dS) never go through LDS: the C-layout registers of a tile, exchanged pairwise with lane ^ 32, ARE the 8 consecutive
+//     reduce indices an MFMA B operand needs (rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5): a lane holds 0-3 | 8-11 | ..., its partner
+//     4-7 | 12-15 | ...).  They are split in registers.  The products that consume them are evaluated transposed (O^T = V^T P^T,
+//     dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS), which also makes the results row-per-lane: 4 consecutive d per register
+//     group = one 16-byte global store.
+//   * The backward needs P / dS in BOTH orientations (dQ reduces over keys, dV / dK over queries): instead of transposing through
+//     LDS it evaluates S and dP twice, once per orientation (the operands are already in LDS; 48 extra MFMAs per wave).
+// Padded keys are masked (P = 0), padded queries are never stored.  No padding work beyond rounding K_m up to 32.
 #include "gemm.cuh"
 #include "kernels.h"
 
 namespace sast {
 
-constexpr int ADH = 32;    // LDS tile height = maximum dim_head
+constexpr int ADH = 32;    // plane row = maximum dim_head
 
-// all-reduce over the 32 lanes of a half wave (common.cuh: DPP + ds_swizzle, no ds_bpermute)
-__device__ __forceinline__ float half_max(float v) { return group_reduce<32>(v, OpMax{}); }
-__device__ __forceinline__ float half_sum(float v) { return group_reduce<32>(v, OpSum{}); }
 __device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-// stage rows [r0, r0+K) x dh channels of `src` (row stride ld, channel offset coff) transposed into dst[d][tok].
-// Two steps so that the loads of ALL staged matrices are in flight together (branch-free: clamped row + select at
-// commit time; a predicated load would make hipcc drain vmcnt after every single one).  64*NTMAX threads cover the
-// 32*NTMAX x 8 float4 slots in 4 rounds.
+// ---- LDS image of one staged matrix: 3 planes (h, m, l) of [KT][32] bf16
+__device__ __forceinline__ int plane_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+// stage rows [r0, r0+K) x dh channels of `src` (row stride ld, channel offset coff), scaled by `mul`, as bf16x3 planes.
+// Two steps so that the loads of ALL staged matrices are in flight together (branch-free: clamped row + select at commit time; a
+// predicated load would make hipcc drain vmcnt after every single one).  64*NTMAX threads cover the 32*NTMAX x 8 float4 slots in
+// 4 rounds.
 struct Staged { float4 v[4]; };
 template <int NTMAX>
 __device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K, int dh) {
@@ -40,108 +51,152 @@ __device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int
   return st;
 }
 template <int NTMAX>
-__device__ __forceinline__ void stage_commit(float* dst, const Staged& st, int K, int KT, float mul, int dh) {
-  constexpr int LDT = 32 * NTMAX + 1;
+__device__ __forceinline__ void stage_commit(char* mat, const Staged& st, int K, int KT, float mul, int dh) {
+  constexpr int PLANE = 32 * NTMAX * 64;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int s = threadIdx.x + it * 64 * NTMAX, row = s >> 3, dq = (s & 7) * 4;
+    const int s = threadIdx.x + it * 64 * NTMAX, row = s >> 3, q = s & 7;
     if (s < KT * 8) {
-      const float m = (row < K && dq < dh) ? mul : 0.f;   // channels dh..31 of the tile are zero
-      float* d = dst + dq * LDT + row;
-      d[0] = st.v[it].x * m; d[LDT] = st.v[it].y * m; d[2 * LDT] = st.v[it].z * m; d[3 * LDT] = st.v[it].w * m;
+      const float m = (row < K && 4 * q < dh) ? mul : 0.f;   // rows >= K and channels dh..31 of the image are zero
+      const float4 v = make_float4(st.v[it].x * m, st.v[it].y * m, st.v[it].z * m, st.v[it].w * m);
+      store_split3(reinterpret_cast<float*>(mat + plane_off(row, q >> 1) + (q & 1) * 8), PLANE / 4, v);
     }
+  }
+}
+
+// operand with the reduce index along d: 8 consecutive d (chunk c = 2 * kstep + lane / 32) of token `row`
+template <int NTMAX>
+__device__ __forceinline__ Split3 rd_read(const char* mat, int row, int chunk) {
+  constexpr int PLANE = 32 * NTMAX * 64;
+  const char* p = mat + plane_off(row, chunk);
+  return Split3{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + PLANE), *reinterpret_cast<const bf16x8*>(p + 2 * PLANE)};
+}
+// operand with the reduce index along tokens t0 .. t0+15 and the index along d (lane & 31): per plane two transposing reads of a
+// 4 (token) x 16 (d) block each (ds_read_b64_tr_b16: lane i of a 16-lane group addresses row i / 4, 8-byte granule i % 4 and
+// receives column i); gemm.cuh: psi_read pins the same instruction for the index-contiguous GEMM operands
+template <int NTMAX>
+__device__ __forceinline__ Split3 tk_read(const char* mat, int t0, int lane) {
+  using lds_bf16x4 = __attribute__((address_space(3))) bf16x4;
+  constexpr int PLANE = 32 * NTMAX * 64;
+  const int i = lane & 15;
+  const int g = 4 * ((lane >> 4) & 1) + (i & 3);                 // logical granule of the row: d = 4 g .. 4 g + 3
+  const int r1 = t0 + 8 * (lane >> 5) + (i >> 2), r2 = r1 + 4;
+  const char* q1 = mat + plane_off(r1, g >> 1) + (g & 1) * 8;
+  const char* q2 = mat + plane_off(r2, g >> 1) + (g & 1) * 8;
+  bf16x8 r[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q1 + p * PLANE));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(q2 + p * PLANE));
+    r[p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+  return Split3{r[0], r[1], r[2]};
+}
+// B operand from a C-layout tile (rows = reduce index, column = this lane's index): the 8 consecutive rows 16 u + 8 (lane / 32) + 0..7
+__device__ __forceinline__ Split3 c_tile_operand(const f32x16& c, int u) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    // v_permlane32_swap(X, Y): r[0] = {low half: own X, high half: partner's Y}, r[1] = {low half: partner's X, high half: own Y}
+    // (common.cuh: lane_peer<32>): a lane of the low half ends with its own row 16u+e and the partner's 16u+4+e, a lane of the high
+    // half with the partner's 16u+8+e and its own 16u+12+e
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(c[8 * u + e]), __float_as_int(c[8 * u + 4 + e]), false, false);
+    v[e] = __int_as_float(r[0]);
+    v[4 + e] = __int_as_float(r[1]);
+  }
+  return split3(v);
+}
+// acc += A x B with both operands split: the six significant bf16 products, smallest terms first (gemm.cuh: compute)
+__device__ __forceinline__ f32x16 mfma6(const Split3& a, const Split3& b, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ float pair_sum(float v) { return v + lane_peer<32>(v); }
+__device__ __forceinline__ float pair_max(float v) { return fmaxf(v, lane_peer<32>(v)); }
+// the transposed result tile (rows = d, column = this lane's token): rows 8 q + 4 (lane / 32) + 0..3 are 4 consecutive floats
+__device__ __forceinline__ void store_rows_per_lane(float* __restrict__ dst, const f32x16& acc, float mul, int lane, int dh) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int d0 = 8 * q + 4 * (lane >> 5);
+    if (d0 < dh) st4(dst + d0, make_float4(acc[4 * q] * mul, acc[4 * q + 1] * mul, acc[4 * q + 2] * mul, acc[4 * q + 3] * mul));
   }
 }
 
 // ------------------------------------------------------------------ forward
 template <int NTMAX, int NT>
-__device__ __forceinline__ void attn_fwd_body(float* sm, const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
+__device__ __forceinline__ void attn_fwd_body(char* sm, const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
                                               int r0, int K, int C, int heads, int h, float scale, int dh) {
-  constexpr int LDT = 32 * NTMAX + 1, KT = NT * 32;
-  float* Qt = sm;                 // [32][LDT]  (pre-scaled)
-  float* Kt = sm + 32 * LDT;
-  float* Vt = sm + 2 * 32 * LDT;
-  // P [32*NTMAX][LDT]: for NTMAX = 2 it aliases Qt|Kt once S is in registers; for NTMAX = 4 it has its own storage
-  float* P = NTMAX == 2 ? sm : sm + 3 * 32 * LDT;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
+  constexpr int KT = NT * 32, MAT = 3 * 32 * NTMAX * 64;
+  char* Qm = sm;                  // pre-scaled q
+  char* Km = sm + MAT;
+  char* Vm = sm + 2 * MAT;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
   const int C3 = 3 * C, coff = h * 3 * dh;
   {
     const Staged sq = stage_issue<NTMAX>(qkv, C3, coff, r0, K, dh), sk = stage_issue<NTMAX>(qkv, C3, coff + dh, r0, K, dh),
                  sv = stage_issue<NTMAX>(qkv, C3, coff + 2 * dh, r0, K, dh);
-    stage_commit<NTMAX>(Qt, sq, K, KT, scale, dh);
-    stage_commit<NTMAX>(Kt, sk, K, KT, 1.f, dh);
-    stage_commit<NTMAX>(Vt, sv, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Qm, sq, K, KT, scale, dh);
+    stage_commit<NTMAX>(Km, sk, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Vm, sv, K, KT, 1.f, dh);
   }
   __syncthreads();
-  const bool active = w < NT;
+  if (w >= NT) return;
+  // S^T tiles: rows = keys of tile t, column = this lane's query i = 32 w + l31
   f32x16 s[NT];
-  float inv[16];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    inv[e] = 0.f;
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) s[t][e] = 0.f;
+    for (int e = 0; e < 16; ++e) s[t][e] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const Split3 qb = rd_read<NTMAX>(Qm, w * 32 + l31, 2 * u + hf);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s[t] = mfma6(rd_read<NTMAX>(Km, t * 32 + l31, 2 * u + hf), qb, s[t]);
   }
-  if (active) {
+  // softmax over the keys of query i: this lane's 16 NT values and its partner's (lane ^ 32)
+  float mloc = -INFINITY;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      const float a = Qt[kk * LDT + w * 32 + l31];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + t * 32 + l31], s[t], 0, 0, 0);
-    }
-    bool cv[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) cv[t] = t * 32 + l31 < K;
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float v[NT], mloc = -INFINITY;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { v[t] = cv[t] ? s[t][e] : -INFINITY; mloc = fmaxf(mloc, v[t]); }
-      const float m = half_max(mloc);
-      float ploc = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) { const float pt = cv[t] ? __expf(v[t] - m) : 0.f; s[t][e] = pt; ploc += pt; }
-      const float sum = half_sum(ploc);
-      inv[e] = 1.0f / sum;
-      const int i = w * 32 + crow(e, lane);
-      if (l31 == 0 && i < K) lse[(size_t)(r0 + i) * heads + h] = m + logf(sum);
+      const bool kv = t * 32 + crow(e, lane) < K;
+      s[t][e] = kv ? s[t][e] : -INFINITY;
+      mloc = fmaxf(mloc, s[t][e]);
     }
-  }
-  if (NTMAX == 2) __syncthreads();   // everyone is done with Qt / Kt -> reuse as P
-  if (active) {
+  const float m = pair_max(mloc);
+  float ploc = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      float* pr = P + (w * 32 + crow(e, lane)) * LDT + l31;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) pr[t * 32] = s[t][e];
+      const float pt = (t * 32 + crow(e, lane) < K) ? __expf(s[t][e] - m) : 0.f;
+      s[t][e] = pt;
+      ploc += pt;
     }
-  }
-  __syncthreads();
-  if (!active) return;
+  const float sum = pair_sum(ploc);
+  const int i = w * 32 + l31;
+  if (hf == 0 && i < K) lse[(size_t)(r0 + i) * heads + h] = m + logf(sum);
+  // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  const float* pa = P + (w * 32 + l31) * LDT;
-  const float* vb = Vt + l31 * LDT;
-#pragma unroll 8
-  for (int ks = 0; ks < KT / 2; ++ks) {
-    const int kk = ks * 2 + (lane >> 5);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[kk], vb[kk], acc, 0, 0, 0);
-  }
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = w * 32 + crow(e, lane);
-    if (i < K && l31 < dh) o[(size_t)(r0 + i) * C + h * dh + l31] = acc[e] * inv[e];
-  }
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc = mfma6(tk_read<NTMAX>(Vm, t * 32 + 16 * u, lane), c_tile_operand(s[t], u), acc);
+  if (i < K) store_rows_per_lane(o + (size_t)(r0 + i) * C + h * dh, acc, 1.0f / sum, lane, dh);
 }
 
 template <int NTMAX>
 __global__ __launch_bounds__(64 * NTMAX) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                    float* __restrict__ lse, const int* __restrict__ row_off,
                                                                    const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
-  constexpr int LDT = 32 * NTMAX + 1;
-  __shared__ float sm[3 * 32 * LDT + (NTMAX == 2 ? 0 : 32 * NTMAX * LDT)];
+  __shared__ __attribute__((aligned(16))) char sm[3 * 3 * 32 * NTMAX * 64];
   const int g = blockIdx.x, h = blockIdx.y;
   const int K = Kw[g];
   if (K == 0) return;
@@ -155,156 +210,129 @@ __global__ __launch_bounds__(64 * NTMAX) void attn_fwd_mfma_kernel(const float* 
 }
 
 // ------------------------------------------------------------------ backward
-// PROWS: rows of the P / dS buffer = upper bound of the tokens per partition.  The buffer ALIASES the V tile (dead once dP is
-// in registers) and is the last LDS region; for the 1Mpx partitions (T = 60) the kernel then needs 40.6 KB instead of 49.9 KB
-// of LDS: 4 workgroups per CU instead of 3.
-template <int NTMAX, int NT, int PROWS>
-__device__ __forceinline__ void attn_bwd_body(float* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
+// Pass B (wave w owns QUERY tile w, keys over all tiles; scores transposed): P^T, D_i, dS^T -> dQ; D_i is left in LDS.
+// Pass A (wave w owns KEY tile w, queries over all tiles; scores in the plain orientation): P, dS -> dV, dK.
+template <int NTMAX, int NT>
+__device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
                                               const float* __restrict__ lse, float* __restrict__ dqkv, int r0, int K, int C, int heads,
                                               int h, float scale, int dh) {
-  constexpr int LDT = 32 * NTMAX + 1, KT = NT * 32;
-  constexpr int KTR = KT < PROWS ? KT : PROWS;   // reduce length over QUERY rows of P / dS (rows >= PROWS do not exist)
-  float* Qt = sm;                 // pre-scaled q
-  float* Kt = Qt + 32 * LDT;
-  float* Gt = Kt + 32 * LDT;      // dO
-  float* Vt = Gt + 32 * LDT;
-  float* PB = Vt;                 // [PROWS][LDT]: P, then dS -- over the V tile
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31;
+  constexpr int KT = NT * 32, MAT = 3 * 32 * NTMAX * 64;
+  char* Qm = sm;                  // pre-scaled q
+  char* Km = Qm + MAT;
+  char* Vm = Km + MAT;
+  char* Gm = Vm + MAT;            // dO
+  float* lse_s = reinterpret_cast<float*>(Gm + MAT);     // [32 NTMAX] log-sum-exp of the queries
+  float* D_s = lse_s + 32 * NTMAX;                       // [32 NTMAX] D_i = sum_j P_ij dP_ij
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
   const int C3 = 3 * C, coff = h * 3 * dh;
   {
     const Staged sq = stage_issue<NTMAX>(qkv, C3, coff, r0, K, dh), sk = stage_issue<NTMAX>(qkv, C3, coff + dh, r0, K, dh);
     const Staged sv = stage_issue<NTMAX>(qkv, C3, coff + 2 * dh, r0, K, dh), sg = stage_issue<NTMAX>(dout, C, h * dh, r0, K, dh);
-    stage_commit<NTMAX>(Qt, sq, K, KT, scale, dh);
-    stage_commit<NTMAX>(Kt, sk, K, KT, 1.f, dh);
-    stage_commit<NTMAX>(Vt, sv, K, KT, 1.f, dh);
-    stage_commit<NTMAX>(Gt, sg, K, KT, 1.f, dh);
+    const int il = threadIdx.x;
+    const float lv = lse[(size_t)(r0 + min(il, K - 1)) * heads + h];      // 64 NTMAX threads >= KT: clamped, branch-free
+    stage_commit<NTMAX>(Qm, sq, K, KT, scale, dh);
+    stage_commit<NTMAX>(Km, sk, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Vm, sv, K, KT, 1.f, dh);
+    stage_commit<NTMAX>(Gm, sg, K, KT, 1.f, dh);
+    if (il < 32 * NTMAX) lse_s[il] = lv;
   }
   __syncthreads();
   const bool active = w < NT;
   f32x16 s[NT], dp[NT];
-#pragma unroll
-  for (int e = 0; e < 16; ++e)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { s[t][e] = 0.f; dp[t][e] = 0.f; }
   if (active) {
+    // ---- pass B: S^T[j][i] = K_t Q_w^T, dP^T[j][i] = V_t dO_w^T  (column = query i = 32 w + l31)
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      const float a = Qt[kk * LDT + w * 32 + l31], ga = Gt[kk * LDT + w * 32 + l31];
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[t][e] = 0.f; dp[t][e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const Split3 qb = rd_read<NTMAX>(Qm, w * 32 + l31, 2 * u + hf), gb = rd_read<NTMAX>(Gm, w * 32 + l31, 2 * u + hf);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        s[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Kt[kk * LDT + t * 32 + l31], s[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga, Vt[kk * LDT + t * 32 + l31], dp[t], 0, 0, 0);
+        s[t] = mfma6(rd_read<NTMAX>(Km, t * 32 + l31, 2 * u + hf), qb, s[t]);
+        dp[t] = mfma6(rd_read<NTMAX>(Vm, t * 32 + l31, 2 * u + hf), gb, dp[t]);
       }
     }
-    bool cv[NT];
+    const int i = w * 32 + l31;
+    const bool qv = i < K;
+    const float li = lse_s[i];
+    float dloc = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) cv[t] = t * 32 + l31 < K;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = w * 32 + crow(e, lane);
-      const bool rv = i < K;
-      const float li = rv ? lse[(size_t)(r0 + i) * heads + h] : 0.f;
-      float dloc = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const float pt = (rv && cv[t]) ? __expf(s[t][e] - li) : 0.f;
+      for (int e = 0; e < 16; ++e) {
+        const float pt = (qv && t * 32 + crow(e, lane) < K) ? __expf(s[t][e] - li) : 0.f;
         s[t][e] = pt;
         dloc += pt * dp[t][e];
       }
-      const float D = half_sum(dloc);
+    const float D = pair_sum(dloc);
+    if (hf == 0) D_s[i] = D;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) dp[t][e] = s[t][e] * (dp[t][e] - D);     // dS
-    }
-  }
-  __syncthreads();   // every wave is done with the V tile -> P may overwrite it
-  if (active) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = w * 32 + crow(e, lane);
-      if (i < PROWS) {
-        float* pr = PB + i * LDT + l31;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) pr[t * 32] = s[t][e];
-      }
-    }
-  }
-  __syncthreads();
-  f32x16 acc;
-  // ---- dV tile (keys 32w..32w+31): sum_i P[i][j] dO[i][d]
-  if (active) {
+      for (int e = 0; e < 16; ++e) dp[t][e] = s[t][e] * (dp[t][e] - D);     // dS^T
+    // dQ^T[d][i] = sum_j K^T[d][j] dS^T[j][i]   (x scale: q was staged pre-scaled, dQ is the gradient of the raw q)
+    f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const float* gb = Gt + l31 * LDT;
-#pragma unroll 8
-    for (int ks = 0; ks < KTR / 2; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PB[kk * LDT + w * 32 + l31], gb[kk], acc, 0, 0, 0);
-    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int j = w * 32 + crow(e, lane);
-      if (j < K && l31 < dh) dqkv[(size_t)(r0 + j) * C3 + coff + 2 * dh + l31] = acc[e];
-    }
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc = mfma6(tk_read<NTMAX>(Km, t * 32 + 16 * u, lane), c_tile_operand(dp[t], u), acc);
+    if (qv) store_rows_per_lane(dqkv + (size_t)(r0 + i) * C3 + coff, acc, scale, lane, dh);
   }
-  __syncthreads();   // P fully consumed -> overwrite with dS
-  if (active) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int i = w * 32 + crow(e, lane);
-      if (i < PROWS) {
-        float* pr = PB + i * LDT + l31;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) pr[t * 32] = dp[t][e];
-      }
-    }
-  }
-  __syncthreads();
+  __syncthreads();   // D_s complete
   if (!active) return;
-  // ---- dK tile (keys 32w..): sum_i dS[i][j] (scale*q)[i][d]
+  // ---- pass A: S[i][j] = Q_t K_w^T, dP[i][j] = dO_t V_w^T  (column = key j = 32 w + l31, rows = queries of tile t)
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  {
-    const float* qb = Qt + l31 * LDT;
-#pragma unroll 8
-    for (int ks = 0; ks < KTR / 2; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(PB[kk * LDT + w * 32 + l31], qb[kk], acc, 0, 0, 0);
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[t][e] = 0.f; dp[t][e] = 0.f; }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const Split3 kb = rd_read<NTMAX>(Km, w * 32 + l31, 2 * u + hf), vb = rd_read<NTMAX>(Vm, w * 32 + l31, 2 * u + hf);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = mfma6(rd_read<NTMAX>(Qm, t * 32 + l31, 2 * u + hf), kb, s[t]);
+      dp[t] = mfma6(rd_read<NTMAX>(Gm, t * 32 + l31, 2 * u + hf), vb, dp[t]);
     }
   }
+  const int j = w * 32 + l31;
+  const bool kv = j < K;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int j = w * 32 + crow(e, lane);
-    if (j < K && l31 < dh) dqkv[(size_t)(r0 + j) * C3 + coff + dh + l31] = acc[e];
-  }
-  // ---- dQ tile (queries 32w..): scale * sum_j dS[i][j] K[j][d]
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  {
-    const float* da = PB + min(w * 32 + l31, PROWS - 1) * LDT;   // query rows >= PROWS do not exist (their results are never stored)
-    const float* kb = Kt + l31 * LDT;
-#pragma unroll 8
-    for (int ks = 0; ks < KT / 2; ++ks) {
-      const int kk = ks * 2 + (lane >> 5);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(da[kk], kb[kk], acc, 0, 0, 0);
+    for (int e = 0; e < 16; ++e) {
+      const int i = t * 32 + crow(e, lane);
+      const float pt = (kv && i < K) ? __expf(s[t][e] - lse_s[i]) : 0.f;
+      s[t][e] = pt;                                   // P
+      dp[t][e] = pt * (dp[t][e] - D_s[i]);            // dS
     }
-  }
+  // dV^T[d][j] = sum_i dO^T[d][i] P[i][j];  dK^T[d][j] = sum_i (scale q)^T[d][i] dS[i][j]
+  f32x16 av, ak;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const int i = w * 32 + crow(e, lane);
-    if (i < K && l31 < dh) dqkv[(size_t)(r0 + i) * C3 + coff + l31] = acc[e] * scale;
+  for (int e = 0; e < 16; ++e) { av[e] = 0.f; ak[e] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      av = mfma6(tk_read<NTMAX>(Gm, t * 32 + 16 * u, lane), c_tile_operand(s[t], u), av);
+      ak = mfma6(tk_read<NTMAX>(Qm, t * 32 + 16 * u, lane), c_tile_operand(dp[t], u), ak);
+    }
+  if (kv) {
+    store_rows_per_lane(dqkv + (size_t)(r0 + j) * C3 + coff + 2 * dh, av, 1.f, lane, dh);
+    store_rows_per_lane(dqkv + (size_t)(r0 + j) * C3 + coff + dh, ak, 1.f, lane, dh);
   }
 }
 
-template <int NTMAX, int PROWS>
+template <int NTMAX>
 __global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                    const int* __restrict__ row_off, const int* __restrict__ Kw, int C,
                                                                    int heads, float scale, int dh, int W, LsFinish f0, LsFinish f1,
                                                                    int fC) {
-  constexpr int LDT = 32 * NTMAX + 1;
-  static_assert(PROWS >= 32 && PROWS <= 32 * NTMAX, "P rows");
-  __shared__ float sm[3 * 32 * LDT + PROWS * LDT];
+  __shared__ __attribute__((aligned(16))) char sm[4 * 3 * 32 * NTMAX * 64 + 2 * 32 * NTMAX * 4];
   if (blockIdx.x >= W) {   // side workgroups: the LayerScale'd fc2 / proj gradient finish of the same MS-WSA layer (independent work
     if (blockIdx.y == 0) {  // that used to be a launch of its own), one wave per output channel
       const int row = (blockIdx.x - W) * NTMAX + (threadIdx.x >> 6);
@@ -318,12 +346,27 @@ __global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* 
   if (K == 0) return;
   const int r0 = row_off[g];
   switch ((K + 31) >> 5) {
-    case 1: attn_bwd_body<NTMAX, 1, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
-    case 2: attn_bwd_body<NTMAX, 2, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
-    case 3: if constexpr (NTMAX >= 3) attn_bwd_body<NTMAX, 3, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
-    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4, PROWS>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 1: attn_bwd_body<NTMAX, 1>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 2: attn_bwd_body<NTMAX, 2>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 3: if constexpr (NTMAX >= 3) attn_bwd_body<NTMAX, 3>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
   }
 }
+
+// launch through SAST_LAUNCH, or -- in the roofline leg of bench.py (prof_enabled) -- with kernel-exact start / stop events and the
+// algorithmic work of the launch from the device-side kept-token counts: QK^T and PV are 2 K_m^2 dh flop each per (group, head)
+// = 4 C sum_m K_m^2 per launch, the backward's five products 2.5x that; bytes = the compact rows read and written once
+#define SAST_ATTN_LAUNCH(TAG, FLOPS_PER_K2, ROWS_X_C, KERNEL, GRID, BLOCK, ...)                                             \
+  do {                                                                                                                    \
+    if (prof_enabled()) {                                                                                                 \
+      double sk_, sk2_; hipEvent_t e0_, e1_;                                                                              \
+      prof_sum_k(Kw, W, st, &sk_, &sk2_);                                                                                 \
+      prof_kernel_events_ex(TAG, (FLOPS_PER_K2) * (double)C * sk2_, 4.0 * (ROWS_X_C) * (double)C * sk_, st, &e0_, &e1_);   \
+      SAST_EXT_LAUNCH(KERNEL, GRID, BLOCK, 0, st, e0_, e1_, 0, __VA_ARGS__);                                               \
+    } else {                                                                                                              \
+      SAST_LAUNCH(KERNEL, GRID, BLOCK, 0, st, __VA_ARGS__);                                                               \
+    }                                                                                                                     \
+  } while (0)
 
 // T: tokens per partition (upper bound of K_m)
 int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
@@ -331,11 +374,11 @@ int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_
   if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
-  // the LDS tiles are sized by the number of 32-token tiles a partition can need: 3 for the Gen1 partitions (T = 80) keeps
-  // two workgroups per CU where the 4-tile variant fits one
-  if (T <= 64) SAST_LAUNCH((attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
-  else if (T <= 96) SAST_LAUNCH((attn_fwd_mfma_kernel<3>), dim3(W, heads), dim3(192), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
-  else SAST_LAUNCH((attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), 0, st, qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  // the LDS images are sized by the number of 32-token tiles a partition can need (36.9 KB for T <= 64: four workgroups per CU).
+  // bytes: QKV (3C) read + O (C) written per kept row
+  if (T <= 64) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<2>", 4.0, 4.0, (attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else if (T <= 96) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<3>", 4.0, 4.0, (attn_fwd_mfma_kernel<3>), dim3(W, heads), dim3(192), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<4>", 4.0, 4.0, (attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -349,11 +392,10 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
   const LsFinish& a1 = f1 ? *f1 : z;
   if (!f0 || !f1) fC = 0;
   const int wpb = T <= 64 ? 2 : (T <= 96 ? 3 : 4), side = (2 * fC + wpb - 1) / wpb;
-  if (T <= 60) SAST_LAUNCH((attn_bwd_mfma_kernel<2, 60>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 64) SAST_LAUNCH((attn_bwd_mfma_kernel<2, 64>), dim3(W + side, heads), dim3(128), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 80) SAST_LAUNCH((attn_bwd_mfma_kernel<3, 80>), dim3(W + side, heads), dim3(192), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 96) SAST_LAUNCH((attn_bwd_mfma_kernel<3, 96>), dim3(W + side, heads), dim3(192), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
-  else SAST_LAUNCH((attn_bwd_mfma_kernel<4, 128>), dim3(W + side, heads), dim3(256), 0, st, qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  // bytes: QKV (3C) + dO (C) read, dQKV (3C) written per kept row
+  if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2>", 10.0, 7.0, (attn_bwd_mfma_kernel<2>), dim3(W + side, heads), dim3(128), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else if (T <= 96) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<3>", 10.0, 7.0, (attn_bwd_mfma_kernel<3>), dim3(W + side, heads), dim3(192), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<4>", 10.0, 7.0, (attn_bwd_mfma_kernel<4>), dim3(W + side, heads), dim3(256), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -10,7 +10,7 @@
 
 namespace sast {
 
-struct ProfLaunch { hipEvent_t e0, e1; double flops; std::string tag; };
+struct ProfLaunch { hipEvent_t e0, e1; double flops; std::string tag; double bytes = 0.0; };
 static bool g_on = false;
 static bool g_shapes = false;   // sast_prof_enable(2): one report row per (instantiation, problem shape)
 static std::vector<ProfLaunch> g_launches;
@@ -55,6 +55,7 @@ void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int*
   if (dM) { int v; hipMemcpyAsync(&v, dM, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < m) m = v; }
   if (dR) { int v; hipMemcpyAsync(&v, dR, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < r) r = v; }
   l.flops = 2.0 * (double)m * (double)NJ * (double)G * (double)r;
+  l.bytes = 4.0 * ((double)m * r + (double)NJ * G * r + (double)m * NJ * G);   // A + B + C once each (operands read / written once)
   l.tag = tag;
   if (g_shapes) { char sh[96]; snprintf(sh, sizeof sh, " |M=%d N=%d R=%d", m, NJ * G, r); l.tag += sh; }
   g_launches.push_back(l);
@@ -75,8 +76,9 @@ void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, i
   ProfLaunch l;
   hipEventCreate(&l.e0);
   hipEventCreate(&l.e1);
-  l.flops = flops_static + 2.0 * (double)dev_min(M1, dM1, st) * NJ1 * G1 * (double)dev_min(R1, dR1, st) +
-            2.0 * (double)dev_min(M2, dM2, st) * NJ2 * G2 * (double)dev_min(R2, dR2, st);
+  const double m1 = dev_min(M1, dM1, st), r1 = dev_min(R1, dR1, st), m2 = dev_min(M2, dM2, st), r2 = dev_min(R2, dR2, st);
+  l.flops = flops_static + 2.0 * m1 * NJ1 * G1 * r1 + 2.0 * m2 * NJ2 * G2 * r2;
+  l.bytes = 4.0 * (m1 * r1 + (double)NJ1 * G1 * r1 + m1 * NJ1 * G1) + 4.0 * (m2 * r2 + (double)NJ2 * G2 * r2 + m2 * NJ2 * G2);
   l.tag = tag;
   if (g_shapes) {
     char sh[160];
@@ -87,6 +89,28 @@ void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, i
   g_launches.push_back(l);
   *e0 = l.e0;
   *e1 = l.e1;
+}
+
+// any other kernel (the attention kernels): the caller supplies the algorithmic FLOPs and bytes of the launch
+void prof_kernel_events_ex(const char* tag, double flops, double bytes, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1) {
+  ProfLaunch l;
+  hipEventCreate(&l.e0);
+  hipEventCreate(&l.e1);
+  l.flops = flops;
+  l.bytes = bytes;
+  l.tag = tag;
+  g_launches.push_back(l);
+  *e0 = l.e0;
+  *e1 = l.e1;
+}
+// sum over the groups of K_m and K_m^2 (device array Kw[W], read back: profiling mode only)
+void prof_sum_k(const int* Kw, int W, hipStream_t st, double* sum_k, double* sum_k2) {
+  std::vector<int> h(W);
+  hipMemcpyAsync(h.data(), Kw, sizeof(int) * W, hipMemcpyDeviceToHost, st);
+  hipStreamSynchronize(st);
+  double a = 0, b = 0;
+  for (int v : h) { a += v; b += (double)v * v; }
+  *sum_k = a; *sum_k2 = b;
 }
 
 // op-level scopes (C-ABI entry points): tag = "op:<name> C=<c> M=<m>"
@@ -129,21 +153,21 @@ int sast_prof_enable(int on) {
   return 0;
 }
 
-// writes "tag\tcalls\ttotal_ms\ttotal_flops\n" lines (sorted by time) into buf; returns bytes needed
+// writes "tag\tcalls\ttotal_ms\ttotal_flops\ttotal_bytes\n" lines (sorted by time) into buf; returns bytes needed
 size_t sast_prof_report(char* buf, size_t cap) {
   hipDeviceSynchronize();
-  struct Acc { int n = 0; double ms = 0, fl = 0; };
+  struct Acc { int n = 0; double ms = 0, fl = 0, by = 0; };
   std::map<std::string, Acc> acc;
   for (auto& l : sast::g_launches) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, l.e0, l.e1) != hipSuccess) continue;
     Acc& a = acc[l.tag];
-    a.n++; a.ms += ms; a.fl += l.flops;
+    a.n++; a.ms += ms; a.fl += l.flops; a.by += l.bytes;
   }
   std::string out;
   for (auto& kv : acc) {
-    char line[64];
-    snprintf(line, sizeof line, "\t%d\t%.6f\t%.6e\n", kv.second.n, kv.second.ms, kv.second.fl);
+    char line[96];
+    snprintf(line, sizeof line, "\t%d\t%.6f\t%.6e\t%.6e\n", kv.second.n, kv.second.ms, kv.second.fl, kv.second.by);
     out += kv.first + line;
   }
   if (buf && cap) { const size_t n = out.size() < cap - 1 ? out.size() : cap - 1; memcpy(buf, out.data(), n); buf[n] = 0; }

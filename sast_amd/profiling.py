@@ -93,9 +93,10 @@ def _short(tag: str) -> str:
     return f"gemm_kernel<{names[0]}, {names[1]}, {names[2]}, {names[3]}{', split' if m.group(1) else ''}>"
 
 
-def gemm_report(run_steps, n_steps: int = 3, per_shape: bool = False):
-    """run_steps(n): executes n eager steps.  Returns [(name, calls, total_ms, total_flops)] sorted by time; per_shape: one row
-    per (instantiation, problem shape), the shape appended to the name after " |"."""
+def kernel_report(run_steps, n_steps: int = 3, per_shape: bool = False):
+    """run_steps(n): executes n eager steps with every launch of the GEMM-template kernels AND of the attention kernels bracketed by
+    kernel-exact HIP events.  Returns rows {name, calls, ms, flops, bytes} sorted by time (op-level scopes are named "op:...");
+    per_shape: one row per (instantiation, problem shape), the shape appended to the name after " |"."""
     lib = L.lib()
     torch.cuda.synchronize()
     lib.sast_prof_enable(2 if per_shape else 1)
@@ -109,46 +110,132 @@ def gemm_report(run_steps, n_steps: int = 3, per_shape: bool = False):
         lib.sast_prof_enable(0)
     rows = []
     for line in buf.value.decode().splitlines():
-        tag, n, ms, fl = line.rsplit("\t", 3)
+        tag, n, ms, fl, by = line.rsplit("\t", 4)
         tag, _, shape = tag.partition(" |")
-        rows.append((_short(tag) + (" |" + shape if shape else ""), int(n), float(ms), float(fl)))
-    rows.sort(key=lambda r: -r[2])
+        name = tag if tag.startswith(("attn_", "op:")) else _short(tag)
+        rows.append({"name": name + (" |" + shape if shape else ""), "calls": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
+    rows.sort(key=lambda r: -r["ms"])
     return rows
 
 
-def dominant_kernel_roofline(trainer, n_steps: int = 3):
+def gemm_report(run_steps, n_steps: int = 3, per_shape: bool = False):
+    """(tools) the same as tuples (name, calls, total_ms, total_flops)"""
+    return [(r["name"], r["calls"], r["ms"], r["flops"]) for r in kernel_report(run_steps, n_steps, per_shape)]
+
+
+PEAK_HBM_TBS = 8.0                    # HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (measured copy rate: 6.29 TB/s)
+
+
+def algorithmic_bytes_per_step(hw, batch, embed_dim=64, in_bytes=4, fpn_channels=(128, 256, 512), fpn_depth=0.67, n_params=0,
+                               fwd_only=False, with_fpn=True):
+    """SURVEY.md section 8(d) rule -- every LOGICAL operator reads its input once and writes its output once, fp32 activations,
+    weights once per batch: per stage 12 A_s + 4 L_s with A_s = 4 L_s C_s bytes per frame (downsample write A; STP read A + write A +
+    token scores; each of the two MS-WSA layers read A + write A; ConvLSTM read 3A + write 2A), the event tensor once
+    (20 Hp Wp in_bytes), the PAFPN's 32 conv-BN-SiLU units (in + out), the weights (4 bytes per parameter) once.  The backward is
+    counted as 2x the forward (saved activations re-read, gradients written), the optimizer as 28 bytes per parameter (p, g, m, v read;
+    p, m, v written).  Dense (every token kept): an upper bound of the algorithmic traffic of a sparse step."""
+    H, W = hw
+    fwd = 20.0 * H * W * in_bytes
+    for s in range(4):
+        L_s, C_s = (H >> (2 + s)) * (W >> (2 + s)), embed_dim << s
+        fwd += 12.0 * 4 * L_s * C_s + 4.0 * L_s
+    if with_fpn:
+        c0, c1, c2 = fpn_channels
+        p0, p1, p2 = ((H >> k) * (W >> k) for k in (3, 4, 5))
+        n = round(3 * fpn_depth)
+
+        def csp(cin, cout, px):
+            h = cout // 2
+            return px * (2 * (cin + h) + n * ((h + h) + (h + h)) + (2 * h + cout))
+
+        units = p2 * (c2 + c1) + csp(2 * c1, c1, p1) + p1 * (c1 + c0) + csp(2 * c0, c0, p0) + (p0 * c0 + p1 * c0) + csp(2 * c0, c1, p1) + \
+            (p1 * c1 + p2 * c1) + csp(2 * c1, c2, p2)
+        fwd += 4.0 * units
+    fwd *= batch
+    fwd += 4.0 * n_params
+    return fwd if fwd_only else 3.0 * fwd + 28.0 * n_params
+
+
+def pmc_bytes_per_step():
+    """whole-step HBM bytes of the committed rocprofv3 --pmc summary (None when the summary does not say how many steps it covers)"""
+    try:
+        with open(_PMC_SUMMARY) as f:
+            d = json.load(f)
+        return float(d["total_bytes"]) / float(d["steps"]) if d.get("steps") else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=None, batch=None):
     # rank-local on purpose: this leg runs on rank 0 only, after the timed region -- it must not enter a collective (the
     # other ranks are already past it), so it replays forward + backward without the gradient all-reduce / optimizer step
     def run(n):
         for _ in range(n):
             trainer.fwd_bwd()
 
-    rows = [r for r in gemm_report(run, n_steps) if not r[0].startswith("op:")]
-    # GEMM launches are timed with hipExtLaunchKernelGGL start/stop events (stamped at the kernel's own begin / end, the
-    # same quantity rocprofv3 reports); a plain record-launch-record bracket would add ~8 us (reported for reference)
+    rows = [r for r in kernel_report(run, n_steps) if not r["name"].startswith("op:")]
+    # launches are timed with hipExtLaunchKernelGGL start/stop events (stamped at the kernel's own begin / end, the same
+    # quantity rocprofv3 reports); a plain record-launch-record bracket would add ~8 us (reported for reference)
     calib_ms = float(L.lib().sast_prof_calibrate(C.c_void_p(torch.cuda.current_stream().cuda_stream), 200))
-    rows.sort(key=lambda r: -r[2])
-    name, calls, ms, flops = rows[0]
+    top = rows[0]                                                # the kernel with the largest share of the step, GEMM template or attention
+    name, calls, ms, flops, nbytes = top["name"], top["calls"], top["ms"], top["flops"], top["bytes"]
+    gemm_rows = [r for r in rows if not r["name"].startswith("attn_")]
+    attn_rows = [r for r in rows if r["name"].startswith("attn_")]
     achieved = flops / (ms * 1e-3) / 1e12
-    total_ms = sum(r[2] for r in rows)
-    total_fl = sum(r[3] for r in rows)
+    achieved_tbs = nbytes / (ms * 1e-3) / 1e12
     stamp = pmc_summary_stamp()
     split3 = L.lib().sast_mfma_split3() == 1
+    is_gemm = not name.startswith("attn_")
     pipe = {}
-    if split3:
+    if split3 and is_gemm:
         # the default build executes an fp32 product tile as 6 bf16 MFMAs on an exact 3-way operand split: the contract's `peak`
         # stays the dense MFMA peak of the dtype the path computes in (f32: 157.3), the bound of the pipe actually used is given too
         eff = PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS
         pipe = {"executed_as": "fp32 operands split exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate "
                                "(error <= 2^-23 |x||y| per product); SAST_MFMA_SPLIT3=0 builds the v_mfma_f32_32x32x2_f32 form",
                 "peak_of_executed_pipe": eff, "frac_of_executed_pipe": achieved / eff}
-    return {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", **pipe,
-            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, "
-            "profiles/pmc_hbm_traffic_latest.json)", "traffic_profile_csrc_sha": stamp, "traffic_stale": stamp != csrc_sha(), "kernel": name,
-            "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
-            "algorithmic_gflop_per_launch": flops / calls / 1e9,
-            "all_gemm_kernels": {"ms_per_step": total_ms / n_steps, "gflop_per_step": total_fl / n_steps / 1e9,
-                                 "achieved_tflops": total_fl / (total_ms * 1e-3) / 1e12},
-            "plain_event_bracket_overhead_us": 1e3 * calib_ms,
-            "method": "hipExtLaunchKernelGGL start/stop events on the launch stream for every launch of the GEMM-template kernels "
-                      "(libsast_hip sast_prof_*); eager, un-timed extra steps"}
+    elif not is_gemm:
+        pipe = {"executed_as": "v_mfma_f32_32x32x2_f32 (f32-input MFMA), softmax in the MFMA C layout"}
+    # which roof is nearer for this kernel: time at the MFMA peak vs time at the HBM peak for its algorithmic work
+    t_mfma, t_hbm = flops / (PEAK_F32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_TBS * 1e12)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    out = {"bound": bound,
+           "achieved": achieved if bound == "mfma" else 1e3 * achieved_tbs,
+           "peak": PEAK_F32_MFMA_TFLOPS if bound == "mfma" else 1e3 * PEAK_HBM_TBS,
+           "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+           "frac": (achieved / PEAK_F32_MFMA_TFLOPS) if bound == "mfma" else achieved_tbs / PEAK_HBM_TBS,
+           **pipe,
+           "achieved_tflops": achieved, "frac_of_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+           "achieved_algorithmic_gbs": 1e3 * achieved_tbs, "frac_of_hbm_peak": achieved_tbs / PEAK_HBM_TBS,
+           "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)",
+           "traffic_profile_csrc_sha": stamp, "traffic_stale": stamp != csrc_sha(), "kernel": name,
+           "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
+           "algorithmic_gflop_per_launch": flops / calls / 1e9, "algorithmic_mbytes_per_launch": nbytes / calls / 1e6,
+           "ranked_over": "every launch of the GEMM-template kernels and of the attention kernels (kernel-exact HIP events)",
+           "all_gemm_kernels": {"ms_per_step": sum(r["ms"] for r in gemm_rows) / n_steps, "gflop_per_step": sum(r["flops"] for r in gemm_rows) / n_steps / 1e9,
+                                "achieved_tflops": sum(r["flops"] for r in gemm_rows) / (sum(r["ms"] for r in gemm_rows) * 1e-3 + 1e-30) / 1e12},
+           "all_attention_kernels": {"ms_per_step": sum(r["ms"] for r in attn_rows) / n_steps, "gflop_per_step": sum(r["flops"] for r in attn_rows) / n_steps / 1e9,
+                                     "achieved_tflops": sum(r["flops"] for r in attn_rows) / (sum(r["ms"] for r in attn_rows) * 1e-3 + 1e-30) / 1e12,
+                                     "achieved_algorithmic_gbs": sum(r["bytes"] for r in attn_rows) / (sum(r["ms"] for r in attn_rows) * 1e-3 + 1e-30) / 1e9},
+           "plain_event_bracket_overhead_us": 1e3 * calib_ms,
+           "method": "hipExtLaunchKernelGGL start/stop events on the launch stream for every launch of the GEMM-template and attention "
+                     "kernels (libsast_hip sast_prof_*); eager, un-timed extra steps; algorithmic FLOPs / bytes from the device-side row and "
+                     "kept-token counts"}
+    if ms_per_step is not None and hw is not None:
+        # the whole step against its roofs: algorithmic FLOPs of all matrix work (GEMMs + attention) at the f32-MFMA peak, algorithmic
+        # bytes (SURVEY 8d rule, dense upper bound) at the HBM peak; T_roof = the larger of the two; frac = T_roof / measured step time
+        n_params = int(trainer.flat.numel) if getattr(trainer, "flat", None) is not None else 0
+        gflop = sum(r["flops"] for r in rows) / n_steps / 1e9
+        fwd_only = bool(getattr(trainer, "fwd_only", False))
+        b_alg = algorithmic_bytes_per_step(hw, batch, n_params=n_params, fwd_only=fwd_only, with_fpn=not fwd_only or bool(getattr(trainer, "infer", False)))
+        t_m, t_h = gflop / PEAK_F32_MFMA_TFLOPS, b_alg / (PEAK_HBM_TBS * 1e12) * 1e3      # ms
+        b_cnt = pmc_bytes_per_step()
+        out["whole_step"] = {"gflop": gflop, "bytes_algorithmic": b_alg, "bytes_counter": b_cnt,
+                             "bytes_counter_over_algorithmic": (b_cnt / b_alg) if b_cnt else None,
+                             "t_mfma_ms": t_m, "t_hbm_ms": t_h, "t_roof_ms": max(t_m, t_h), "bound": "mfma" if t_m >= t_h else "hbm",
+                             "ms_per_step": ms_per_step, "frac": max(t_m, t_h) / ms_per_step,
+                             "achieved_tflops": gflop / ms_per_step, "achieved_counter_tbs": (b_cnt / (ms_per_step * 1e-3) / 1e12) if b_cnt else None,
+                             "note": "gflop: algorithmic 2*M*N*K of every GEMM / conv + 4*C*sum K_m^2 (x2.5 backward) of the attention launches, from "
+                                     "device-side counts; bytes_algorithmic: SURVEY 8d rule (dense upper bound, backward = 2x forward, optimizer 28 B/param); "
+                                     "bytes_counter: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per step, valid when traffic_stale is false"}
+    return out

@@ -70,6 +70,10 @@ class TrainStep:
         self.loss = self.P = self.losses = None
         self._graphs = None
         self._seg_state = None
+        # measure_exposed: every step records (main stream idle, side stream done) event pairs -- how long the step waits for the
+        # last bucket's all-reduce + update AFTER its own backward has finished (bench.py: `allreduce_exposed_ms`)
+        self.measure_exposed = False
+        self._exposed = []
 
     # ---------------------------------------------------------------- forward + backward segments
     def forward(self, xs: Sequence[torch.Tensor], states=None, labels=None, indices=None, token_masks=None):
@@ -160,7 +164,23 @@ class TrainStep:
 
     def finish(self):
         if self.side is not None and self.segmented:
-            torch.cuda.current_stream().wait_stream(self.side)
+            main = torch.cuda.current_stream()
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)            # the main stream has nothing left of this step ...
+                e1.record(self.side)       # ... the side stream still owes the last bucket's reduce + update
+                self._exposed.append((e0, e1))
+            main.wait_stream(self.side)
+
+    def exposed_ms(self):
+        """mean time per step by which the side stream (bucket all-reduce + AdamW) finished AFTER the main stream (0 when it was
+        done first); for the unsegmented step with world > 1 the whole reduce + update is exposed and bracketed directly"""
+        torch.cuda.synchronize()
+        if not self._exposed:
+            return None
+        v = [max(0.0, a.elapsed_time(b)) for a, b in self._exposed]
+        self._exposed = []
+        return sum(v) / len(v)
 
     # ---------------------------------------------------------------- eager step
     def step(self, xs, states=None, labels=None, indices=None, token_masks=None):
@@ -208,7 +228,13 @@ class TrainStep:
         if not self.segmented:
             self._graphs[0].replay()
             if self.world > 1:
+                if self.measure_exposed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self._after_segment(0, first=True)
+                if self.measure_exposed:
+                    e1.record()
+                    self._exposed.append((e0, e1))
             return self.loss
         for i, g in enumerate(self._graphs):
             g.replay()

@@ -49,7 +49,8 @@ def main():
             import os, sys
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from sast_amd.profiling import csrc_sha
-            json.dump({"csrc_sha": csrc_sha(), "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-reports wide reads by 2x)",
+            steps = max([v["launches"] for k, v in out.items() if k.startswith("input_prep_kernel")] or [0])   # one input kernel per forward
+            json.dump({"csrc_sha": csrc_sha(), "steps": steps, "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE under-reports wide reads by 2x)",
                        "total_bytes": tot, "kernels": dict(ranked)}, fh, indent=1)
 
 
