@@ -728,6 +728,45 @@ def test_full_size_backbone(golden_dir, dev, tag, hw, part):
         assert abs(float(t.abs().max()) - ref[f"h{k}"]["maxabs"]) <= 1e-4
 
 
+def _sparse_ref():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_stats_sparse.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("key", sorted(_sparse_ref().keys()))
+def test_full_size_sparse_selection_vs_reference(dev, key):
+    """Index-exact selection at full size WITH SPARSE SELECTION, pinned to the reference itself: the imported reference's
+    index_window / asy_index / K of every stage and layer (sha256 in tests/golden/full_stats_sparse.json, written by
+    tests/golden/make_golden.py --sparse-only; 1Mpx B = 4 and B = 8, Gen1 B = 4; AMP 2e-2 ~ 30 % and AMP 1 ~ 10 % of the tokens kept)
+    against the HIP path's selection on the same weights and events.  The seeds are the ones whose closest decision is furthest from
+    its threshold (tests/golden/margin_search.py: >= 1e-6 relative at AMP 2e-2, ten times the fp32 rounding noise of the softmax
+    values; >= 6e-5 at AMP 1), so an exact match is required -- no band.  LayerScale 0.5: the attention / MLP branch of every block
+    feeds the next stage's scoring at full weight."""
+    import hashlib
+    from sast_amd.detection import RNNDetector
+    ref = _sparse_ref()[key]
+    hw, part = tuple(ref["hw"]), tuple(ref["partition"])
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, amp=ref["amp"])
+    params = O.init_backbone_params(ocfg, seed=ref["seed"], ls_init=ref["ls_init"])
+    net = RNNDetector(_rcfg(hw, part, 64, ref["amp"], ref["ls_init"])).to(dev)
+    load_params(net, params)
+    x = O.count_events(ref["B"], hw, seed=100 + ref["seed"], density=ref["density"]).to(dev)
+    with torch.no_grad():
+        out, _st, P = net(x)
+    assert [int(p) for p in P] == ref["P"], (key, [int(p) for p in P], ref["P"])
+    assert max(ref["kept_fraction"][:3]) < 0.5
+    for s, stage in enumerate(net.stages):
+        for li, sel in enumerate(stage.last_index_list):
+            got = sel.to_index_list()
+            for nm in ("index_window", "asy_index", "K"):
+                h = hashlib.sha256(got[LIST_NAMES.index(nm)].cpu().numpy().astype(np.int64).tobytes()).hexdigest()
+                assert h == ref[nm + "_sha256"][s][li], f"{key}: stage {s} layer {li}: {nm} differs from the reference's (margin_min {ref['margin_min']:.1e})"
+    for k in (1, 2, 3, 4):
+        t = out[k].double()
+        assert abs(float(t.abs().mean()) - ref[f"h{k}"]["absmean"]) <= 1e-5
+        assert abs(float(t.abs().max()) - ref[f"h{k}"]["maxabs"]) <= 1e-4
+
+
 def _cpu_lists(net):
     """the device-side selections of the last forward as the oracle's nested index lists [stage][block][layer]"""
     return [[[[t.cpu() for t in sel.to_index_list()] for sel in stage.last_index_list]] for stage in net.stages]

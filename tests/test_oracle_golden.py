@@ -241,3 +241,35 @@ def test_sequence_gather_and_rnn_states(golden_dir):
     for i in range(4):
         assert torch.equal(rs[i][0], torch.from_numpy(g[f"reset_bool_h_{i}"])) and torch.equal(rs[i][1], torch.from_numpy(g[f"reset_bool_c_{i}"]))
     assert O.select_backbone_features(feats_seq, [[], None, [], []]) is None
+
+
+def _sparse_cases(golden_dir=None):
+    import os as _os
+    d = golden_dir or _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+    with open(_os.path.join(d, "full_stats_sparse.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("key", sorted(_sparse_cases().keys()))
+def test_full_size_sparse_selection_of_the_reference(golden_dir, key):
+    """F-7, sparse: the oracle against what the IMPORTED REFERENCE selected at full size with less than half of the tokens kept
+    (tests/golden/full_stats_sparse.json, written by make_golden.py --sparse-only): sha256 of index_window / asy_index / K of every
+    stage and layer, P, M, sum K, output statistics.  The same hashes are asserted on the HIP path by
+    tests/test_gpu_parity.py::test_full_size_sparse_selection_vs_reference."""
+    import hashlib
+    ref = _sparse_cases(golden_dir)[key]
+    hw, part = tuple(ref["hw"]), tuple(ref["partition"])
+    cfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, amp=ref["amp"])
+    params = O.init_backbone_params(cfg, seed=ref["seed"], ls_init=ref["ls_init"])
+    x = O.count_events(ref["B"], hw, seed=100 + ref["seed"], density=ref["density"])
+    with torch.no_grad():
+        out, _st, P, lists = O.backbone(x, None, params, cfg, return_lists=True)
+    assert [int(p) for p in P] == ref["P"]
+    assert max(ref["kept_fraction"][:3]) < 0.5                     # really sparse
+    for nm, idx in (("index_window", 0), ("asy_index", 3), ("K", 4)):
+        got = [[hashlib.sha256(l[idx].numpy().astype(np.int64).tobytes()).hexdigest() for l in ls[0]] for ls in lists]
+        assert got == ref[nm + "_sha256"], nm
+    assert [[len(l[3]) for l in ls[0]] for ls in lists] == ref["sumK"]
+    for k in (1, 2, 3, 4):
+        t = out[k].double()
+        assert abs(float(t.abs().mean()) - ref[f"h{k}"]["absmean"]) < 1e-6
