@@ -536,12 +536,13 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
         for (int ks = 0; ks < HK; ++ks) b[t][ks] = bs[(hf * HK + ks) * LDB + wn * T::WTN + t * 32 + l31];
       }
     }
-    if (SPLIT && LA::RC && do_colsum) {
-      static_assert(!(SPLIT && PSA && LA::RC), "read-side column sums need the fp32 A operand");
+    if constexpr (SPLIT && LA::RC && !PSA) {   // read-side column sums need the fp32 A operand (a presplit reduce-contiguous A has none:
+      if (do_colsum) {                          // every weight-gradient job of the model has an index-contiguous A)
 #pragma unroll
       for (int t = 0; t < T::TM; ++t)
 #pragma unroll
         for (int ks = 0; ks < HK; ++ks) csum[t] += a[t][ks];
+      }
     }
     if constexpr (SAST_MFMA_BF16 && HK == 8) {
       // reduced-precision build (libsast_hip_bf16.so, `bench.py --precision bf16`): operands rounded to bf16 (RNE), ONE MFMA per tile

@@ -47,12 +47,31 @@ struct EpStoreT : EpStore {  // distinct type: keeps the instrumented instantiat
   EpStoreT(float* c_, int ld_, const float* b_) : EpStore{c_, ld_, b_} {}
 };
 
+struct EpAtomicNT {  // c += v (grid-level split of the reduction of a plain GEMM: the output must be zero on entry; bias ignored)
+  float* c; int ldc;
+  using Col = EpNone; using Aux = EpNone;
+  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux&) const { atomicAdd(c + (size_t)m * ldc + j, v[0]); }
+};
+
 extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bias, float* c, int M, int N, int K, int tile,
                                  sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   const LdRows la{a, K, nullptr};
   const LdWeightNT lb{w, K, 0};
   const EpStoreT ep(c, N, bias);
+  // LARGE tiles with the reduction split over the GRID (atomic epilogue into a zeroed output): tile = 100 * kind + splits,
+  // kind 6 = 128x128 (4 waves of 64x64), 7 = 64x128 (4 waves of 32x64), 8 = 128x64 (4 waves of 32x64)
+  if (tile >= 600 && tile < 900) {
+    const int splits = tile % 100;
+    const EpAtomicNT ea{c, N};
+    switch (tile / 100) {
+      case 6: return launch_gemm_split<TileBig>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
+      case 7: return launch_gemm_split<TileMid>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
+      case 8: return launch_gemm_split<TileN64>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
+    }
+  }
   switch (tile) {
     case 0: return launch_gemm<TileSmall>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 1: return launch_gemm<TileMid>(la, lb, ep, M, N, K, nullptr, nullptr, st);
