@@ -179,6 +179,15 @@ typedef struct SastLstmArgs {
 int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream);
 int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);
 
+/* Depth-wise k x k convolution with bias on NHWC rows (zero padding k / 2, stride 1): `conv3x3_dws` of DWSConvLSTM2d with
+ * dws_conv=True (models/layers/rnn.py:24-28; applied to the previous hidden state :52-53, or to x and h separately when
+ * dws_conv_only_hidden=False :55-56 -- a depth-wise conv of cat(x, h) is the two halves convolved on their own).
+ * x, y, dy, dx: [B, H, W, C] fp32; w: [C][k][k] (the Conv2d(groups=C) weight, contiguous); b: [C] or NULL; k odd, k*k <= 49, C % 4 == 0.
+ * bwd: dx may be NULL; dw / db are ACCUMULATED into. */
+int sast_dwconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int C, int k, sast_stream_t stream);
+int sast_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int H, int W, int C, int k,
+                    sast_stream_t stream);
+
 /* a13  BaseConv = Conv2d(no bias, same pad) + BatchNorm2d + SiLU -- yolox/models/network_blocks.py:29-54 */
 /* the conv epilogue accumulates the batch statistics with atomics; same-address atomics serialise at the memory side, so
    the row tiles spread them over SAST_BN_STAT_COPIES copies that the BatchNorm kernel adds up */

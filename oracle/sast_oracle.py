@@ -182,9 +182,9 @@ def selection_margins(scores: Tensor, B: int, N: int, T: int, bounce: float):
 # --------------------------------------------------------------------------- a9
 def mlp_glu(x: Tensor, p: Params, pre: str) -> Tensor:
     """ops.py:111-175: Linear(C->2*inner) -> value * GELU_erf(gate) -> Linear(inner->C)."""
-    y = F.linear(x, p[pre + "net.0.proj.weight"], p[pre + "net.0.proj.bias"])
+    y = F.linear(x, p[pre + "net.0.proj.weight"], p.get(pre + "net.0.proj.bias"))       # (mlp_bias: False -> no bias keys)
     val, gate = torch.tensor_split(y, 2, dim=-1)
-    return F.linear(val * F.gelu(gate), p[pre + "net.2.weight"], p[pre + "net.2.bias"])
+    return F.linear(val * F.gelu(gate), p[pre + "net.2.weight"], p.get(pre + "net.2.bias"))
 
 
 def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: AttnCfg) -> Tensor:
@@ -204,7 +204,7 @@ def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: A
     shortcut = x[asy_index]
     x = x[index_token].view(M, -1, C)
 
-    qkv = F.linear(x, p[pre + "qkv.weight"], p[pre + "qkv.bias"])
+    qkv = F.linear(x, p[pre + "qkv.weight"], p.get(pre + "qkv.bias"))                  # (attention_bias: False -> no bias keys)
     q, k, v = qkv.view(M, -1, heads, dh * 3).transpose(1, 2).chunk(3, dim=3)
     attn = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
     Kmax = q.shape[2]
@@ -214,7 +214,7 @@ def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: A
     attn = amap[index_token].view(M, -1, Kmax, heads).transpose(1, 3)
     attn = attn.softmax(dim=-1)
     x = (attn @ v).transpose(1, 2)
-    x = F.linear(x.reshape(M, -1, C), p[pre + "proj.weight"], p[pre + "proj.bias"])
+    x = F.linear(x.reshape(M, -1, C), p[pre + "proj.weight"], p.get(pre + "proj.bias"))
 
     XX[index_token] = x.view(-1, C)
     x = XX[asy_index]
@@ -341,12 +341,19 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
 
 # --------------------------------------------------------------------------- a12
 def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: str):
-    """rnn.py:36-69 with dws_conv=False.  NCHW."""
+    """rnn.py:36-69.  NCHW.  dws_conv=True <=> the dict holds `<pre>conv3x3_dws.weight`: [C,1,k,k] = on the previous hidden state
+    (dws_conv_only_hidden=True, :52-53), [2C,1,k,k] = on cat(x, h) (:55-56)."""
     C = x.shape[1]
     if hc is None:
         hc = (torch.zeros_like(x), torch.zeros_like(x))
     h0, c0 = hc
-    mix = F.conv2d(torch.cat((x, h0), dim=1), p[pre + "conv1x1.weight"], p[pre + "conv1x1.bias"])
+    wd = p.get(pre + "conv3x3_dws.weight")
+    if wd is not None and wd.shape[0] == C:
+        h0 = F.conv2d(h0, wd, p.get(pre + "conv3x3_dws.bias"), padding=wd.shape[-1] // 2, groups=C)
+    xh = torch.cat((x, h0), dim=1)
+    if wd is not None and wd.shape[0] == 2 * C:
+        xh = F.conv2d(xh, wd, p.get(pre + "conv3x3_dws.bias"), padding=wd.shape[-1] // 2, groups=2 * C)
+    mix = F.conv2d(xh, p[pre + "conv1x1.weight"], p[pre + "conv1x1.bias"])
     gates, cin = torch.tensor_split(mix, [C * 3], dim=1)
     f, i, o = torch.tensor_split(torch.sigmoid(gates), 3, dim=1)
     c1 = f * c0 + i * torch.tanh(cin)
@@ -710,7 +717,7 @@ def mlp_inner_dim(C: int, ratio: int = 4) -> int:
     return math.floor(int(C * ratio) * 2 / 3 / 32) * 32
 
 
-def init_backbone_params(cfg: BackboneCfg, seed: int = 0, ls_init: float = 1e-5) -> Params:
+def init_backbone_params(cfg: BackboneCfg, seed: int = 0, ls_init: float = 1e-5, dws_conv: Optional[str] = None, dws_kernel: int = 3) -> Params:
     """random-init parameter dict with the reference's names/shapes.
 
     The draw order is NOT the reference's (App. D-15); weights always travel by dict, never by seed.
@@ -753,6 +760,10 @@ def init_backbone_params(cfg: BackboneCfg, seed: int = 0, ls_init: float = 1e-5)
                 p[a + "to_controls.weight"] = torch.ones(C, 20)
         p[pre + "lstm.conv1x1.weight"] = U((4 * C, 2 * C, 1, 1), 2 * C)
         p[pre + "lstm.conv1x1.bias"] = U((4 * C,), 2 * C)
+        if dws_conv is not None:      # "hidden": dws_conv_only_hidden=True; "xh": on cat(x, h)  (drawn last: the other tensors keep their values)
+            cd = C if dws_conv == "hidden" else 2 * C
+            p[pre + "lstm.conv3x3_dws.weight"] = U((cd, 1, dws_kernel, dws_kernel), dws_kernel * dws_kernel)
+            p[pre + "lstm.conv3x3_dws.bias"] = U((cd,), dws_kernel * dws_kernel)
         cin = C
     return p
 

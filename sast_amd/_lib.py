@@ -104,6 +104,8 @@ _SIGNATURES = {
     "sast_mswsa_bwd": (C.c_int, [C.POINTER(SastMswsaArgs), P]),
     "sast_lstm_fwd": (C.c_int, [C.POINTER(SastLstmArgs), P]),
     "sast_lstm_bwd": (C.c_int, [C.POINTER(SastLstmArgs), P]),
+    "sast_dwconv_fwd": (C.c_int, [P, P, P, P] + [C.c_int] * 5 + [P]),
+    "sast_dwconv_bwd": (C.c_int, [P, P, P, P, P, P] + [C.c_int] * 5 + [P]),
     "sast_conv_bn_ws_floats": (C.c_int, [C.c_int]),
     "sast_conv_bn_silu_fwd": (C.c_int, [C.POINTER(SastConvBnArgs), P]),
     "sast_conv_bn_silu_bwd": (C.c_int, [C.POINTER(SastConvBnArgs), P]),

@@ -10,6 +10,7 @@ There is no CPU implementation: every op raises if its tensors are not on a HIP 
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 from typing import Optional, Tuple
@@ -53,9 +54,18 @@ def _gbuf(p: Optional[torch.Tensor]):
     return g
 
 
+_SCRATCH_KEEP = collections.deque(maxlen=256)
+
+
 def _scratch_grad(p: torch.Tensor):
-    """for frozen parameters the kernels still need somewhere to accumulate; use a throw-away buffer."""
-    return torch.zeros_like(p)
+    """for frozen parameters (and for the resident zero vectors standing in for absent biases) the kernels still need somewhere to
+    accumulate: a throw-away buffer.  It must OUTLIVE the launch it is handed to: callers pass raw pointers, and a buffer freed before
+    the launch is handed out again by the caching allocator -- to the next parameter's freshly created `.grad`, which the kernel would
+    then corrupt through the stale pointer (found with the attention_bias=False fixture).  The last 256 scratch buffers are kept alive
+    here; call sites that create several also hold them in a local until the launch is enqueued."""
+    t = torch.zeros_like(p)
+    _SCRATCH_KEEP.append(t)
+    return t
 
 
 def _g(p):
@@ -606,7 +616,8 @@ class _MSWSA(torch.autograd.Function):
             _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
-        _fill(a, **{"d_" + k: _ptr(_g(v)) for k, v in p.items()})
+        grads = {k: _g(v) for k, v in p.items()}          # held until the launch is enqueued (scratch buffers among them)
+        _fill(a, **{"d_" + k: _ptr(v) for k, v in grads.items()})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
         return (dxin, None, None, None, None) + (None,) * len(params)
 
@@ -670,6 +681,46 @@ def conv_lstm(x_nhwc, h0, c0, w, b, two_h=False):
     are then summed inside the backward kernel instead of by an autograd add launch)"""
     h1, h1b, c1 = _LSTM.apply(x_nhwc, h0, c0, w, b)
     return (h1, h1b if TWO_OUT else h1, c1) if two_h else (h1, c1)
+
+
+class _DwConv(torch.autograd.Function):
+    """depth-wise k x k conv with bias on NHWC rows (DWSConvLSTM2d.conv3x3_dws, rnn.py:24-28).  c0: the conv uses the channels
+    [c0, c0 + C) of the parameters (the two halves of a depth-wise conv over cat(x, h) run as two calls on the same parameters)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, c0):
+        _need_gpu(x, w)
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        k = w.shape[-1]
+        if w.dim() != 4 or w.shape[1] != 1 or w.shape[2] != k or not w.is_contiguous() or c0 < 0 or c0 + Cc > w.shape[0]:
+            raise RuntimeError("sast_amd: dwconv needs the contiguous Conv2d(groups=C) weight [C, 1, k, k]")
+        y = torch.empty_like(x)
+        L.check(L.lib().sast_dwconv_fwd(x.data_ptr(), w.data_ptr() + 4 * c0 * k * k, (b.data_ptr() + 4 * c0) if b is not None else None,
+                                        y.data_ptr(), B, H, W, Cc, k, _stream()), "dwconv_fwd")
+        ctx.save_for_backward(x)
+        ctx.params = (w, b, c0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w, b, c0 = ctx.params
+        B, H, W, Cc = x.shape
+        k = w.shape[-1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = _g(w)
+        gb = _g(b) if b is not None else torch.zeros(w.shape[0], device=x.device)
+        L.check(L.lib().sast_dwconv_bwd(x.data_ptr(), w.data_ptr() + 4 * c0 * k * k, dy.data_ptr(), _ptr(dx), gw.data_ptr() + 4 * c0 * k * k,
+                                        gb.data_ptr() + 4 * c0, B, H, W, Cc, k, _stream()), "dwconv_bwd")
+        return dx, None, None, None
+
+
+def dwconv(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], c0: int = 0) -> torch.Tensor:
+    """x (B,H,W,C) fp32 NHWC, w [Cw,1,k,k] (channels c0 .. c0+C-1 used), b [Cw] or None -> (B,H,W,C); parameter gradients accumulate
+    in place into w.grad / b.grad (module contract, see the header)"""
+    return _DwConv.apply(x_nhwc, w, b, int(c0))
 
 
 # ---------------------------------------------------------------------------------------------- a13
@@ -1155,9 +1206,10 @@ class _HeadPredLoss(torch.autograd.Function):
             rf, cf = feats[2 * k], feats[2 * k + 1]
             w_reg, b_reg, w_obj, b_obj, w_cls, b_cls = ctx.params[k]
             drf, dcf = torch.empty_like(rf), torch.empty_like(cf)
+            gp = [_g(t) for t in (w_reg, b_reg, w_obj, b_obj, w_cls, b_cls)]      # held until the launch is enqueued
             L.check(L.lib().sast_head_pred_bwd(draw.data_ptr(), rf.data_ptr(), cf.data_ptr(), w_reg.data_ptr(), w_obj.data_ptr(), w_cls.data_ptr(),
-                                               drf.data_ptr(), dcf.data_ptr(), _g(w_reg).data_ptr(), _g(b_reg).data_ptr(), _g(w_obj).data_ptr(),
-                                               _g(b_obj).data_ptr(), _g(w_cls).data_ptr(), _g(b_cls).data_ptr(), B, int(h), int(w), hid,
+                                               drf.data_ptr(), dcf.data_ptr(), gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr(),
+                                               gp[3].data_ptr(), gp[4].data_ptr(), gp[5].data_ptr(), B, int(h), int(w), hid,
                                                num_classes, off, A, _stream()), "head_pred_bwd")
             off += int(h) * int(w)
             grads += [drf, dcf, None, None, None, None, None, None]

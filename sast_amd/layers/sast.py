@@ -76,8 +76,6 @@ class MS_WSA(nn.Module):
         super().__init__()
         if dim_head not in (24, 32):
             raise NotImplementedError("sast_amd: the attention kernels are built for dim_head 32 and 24 (the widths the reference ships)")
-        if not bias:
-            raise NotImplementedError("sast_amd: attention_bias=False is not implemented")
         self.num_heads = dim // dim_head
         self.dim_head = dim_head
         self.scale = dim_head ** -0.5
@@ -87,8 +85,6 @@ class MS_WSA(nn.Module):
         ls_init_value, drop_path, mlp_expand_ratio, mlp_act_layer, mlp_bias, drop_mlp = sub_layer_params
         if drop_path > 0:
             raise NotImplementedError("sast_amd: drop_path > 0 is not implemented (reference default 0)")
-        if not mlp_bias:
-            raise NotImplementedError("sast_amd: mlp_bias=False is not implemented")
         self.ls1 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop1 = nn.Identity()
         self.norm2 = norms[1]
@@ -99,12 +95,22 @@ class MS_WSA(nn.Module):
         # aliased container, same state_dict duplicates as the reference (SAST.py:194)
         self.sub_layers = nn.ModuleList([self.ls1, self.drop1, self.norm2, self.mlp, self.ls2, self.drop2])
         self.eps = 1e-6
+        # attention_bias: False / mlp_bias: False (SAST.py:180-181, ops.py:128,160-166): the kernels always add a bias vector, a linear
+        # without one gets a resident zero vector (not a parameter, not in the state_dict; its "gradient" goes to a throw-away buffer)
+        inner = self.mlp.inner_dim
+        for name, lin, n in (("_zero_qkv_b", self.qkv, 3 * dim), ("_zero_proj_b", self.proj, dim),
+                             ("_zero_fc1_b", self.mlp.net[0].proj, 2 * inner), ("_zero_fc2_b", self.mlp.net[2], dim)):
+            if lin.bias is None:
+                self.register_buffer(name, torch.zeros(n), persistent=False)
 
     def kernel_params(self) -> dict:
         return dict(ln1_w=self.norm1.weight, ln1_b=self.norm1.bias, ln2_w=self.norm2.weight, ln2_b=self.norm2.bias,
-                    qkv_w=self.qkv.weight, qkv_b=self.qkv.bias, proj_w=self.proj.weight, proj_b=self.proj.bias,
-                    ls1=getattr(self.ls1, "gamma", None), fc1_w=self.mlp.net[0].proj.weight, fc1_b=self.mlp.net[0].proj.bias,
-                    fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias, ls2=getattr(self.ls2, "gamma", None))
+                    qkv_w=self.qkv.weight, qkv_b=self.qkv.bias if self.qkv.bias is not None else self._zero_qkv_b,
+                    proj_w=self.proj.weight, proj_b=self.proj.bias if self.proj.bias is not None else self._zero_proj_b,
+                    ls1=getattr(self.ls1, "gamma", None), fc1_w=self.mlp.net[0].proj.weight,
+                    fc1_b=self.mlp.net[0].proj.bias if self.mlp.net[0].proj.bias is not None else self._zero_fc1_b,
+                    fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias if self.mlp.net[2].bias is not None else self._zero_fc2_b,
+                    ls2=getattr(self.ls2, "gamma", None))
 
     def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False) -> torch.Tensor:
         """fused path: x (B,H,W,C) in IMAGE layout + device-side selection."""

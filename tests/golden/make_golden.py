@@ -84,9 +84,10 @@ def run_ref_block(ref, params, x, r, pe_mod, acfg, first=True, index_list=None, 
     return blk, xx, out, cnt, lists
 
 
-def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32):
+def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bias=True):
+    """bias=False: attention_bias: False and mlp_bias: False (qkv / proj / MLP linears without bias vectors, SAST.py:180-181)"""
     H, W, part = 16, 20, (4, 5)
-    acfg = dict(partition_size=part, dim_head=dim_head, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
+    acfg = dict(partition_size=part, dim_head=dim_head, attention_bias=bias, mlp_activation="gelu", mlp_bias=bias,
                 mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=0.5, enable_CB=enable_cb, AMP=amp, BOUNCE=1e-3)
     ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb, dim_head=dim_head)
     pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
@@ -97,6 +98,8 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32):
         x = torch.randn(B, H, W, C, generator=g)
         r = torch.rand(B, 20, generator=g) * 0.05
         params = block_params(C, seed, 0.5)
+        if not bias:
+            params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
         blk, xx, out, cnt, lists = run_ref_block(ref, params, x, r, pe_mod, acfg)
         # margins via the oracle's scores
         _o, _c, _l, sc = O.sast_block(x, pe, r, params, "att_blocks.0.att.", ocfg, return_scores=True)
@@ -125,7 +128,7 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32):
     assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
     d = dict(x=np_(x), r=np_(r), out=np_(out), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)),
-             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head))
+             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head), bias=np.int64(bias))
     d.update(lists_to_np(lists, ""))
     named = dict(blk.named_parameters())
     for k, v in named.items():
@@ -336,6 +339,46 @@ def gen_full_sparse(ref, seeds):
         json.dump(res, f, indent=1)
 
 
+def gen_lstm_dws(ref):
+    """a12 with dws_conv=True (the reference class default, rnn.py:13,24-28): DWSConvLSTM2d of the reference, depth-wise conv on the
+    previous hidden state (only_hidden) and on cat(x, h); with a previous state and without one (the zero state is convolved too:
+    the depth-wise bias reaches the gates).  Outputs and every gradient of sum(w_h * h1) + sum(w_c * c1)."""
+    B, C, H, W = 2, 32, 8, 10
+    d = {}
+    for mode, only_hidden in (("hidden", True), ("xh", False)):
+        cfgp = O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=C)
+        full = O.init_backbone_params(cfgp, seed=71, dws_conv=mode)
+        params = {k[len("stages.0.lstm."):]: v for k, v in full.items() if k.startswith("stages.0.lstm.")}
+        m = ref.rnn.DWSConvLSTM2d(C, dws_conv=True, dws_conv_only_hidden=only_hidden, dws_conv_kernel_size=3)
+        m.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+        g = torch.Generator().manual_seed(72)
+        x = torch.randn(B, C, H, W, generator=g)
+        h0, c0 = torch.randn(B, C, H, W, generator=g) * 0.5, torch.randn(B, C, H, W, generator=g) * 0.5
+        wh, wc = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+        for tag, prev in (("prev", True), ("zero", False)):
+            xx, hh, cc = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+            m.zero_grad()
+            h1, c1 = m(xx, (hh, cc) if prev else None)
+            ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+            po = {"lstm." + k: v.clone().requires_grad_(True) for k, v in params.items()}
+            xo, ho, co = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+            oh, oc = O.conv_lstm(xo, (ho, co) if prev else None, po, "lstm.")
+            assert torch.equal(oh, h1) and torch.equal(oc, c1), (mode, tag)
+            ((oh * wh).sum() + (oc * wc).sum()).backward()
+            for k, v in m.named_parameters():
+                assert torch.allclose(po["lstm." + k].grad, v.grad, atol=1e-6, rtol=1e-5), (mode, tag, k)
+            pre = f"{mode}_{tag}_"
+            d[pre + "h1"], d[pre + "c1"], d[pre + "dx"] = np_(h1), np_(c1), np_(xx.grad)
+            if prev:
+                d[pre + "dh0"], d[pre + "dc0"] = np_(hh.grad), np_(cc.grad)
+            for k, v in m.named_parameters():
+                d[pre + "g_" + k] = np_(v.grad)
+        d[mode + "_param_checksum"] = np.float64(param_checksum(params))
+    d.update(x=np_(x), h0=np_(h0), c0=np_(c0), wh=np_(wh), wc=np_(wc), seed=np.int64(71))
+    np.savez_compressed(os.path.join(HERE, "lstm_dws.npz"), **d)
+    print("lstm_dws ok")
+
+
 def gen_head_eval(ref):
     """YOLOX head, inference path: the oracle restatement against the reference module in eval mode."""
     if ref.yolo_head is None:
@@ -501,6 +544,12 @@ def main():
         gen_head_eval(ref)
         gen_head_train(ref)
         return
+    if "--lstm-dws-only" in sys.argv:
+        gen_lstm_dws(ref)
+        return
+    if "--nobias-only" in sys.argv:
+        gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
+        return
     if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
         gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
         gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
@@ -513,6 +562,7 @@ def main():
     gen_block(ref, "block_cb", 2, 2e-2, enable_cb=True)
     gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
     gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
+    gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)
@@ -520,6 +570,7 @@ def main():
     gen_head_train(ref)
     gen_masked_backbone(ref)
     gen_full_stats(ref)
+    gen_lstm_dws(ref)
     gen_sequence_gather(ref)
 
 

@@ -124,7 +124,7 @@ def test_input_prep_one_launch(golden_dir, dev):
 
 
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
-                                  "block_large_c96"])
+                                  "block_large_c96", "block_nobias"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
@@ -134,7 +134,12 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     params = block_params(C, int(g["seed"]))
     cb = bool(g["enable_cb"]) if "enable_cb" in g else False     # Context Broadcasting fixture (SAST.py:240-246)
     dh = int(g["dim_head"]) if "dim_head" in g else 32      # 24: the reference's "small" size
-    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"]), cb=cb, dim_head=dh), first_block=True).to(dev)
+    bias = bool(int(g["bias"])) if "bias" in g else True    # False: attention_bias / mlp_bias False (linears without bias vectors)
+    if not bias:
+        params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
+    acfg = attn_cfg((4, 5), float(g["amp"]), cb=cb, dim_head=dh)
+    acfg.update(attention_bias=bias, mlp_bias=bias)
+    blk = SAST_block(C, acfg, first_block=True).to(dev)
     load_params(blk, params, "att_blocks.0.att.")
     pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     xd = x.to(dev).requires_grad_(True)
@@ -157,6 +162,36 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
                               O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), enable_cb=cb, dim_head=dh), kink_log=kl)
     (oo ** 2).mean().backward()
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
+
+
+def test_frozen_parameters_do_not_corrupt_neighbours(golden_dir, dev):
+    """parameters with requires_grad=False get throw-away gradient buffers (functional._scratch_grad); those must outlive the launch --
+    a buffer freed before it was handed out again as the NEXT parameter's fresh `.grad` and the kernel corrupted it through the stale
+    pointer (round 3, found with the attention_bias=False fixture).  Freeze the four biases of both MS-WSA layers and compare every
+    other gradient with the reference's (the fixture was generated with all parameters trainable: the others must not change)."""
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    g = _load(golden_dir, "block_amp2e-2")
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    B, H, W, C = x.shape
+    params = block_params(C, int(g["seed"]))
+    blk = SAST_block(C, attn_cfg((4, 5), float(g["amp"])), first_block=True).to(dev)
+    load_params(blk, params, "att_blocks.0.att.")
+    frozen = [k for k, v in blk.named_parameters() if k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k)]
+    for k, v in blk.named_parameters():
+        if k in frozen:
+            v.requires_grad_(False)
+    assert len(frozen) >= 8
+    pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    out, _cnt, _lists = blk(x.to(dev).requires_grad_(True), pe, r.to(dev), None)
+    (out ** 2).mean().backward()
+    for k, v in blk.named_parameters():
+        if "sub_layers" in k or k in frozen or "to_scores." in k:
+            continue
+        grad_close(k, v.grad, torch.from_numpy(g["g_" + k]))
+    for k, v in blk.named_parameters():
+        if k in frozen:
+            assert v.grad is None
 
 
 def test_stage_two_blocks_vs_golden(golden_dir, dev):
@@ -896,6 +931,65 @@ def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
         if "sub_layers" in k:
             continue
         grad_close(k, v.grad, po[k].grad)
+
+
+@pytest.mark.parametrize("mode", ["hidden", "xh"])
+def test_conv_lstm_depthwise_vs_golden(golden_dir, dev, mode):
+    """a12 with dws_conv=True (the reference class default, rnn.py:13,24-28): DWSConvLSTM2d with the depth-wise 3x3 conv on the previous
+    hidden state (`hidden`) or on cat(x, h) (`xh`), through sast_dwconv_* + the fused 1x1 / gates launch, against the reference module's
+    outputs and gradients (fixture lstm_dws.npz); with a previous state and from the zero state (which is convolved too)."""
+    from sast_amd.layers import DWSConvLSTM2d
+    g = _load(golden_dir, "lstm_dws")
+    C = g["x"].shape[1]
+    full = O.init_backbone_params(O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=C), seed=int(g["seed"]), dws_conv=mode)
+    params = {k[len("stages.0.lstm."):]: v for k, v in full.items() if k.startswith("stages.0.lstm.")}
+    m = DWSConvLSTM2d(C, dws_conv=True, dws_conv_only_hidden=(mode == "hidden"), dws_conv_kernel_size=3).to(dev)
+    m.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    wh, wc = torch.from_numpy(g["wh"]).to(dev), torch.from_numpy(g["wc"]).to(dev)
+    for tag in ("prev", "zero"):
+        x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+        h0, c0 = torch.from_numpy(g["h0"]).to(dev).requires_grad_(True), torch.from_numpy(g["c0"]).to(dev).requires_grad_(True)
+        m.zero_grad()
+        h1, c1 = m(x, (h0, c0) if tag == "prev" else None)
+        pre = f"{mode}_{tag}_"
+        abs_close(h1, torch.from_numpy(g[pre + "h1"]), FWD_ATOL, pre + "h1")
+        abs_close(c1, torch.from_numpy(g[pre + "c1"]), FWD_ATOL, pre + "c1")
+        ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+        maxnorm_close(x.grad, torch.from_numpy(g[pre + "dx"]), GRAD_RTOL, pre + "dx")
+        if tag == "prev":
+            maxnorm_close(h0.grad, torch.from_numpy(g[pre + "dh0"]), GRAD_RTOL, pre + "dh0")
+            maxnorm_close(c0.grad, torch.from_numpy(g[pre + "dc0"]), GRAD_RTOL, pre + "dc0")
+        for k, v in m.named_parameters():
+            grad_close(pre + k, v.grad, torch.from_numpy(g[pre + "g_" + k]))
+
+
+def test_backbone_with_depthwise_lstm(dev):
+    """the whole backbone with lstm.dws_conv: True (the reference's class default; the shipped YAML sets False), two timesteps with
+    the recurrent state carried, forward and backward against the oracle"""
+    from sast_amd.detection import RNNDetector
+    hw, part, E = (128, 160), (4, 5), 32
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=81, ls_init=0.5, dws_conv="hidden")
+    cfg = _rcfg(hw, part, E, 2e-2, 0.5)
+    cfg.stage.lstm.dws_conv = True
+    net = RNNDetector(cfg).to(dev)
+    load_params(net, params)
+    x0, x1 = O.count_events(2, hw, seed=82, density=0.05), O.count_events(2, hw, seed=83, density=0.05)
+    out0, st0, P0 = net(x0.to(dev))
+    out1, _st1, P1 = net(x1.to(dev), st0)
+    loss = sum((out1[k] ** 2).mean() for k in (1, 2, 3, 4))
+    loss.backward()
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    kl = {}
+    o0, s0, Po0 = O.backbone(x0, None, po, ocfg, kink_log=kl)
+    o1, _s1, Po1 = O.backbone(x1, s0, po, ocfg, kink_log=kl)
+    loss_o = sum((o1[k] ** 2).mean() for k in (1, 2, 3, 4))
+    loss_o.backward()
+    assert [int(p) for p in P0] == Po0 and [int(p) for p in P1] == Po1
+    for k in (1, 2, 3, 4):
+        abs_close(out1[k], o1[k], FWD_ATOL, f"h{k}")
+    assert abs(float(loss) - float(loss_o)) <= 1e-5 * abs(float(loss_o))
+    net_grads_close(net.named_parameters(), lambda k: po[k].grad, kl)
 
 
 def test_sequence_gather_vs_golden(golden_dir, dev):

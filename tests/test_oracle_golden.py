@@ -42,11 +42,13 @@ def test_non_zero_ratio(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
-                                  "block_large_c96"])
+                                  "block_large_c96", "block_nobias"])
 def test_sast_block(golden_dir, name):
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
     params = _block_params(x.shape[-1], int(g["seed"]))
+    if "bias" in g and not int(g["bias"]):       # attention_bias: False, mlp_bias: False -- the linears have no bias vectors
+        params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
     cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]),
                     dim_head=int(g["dim_head"]) if "dim_head" in g else 32)
@@ -273,3 +275,26 @@ def test_full_size_sparse_selection_of_the_reference(golden_dir, key):
     for k in (1, 2, 3, 4):
         t = out[k].double()
         assert abs(float(t.abs().mean()) - ref[f"h{k}"]["absmean"]) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["hidden", "xh"])
+def test_conv_lstm_depthwise(golden_dir, mode):
+    """a12 with dws_conv=True (the reference class default): the oracle's conv_lstm against the reference DWSConvLSTM2d (fixture
+    lstm_dws.npz) -- depth-wise conv on the previous hidden state / on cat(x, h), with a previous state and from the zero state."""
+    g = _load(golden_dir, "lstm_dws")
+    C = g["x"].shape[1]
+    full = O.init_backbone_params(O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=C), seed=int(g["seed"]), dws_conv=mode)
+    params = {k[len("stages.0."):]: v for k, v in full.items() if k.startswith("stages.0.lstm.")}
+    assert abs(_checksum(params) - float(g[mode + "_param_checksum"])) < 1e-6 * float(g[mode + "_param_checksum"])
+    wh, wc = torch.from_numpy(g["wh"]), torch.from_numpy(g["wc"])
+    for tag in ("prev", "zero"):
+        x = torch.from_numpy(g["x"]).clone().requires_grad_(True)
+        h0, c0 = torch.from_numpy(g["h0"]).clone().requires_grad_(True), torch.from_numpy(g["c0"]).clone().requires_grad_(True)
+        po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        h1, c1 = O.conv_lstm(x, (h0, c0) if tag == "prev" else None, po, "lstm.")
+        pre = f"{mode}_{tag}_"
+        assert torch.allclose(h1, torch.from_numpy(g[pre + "h1"]), atol=ATOL, rtol=0) and torch.allclose(c1, torch.from_numpy(g[pre + "c1"]), atol=ATOL, rtol=0)
+        ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+        assert torch.allclose(x.grad, torch.from_numpy(g[pre + "dx"]), atol=1e-6, rtol=1e-4)
+        for k, v in po.items():
+            assert torch.allclose(v.grad, torch.from_numpy(g[pre + "g_" + k[len("lstm."):]]), atol=1e-5, rtol=1e-4), (tag, k)
