@@ -95,6 +95,52 @@ struct EpBnSilu2 {
     (j < C ? y0 + (size_t)m * C + j : y1 + (size_t)m * C + (j - C))[0] = z * sigmoid_exact(z);
   }
 };
+#ifdef SAST_EXP_SKIP_FOLDABLE_BN_APPLY
+// timing-only stand-ins (tools/bn_fold_bound.py): the conv epilogue ALSO writes a finite, realistically scaled y = silu(gamma z + beta)
+// and (mean, rstd) = (0, 1), so that everything downstream of a dropped apply launch keeps computing on ordinary data (garbage / NaN
+// operands would bias the measurement through the clocks: DVFS)
+struct EpStoreStatsY {
+  static constexpr bool COLSTATS = true;
+  float* c; int ldc; double* sums; float* y; int ldy; const float* gamma; const float* beta; float* stats; int C;
+  struct Col { float g, b; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const { stats[j] = 0.f; stats[C + j] = 1.f; return Col{gamma[j], beta[j]}; }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
+    c[(size_t)m * ldc + j] = v[0];
+    const float z = v[0] * k.g + k.b;
+    y[(size_t)m * ldy + j] = z * sigmoid_exact(z);
+  }
+  __device__ __forceinline__ void stat(float v, const Col&, const Aux&, float& a, float& b) const { a += v; b += v * v; }
+  __device__ __forceinline__ void flush(int copy, int j, int NJ, float s, float q) const {
+    double* sp = sums + (size_t)copy * 2 * NJ;
+    atomicAdd(sp + j, (double)s); atomicAdd(sp + NJ + j, (double)q);
+  }
+};
+struct EpStoreStats2Y {
+  static constexpr bool COLSTATS = true;
+  float* c1; float* c2; int C; double* sums1; double* sums2; float* y1; float* y2; const float* g1; const float* b1; const float* g2; const float* b2;
+  float* st1; float* st2;
+  struct Col { float g, b; };
+  using Aux = EpNone;
+  __device__ __forceinline__ Col col(int j) const {
+    if (j < C) { st1[j] = 0.f; st1[C + j] = 1.f; return Col{g1[j], b1[j]}; }
+    st2[j - C] = 0.f; st2[j] = 1.f; return Col{g2[j - C], b2[j - C]};
+  }
+  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
+    const float z = v[0] * k.g + k.b, yv = z * sigmoid_exact(z);
+    if (j < C) { c1[(size_t)m * C + j] = v[0]; y1[(size_t)m * C + j] = yv; }
+    else { c2[(size_t)m * C + (j - C)] = v[0]; y2[(size_t)m * C + (j - C)] = yv; }
+  }
+  __device__ __forceinline__ void stat(float v, const Col&, const Aux&, float& a, float& b) const { a += v; b += v * v; }
+  __device__ __forceinline__ void flush(int copy, int j, int, float s, float q) const {
+    double* sp = (j < C ? sums1 : sums2) + (size_t)copy * 2 * C;
+    const int jj = j < C ? j : j - C;
+    atomicAdd(sp + jj, (double)s); atomicAdd(sp + C + jj, (double)q);
+  }
+};
+#endif
 // forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
 // fp64 per-channel sum / sum of squares, one atomic pair per channel per block.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
@@ -477,6 +523,14 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
                         : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
                : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
+#ifdef SAST_EXP_SKIP_FOLDABLE_BN_APPLY
+  if (a->training && a->momentum < 0.f) {
+    const EpStoreStatsY ep{a->conv_out, C, sums, a->y, a->ldy, a->bn_w, a->bn_b, a->stats, C};
+    return one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
+                        : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
+               : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
+  }
+#endif
   if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
     rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
@@ -579,6 +633,14 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
     zero_fill(a->bn_ws1, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
   }
   const LdRows2 la{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2};
+#ifdef SAST_EXP_SKIP_FOLDABLE_BN_APPLY
+  if (a->momentum0 < 0.f) {
+    const EpStoreStats2Y epy{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1, a->y0, a->y1, a->bn_w0, a->bn_b0, a->bn_w1, a->bn_b1,
+                             a->stats0, a->stats1};
+    return a->ksize == 3 ? conv_gemm(a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx), LdWeightNT2{a->w0, a->w1, K, C}, epy, M, 2 * C, K, st)
+                         : gemm_auto(la, LdWeightNT2{a->w0, a->w1, K, C}, epy, M, 2 * C, K, st);
+  }
+#endif
   const EpStoreStats2 ep{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1};
   int rc = a->ksize == 3 ? conv_gemm(a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx), LdWeightNT2{a->w0, a->w1, K, C}, ep, M,
                                      2 * C, K, st)
