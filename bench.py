@@ -58,7 +58,7 @@ class Trainer:
     """bench harness around sast_amd.training.TrainStep (the reference's step is Lightning's, modules/detection.py:113-221)."""
 
     def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False, yolox_loss=False, segmented=None,
-                 label_every=0):
+                 label_every=0, sync_bn=False):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.training import TrainStep
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -89,6 +89,15 @@ class Trainer:
         self.net.to(dev)
         self.fpn.to(dev)
         self.world = world
+        # --sync-bn: the reference's DDP runs use SyncBatchNorm (train.py:167).  The statistics all-reduces sit between the two phases of
+        # every conv + BatchNorm unit and are not captured into hipGraphs: the step then runs eagerly (training.TrainStep.capture refuses)
+        self.sync_bn = bool(sync_bn) and world > 1 and not infer
+        if self.sync_bn:
+            from sast_amd.detection import convert_sync_batchnorm
+            convert_sync_batchnorm(self.fpn)
+            if self.head is not None:
+                convert_sync_batchnorm(self.head)
+            use_graph = False
         self.segmented = ((world > 1) and os.environ.get("SAST_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
         self.ts = TrainStep(self.net, self.fpn, self.head if yolox_loss else None, lr=2e-4, weight_decay=0.0, clip_value=1.0, world=world,
                             segmented=self.segmented)
@@ -289,6 +298,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32", help="f32: the product path (BASELINE metric).  bf16: the separately "
                     "built reduced-precision library (GEMM operands rounded to bf16, fp32 accumulate; the arithmetic class of the reference's AMP-16 "
                     "experiments) -- reported as a different metric, index decisions differ from the fp32 reference's")
+    ap.add_argument("--sync-bn", action="store_true", help="N > 1: SyncBatchNorm in the PAFPN / head like the reference's DDP runs (train.py:167); "
+                    "eager step (the statistics all-reduces are not captured into hipGraphs).  Default: per-rank batch statistics")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -326,7 +337,7 @@ def main():
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
     tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer,
-                 yolox_loss=args.loss == "yolox", segmented=args.segmented, label_every=args.label_every)
+                 yolox_loss=args.loss == "yolox", segmented=args.segmented, label_every=args.label_every, sync_bn=args.sync_bn)
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -394,6 +405,8 @@ def main():
                        "collective_ranks": world, "collective_backend": (dist.get_backend() if world > 1 else None),
                        "gradient_bytes_per_rank": 4 * int(tr.flat.numel),
                        "allreduce_exposed_ms": exposed_ms,
+                       # the reference's DDP runs convert BatchNorm to SyncBatchNorm (train.py:167); false = per-rank batch statistics
+                       "sync_batchnorm": bool(tr.sync_bn),
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
                        "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},

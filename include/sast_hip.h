@@ -222,6 +222,19 @@ typedef struct SastConvBnArgs {
   const float* p_conv_out; const float* p_stats; const float* p_bn_w; const float* p_bn_b; float* p_bn_ws;
   const float* p2_conv_out; const float* p2_stats; const float* p2_bn_w; const float* p2_bn_b; float* p2_bn_ws;
   const float* dy2;      /* bwd, optional: a second gradient of y (y consumed by two ops; row stride lddy), added to dy on the fly */
+  /* SyncBatchNorm -- the reference trains with sync_batchnorm=True whenever it runs DDP (train.py:167; torch.nn.SyncBatchNorm
+     semantics): training-mode calls split around the HOST's all-reduce of the statistics (the library never calls a collective).
+       0      the whole op on the rows of this process (BatchNorm2d)
+       fwd 1  conv + this process's fp64 column sums into bn_ws, return.  The host all-reduces (SUM) the fp64 block
+              bn_ws[0, 4*COPIES*Cout) floats and the row counts M of the ranks;
+       fwd 2  BatchNorm + SiLU from bn_ws as it now is, over m_total rows (running statistics updated with the global mean and the
+              unbiased global variance, like torch); the conv is not run again.
+       bwd 1  this process's (sum dz, sum dz*xhat) into the fp32 block bn_ws[4*COPIES*Cout, 6*COPIES*Cout) (not run when
+              bn_red_done: the consumer's dX epilogue has them already), return.  The host adds the block, summed over its COPIES,
+              to d_bn_b / d_bn_w -- the affine gradients stay LOCAL sums as in torch.nn.SyncBatchNorm (DDP averages them with every
+              other gradient) -- and then all-reduces (SUM) the block;
+       bwd 2  the rest (BatchNorm-backward apply with 1 / m_total, dW, dX, producer folding); d_bn_w / d_bn_b NULL. */
+  int32_t sync_phase, m_total;
 } SastConvBnArgs;
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < BN_STAT_COPIES; ++k) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
-    if (blockIdx.x == 0) { dbeta[c] += s1; dgamma[c] += s2; }
+    if (blockIdx.x == 0 && dbeta) { dbeta[c] += s1; dgamma[c] += s2; }   // NULL: the host already published them (SyncBatchNorm: LOCAL sums)
     bsm[c] = stats[c]; bsm[C + c] = stats[C + c]; bsm[2 * C + c] = gamma[c]; bsm[3 * C + c] = beta[c];
     bsm[4 * C + c] = s1 * invM; bsm[5 * C + c] = s2 * invM;
   }
@@ -377,12 +377,12 @@ void bn_bwd_reduce_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int
   SAST_LAUNCH(bn_bwd_reduce_kernel, dim3((M + rpb - 1) / rpb, njobs), dim3(BN_RED_THREADS), sizeof(float4) * 2 * RP * c4n, st, j0, j1, M, C,
                      rpb);
 }
-void bn_bwd_apply_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int M, int C, int training, hipStream_t st) {
+void bn_bwd_apply_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int M, int C, int training, hipStream_t st, int m_stat = 0) {
   const size_t n4 = (size_t)M * (C / 4);
   int iters = (int)(n4 / (256 * 512));
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
   SAST_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), njobs), dim3(256), sizeof(float) * 6 * C, st,
-                     j0, j1, n4, C, 1.0f / (float)M, training, iters, div_mul_of((unsigned)(C / 4), n4));
+                     j0, j1, n4, C, 1.0f / (float)(m_stat > 0 ? m_stat : M), training, iters, div_mul_of((unsigned)(C / 4), n4));   // m_stat: rows behind the sums (all ranks)
 }
 
 inline ConvGeom geom_of(int B, int H, int W, int Cin, int k, int stride, int pad, int replicate, int ldx) {
@@ -509,8 +509,12 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
   if ((unsigned long long)M * (C / 4) >= (1ull << 31)) return SAST_EINVAL;   // element indices of the BatchNorm passes are 31-bit
   double* sums = (double*)a->bn_ws;
-  if (a->training && !a->bn_ws_zeroed) zero_fill(a->bn_ws, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
-  int rc;
+  // SyncBatchNorm (include/sast_hip.h: sync_phase): 1 = conv + this process's column sums, 2 = BatchNorm + SiLU from the sums the host
+  // all-reduced in between, over the m_total rows of all ranks
+  const int phase = a->training ? a->sync_phase : 0;
+  if (phase < 0 || phase > 2 || (phase == 2 && a->m_total < M)) return SAST_EINVAL;
+  if (a->training && !a->bn_ws_zeroed && phase != 2) zero_fill(a->bn_ws, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
+  int rc = SAST_OK;
   static int sep = -1;
   if (sep < 0) { const char* e = getenv("SAST_BN_STATS_SEPARATE"); sep = e ? atoi(e) : 0; }
   const bool one = k == 1 && a->stride == 1;
@@ -531,7 +535,8 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
                : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
 #endif
-  if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
+  if (phase == 2) {            // the conv and its sums are phase 1's
+  } else if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
     rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
                       : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
@@ -543,19 +548,20 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
              : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (rc) return rc;
-  if (a->training && sep) {
+  if (a->training && sep && phase != 2) {
     int rpb = (M + sep - 1) / sep;
     rpb = rpb < 8 ? 8 : rpb;
     const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
     SAST_LAUNCH(bn_stats_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(double) * 2 * RP * C, st, a->conv_out, M, C, sums, rpb);
   }
+  if (phase == 1) { SAST_CHECK_LAUNCH(); return SAST_OK; }
   const size_t n4 = (size_t)M * (C / 4);
   int iters = (int)(n4 / (256 * 512));     // >= 512 blocks while the image allows it; the per-block statistics prologue is 2C*COPIES loads
   iters = iters < 1 ? 1 : (iters > 8 ? 8 : iters);
   {
     const BnFwdJob jb{a->conv_out, sums, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, a->momentum, a->eps};
     SAST_LAUNCH(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 1), dim3(256), sizeof(float) * 2 * C, st,
-                       jb, jb, M, n4, C, a->training, iters, div_mul_of((unsigned)(C / 4), n4));
+                       jb, jb, phase == 2 ? a->m_total : M, n4, C, a->training, iters, div_mul_of((unsigned)(C / 4), n4));
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -569,13 +575,16 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
   float* sums = a->bn_ws + 4 * BN_STAT_COPIES * C;      // [COPIES][2C]
   float* dconv = a->ws;                // [M, C]
-  if (!a->bn_ws_zeroed) {
+  const int phase = a->training ? a->sync_phase : 0;   // SyncBatchNorm: 1 = this process's (sum dz, sum dz*xhat) only, 2 = everything after the host's all-reduce
+  if (phase < 0 || phase > 2 || (phase == 2 && a->m_total < M)) return SAST_EINVAL;
+  if (!a->bn_ws_zeroed && phase != 2) {
     if (a->bn_red_done) return SAST_EINVAL;   // the consumer has already accumulated into it
     zero_fill(sums, sizeof(float) * 2 * BN_STAT_COPIES * C, st);
   }
   const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b, a->dy2, C};
-  if (!a->bn_red_done) bn_bwd_reduce_launch(jb, jb, 1, M, C, st);   // skipped when the conv consuming y folded it into its dX epilogue
-  bn_bwd_apply_launch(jb, jb, 1, M, C, a->training, st);
+  if (!a->bn_red_done && phase != 2) bn_bwd_reduce_launch(jb, jb, 1, M, C, st);   // skipped when the conv consuming y folded it into its dX epilogue
+  if (phase == 1) { SAST_CHECK_LAUNCH(); return SAST_OK; }
+  bn_bwd_apply_launch(jb, jb, 1, M, C, a->training, st, phase == 2 ? a->m_total : 0);
   SAST_CHECK_LAUNCH();
   // producers of x / x2 whose only consumer is this conv: their reductions ride on this conv's dX epilogue
   const int C2 = a->Cin - a->Cin1;

@@ -19,6 +19,7 @@ class BaseConv(nn.Module):
         self.conv = nn.Module()
         self.conv.weight = channels_last_conv_weight(out_channels, in_channels, ksize)
         self.bn = nn.BatchNorm2d(out_channels)
+        self.sync_bn = None       # a functional.SyncBatchNormGroup after convert_sync_batchnorm: batch statistics over all ranks
 
     def forward_nhwc(self, x, arena=None, sole=False, two_outputs=False):
         """arena: optional `BnArena` handing out zero-filled reduction scratch (one memset per FPN forward) and
@@ -29,7 +30,7 @@ class BaseConv(nn.Module):
         bn = self.bn
         ws = arena.take(SF.bn_ws_floats(bn.num_features)) if arena is not None else None
         y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
-                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole, two_outputs=two_outputs)
+                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole, two_outputs=two_outputs, sync=self.sync_bn)
         if self.training and bn.num_batches_tracked is not None:
             if arena is not None:
                 arena.counters.append(bn.num_batches_tracked)
@@ -41,6 +42,25 @@ class BaseConv(nn.Module):
         if isinstance(x, (tuple, list)):
             raise TypeError("sast_amd: the two-source (virtual concat) input is an internal NHWC feature; use forward_nhwc")
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
+
+
+def sync_active(conv: "BaseConv") -> bool:
+    """training-mode statistics of this unit span several ranks: the stacked two-conv launches (one process's rows) are not used"""
+    return conv.sync_bn is not None and conv.sync_bn.active()
+
+
+def convert_sync_batchnorm(module: nn.Module, process_group=None):
+    """the reference's Trainer(sync_batchnorm=True) under DDP (train.py:167; torch.nn.SyncBatchNorm.convert_sync_batchnorm): every
+    conv + BatchNorm + SiLU unit below `module` takes its training-mode batch statistics over the rows of ALL ranks of `process_group`.
+    The BatchNorm2d modules stay what they are (same parameters, buffers and state_dict keys); one functional.SyncBatchNormGroup is shared
+    by the units and issues the all-reduces between the two phases of the fused op.  Returns `module`."""
+    grp = SF.SyncBatchNormGroup(process_group)
+    for m in module.modules():
+        if isinstance(m, BaseConv):
+            m.sync_bn = grp
+        if hasattr(m, "_sync_group"):
+            m._sync_group = grp
+    return module
 
 
 class BnArena:
@@ -116,7 +136,7 @@ class CSPLayer(nn.Module):
     def forward_nhwc(self, x, arena=None, sole_input=False, two_outputs=False):
         """sole_input: nothing but this layer consumes x (then the BatchNorm-backward reductions of the convs that produced x
         ride on this layer's input-gradient launch); two_outputs: see BaseConv.forward_nhwc"""
-        if self.training and SF.CONV_PAIR:
+        if self.training and SF.CONV_PAIR and not sync_active(self.conv1):
             # conv1 and conv2 read the same input: one GEMM over the stacked weights, one BatchNorm pass for both, and a
             # backward whose dX is already the sum of the two input gradients
             x1, x2 = self._conv12(x, arena, sole_input)

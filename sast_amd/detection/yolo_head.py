@@ -51,6 +51,7 @@ class YOLOXHead(nn.Module):
             self.reg_preds.append(_PredConv(hidden, 4))
             self.obj_preds.append(_PredConv(hidden, 1))
         self.use_l1 = False
+        self._sync_group = None      # set by network_blocks.convert_sync_batchnorm
         self.hw = None
         self.initialize_biases(prior_prob=0.01)
 
@@ -66,9 +67,12 @@ class YOLOXHead(nn.Module):
         if not hasattr(self, "_bn_floats"):
             self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         ar = BnArena(self._bn_floats, feats[0].device)     # one memset / one counter update for the 15 BatchNorms
+        sync = self._sync_group is not None and self._sync_group.active()
+        if sync:
+            self._sync_group.exchange_batch(feats[0].shape[0], feats[0].device)
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x, ar)
-            if SF.CONV_PAIR:
+            if SF.CONV_PAIR and not sync:
                 # the first conv of both towers reads the stem output: one stacked 3x3 GEMM + shared BatchNorm launches, and (sole
                 # consumer of the stem output) the stem's BatchNorm-backward reduction in the pair's dX epilogue
                 c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]

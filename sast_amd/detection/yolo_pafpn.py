@@ -31,12 +31,15 @@ class YOLOPAFPN(nn.Module):
         self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
         self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
         self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
+        self._sync_group = None      # set by network_blocks.convert_sync_batchnorm
 
     def forward_nhwc(self, feats: Dict[int, object]):
         x2, x1, x0 = (feats[f] for f in self.in_features)
         if not hasattr(self, "_bn_floats"):
             self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         ar = BnArena(self._bn_floats, x0.device)                            # one memset for all 32 BatchNorm reductions
+        if self.training and self._sync_group is not None and self._sync_group.active():
+            self._sync_group.exchange_batch(x0.shape[0], x0.device)           # SyncBatchNorm: the sample counts of all ranks, once per pass
         # outputs with two consumers come as (y, alias) pairs: autograd then delivers the two gradients separately and the producing
         # conv's BatchNorm-backward kernels add them while reading (no accumulation launch)
         fpn_out0, fpn_out0b = self.lateral_conv0.forward_nhwc(x0, ar, two_outputs=True)

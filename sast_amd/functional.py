@@ -739,9 +739,52 @@ class BnHandle:
         return self
 
 
+class SyncBatchNormGroup:
+    """SyncBatchNorm for the conv + BatchNorm + SiLU units: the reference trains with `sync_batchnorm=True` whenever it runs DDP
+    (train.py:167 -> torch.nn.SyncBatchNorm: batch statistics over the rows of ALL ranks, affine gradients local).  One object is shared
+    by the BaseConvs of a model (`sast_amd.detection.convert_sync_batchnorm`); the C entry points are called in two phases around the
+    all-reduces issued here (include/sast_hip.h: SastConvBnArgs.sync_phase).  Collectives cannot be captured into a hipGraph by this
+    design (training.py keeps every RCCL call outside the graphs), so a model converted with it runs its PAFPN / head eagerly."""
+
+    def __init__(self, process_group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._ratio = None
+        self.n_collectives = 0
+
+    def active(self) -> bool:
+        return self.world > 1
+
+    def exchange_batch(self, n_local: int, device):
+        """once per pass over a model: every BatchNorm of the pass sees rows = samples * H_out * W_out, so the rows of all ranks follow
+        from the SAMPLE counts (they differ between ranks when a step keeps only the labelled samples, modules/detection.py:161-171)"""
+        t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+        self.dist.all_reduce(t, group=self.group)
+        self.n_collectives += 1
+        self._ratio = (int(round(float(t.item()))), int(n_local))
+
+    def rows_total(self, m_local: int, batch_local: int) -> int:
+        if self._ratio is None or self._ratio[1] != batch_local:
+            raise RuntimeError("sast_amd: SyncBatchNormGroup.exchange_batch(batch) must be called at the start of the pass")
+        return m_local // batch_local * self._ratio[0]
+
+    def all_reduce(self, t):
+        self.dist.all_reduce(t, group=self.group)
+        self.n_collectives += 1
+
+
+def _bn_ws_blocks(bn_ws, Cout):
+    """(fp64 forward sums, fp32 backward sums) views of one conv's reduction scratch (include/sast_hip.h: SAST_BN_WS_FLOATS)"""
+    n = bn_ws.numel() // 6
+    raw = bn_ws.data         # the scratch is saved for the backward (and is a slice of an arena other units saved too): the collectives
+    return raw[:4 * n].view(torch.float64), raw[4 * n:]      # write it like the kernels do, outside autograd's version counting
+
+
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers, handle, two_y):
+    def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers, handle, two_y,
+                sync=None):
         _need_gpu(x, w)
         x = x.contiguous()
         if not is_channels_last_weight(w):
@@ -766,7 +809,15 @@ class _ConvBnSilu(torch.autograd.Function):
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin1,
                   ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
                   run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1)
+        m_total = 0
+        if sync is not None and training and sync.active():
+            a.sync_phase = 1
+            L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
+            sync.all_reduce(_bn_ws_blocks(bn_ws, Cout)[0])
+            m_total = sync.rows_total(M, B)
+            a.sync_phase, a.m_total = 2, m_total
         L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
+        ctx.sync = (sync, m_total) if m_total else None
         ctx.save_for_backward(x, x2, conv_out, stats, bn_ws)
         ctx.params = (w, bn_w, bn_b)
         ctx.meta = (B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M)
@@ -811,11 +862,23 @@ class _ConvBnSilu(torch.autograd.Function):
                   ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
                   eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w),
                   d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2), **pk)
+        if ctx.sync is not None:
+            sync, m_total = ctx.sync
+            a.sync_phase = 1
+            L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
+            red = _bn_ws_blocks(bn_ws, Cout)[1]
+            loc = red.view(-1, 2, Cout).sum(0)              # this process's (sum dz, sum dz * xhat): the affine gradients stay local
+            for prm, v in ((bn_b, loc[0]), (bn_w, loc[1])):
+                g = _gbuf(prm)
+                if g is not None:
+                    g.add_(v)
+            sync.all_reduce(red)
+            a.sync_phase, a.m_total, a.d_bn_w, a.d_bn_b = 2, m_total, None, None
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 14
+        return (dx, dx2) + (None,) * 15
 
 
 def bn_ws_floats(cout: int) -> int:
@@ -958,12 +1021,15 @@ BN_FOLD = os.environ.get("SAST_BN_FOLD", "1") != "0"   # fold producers' BatchNo
 
 
 def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None,
-                 sole_consumer=False, two_outputs=False):
+                 sole_consumer=False, two_outputs=False, sync=None):
     """x_nhwc: a tensor, or a pair (xa, xb) standing for their channel concat (1x1 convs; the concat is never built).
-    bn_ws: optional zero-filled fp32[bn_ws_floats(Cout)] scratch (consumed: do not reuse within a step)."""
+    bn_ws: optional zero-filled fp32[bn_ws_floats(Cout)] scratch (consumed: do not reuse within a step).
+    sync: a SyncBatchNormGroup -- training-mode batch statistics over the rows of all its ranks."""
     x, x2 = x_nhwc if isinstance(x_nhwc, (tuple, list)) else (x_nhwc, None)
+    if sync is not None and not (training and sync.active()):
+        sync = None
     if two_outputs and (not TWO_OUT or not training or not torch.is_grad_enabled()):    # nothing to gain without a training-mode backward
-        y = conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, sole_consumer)
+        y = conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, sole_consumer, sync=sync)
         return y, y
     if not training and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, x2, w, bn_w, bn_b))):
         return _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, float(eps))
@@ -973,10 +1039,10 @@ def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, traini
     prods = _producers(x, x2, sole_consumer)
     if two_outputs:     # (y, y_alias) for an output with two consumers: their gradients meet inside the BatchNorm-backward kernels
         return _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, True, float(momentum), float(eps), bn_ws, prods,
-                                 None, True)
+                                 None, True, sync)
     handle = BnHandle() if training else None
     y = _ConvBnSilu.apply(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, bool(training), float(momentum), float(eps), bn_ws, prods,
-                          handle, False)
+                          handle, False, sync)
     if handle is not None:
         y._sast_bn = handle      # lets a sole consumer of y fold this conv's BatchNorm-backward reduction into its dX epilogue
     return y

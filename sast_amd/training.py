@@ -199,6 +199,11 @@ class TrainStep:
         (never captured).  not segmented and world == 1: ONE graph including the optimizer update; not segmented and
         world > 1: one graph for forward + backward, all-reduce + update behind it."""
         self.flat.check_views()
+        for m in (self.fpn, self.head):
+            grp = getattr(m, "_sync_group", None)
+            if grp is not None and grp.active():
+                raise RuntimeError("sast_amd.TrainStep.capture: the model was converted with convert_sync_batchnorm; its statistics "
+                                   "all-reduces sit inside the PAFPN / head passes and are not captured into hipGraphs -- run step()")
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):

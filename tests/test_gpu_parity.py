@@ -1428,3 +1428,78 @@ def test_mean_squares_matches_torch(dev):
     assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(lb))
     for p, q in zip(a, b):
         assert torch.allclose(p.grad, q.grad, rtol=1e-6, atol=1e-9)
+
+
+_SYNC_BN_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from oracle import sast_oracle as O                      # the checker: the PAFPN on the CONCATENATED batch of both ranks
+from sast_amd.detection import YOLOPAFPN, convert_sync_batchnorm
+from test_gpu_parity import load_params
+dist.init_process_group("gloo")                          # two ranks sharing the one GPU of the box: the collectives are what is tested
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+splits = {"even": (2, 2), "ragged": (1, 3)}[sys.argv[2]]
+chans, hw = (64, 128, 256), (32, 40)
+params = O.init_pafpn_params(chans, seed=5)
+gen = torch.Generator().manual_seed(77)
+full = {k: torch.randn(sum(splits), c, hw[0] >> i, hw[1] >> i, generator=gen) for i, (k, c) in enumerate(zip((2, 3, 4), chans))}
+lo = sum(splits[:rank]); hi = lo + splits[rank]
+net = convert_sync_batchnorm(YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev))
+load_params(net, params)
+net.train()
+feats = {k: v[lo:hi].to(dev).requires_grad_(True) for k, v in full.items()}
+outs = net(feats)
+sum((o ** 2).mean() for o in outs).backward()
+grads = {k: p.grad.clone() for k, p in net.named_parameters()}
+for g in grads.values():                                 # DDP: mean over ranks
+    dist.all_reduce(g); g /= world
+# the oracle on the whole batch; the objective the two ranks minimise together is the MEAN of their local losses
+p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+bufs = {k: v.clone() for k, v in params.items() if "running_" in k}
+fin = {k: v.clone().requires_grad_(True) for k, v in full.items()}
+ref = O.pafpn(fin, p, training=True, bufs=bufs)
+loss = 0
+b = 0
+for n in splits:
+    loss = loss + sum((o[b:b + n] ** 2).mean() for o in ref) / world
+    b += n
+loss.backward()
+def close(a, r, tol, what):
+    err = float((a.detach().cpu().double() - r.detach().double()).abs().max()); scale = float(r.detach().abs().max()) + 1e-30
+    assert err <= tol * scale, f"rank {rank} {what}: {err / scale:.3e} > {tol:.1e}"
+    return err / scale
+worst = 0.0
+for o, r in zip(outs, ref):
+    err = float((o.detach().cpu() - r[lo:hi].detach()).abs().max())
+    assert err <= 3e-5, f"rank {rank} forward: {err:.3e}"
+for k in (2, 3, 4):
+    worst = max(worst, close(feats[k].grad, fin[k].grad[lo:hi] * world, 3e-4, f"din{k}"))
+for k, g in grads.items():
+    worst = max(worst, close(g, p[k].grad, 3e-4, k))
+sd = net.state_dict()
+for k, v in bufs.items():
+    close(sd[k], v, 1e-5, k)
+assert net._sync_group.n_collectives == 1 + 2 * 32, net._sync_group.n_collectives
+print(f"ok rank {rank} worst grad err {worst:.2e}")
+'''
+
+
+@pytest.mark.parametrize("split", ["even", "ragged"])
+def test_sync_batchnorm_two_ranks_match_whole_batch(dev, tmp_path, split):
+    """the reference trains with SyncBatchNorm under DDP (train.py:167).  Two ranks (gloo, sharing the GPU), each with its part of a
+    batch -- equal halves, and 1 + 3 samples as after a label-sparse selection -- through the PAFPN converted with
+    convert_sync_batchnorm: outputs, input gradients, rank-averaged parameter gradients and running statistics equal the oracle's PAFPN
+    on the whole batch (torch BatchNorm over all rows = SyncBatchNorm over the ranks)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_SYNC_BN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29741" if split == "even" else "29742", str(script), root, split],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok rank") == 2, r.stdout[-2000:]
+    print(r.stdout[-300:])

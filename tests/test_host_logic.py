@@ -304,3 +304,26 @@ def test_kink_aware_scores_gradient_comparison():
     if float((0.4 * s.grad[5, 3] * x[5]).abs().max()) > 1e-3 * float(rW.abs().max()):
         with pytest.raises(AssertionError):
             scores_grads_close("blk.", bad, db, rW, rb, rec)
+
+
+def test_convert_sync_batchnorm_marks_every_unit_and_is_inert_on_one_rank():
+    """train.py:167 (sync_batchnorm under DDP): the conversion shares ONE group object between all conv + BatchNorm + SiLU units and the
+    models that open a pass; without a process group (world 1) it is inactive, so the fused two-conv launches stay in use"""
+    from sast_amd.detection import YOLOPAFPN, YOLOXHead, BaseConv, convert_sync_batchnorm
+    from sast_amd.detection.network_blocks import sync_active
+    from sast_amd.functional import SyncBatchNormGroup
+    fpn = YOLOPAFPN(depth=0.33, in_stages=(2, 3, 4), in_channels=(16, 32, 64))
+    head = YOLOXHead(num_classes=2, strides=(8, 16, 32), in_channels=(16, 32, 64))
+    both = torch.nn.ModuleList([fpn, head])
+    keys = list(both.state_dict().keys())
+    assert convert_sync_batchnorm(both) is both
+    units = [m for m in both.modules() if isinstance(m, BaseConv)]
+    assert len(units) > 20 and all(isinstance(m.sync_bn, SyncBatchNormGroup) for m in units)
+    assert len({id(m.sync_bn) for m in units} | {id(fpn._sync_group), id(head._sync_group)}) == 1
+    assert not fpn._sync_group.active() and not any(sync_active(m) for m in units)
+    assert list(both.state_dict().keys()) == keys          # same parameters / buffers / names: checkpoints are unaffected
+    g = SyncBatchNormGroup()
+    g._ratio = (7, 2)                                      # 7 samples over all ranks, 2 here
+    assert g.rows_total(2 * 40 * 50, 2) == 7 * 40 * 50
+    with pytest.raises(RuntimeError):
+        g.rows_total(3 * 40 * 50, 3)                       # a pass with another local batch needs its own exchange
