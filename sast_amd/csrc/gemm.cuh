@@ -300,16 +300,23 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   // 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (each with a private L2); with xcd_remap the launch order is
   // re-read so that consecutive work items -- the column tiles that share the same A rows, and all tiles of one reduction
   // split -- run on the SAME XCD at about the same time and share its L2 instead of fetching the rows once per XCD.
+  // The remap deals CONTIGUOUS ranges of work items to the XCDs, so it must be built on the work that exists: with a device-side row
+  // count (the kept tokens of an MS-WSA layer) only the first ceil(Meff / BM) row tiles are real, and a map over the launched grid would
+  // hand ALL of them to the first one or two XCDs while the other six run nothing but empty workgroups (measured: a 215-row fc1 launch
+  // took as long as the 1920-row one it was sized for).  The blocks past the effective range exit.
+  const int Meff = dM ? min(M, *dM) : M;
+  const int ntile = nbj * ((Meff + BM - 1) / BM);
+  const int nwork = ntile * nsplit;
   int work = block;
   if (xcd_remap) {
-    work = (block & 7) * (nblocks >> 3) + (block >> 3);
+    const int per = dM ? (nwork + 7) >> 3 : nblocks >> 3;
+    if ((block >> 3) >= per) return;
+    work = (block & 7) * per + (block >> 3);
   }
-  const int ntile = nbj * ((M + BM - 1) / BM);
-  if (work >= ntile * nsplit) return;
+  if (work >= nwork) return;
   const int tile_id = SPLIT ? work % ntile : work, split_id = SPLIT ? work / ntile : 0;
   const int bj = tile_id % nbj, bm = tile_id / nbj;
   const int m0 = bm * BM, j0 = bj * BJ;
-  const int Meff = dM ? min(M, *dM) : M;
   int Reff_ = dR ? min(R, *dR) : R;
   if constexpr (LoaderWantsM0<LB>::value) Reff_ = min(Reff_, lb.reduce_len(m0));   // row-tile dependent reduction length (parity classes)
   const int Reff = Reff_;
