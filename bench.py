@@ -58,7 +58,7 @@ class Trainer:
     """bench harness around sast_amd.training.TrainStep (the reference's step is Lightning's, modules/detection.py:113-221)."""
 
     def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False, yolox_loss=False, segmented=None,
-                 label_every=0, sync_bn=False):
+                 label_every=0, sync_bn=False, event_dtype="int32"):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.training import TrainStep
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -105,6 +105,8 @@ class Trainer:
         # seq_len > 1 (opt-in, --seq-len): the reference's BPTT step shape (modules/detection.py:141-177): L timesteps with the
         # recurrent states carried, PAFPN + loss on the last one, one backward through time.  Default 1 = BASELINE's metric.
         self.xs = [synthetic_events(BATCH, HW, seed=rank + 1000 * t).to(dev) for t in range(seq_len)]
+        if event_dtype == "uint8":      # the dataset's storage type (data/genx_utils/sequence_base.py:88-98): stays bytes up to the stem conv
+            self.xs = [x.to(torch.uint8) for x in self.xs]
         self.x = self.xs[0]
         self.fwd_only = fwd_only or infer     # --fwd-only: backbone forward, the reference's own benchmark.py protocol (BASELINE config C2)
         self.loss = None
@@ -300,6 +302,8 @@ def main():
                     "experiments) -- reported as a different metric, index decisions differ from the fp32 reference's")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: SyncBatchNorm in the PAFPN / head like the reference's DDP runs (train.py:167); "
                     "eager step (the statistics all-reduces are not captured into hipGraphs).  Default: per-rank batch statistics")
+    ap.add_argument("--event-dtype", choices=["int32", "uint8"], default="int32", help="int32: the reference's benchmark.py protocol (`.int()`); "
+                    "uint8: the dataset's storage type -- the event tensor stays bytes up to the stem conv's loaders")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -337,7 +341,8 @@ def main():
     run_stream.wait_stream(torch.cuda.current_stream())
     torch.cuda.set_stream(run_stream)
     tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer,
-                 yolox_loss=args.loss == "yolox", segmented=args.segmented, label_every=args.label_every, sync_bn=args.sync_bn)
+                 yolox_loss=args.loss == "yolox", segmented=args.segmented, label_every=args.label_every, sync_bn=args.sync_bn,
+                 event_dtype=args.event_dtype)
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -407,6 +412,7 @@ def main():
                        "allreduce_exposed_ms": exposed_ms,
                        # the reference's DDP runs convert BatchNorm to SyncBatchNorm (train.py:167); false = per-rank batch statistics
                        "sync_batchnorm": bool(tr.sync_bn),
+                       "event_dtype": args.event_dtype,
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
                        "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},

@@ -50,6 +50,10 @@ int sast_nzratio_padded(const void* x, int dtype, int B, int Cin, int H, int W, 
  * workgroup finishes the ratios and clears it), so a caller allocates and clears it once. */
 int sast_input_prep(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, float* y,
                     sast_stream_t stream);
+/* the same for the event tensor as the dataset stores it (uint8 counts, data/genx_utils/sequence_base.py:88-98): y keeps the BYTES,
+ * (B,Hp,Wp,C) uint8 NHWC, zero padded -- a quarter of the traffic of the fp32 copy.  The stem conv reads it directly
+ * (SastDownArgs.x_dtype = SAST_DT_U8); the `.float()` of modules/detection.py:143-144 / sast_rnn.py:153 happens in its loaders. */
+int sast_input_prep_u8(const uint8_t* x, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, uint8_t* y, sast_stream_t stream);
 
 /* layout changes at the NCHW API boundary (reference: ops.py:19-30 nChw_2_nhwC / nhwC_2_nChw, x.float() sast_rnn.py:153) */
 int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream);
@@ -87,6 +91,9 @@ typedef struct SastDownArgs {
   const float* dy; float* dx; /* dx may be NULL (stem) */
   float* dw; float* d_ln_w; float* d_ln_b;
   float* ws;             /* fp32[B*Ho*Wo*Cout] */
+  int32_t x_dtype;       /* SAST_DT_F32 (0): x is fp32 NHWC.  SAST_DT_U8: x is the uint8 event tensor in NHWC bytes as written by
+                            sast_input_prep_u8 (stem only: dx must be NULL) -- the conv loaders widen the bytes themselves, the fp32
+                            copy of the input never exists (modules/detection.py:143-144 does `.float()` first) */
 } SastDownArgs;
 int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream);
 int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream);

@@ -33,6 +33,7 @@ def _struct(name, spec):
 SastDownArgs = _struct("SastDownArgs", [
     (I32, "B H W Cin Cout factor"),
     (P, "x w ln_w ln_b pe conv_out mean rstd y dy dx dw d_ln_w d_ln_b ws"),
+    (I32, "x_dtype"),
 ])
 SastScoreArgs = _struct("SastScoreArgs", [
     (I32, "B L C r_stride"), (F32, "amp"),
@@ -81,6 +82,7 @@ _SIGNATURES = {
     "sast_nchw_to_nhwc_padded": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_nhwc_to_nchw": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "sast_input_prep": (C.c_int, [P] + [C.c_int] * 7 + [P, P, P, P]),
+    "sast_input_prep_u8": (C.c_int, [P] + [C.c_int] * 6 + [P, P, P, P]),
     "sast_add_rows": (C.c_int, [P, P, P, C.c_int, C.c_int, C.c_int, P]),
     "sast_mean_square_fwd": (C.c_int, [P, P, C.c_int, P, P]),
     "sast_mean_square_bwd": (C.c_int, [P, P, C.c_int, P, C.c_int, P, P]),

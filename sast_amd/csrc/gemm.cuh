@@ -1228,6 +1228,54 @@ struct LdIm2col {
   }
   SAST_DEFAULT_FINISH
 };
+// the stem reading the event tensor as stored -- uint8 counts, NHWC (4x less input traffic than the fp32 copy): four
+// channels of a pixel are ONE 32-bit load; the bytes are widened at the LDS store (`finish`), so the load stays untouched in flight
+__device__ __forceinline__ float4 widen_u8x4(float raw) {
+  const unsigned w = __float_as_uint(raw);
+  return make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+}
+struct LdIm2colQ8 {
+  static constexpr bool RC = true;
+  const unsigned char* x; ConvGeom g;          // g.ldx = bytes per pixel (= Cin, a multiple of 4)
+  struct Ctx { const unsigned char* img; int iy0, ix0; bool ok; };
+  __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
+    const bool ok = i < Ieff;
+    const int ii = ok ? i : 0;
+    const int t = fast_div(ii, g.Wo, g.wo_mul), ox = ii - t * g.Wo, b = fast_div(t, g.Ho, g.ho_mul), oy = t - b * g.Ho;
+    return Ctx{x + (size_t)b * g.H * g.W * g.ldx, oy * g.stride - g.pad, ox * g.stride - g.pad, ok};
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    int kh, kw, ch;
+    split_tap(g, g.Cin, g.cin_mul, min(r, Reff - 4), kh, kw, ch);
+    const int iy = c.iy0 + kh, ix = c.ix0 + kw;
+    const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+    ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
+    v.x = *reinterpret_cast<const float*>(c.img + ((size_t)cy * g.W + cx) * g.ldx + ch);
+    aux = 0.f;
+  }
+  __device__ __forceinline__ float4 finish(float4 v, float, bool ok) const { return sel4(ok, widen_u8x4(v.x)); }
+};
+struct LdIm2colTQ8 {
+  static constexpr bool RC = false;
+  const unsigned char* x; ConvGeom g;
+  struct Ctx { int kh, kw, c; bool ok; };
+  __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
+    Ctx c;
+    c.ok = j < NJ;
+    split_tap(g, g.Cin, g.cin_mul, c.ok ? j : 0, c.kh, c.kw, c.c);
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
+    const int rr = min(r, Reff - 1);
+    const int t = fast_div(rr, g.Wo, g.wo_mul), ox = rr - t * g.Wo, b = fast_div(t, g.Ho, g.ho_mul), oy = t - b * g.Ho;
+    const int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
+    const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
+    ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
+    v.x = *reinterpret_cast<const float*>(x + ((size_t)(b * g.H + cy) * g.W + cx) * g.ldx + c.c);
+    aux = 0.f;
+  }
+  __device__ __forceinline__ float4 finish(float4 v, float, bool ok) const { return sel4(ok, widen_u8x4(v.x)); }
+};
 // the same when the channel count is a multiple of the k-tile (every conv of the path except the stem, Cin = 20): a k-tile then lies
 // inside ONE tap, which is decoded from the wave-uniform tile base on the scalar unit -- per lane only the pixel clamp and the
 // address remain (the generic form spends ~35 VALU instructions per float4 on the decode; with the conv loaders of two jobs

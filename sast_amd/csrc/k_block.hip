@@ -155,6 +155,10 @@ int sast_input_prep(const void* x, int dtype, int B, int C, int H, int W, int Hp
   if (!x || !ws || !r || !y || H > Hp || W > Wp || H % 4 || W % 4 || Hp % 32 || Wp % 32 || C != 20 || ((Hp / 32) * (Wp / 32)) % 2) return SAST_EINVAL;
   return input_prep_dispatch(x, dtype, y, ws, r, B, C, H, W, Hp, Wp, (hipStream_t)stream);
 }
+int sast_input_prep_u8(const uint8_t* x, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, uint8_t* y, sast_stream_t stream) {
+  if (!x || !ws || !r || !y || H > Hp || W > Wp || H % 4 || W % 4 || Hp % 32 || Wp % 32 || C != 20 || ((Hp / 32) * (Wp / 32)) % 2) return SAST_EINVAL;
+  return input_prep_u8(x, y, ws, r, B, C, H, W, Hp, Wp, (hipStream_t)stream);
+}
 int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream) {
   return nhwc_to_nchw_launch(x, y, B, C, H * W, (hipStream_t)stream);
 }

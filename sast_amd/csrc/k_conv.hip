@@ -480,7 +480,11 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
   const int k = 2 * a->factor - 1;
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
-  int rc = conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
+  int rc;
+  if (a->x_dtype == SAST_DT_U8)       // the stem on the stored uint8 event tensor (NHWC bytes, written by sast_input_prep_u8)
+    rc = gemm_auto(LdIm2colQ8{(const unsigned char*)a->x, g}, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
+  else if (a->x_dtype != SAST_DT_F32) return SAST_EINVAL;
+  else rc = conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, EpStore{a->conv_out, a->Cout, nullptr}, M, a->Cout, K, st);
   if (rc) return rc;
   return ln_fwd_launch(a->conv_out, a->y, a->ln_w, a->ln_b, a->pe, g.Ho * g.Wo, a->mean, a->rstd, M, a->Cout, 1e-5f, st);
 }
@@ -494,6 +498,11 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
   float* dconv = a->ws;
   int rc = ln_bwd_launch(a->conv_out, a->dy, a->ln_w, a->mean, a->rstd, dconv, a->d_ln_w, a->d_ln_b, M, a->Cout, st);
   if (rc) return rc;
+  if (a->x_dtype == SAST_DT_U8) {     // an integer input has no gradient: the weight gradient only
+    if (a->dx) return SAST_EINVAL;
+    return gemm_tn(LdRowsT{dconv, a->Cout}, LdIm2colTQ8{(const unsigned char*)a->x, g}, a->dw, K, a->Cout, K, M, st);
+  }
+  if (a->x_dtype != SAST_DT_F32) return SAST_EINVAL;
   return conv_bwd_pair(dconv, a->x, g, a->Cout, a->w, a->dw, a->dx, a->Cin, st);
 }
 

@@ -145,11 +145,14 @@ int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int
 // the lanes of the wave.  Counts: wave -> LDS -> one atomic per (level, channel) and workgroup; the LAST workgroup (ticket) turns the
 // counts into ratios and clears counters and ticket again, so the scratch stays zero between calls.
 constexpr int PREP_WAVES = 2;
-template <typename T, int C>
-__global__ __launch_bounds__(64 * PREP_WAVES) void input_prep_kernel(const T* __restrict__ x, float* __restrict__ y, int* __restrict__ ws,
+// TY = float: y is the fp32 NHWC copy.  TY = unsigned char (uint8 input only): y keeps the stored bytes, NHWC -- the stem conv's loaders
+// widen them (gemm.cuh: LdIm2colQ8), a quarter of the bytes written here and read there.
+template <typename T, int C, typename TY = float>
+__global__ __launch_bounds__(64 * PREP_WAVES) void input_prep_kernel(const T* __restrict__ x, TY* __restrict__ y, int* __restrict__ ws,
                                                                      float* __restrict__ r, int B, int H, int W, int Hp, int Wp,
                                                                      float s0, float s1, float s2, float s3) {
-  __shared__ __attribute__((aligned(16))) float tile_s[PREP_WAVES][8 * 32 * C];
+  __shared__ __attribute__((aligned(16))) TY tile_s[PREP_WAVES][8 * 32 * C];
+  constexpr bool BYTES = sizeof(TY) == 1;
   __shared__ int cnt_s[4 * C];
   __shared__ int last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void input_prep_kernel(const T* __
   const int y0 = ty * 32 + cy * 4, x0 = tx * 32 + cx * 4;
   const bool inside = live && y0 < H && x0 < W;  // H, W are multiples of 4: a cell is inside or in the zero padding as a whole
   struct alignas(4 * sizeof(T)) Vec4 { T v[4]; };
-  float* tl = tile_s[wave];
+  TY* tl = tile_s[wave];
   float m[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) m[c] = -INFINITY;
@@ -189,15 +192,25 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void input_prep_kernel(const T* __
           m[c0 + ch] = fmaxf(m[c0 + ch], v[ch][px]);
         }
 #pragma unroll
-      for (int px = 0; px < 4; ++px) st4(tl + ((cy * 32 + cx * 4 + px) * C + c0), make_float4(v[0][px], v[1][px], v[2][px], v[3][px]));
+      for (int px = 0; px < 4; ++px) {
+        if constexpr (BYTES) {
+          const unsigned w = inside ? ((unsigned)q[c0].v[px] | ((unsigned)q[c0 + 1].v[px] << 8) | ((unsigned)q[c0 + 2].v[px] << 16) |
+                                       ((unsigned)q[c0 + 3].v[px] << 24)) : 0u;
+          *reinterpret_cast<unsigned*>(tl + ((cy * 32 + cx * 4 + px) * C + c0)) = w;
+        } else {
+          st4((float*)tl + ((cy * 32 + cx * 4 + px) * C + c0), make_float4(v[0][px], v[1][px], v[2][px], v[3][px]));
+        }
+      }
     }
     if (rr < 3) request(rr + 1);
     __syncthreads();
     if (live) {
-      constexpr int ROW4 = 32 * C / 4;           // float4 per 32-pixel row segment
+      constexpr int VE = 16 / sizeof(TY);                // elements per 16-byte vector
+      constexpr int ROW4 = 32 * C / VE;                  // 16-byte vectors per 32-pixel row segment
       for (int i = lane; i < 8 * ROW4; i += 64) {
         const int row = i / ROW4, off = i - row * ROW4;
-        st4(y + (((size_t)b * Hp + ty * 32 + row * 4 + rr) * Wp + tx * 32) * C + 4 * off, ld4(tl + row * 32 * C + 4 * off));
+        *reinterpret_cast<float4*>(y + (((size_t)b * Hp + ty * 32 + row * 4 + rr) * Wp + tx * 32) * C + VE * off) =
+            *reinterpret_cast<const float4*>(tl + row * 32 * C + VE * off);
       }
     }
   }
@@ -241,8 +254,8 @@ __global__ __launch_bounds__(64 * PREP_WAVES) void input_prep_kernel(const T* __
   }
 }
 
-template <typename T>
-int input_prep_launch(const void* x, float* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
+template <typename T, typename TY = float>
+int input_prep_launch(const void* x, TY* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   if (C != 20) return SAST_EINVAL;               // the stacked-histogram representation of the path: 2 polarities x 10 bins
   const int tiles = B * (Hp / 32) * (Wp / 32);
   float s[4];
@@ -252,10 +265,13 @@ int input_prep_launch(const void* x, float* y, int* ws, float* r, int B, int C, 
     s[l] = (float)((double)B / numel);
     f *= 2;
   }
-  SAST_LAUNCH((input_prep_kernel<T, 20>), dim3((tiles + PREP_WAVES - 1) / PREP_WAVES), dim3(64 * PREP_WAVES), 0, st, (const T*)x, y, ws, r,
+  SAST_LAUNCH((input_prep_kernel<T, 20, TY>), dim3((tiles + PREP_WAVES - 1) / PREP_WAVES), dim3(64 * PREP_WAVES), 0, st, (const T*)x, y, ws, r,
                      B, H, W, Hp, Wp, s[0], s[1], s[2], s[3]);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
+}
+int input_prep_u8(const unsigned char* x, unsigned char* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
+  return input_prep_launch<unsigned char, unsigned char>(x, y, ws, r, B, C, H, W, Hp, Wp, st);
 }
 int input_prep_dispatch(const void* x, int dtype, float* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st) {
   switch (dtype) {

@@ -10,6 +10,7 @@ int zero_fill(void* p, size_t bytes, hipStream_t st);   // kernel-based clear (g
 int nzr_dispatch(const void* x, int dtype, int* cnt, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st);
 int nchw_to_nhwc_dispatch(const void* x, int dtype, float* y, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st);
 int input_prep_dispatch(const void* x, int dtype, float* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st);
+int input_prep_u8(const unsigned char* x, unsigned char* y, int* ws, float* r, int B, int C, int H, int W, int Hp, int Wp, hipStream_t st);
 int nhwc_to_nchw_launch(const float* x, float* y, int B, int C, int HW, hipStream_t st);
 int ln_fwd_launch(const float* x, float* y, const float* gamma, const float* beta, const float* add, int add_rows,
                   float* mean, float* rstd, int rows, int C, float eps, hipStream_t st);

@@ -197,7 +197,9 @@ class RNNDetector(nn.Module):
         pad = self.in_res_hw if (x.shape[-2] < self.in_res_hw[0] or x.shape[-1] < self.in_res_hw[1]) else None
         if not hasattr(self, "_prep_ws"):
             self._prep_ws = {}                # scratch of the input kernel, owned by this module (one per device and batch size)
-        r, xin = SF.input_prep(x, pad, self._prep_ws)   # ratios, cast, padding and layout change in one launch that reads x once
+        # ratios, cast, padding and layout change in one launch that reads x once; a uint8 tensor (the dataset's storage type) stays bytes:
+        # the stem conv's loaders widen them, the fp32 copy of the input is never written
+        r, xin = SF.input_prep(x, pad, self._prep_ws, keep_bytes=SF.STEM_U8)
         states, output, P = [], {}, []
         for i, stage in enumerate(self.stages):
             if cut_before_stage is not None and i == cut_before_stage and torch.is_grad_enabled() and xin.requires_grad:

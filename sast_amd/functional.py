@@ -130,11 +130,16 @@ def nchw_to_nhwc_float(x: torch.Tensor, pad_hw=None) -> torch.Tensor:
 _PREP_WS = {}
 
 
+STEM_U8 = os.environ.get("SAST_STEM_U8", "1") != "0"     # uint8 event tensors stay bytes up to the stem conv's loaders
+
+
 @torch.no_grad()
-def input_prep(x: torch.Tensor, pad_hw=None, ws_cache: Optional[dict] = None):
+def input_prep(x: torch.Tensor, pad_hw=None, ws_cache: Optional[dict] = None, keep_bytes: bool = False):
     """non_zero_ratio (sast_rnn.py:45-60) + x.float() + zero padding to pad_hw (utils/padding.py:29-53) + NCHW->NHWC (ops.py:19-24)
     in ONE launch that reads the event tensor once -> (r (B,4,C) fp32, x_nhwc (B,Hp,Wp,C) fp32).  Falls back to the two separate
-    launches for shapes the fused kernel does not cover (padded sizes that are not multiples of 32, channel counts other than 20)."""
+    launches for shapes the fused kernel does not cover (padded sizes that are not multiples of 32, channel counts other than 20).
+    keep_bytes (uint8 input, the dataset's storage type): x_nhwc stays uint8 -- only `downsample_ln` (the stem) may consume it; its
+    loaders do the `.float()`.  Ignored (fp32 result) for other dtypes and for the fallback shapes."""
     _need_gpu(x)
     if x.dtype not in _DT:
         x = x.float()
@@ -157,9 +162,13 @@ def input_prep(x: torch.Tensor, pad_hw=None, ws_cache: Optional[dict] = None):
             raise RuntimeError("sast_amd: input_prep needs one un-captured warm-up call (per model and batch size) before graph capture")
         ws = cache[key] = torch.zeros(B * 4 * Cc + 1, device=x.device, dtype=torch.int32)
     r = torch.empty(B, 4, Cc, device=x.device, dtype=torch.float32)
-    y = torch.empty(B, Hp, Wp, Cc, device=x.device, dtype=torch.float32)
+    u8 = keep_bytes and x.dtype == torch.uint8
+    y = torch.empty(B, Hp, Wp, Cc, device=x.device, dtype=torch.uint8 if u8 else torch.float32)
     try:
-        L.check(L.lib().sast_input_prep(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, Hp, Wp, ws.data_ptr(), r.data_ptr(), y.data_ptr(), _stream()), "input_prep")
+        if u8:
+            L.check(L.lib().sast_input_prep_u8(x.data_ptr(), B, Cc, H, W, Hp, Wp, ws.data_ptr(), r.data_ptr(), y.data_ptr(), _stream()), "input_prep_u8")
+        else:
+            L.check(L.lib().sast_input_prep(x.data_ptr(), _DT[x.dtype], B, Cc, H, W, Hp, Wp, ws.data_ptr(), r.data_ptr(), y.data_ptr(), _stream()), "input_prep")
     except Exception:
         cache.pop(key, None)         # a failed launch may leave counters / the ticket non-zero: never reuse this buffer
         raise
@@ -254,24 +263,28 @@ class _DownsampleLN(torch.autograd.Function):
         conv_out = torch.empty(M, Cout, device=dev)
         stats = torch.empty(2, M, device=dev)
         y = torch.empty(B, Ho, Wo, Cout, device=dev)
+        if x.dtype not in (torch.float32, torch.uint8):
+            raise RuntimeError("sast_amd: downsample_ln reads fp32 rows, or (the stem) the uint8 event tensor from input_prep(keep_bytes=True)")
+        xdt = _DT[x.dtype]
         a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
-                  pe=_ptr(pe), conv_out=conv_out, mean=stats[0], rstd=stats[1], y=y)
+                  pe=_ptr(pe), conv_out=conv_out, mean=stats[0], rstd=stats[1], y=y, x_dtype=xdt)
         L.check(L.lib().sast_downsample_ln_fwd(C.byref(a), _stream()), "downsample_ln_fwd")
         ctx.save_for_backward(x, conv_out, stats)
         ctx.params = (w, ln_w, ln_b)
-        ctx.meta = (B, H, W, Cin, Cout, factor)
+        ctx.meta = (B, H, W, Cin, Cout, factor, xdt)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, conv_out, stats = ctx.saved_tensors
         w, ln_w, ln_b = ctx.params
-        B, H, W, Cin, Cout, factor = ctx.meta
+        B, H, W, Cin, Cout, factor, xdt = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = torch.empty(conv_out.numel(), device=x.device)
         a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
-                  conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=_g(w), d_ln_w=_g(ln_w), d_ln_b=_g(ln_b), ws=ws)
+                  conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=_g(w), d_ln_w=_g(ln_w), d_ln_b=_g(ln_b), ws=ws,
+                  x_dtype=xdt)
         L.check(L.lib().sast_downsample_ln_bwd(C.byref(a), _stream()), "downsample_ln_bwd")
         return dx, None, None, None, None, None
 

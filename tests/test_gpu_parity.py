@@ -1503,3 +1503,40 @@ def test_sync_batchnorm_two_ranks_match_whole_batch(dev, tmp_path, split):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stdout.count("ok rank") == 2, r.stdout[-2000:]
     print(r.stdout[-300:])
+
+
+@pytest.mark.parametrize("hw,raw,B", [((128, 160), (120, 152), 2), ((384, 640), (360, 640), 2)])
+def test_stem_reads_uint8_event_tensor(dev, hw, raw, B):
+    """the dataset stores uint8 counts (data/genx_utils/sequence_base.py:88-98); the reference pads and `.float()`s them
+    (modules/detection.py:143-144, sast_rnn.py:153).  Here a uint8 tensor stays bytes through the input kernel (NHWC, zero padded) and the
+    stem conv's loaders widen them: same ratios, bit-identical forward and the same stem gradients as the fp32-copy path (int32 input),
+    and equal to the oracle on the padded tensor."""
+    from sast_amd import functional as SF
+    from sast_amd.detection import RNNDetector
+    part, E = ((4, 5), 32) if hw == (128, 160) else ((6, 10), 32)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    params = O.init_backbone_params(ocfg, seed=61, ls_init=0.5)
+    load_params(net, params)
+    x = O.count_events(B, raw, seed=62, density=0.05)                          # uint8 counts 0..10, unpadded
+    assert x.dtype == torch.uint8 and int(x.max()) > 1
+    xp = torch.nn.functional.pad(x, (0, hw[1] - raw[1], 0, hw[0] - raw[0]))
+    r, y = SF.input_prep(x.to(dev), hw, {}, keep_bytes=True)
+    assert y.dtype == torch.uint8 and torch.equal(y.cpu(), xp.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(r.cpu(), O.non_zero_ratio(xp))
+    outs = {}
+    for name, xin in (("bytes", x.to(dev)), ("fp32 copy", x.int().to(dev))):
+        net.zero_grad(set_to_none=True)
+        o, _s, P = net(xin)
+        sum((o[k] ** 2).mean() for k in (1, 2, 3, 4)).backward()
+        outs[name] = ({k: o[k].detach() for k in o}, [int(p) for p in P], net.stages[0].downsample_cf2cl.conv.weight.grad.clone())
+    (oa, Pa, ga), (ob, Pb, gb) = outs["bytes"], outs["fp32 copy"]
+    assert Pa == Pb
+    for k in (1, 2, 3, 4):
+        assert torch.equal(oa[k], ob[k]), k
+    maxnorm_close(ga, gb, 1e-5, "stem dW, bytes vs fp32 copy")
+    if hw == (128, 160):
+        oo, _s, Po = O.backbone(xp, None, params, ocfg)
+        assert Pa == [int(p) for p in Po]
+        for k in (1, 2, 3, 4):
+            abs_close(oa[k].cpu(), oo[k], FWD_ATOL, f"stage {k}")
