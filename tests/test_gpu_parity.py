@@ -1540,3 +1540,45 @@ def test_stem_reads_uint8_event_tensor(dev, hw, raw, B):
         assert Pa == [int(p) for p in Po]
         for k in (1, 2, 3, 4):
             abs_close(oa[k].cpu(), oo[k], FWD_ATOL, f"stage {k}")
+
+
+def test_batch_16_equals_two_copies_of_batch_8(dev):
+    """maximum size by a size-independent property: every op of the path is per sample except the PAFPN's batch statistics, and those are
+    unchanged when the batch is duplicated.  So the 1Mpx B = 16 step on [x; x] (2 M pixels x 20 channels x 16 samples; 32-bit element
+    indices of the BatchNorm / LayerNorm / conv kernels at their largest) must reproduce the B = 8 step on x: per-sample outputs and
+    selection bit-identical between the two halves and equal to B = 8's (outputs up to the summation order of the tile shapes the
+    row count selects), every parameter gradient of the mean loss equal to B = 8's."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    hw, part, amp, seed = (384, 640), (6, 10), 2e-2, 3
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, amp=amp)
+    params = O.init_backbone_params(ocfg, seed=seed, ls_init=0.5)
+    fparams = O.init_pafpn_params((128, 256, 512), seed=seed + 50)
+    x8 = O.count_events(8, hw, seed=200 + seed, density=0.1)
+    res = {}
+    for B, x in ((8, x8), (16, torch.cat([x8, x8], 0))):
+        net = RNNDetector(_rcfg(hw, part, 64, amp, 0.5)).to(dev)
+        fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(128, 256, 512)).to(dev).train()
+        load_params(net, params)
+        load_params(fpn, fparams)
+        out, _st, P = net(x.to(dev))
+        outs = fpn({k: out[k] for k in (2, 3, 4)})
+        loss = sum((o ** 2).mean() for o in outs) + 0.25 * sum((out[k] ** 2).mean() for k in (1, 2, 3, 4))
+        loss.backward()
+        grads = {"net." + k: v.grad.clone() for k, v in net.named_parameters()}
+        grads.update({"fpn." + k: v.grad.clone() for k, v in fpn.named_parameters()})
+        res[B] = ({k: out[k].detach() for k in out}, [o.detach() for o in outs], [int(p) for p in P], float(loss), grads)
+        del net, fpn, out, outs, loss
+        torch.cuda.empty_cache()
+    (o8, f8, P8, l8, g8), (o16, f16, P16, l16, g16) = res[8], res[16]
+    assert P16 == P8                                        # index_count is per sample (SAST.py:136,159: floor(len / B))
+    for k in (1, 2, 3, 4):
+        assert torch.equal(o16[k][:8], o16[k][8:]), k       # the two copies take identical paths
+        abs_close(o16[k][:8], o8[k], 2e-6, f"h{k}, B=16 vs B=8")   # tile shapes / k-splits follow the row count: another summation order
+    for i, (a, b) in enumerate(zip(f16, f8)):
+        maxnorm_close(a[:8], b, 1e-4, f"pafpn out {i}")     # batch statistics: sums over twice the rows, same mean / variance up to rounding
+        maxnorm_close(a[:8], a[8:], 1e-6, f"pafpn out {i}, copies")   # (the bar of test_full_size_train_parity for the PAFPN outputs)
+    assert abs(l16 - l8) <= 1e-6 * abs(l8)
+    for k in g8:
+        if ".to_scores." in k:
+            continue                                        # behind the scoring ReLU: kink-sensitive (compared kink-aware elsewhere)
+        maxnorm_close(g16[k], g8[k], GRAD_RTOL, k)
