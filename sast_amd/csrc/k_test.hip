@@ -93,6 +93,16 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
     case 18: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 19: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 12: return launch_gemm<Tile<32, 32, 1, 1, 1, 32>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    // deeper register prefetch for the small grids (<= one workgroup per CU: occupancy is not what the registers cost there)
+    case 50: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 51: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4, 6>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 52: return launch_gemm<Tile<32, 64, 1, 2, 1, 16, 4, 8>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 53: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 54: return launch_gemm<Tile<32, 32, 1, 1, 1, 16, 8, 6>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 55: return launch_gemm<Tile<64, 64, 2, 2, 1, 16, 2, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 56: return launch_gemm<Tile<64, 64, 2, 2, 1, 16, 2, 6>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 57: return launch_gemm<Tile<64, 64, 2, 2, 1, 16, 1, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
+    case 58: return launch_gemm<Tile<64, 64, 2, 2, 1, 16, 4, 4>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     // 32-wide k-tiles on presplit operands (two k16 steps per phase)
     case 40: return launch_gemm<Tile<64, 64, 2, 2, 1, 32, 1>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
     case 41: return launch_gemm<Tile<64, 64, 2, 2, 1, 32, 2>>(la, lb, ep, M, N, K, nullptr, nullptr, st);
