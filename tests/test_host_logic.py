@@ -327,3 +327,33 @@ def test_convert_sync_batchnorm_marks_every_unit_and_is_inert_on_one_rank():
     assert g.rows_total(2 * 40 * 50, 2) == 7 * 40 * 50
     with pytest.raises(RuntimeError):
         g.rows_total(3 * 40 * 50, 3)                       # a pass with another local batch needs its own exchange
+
+
+def test_struct_sizes_and_offsets_match_a_c_compiler(tmp_path):
+    """the boundary is a C ABI: the header must compile as plain C (gcc, no HIP), and every struct the Python host fills must have the
+    size and field offsets the C compiler gives it (the ctypes mirrors are written by hand: an appended or reordered field that the
+    field-name test above accepts could still disagree on padding)."""
+    import ctypes as C
+    from sast_amd import _lib
+    names = ["SastDownArgs", "SastScoreArgs", "SastSel", "SastMswsaArgs", "SastLstmArgs", "SastConvBnArgs", "SastConvBn2Args", "SastHeadGeom",
+             "SastSampleGather", "SastSampleMask"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{_lib.HEADER_PATH}"', "int main(void) {"]
+    for n in names:
+        st = getattr(_lib, n)
+        lines.append(f'  printf("{n} %zu", sizeof({n}));')
+        for f, _t in st._fields_:
+            lines.append(f'  printf(" %zu", offsetof({n}, {f}));')
+        lines.append('  printf("\\n");')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "abi"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-o", str(exe), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines()
+    assert len(out) == len(names)
+    for line in out:
+        n, size, *offs = line.split()
+        st = getattr(_lib, n)
+        assert C.sizeof(st) == int(size), (n, C.sizeof(st), size)
+        assert [getattr(st, f).offset for f, _t in st._fields_] == [int(o) for o in offs], n
