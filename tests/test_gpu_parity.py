@@ -1481,6 +1481,32 @@ sd = net.state_dict()
 for k, v in bufs.items():
     close(sd[k], v, 1e-5, k)
 assert net._sync_group.n_collectives == 1 + 2 * 32, net._sync_group.n_collectives
+# the YOLOX head under the same conversion (15 more units, stacked first tower convs replaced by the plain ones): SimOTA assignment of
+# this rank's images, running statistics and the num_fg-weighted loss against the oracle's head on the WHOLE batch
+from sast_amd.detection import YOLOXHead
+hp = O.init_head_params(chans, num_classes=3, seed=9)
+head = convert_sync_batchnorm(YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=chans).to(dev))
+load_params(head, hp)
+head.train()
+gen = torch.Generator().manual_seed(78)
+hfull = [torch.randn(sum(splits), c, hw[0] >> i, hw[1] >> i, generator=gen) for i, c in enumerate(chans)]
+labels = O.synthetic_labels(sum(splits), (hw[0] * 8, hw[1] * 8), 3, max_labels=6, seed=11)
+labels[:, 0, :] = torch.tensor([1.0, 100.0, 90.0, 60.0, 50.0])             # every image has at least one box
+_out, losses = head(tuple(f[lo:hi].to(dev) for f in hfull), labels[lo:hi].to(dev))
+hb = {k: v.clone() for k, v in hp.items() if "running_" in k}
+ref_h = O.yolox_head_train(hfull, labels, hp, bufs=hb)
+fg, mg, _piou = head.last_assignment
+for j, b in enumerate(range(lo, hi)):
+    rfg, rmatched, _rp = ref_h["assign"][b]
+    assert torch.equal(fg[j].cpu().bool(), rfg), f"rank {rank} image {b}: foreground anchors differ"
+    assert torch.equal(mg[j].cpu()[rfg].long(), rmatched.long()), f"rank {rank} image {b}: matched boxes differ"
+hsd = head.state_dict()
+for k, v in hb.items():
+    close(hsd[k], v, 1e-5, "head " + k)
+nfg = torch.tensor([float(sum(int(ref_h["assign"][b][0].sum()) for b in range(lo, hi)))], dtype=torch.float64)
+acc = torch.tensor([float(losses["loss"]) * float(nfg), float(nfg)], dtype=torch.float64)
+dist.all_reduce(acc)
+assert abs(acc[0] / acc[1] - float(ref_h["loss"])) <= 2e-5 * abs(float(ref_h["loss"])), (float(acc[0] / acc[1]), float(ref_h["loss"]))
 print(f"ok rank {rank} worst grad err {worst:.2e}")
 '''
 
@@ -1490,7 +1516,9 @@ def test_sync_batchnorm_two_ranks_match_whole_batch(dev, tmp_path, split):
     """the reference trains with SyncBatchNorm under DDP (train.py:167).  Two ranks (gloo, sharing the GPU), each with its part of a
     batch -- equal halves, and 1 + 3 samples as after a label-sparse selection -- through the PAFPN converted with
     convert_sync_batchnorm: outputs, input gradients, rank-averaged parameter gradients and running statistics equal the oracle's PAFPN
-    on the whole batch (torch BatchNorm over all rows = SyncBatchNorm over the ranks)."""
+    on the whole batch (torch BatchNorm over all rows = SyncBatchNorm over the ranks).  Then the converted YOLOX head on each rank's
+    images: SimOTA assignment index-exact, running statistics of its 15 BatchNorms, and the num_fg-weighted mean of the ranks' losses equal
+    to the oracle's head on the whole batch."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
