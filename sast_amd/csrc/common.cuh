@@ -28,6 +28,9 @@ inline bool launch_failed_take() { const bool f = g_launch_failed != 0; g_launch
 #define SAST_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
 #define SAST_EXT_LAUNCH(...) do { (void)hipGetLastError(); hipExtLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
 #define SAST_CHECK_LAUNCH() do { if (sast::launch_failed_take()) return SAST_ELAUNCH; } while (0)
+// first statement of every extern "C" entry point: a latch left set by an EARLIER entry point that returned through an error path
+// without consuming it (a failed launch inside a void helper, then `return rc`) must not be reported by this, unrelated, call
+#define SAST_ENTRY() ((void)sast::launch_failed_take())
 
 namespace sast {
 

@@ -390,19 +390,11 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 
   // a loader with UNIFORM_TILE gets the k-tile base r0 (wave-uniform) and the lane's offset inside the tile separately: whatever it
   // decodes from r0 alone (the tap of an implicit-GEMM convolution whose channel count is a multiple of BK) runs on the scalar unit
-#ifdef SAST_EXP_A_REUSE   // timing experiment only (wrong results): the A operand is loaded / split / stored every N-th phase
-  int exp_g_ = 0, exp_s_ = 0;
-#define SAST_EXP_A_ON(ctr) (((ctr)++ % SAST_EXP_A_REUSE) == 0)
-#else
-#define SAST_EXP_A_ON(ctr) true
-  int exp_g_ = 0, exp_s_ = 0; (void)exp_g_; (void)exp_s_;
-#endif
   auto gload = [&](int kt, int set) {
     const int r0 = kt * BK;
-    const bool a_on = SAST_EXP_A_ON(exp_g_);
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if ((A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) && a_on) {
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
         if constexpr (LoaderUniformTile<LA>::value) la.load_u(ca[it], r0, ra_off[it], Rl, BK, ra[set][it], aa[set][it], oa[set][it]);
         else la.load(ca[it], r0 + ra_off[it], Rl, ra[set][it], aa[set][it], oa[set][it]);
       }
@@ -424,10 +416,9 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   auto lstore = [&](int buf, int set) {
     float* as = As + buf * A_STAGE;
     float* bs = Bs + buf * B_STAGE;
-    const bool a_on = SAST_EXP_A_ON(exp_s_);
 #pragma unroll
     for (int it = 0; it < A_PER; ++it)
-      if ((A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) && a_on) {
+      if (A_SLOTS % NT == 0 || tid + it * NT < A_SLOTS) {
         const float4 v = la.finish(ra[set][it], aa[set][it], oa[set][it]);
         if constexpr (SPLIT && !LA::RC) {
           if (do_colsum) { csacc[it].x += v.x; csacc[it].y += v.y; csacc[it].z += v.z; csacc[it].w += v.w; }
@@ -888,8 +879,14 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
 // are read back, so the report carries measured time AND algorithmic FLOPs (2*M*N*R with the real M/R).
 void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin);
 // kernel-exact timing: events handed to hipExtLaunchKernelGGL are stamped at the kernel's own begin / end
+// a_cap / b_cap (optional, bytes): the size of the tensor an operand is GATHERED from when that is smaller than its virtual M x R /
+// N x R extent (implicit-GEMM convolutions: the im2col matrix is k*k times the image) -- SURVEY 8d prices an operand at what is read once
 void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st,
-                        hipEvent_t* e0, hipEvent_t* e1);
+                        hipEvent_t* e0, hipEvent_t* e1, double a_cap = -1.0, double b_cap = -1.0);
+template <class L, class = void> struct LoaderSrcBytes { static double get(const L&) { return -1.0; } };
+template <class L> struct LoaderSrcBytes<L, std::void_t<decltype(std::declval<const L&>().src_bytes())>> {
+  static double get(const L& l) { return l.src_bytes(); }
+};
 void prof_kernel_events_ex(const char* tag, double flops, double bytes, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
 void prof_sum_k(const int* Kw, int W, hipStream_t st, double* sum_k, double* sum_k2);
 bool prof_enabled();
@@ -910,7 +907,7 @@ inline int launch_gemm(const LA& la, const LB& lb, const EP& ep, int M, int NJ, 
   const int grid = remap ? (nb + 7) / 8 * 8 : nb;
   if (prof_enabled()) {
     hipEvent_t e0, e1;
-    prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, &e0, &e1);
+    prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, dM, dR, st, &e0, &e1, LoaderSrcBytes<LA>::get(la), LoaderSrcBytes<LB>::get(lb));
     SAST_EXT_LAUNCH((gemm_kernel<T, LA, LB, EP, false>), dim3(grid + ep_side_blocks(ep)), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ,
                           R, dM, dR, (float*)nullptr, 1, remap);
   } else {
@@ -927,13 +924,15 @@ template <class T, class LA, class LB, class EP>
 inline int launch_gemm_split(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, const int* dR,
                              int splits, float* colsum, hipStream_t st) {
   if (M <= 0 || NJ <= 0 || R <= 0) return SAST_OK;
+  // the column sums of a reduce-contiguous A are taken from its fp32 LDS image; a PRESPLIT one has none (gemm_body would add zeros)
+  if (colsum != nullptr && LA::RC && GemmSmem<T, LA, LB>::PSA) return SAST_EINVAL;
   const int nb = ((M + T::BM - 1) / T::BM) * ((NJ + T::BJ - 1) / T::BJ);
   if (splits < 1) splits = 1;
   const int remap = xcd_remap_enabled() && nb * splits >= 16;
   const int grid = remap ? (nb * splits + 7) / 8 * 8 : nb * splits;
   if (prof_enabled()) {
     hipEvent_t e0, e1;
-    prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, &e0, &e1);
+    prof_kernel_events(__PRETTY_FUNCTION__, T::G, M, NJ, R, nullptr, dR, st, &e0, &e1, LoaderSrcBytes<LA>::get(la), LoaderSrcBytes<LB>::get(lb));
     SAST_EXT_LAUNCH((gemm_kernel<T, LA, LB, EP, true>), dim3(grid), dim3(T::NT), 0, st, e0, e1, 0, la, lb, ep, M, NJ, R,
                           (const int*)nullptr, dR, colsum, splits, remap);
   } else {
@@ -951,7 +950,8 @@ inline int gemm_grid(int ntile, int nsplit, int& remap) {
   return remap ? (n + 7) / 8 * 8 : n;
 }
 void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, int NJ1, int R1, const int* dM1, const int* dR1, int G2,
-                         int M2, int NJ2, int R2, const int* dM2, const int* dR2, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
+                         int M2, int NJ2, int R2, const int* dM2, const int* dR2, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1,
+                         double a1_cap = -1.0, double b1_cap = -1.0, double a2_cap = -1.0, double b2_cap = -1.0);
 
 // job 1: split-R weight gradient (TS tile), job 2: plain GEMM (TP tile), one launch
 template <class TS, class LA1, class LB1, class EP1, class TP, class LA2, class LB2, class EP2>
@@ -960,6 +960,7 @@ inline int launch_gemm_dual(const LA1& la1, const LB1& lb1, const EP1& ep1, int 
                             hipStream_t st) {
   using J1 = GemmJob<TS, LA1, LB1, EP1, true>;
   using J2 = GemmJob<TP, LA2, LB2, EP2, false>;
+  if (colsum != nullptr && LA1::RC && GemmSmem<TS, LA1, LB1>::PSA) return SAST_EINVAL;   // see launch_gemm_split
   if (splits < 1) splits = 1;
   const int nt1 = ((M1 + TS::BM - 1) / TS::BM) * ((NJ1 + TS::BJ - 1) / TS::BJ);
   const int nt2 = ((M2 + TP::BM - 1) / TP::BM) * ((NJ2 + TP::BJ - 1) / TP::BJ);
@@ -972,7 +973,8 @@ inline int launch_gemm_dual(const LA1& la1, const LB1& lb1, const EP1& ep1, int 
   constexpr int NTHREADS = TS::NT > TP::NT ? TS::NT : TP::NT;
   if (prof_enabled()) {
     hipEvent_t e0, e1;
-    prof_kernel_events2(__PRETTY_FUNCTION__, 0.0, TS::G, M1, NJ1, R1, nullptr, dR1, TP::G, M2, NJ2, R2, dM2, nullptr, st, &e0, &e1);
+    prof_kernel_events2(__PRETTY_FUNCTION__, 0.0, TS::G, M1, NJ1, R1, nullptr, dR1, TP::G, M2, NJ2, R2, dM2, nullptr, st, &e0, &e1,
+                        LoaderSrcBytes<LA1>::get(la1), LoaderSrcBytes<LB1>::get(lb1), LoaderSrcBytes<LA2>::get(la2), LoaderSrcBytes<LB2>::get(lb2));
     SAST_EXT_LAUNCH((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
   } else {
     SAST_LAUNCH((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, a, b, n1);
@@ -1209,6 +1211,7 @@ __device__ __forceinline__ void split_tap(const ConvGeom& g, int chans, unsigned
 // RC: A[m = (b,oy,ox)][r = (kh,kw,c)]
 struct LdIm2col {
   static constexpr bool RC = true;
+  double src_bytes() const { return 4.0 * g.B * g.H * g.W * g.Cin; }   // host: the image is read once, not k*k times
   const float* x; ConvGeom g;
   struct Ctx { const float* img; int iy0, ix0; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
@@ -1236,6 +1239,7 @@ __device__ __forceinline__ float4 widen_u8x4(float raw) {
 }
 struct LdIm2colQ8 {
   static constexpr bool RC = true;
+  double src_bytes() const { return 1.0 * g.B * g.H * g.W * g.Cin; }
   const unsigned char* x; ConvGeom g;          // g.ldx = bytes per pixel (= Cin, a multiple of 4)
   struct Ctx { const unsigned char* img; int iy0, ix0; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
@@ -1257,6 +1261,7 @@ struct LdIm2colQ8 {
 };
 struct LdIm2colTQ8 {
   static constexpr bool RC = false;
+  double src_bytes() const { return 1.0 * g.B * g.H * g.W * g.Cin; }
   const unsigned char* x; ConvGeom g;
   struct Ctx { int kh, kw, c; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
@@ -1296,6 +1301,7 @@ struct LdIm2colU : LdIm2col {
 // IC: B(t)[r = (b,oy,ox)][j = (kh,kw,c)]   (weight gradient)
 struct LdIm2colT {
   static constexpr bool RC = false;
+  double src_bytes() const { return 4.0 * g.B * g.H * g.W * g.Cin; }
   const float* x; ConvGeom g;
   struct Ctx { int kh, kw, c; bool ok; };
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const {
@@ -1319,6 +1325,7 @@ struct LdIm2colT {
 // replicate padding: the clamped taps (kh < pad at iy == 0, same for x) fold onto output row/col 0.
 struct LdConvDx {
   static constexpr bool RC = true;
+  double src_bytes() const { return 4.0 * g.B * g.Ho * g.Wo * Cout; }   // host: dY is read once, not once per tap
   const float* dy; ConvGeom g; int Cout; int lddy; unsigned cout_mul;   // cout_mul = div_mul_of(Cout, reduce length), never 0
   struct Ctx { const float* img; int iy, ix; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {
@@ -1423,6 +1430,7 @@ struct ConvDxClasses {
 };
 struct LdConvDxP {
   static constexpr bool RC = true;
+  double src_bytes() const { return 4.0 * g.B * g.Ho * g.Wo * Cout; }
   const float* dy; ConvGeom g; int Cout; int lddy; unsigned cout_mul; ConvDxClasses k;
   struct Ctx { const float* img; int iy, ix; unsigned kh, kw; bool ok; };
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const {

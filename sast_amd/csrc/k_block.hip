@@ -132,81 +132,81 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
 
 extern "C" {
 
-int sast_version(void) { return 100; }
-int sast_mfma_split3(void) { return SAST_MFMA_BF16 ? 2 : SAST_MFMA_SPLIT3; }
+int sast_version(void) { SAST_ENTRY(); return 100; }
+int sast_mfma_split3(void) { SAST_ENTRY(); return SAST_MFMA_BF16 ? 2 : SAST_MFMA_SPLIT3; }
 
-int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream) {
+int sast_nzratio(const void* x, int dtype, int B, int Cin, int H, int W, int32_t* cnt_ws, float* r, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !cnt_ws || !r || H % 32 || W % 32) return SAST_EINVAL;
   return nzr_dispatch(x, dtype, cnt_ws, r, B, Cin, H, W, H, W, (hipStream_t)stream);
 }
 int sast_nzratio_padded(const void* x, int dtype, int B, int Cin, int H, int W, int Hp, int Wp, int32_t* cnt_ws, float* r,
-                        sast_stream_t stream) {
+                        sast_stream_t stream) { SAST_ENTRY();
   if (!x || !cnt_ws || !r || Hp % 32 || Wp % 32 || H > Hp || W > Wp || H % 4 || W % 4) return SAST_EINVAL;
   return nzr_dispatch(x, dtype, cnt_ws, r, B, Cin, H, W, Hp, Wp, (hipStream_t)stream);
 }
-int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream) {
+int sast_nchw_to_nhwc(const void* x, int dtype, int B, int C, int H, int W, float* y, sast_stream_t stream) { SAST_ENTRY();
   return nchw_to_nhwc_dispatch(x, dtype, y, B, C, H, W, H, W, (hipStream_t)stream);
 }
-int sast_nchw_to_nhwc_padded(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, float* y, sast_stream_t stream) {
+int sast_nchw_to_nhwc_padded(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, float* y, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !y || H > Hp || W > Wp) return SAST_EINVAL;
   return nchw_to_nhwc_dispatch(x, dtype, y, B, C, H, W, Hp, Wp, (hipStream_t)stream);
 }
-int sast_input_prep(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, float* y, sast_stream_t stream) {
+int sast_input_prep(const void* x, int dtype, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, float* y, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !ws || !r || !y || H > Hp || W > Wp || H % 4 || W % 4 || Hp % 32 || Wp % 32 || C != 20 || ((Hp / 32) * (Wp / 32)) % 2) return SAST_EINVAL;
   return input_prep_dispatch(x, dtype, y, ws, r, B, C, H, W, Hp, Wp, (hipStream_t)stream);
 }
-int sast_input_prep_u8(const uint8_t* x, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, uint8_t* y, sast_stream_t stream) {
+int sast_input_prep_u8(const uint8_t* x, int B, int C, int H, int W, int Hp, int Wp, int32_t* ws, float* r, uint8_t* y, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !ws || !r || !y || H > Hp || W > Wp || H % 4 || W % 4 || Hp % 32 || Wp % 32 || C != 20 || ((Hp / 32) * (Wp / 32)) % 2) return SAST_EINVAL;
   return input_prep_u8(x, y, ws, r, B, C, H, W, Hp, Wp, (hipStream_t)stream);
 }
-int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream) {
+int sast_nhwc_to_nchw(const float* x, int B, int C, int H, int W, float* y, sast_stream_t stream) { SAST_ENTRY();
   return nhwc_to_nchw_launch(x, y, B, C, H * W, (hipStream_t)stream);
 }
 
-int sast_add_rows(const float* x, const float* table, float* y, int rows, int C, int table_rows, sast_stream_t stream) {
+int sast_add_rows(const float* x, const float* table, float* y, int rows, int C, int table_rows, sast_stream_t stream) { SAST_ENTRY();
   if (C % 4) return SAST_EINVAL;
   return add_rows_launch(x, table, y, rows, C, table_rows, (hipStream_t)stream);
 }
 
-int sast_mean_square_fwd(const float* const* x, const size_t* n, int count, float* partials, sast_stream_t stream) {
+int sast_mean_square_fwd(const float* const* x, const size_t* n, int count, float* partials, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !n || !partials || count < 1 || count > 4) return SAST_EINVAL;
   for (int t = 0; t < count; ++t) if (!x[t] || n[t] % 4) return SAST_EINVAL;
   return mean_square_launch(x, nullptr, n, count, SAST_MEAN_SQUARE_BLOCKS, partials, nullptr, 1, (hipStream_t)stream);
 }
 int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, int d_stride, float* const* dx,
-                         sast_stream_t stream) {
+                         sast_stream_t stream) { SAST_ENTRY();
   if (!x || !n || !d_partials || !dx || count < 1 || count > 4 || (d_stride != 0 && d_stride != 1)) return SAST_EINVAL;
   for (int t = 0; t < count; ++t) if (!x[t] || !dx[t] || n[t] % 4) return SAST_EINVAL;
   return mean_square_launch(x, dx, n, count, SAST_MEAN_SQUARE_BLOCKS, nullptr, d_partials, d_stride, (hipStream_t)stream);
 }
 
-int sast_mask_token_fwd(float* x, const uint8_t* mask, const float* token, const float* pos_emb, int rows, int C, int L, sast_stream_t stream) {
+int sast_mask_token_fwd(float* x, const uint8_t* mask, const float* token, const float* pos_emb, int rows, int C, int L, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !mask || !token || C % 4 || L < 1) return SAST_EINVAL;
   return mask_token_fwd_launch(x, mask, token, pos_emb, rows, C, L, (hipStream_t)stream);
 }
-int sast_gather_samples(const SastSampleGather* a, sast_stream_t stream) {
+int sast_gather_samples(const SastSampleGather* a, sast_stream_t stream) { SAST_ENTRY();
   if (!a || !a->out || a->n_src < 1 || a->n_src > SAST_GATHER_MAX_SRC || a->n_out < 0 || a->n_out > SAST_GATHER_MAX_OUT || a->sample_floats % 4) return SAST_EINVAL;
   for (int j = 0; j < a->n_out; ++j) if (a->t_of[j] >= a->n_src || a->b_of[j] >= a->B || !a->src[a->t_of[j]]) return SAST_EINVAL;
   if (a->n_out == 0) return SAST_OK;
   return sample_gather_launch(*a, false, (hipStream_t)stream);
 }
-int sast_gather_samples_bwd(const SastSampleGather* a, sast_stream_t stream) {
+int sast_gather_samples_bwd(const SastSampleGather* a, sast_stream_t stream) { SAST_ENTRY();
   if (!a || a->n_src < 1 || a->n_src > SAST_GATHER_MAX_SRC || a->n_out < 0 || a->n_out > SAST_GATHER_MAX_OUT || a->B < 1 || a->B > 256 ||
       a->sample_floats % 4 || (a->n_out && !a->out)) return SAST_EINVAL;
   for (int t = 0; t < a->n_src; ++t) if (!a->dsrc[t]) return SAST_EINVAL;
   return sample_gather_launch(*a, true, (hipStream_t)stream);
 }
-int sast_zero_samples(float* x, int B, size_t sample_floats, const SastSampleMask* sel, sast_stream_t stream) {
+int sast_zero_samples(float* x, int B, size_t sample_floats, const SastSampleMask* sel, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !sel || B < 1 || B > 256 || sample_floats % 4) return SAST_EINVAL;
   return zero_samples_launch(x, B, sample_floats, *sel, (hipStream_t)stream);
 }
-int sast_mask_token_bwd(const float* dy, const uint8_t* mask, float* dx, float* d_token, int rows, int C, sast_stream_t stream) {
+int sast_mask_token_bwd(const float* dy, const uint8_t* mask, float* dx, float* d_token, int rows, int C, sast_stream_t stream) { SAST_ENTRY();
   if (!dy || !mask || !dx || !d_token || C % 4) return SAST_EINVAL;
   return mask_token_bwd_launch(dy, mask, dx, d_token, rows, C, (hipStream_t)stream);
 }
 
 int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode, double bounce, const SastSel* s,
-                sast_stream_t stream) {
+                sast_stream_t stream) { SAST_ENTRY();
   if (!tok || !s) return SAST_EINVAL;
   const int N = (H / ph) * (W / pw), T = ph * pw;
   // thresholds are evaluated in double and rounded to fp32 once, exactly like the reference's
@@ -218,7 +218,7 @@ int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode,
 }
 
 int sast_select_pair(const float* tok, int B, int H, int W, int ph, int pw, double bounce, const SastSel* win, const SastSel* grid,
-                     sast_stream_t stream) {
+                     sast_stream_t stream) { SAST_ENTRY();
   if (!tok || !win || !grid) return SAST_EINVAL;
   const int N = (H / ph) * (W / pw), T = ph * pw;
   const float thr_w = (float)((1.0 / N) / (1.0 + bounce));
@@ -227,7 +227,7 @@ int sast_select_pair(const float* tok, int B, int H, int W, int ph, int pw, doub
 }
 
 // ------------------------------------------------------------------ scoring + STP
-int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
+int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("score_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
   if (!a || a->C % 4) return SAST_EINVAL;
@@ -242,7 +242,7 @@ int sast_score_stp_fwd(const SastScoreArgs* a, sast_stream_t stream) {
   return stp_fwd_launch(a->xp, a->s, a->scale, a->amp, a->xw, a->tok, a->B, a->L, C, st);
 }
 
-int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) {
+int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("score_bwd", a->C, a->B * a->L, st);
   const int M = a->B * a->L, C = a->C;
@@ -267,7 +267,7 @@ size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
   return (size_t)rows * (2 * inner + C + C + 3 * C + C) + (size_t)C * inner + (size_t)C * C + 2 * C;
 }
 
-int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
+int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("mswsa_fwd", a ? a->C : 0, a ? (a->mode ? -1 : 1) * a->B * a->H * a->W : 0, st);
   if (!a || a->C % 4 || a->inner % 32) return SAST_EINVAL;
@@ -310,7 +310,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) {
   return cb_apply_fwd_launch(a->cb_m, a->Y, a->ls2, a->cb_sum, a->sel.row_tok, dR, R, a->cb_tps, C, a->out, st);
 }
 
-int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
+int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("mswsa_bwd", a->C, (a->mode ? -1 : 1) * a->B * a->H * a->W, st);
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
@@ -390,7 +390,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) {
 }
 
 // ------------------------------------------------------------------ ConvLSTM (1x1 conv on [x|h])
-int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
+int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("lstm_fwd", a ? a->C : 0, a ? a->B * a->L : 0, st);
   if (!a || a->C % 4) return SAST_EINVAL;
@@ -406,7 +406,7 @@ int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) {
   return launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
 }
 
-int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) {
+int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("lstm_bwd", a->C, a->B * a->L, st);
   const int M = a->B * a->L, C = a->C;

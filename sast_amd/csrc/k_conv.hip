@@ -95,52 +95,6 @@ struct EpBnSilu2 {
     (j < C ? y0 + (size_t)m * C + j : y1 + (size_t)m * C + (j - C))[0] = z * sigmoid_exact(z);
   }
 };
-#ifdef SAST_EXP_SKIP_FOLDABLE_BN_APPLY
-// timing-only stand-ins (tools/bn_fold_bound.py): the conv epilogue ALSO writes a finite, realistically scaled y = silu(gamma z + beta)
-// and (mean, rstd) = (0, 1), so that everything downstream of a dropped apply launch keeps computing on ordinary data (garbage / NaN
-// operands would bias the measurement through the clocks: DVFS)
-struct EpStoreStatsY {
-  static constexpr bool COLSTATS = true;
-  float* c; int ldc; double* sums; float* y; int ldy; const float* gamma; const float* beta; float* stats; int C;
-  struct Col { float g, b; };
-  using Aux = EpNone;
-  __device__ __forceinline__ Col col(int j) const { stats[j] = 0.f; stats[C + j] = 1.f; return Col{gamma[j], beta[j]}; }
-  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
-  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
-    c[(size_t)m * ldc + j] = v[0];
-    const float z = v[0] * k.g + k.b;
-    y[(size_t)m * ldy + j] = z * sigmoid_exact(z);
-  }
-  __device__ __forceinline__ void stat(float v, const Col&, const Aux&, float& a, float& b) const { a += v; b += v * v; }
-  __device__ __forceinline__ void flush(int copy, int j, int NJ, float s, float q) const {
-    double* sp = sums + (size_t)copy * 2 * NJ;
-    atomicAdd(sp + j, (double)s); atomicAdd(sp + NJ + j, (double)q);
-  }
-};
-struct EpStoreStats2Y {
-  static constexpr bool COLSTATS = true;
-  float* c1; float* c2; int C; double* sums1; double* sums2; float* y1; float* y2; const float* g1; const float* b1; const float* g2; const float* b2;
-  float* st1; float* st2;
-  struct Col { float g, b; };
-  using Aux = EpNone;
-  __device__ __forceinline__ Col col(int j) const {
-    if (j < C) { st1[j] = 0.f; st1[C + j] = 1.f; return Col{g1[j], b1[j]}; }
-    st2[j - C] = 0.f; st2[j] = 1.f; return Col{g2[j - C], b2[j - C]};
-  }
-  __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
-  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
-    const float z = v[0] * k.g + k.b, yv = z * sigmoid_exact(z);
-    if (j < C) { c1[(size_t)m * C + j] = v[0]; y1[(size_t)m * C + j] = yv; }
-    else { c2[(size_t)m * C + (j - C)] = v[0]; y2[(size_t)m * C + (j - C)] = yv; }
-  }
-  __device__ __forceinline__ void stat(float v, const Col&, const Aux&, float& a, float& b) const { a += v; b += v * v; }
-  __device__ __forceinline__ void flush(int copy, int j, int, float s, float q) const {
-    double* sp = (j < C ? sums1 : sums2) + (size_t)copy * 2 * C;
-    const int jj = j < C ? j : j - C;
-    atomicAdd(sp + jj, (double)s); atomicAdd(sp + C + jj, (double)q);
-  }
-};
-#endif
 // forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
 // fp64 per-channel sum / sum of squares, one atomic pair per channel per block.
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int M, int C, double* __restrict__ sums,
@@ -473,7 +427,7 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
 extern "C" {
 
 // ------------------------------------------------------------------ downsample conv + LayerNorm
-int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
+int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("down_fwd", a ? a->Cout : 0, a ? a->B * a->H * a->W : 0, st);
   if (!a || a->Cin % 4 || a->Cout % 4) return SAST_EINVAL;
@@ -489,7 +443,7 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) {
   return ln_fwd_launch(a->conv_out, a->y, a->ln_w, a->ln_b, a->pe, g.Ho * g.Wo, a->mean, a->rstd, M, a->Cout, 1e-5f, st);
 }
 
-int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
+int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("down_bwd", a->Cout, a->B * a->H * a->W, st);
   const int k = 2 * a->factor - 1;
@@ -507,9 +461,9 @@ int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) {
 }
 
 // ------------------------------------------------------------------ conv + BN + SiLU
-int sast_conv_bn_ws_floats(int Cout) { return SAST_BN_WS_FLOATS(Cout); }
+int sast_conv_bn_ws_floats(int Cout) { SAST_ENTRY(); return SAST_BN_WS_FLOATS(Cout); }
 
-int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
+int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("convbn_fwd", a ? a->Cout * 10 + a->ksize : 0, a ? a->B * a->H * a->W : 0, st);
   if (!a || a->Cin % 4 || a->Cout % 4 || (a->ksize != 1 && a->ksize != 3)) return SAST_EINVAL;
@@ -536,14 +490,6 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
                         : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
                : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
-#ifdef SAST_EXP_SKIP_FOLDABLE_BN_APPLY
-  if (a->training && a->momentum < 0.f) {
-    const EpStoreStatsY ep{a->conv_out, C, sums, a->y, a->ldy, a->bn_w, a->bn_b, a->stats, C};
-    return one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
-                        : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
-               : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
-  }
-#endif
   if (phase == 2) {            // the conv and its sums are phase 1's
   } else if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
@@ -576,7 +522,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) {
   return SAST_OK;
 }
 
-int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
+int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("convbn_bwd", a->Cout * 10 + a->ksize, a->B * a->H * a->W, st);
   const int k = a->ksize, pad = (k - 1) / 2;
@@ -628,7 +574,7 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) {
 }
 
 // ------------------------------------------------------------------ two 1x1 conv + BN + SiLU of the same input
-int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
+int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   if (!a || a->Cin % 4 || a->Cout % 4 || a->Cin1 % 4 || a->Cin1 <= 0 || a->Cin1 > a->Cin || (a->Cin1 < a->Cin && !a->x2)) return SAST_EINVAL;
   ProfScope ps_("convbn2_fwd", a->Cout * 10 + 1, a->B * a->H * a->W, st);
@@ -651,14 +597,6 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
     zero_fill(a->bn_ws1, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
   }
   const LdRows2 la{a->x, a->ldx, a->Cin1, a->Cin1 < a->Cin ? a->x2 : nullptr, a->ldx2};
-#ifdef SAST_EXP_SKIP_FOLDABLE_BN_APPLY
-  if (a->momentum0 < 0.f) {
-    const EpStoreStats2Y epy{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1, a->y0, a->y1, a->bn_w0, a->bn_b0, a->bn_w1, a->bn_b1,
-                             a->stats0, a->stats1};
-    return a->ksize == 3 ? conv_gemm(a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx), LdWeightNT2{a->w0, a->w1, K, C}, epy, M, 2 * C, K, st)
-                         : gemm_auto(la, LdWeightNT2{a->w0, a->w1, K, C}, epy, M, 2 * C, K, st);
-  }
-#endif
   const EpStoreStats2 ep{a->conv_out0, a->conv_out1, C, (double*)a->bn_ws0, (double*)a->bn_ws1};
   int rc = a->ksize == 3 ? conv_gemm(a->x, geom_of(a->B, a->H, a->W, a->Cin, 3, 1, 1, 0, a->ldx), LdWeightNT2{a->w0, a->w1, K, C}, ep, M,
                                      2 * C, K, st)
@@ -675,7 +613,7 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) {
   return SAST_OK;
 }
 
-int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
+int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   if (!a || (a->Cin1 < a->Cin && !a->x2)) return SAST_EINVAL;
   ProfScope ps_("convbn2_bwd", a->Cout * 10 + 1, a->B * a->H * a->W, st);
@@ -733,14 +671,14 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) {
 }
 
 // ------------------------------------------------------------------ upsample / concat
-int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream) {
+int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream) { SAST_ENTRY();
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   const size_t n4 = (size_t)B * 4 * H * W * ((C1 + C2) / 4);
   SAST_LAUNCH(upsample_cat_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
-int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H, int W, int C1, int C2, sast_stream_t stream) {
+int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H, int W, int C1, int C2, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   const size_t n4 = (size_t)B * H * W * (C1 / 4), n4b = (size_t)B * 4 * H * W * (C2 / 4);
@@ -749,14 +687,14 @@ int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H,
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
-int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream) {
+int sast_cat2_fwd(const float* a, const float* b, float* out, int rows, int C1, int C2, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   int rc = slice_copy(a, C1, 0, out, C1 + C2, 0, C1, rows, st);
   if (rc) return rc;
   return slice_copy(b, C2, 0, out, C1 + C2, C1, C2, rows, st);
 }
-int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int C2, sast_stream_t stream) {
+int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int C2, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   int rc = slice_copy(dout, C1 + C2, 0, da, C1, 0, C1, rows, st);
   if (rc) return rc;
@@ -764,7 +702,7 @@ int sast_cat2_bwd(const float* dout, float* da, float* db, int rows, int C1, int
 }
 
 int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const float* lr_step, double beta1, double beta2, float eps,
-               float weight_decay, float grad_scale, float clip_value, sast_stream_t stream) {
+               float weight_decay, float grad_scale, float clip_value, sast_stream_t stream) { SAST_ENTRY();
   if (n % 4) return SAST_EINVAL;
   const size_t n4 = n / 4;
   SAST_LAUNCH(adamw_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr_step, beta1,
@@ -774,7 +712,7 @@ int sast_adamw(float* p, const float* g, float* m, float* v, size_t n, const flo
 }
 int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, float* lr_step, double beta1, double beta2, float eps,
                         float weight_decay, float grad_scale, float clip_value, double initial_lr, double max_lr, double min_lr,
-                        double end1, double end2, sast_stream_t stream) {
+                        double end1, double end2, sast_stream_t stream) { SAST_ENTRY();
   if (n % 4 || !(end2 > end1)) return SAST_EINVAL;
   const size_t n4 = n / 4;
   const OneCycle oc{1, initial_lr, max_lr, min_lr, end1, end2};
@@ -786,11 +724,11 @@ int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, 
 
 #ifdef SAST_TL_ENABLE
 // variant builds only: per-block phase stamps of the LAST GEMM launch of this translation unit (conv / FPN kernels)
-int sast_tl_reset(void) {
+int sast_tl_reset(void) { SAST_ENTRY();
   static unsigned long long zeros[8 * 8192];
   return hipMemcpyToSymbol(HIP_SYMBOL(sast_tl_buf), zeros, sizeof(zeros)) == hipSuccess ? 0 : -5;
 }
-int sast_tl_read(unsigned long long* host_out, int nblocks) {
+int sast_tl_read(unsigned long long* host_out, int nblocks) { SAST_ENTRY();
   if (nblocks > 8192) nblocks = 8192;
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sast_tl_buf), sizeof(unsigned long long) * 8 * nblocks) == hipSuccess ? 0 : -5;
 }

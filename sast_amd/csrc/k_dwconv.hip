@@ -90,7 +90,7 @@ using namespace sast;
 
 extern "C" {
 
-int sast_dwconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int C, int k, sast_stream_t stream) {
+int sast_dwconv_fwd(const float* x, const float* w, const float* b, float* y, int B, int H, int W, int C, int k, sast_stream_t stream) { SAST_ENTRY();
   if (!x || !w || !y || C % 4 || k < 1 || !(k & 1) || k * k > DW_MAX_TAPS || B < 1 || H < 1 || W < 1) return SAST_EINVAL;
   const size_t n4 = (size_t)B * H * W * (C / 4);
   if (n4 >= (1ull << 31) || (size_t)k * k * C * sizeof(float) > 64 * 1024) return SAST_EINVAL;
@@ -101,7 +101,7 @@ int sast_dwconv_fwd(const float* x, const float* w, const float* b, float* y, in
 }
 
 int sast_dwconv_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, int H, int W, int C, int k,
-                    sast_stream_t stream) {
+                    sast_stream_t stream) { SAST_ENTRY();
   if (!x || !w || !dy || !dw || !db || C % 4 || k < 1 || !(k & 1) || k * k > DW_MAX_TAPS || B < 1 || H < 1 || W < 1) return SAST_EINVAL;
   const size_t n4 = (size_t)B * H * W * (C / 4), npix = (size_t)B * H * W;
   if (n4 >= (1ull << 31) || (size_t)k * k * C * sizeof(float) > 64 * 1024) return SAST_EINVAL;

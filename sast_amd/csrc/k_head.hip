@@ -578,14 +578,14 @@ extern "C" {
 
 int sast_head_pred_decode(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
                           const float* b_obj, const float* w_cls, const float* b_cls, float* out, int B, int H, int W, int hidden,
-                          int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) {
+                          int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) { SAST_ENTRY();
   return sast_head_pred_fwd(reg_feat, cls_feat, w_reg, b_reg, w_obj, b_obj, w_cls, b_cls, out, nullptr, B, H, W, hidden, num_classes, stride,
                             anchor_offset, anchors_total, decode, stream);
 }
 
 int sast_head_pred_fwd(const float* reg_feat, const float* cls_feat, const float* w_reg, const float* b_reg, const float* w_obj,
                        const float* b_obj, const float* w_cls, const float* b_cls, float* pred, float* train, int B, int H, int W, int hidden,
-                       int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) {
+                       int num_classes, float stride, int anchor_offset, int anchors_total, int decode, sast_stream_t stream) { SAST_ENTRY();
   if (!reg_feat || !cls_feat || (!pred && !train) || hidden % 4 || num_classes < 1 || num_classes > HEAD_MAX_CLASSES || anchor_offset < 0 ||
       anchor_offset + H * W > anchors_total)
     return SAST_EINVAL;
@@ -599,7 +599,7 @@ int sast_head_pred_fwd(const float* reg_feat, const float* cls_feat, const float
 int sast_head_pred_bwd(const float* draw, const float* reg_feat, const float* cls_feat, const float* w_reg, const float* w_obj,
                        const float* w_cls, float* d_reg_feat, float* d_cls_feat, float* dw_reg, float* db_reg, float* dw_obj, float* db_obj,
                        float* dw_cls, float* db_cls, int B, int H, int W, int hidden, int num_classes, int anchor_offset, int anchors_total,
-                       sast_stream_t stream) {
+                       sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   if (!draw || hidden % 4 || num_classes < 1 || num_classes > HEAD_MAX_CLASSES) return SAST_EINVAL;
   const int HW = H * W;
@@ -622,7 +622,7 @@ size_t sast_yolox_loss_ws_bytes(int B, int anchors_total, int max_labels) {
 }
 
 int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadGeom* geom, int B, int max_labels, int num_classes, int use_l1,
-                    float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream) {
+                    float* losses, float* draw, int32_t* fg_mask, int32_t* matched_gt, float* matched_iou, void* ws, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   HeadLevels lv;
   int rc = make_levels(geom, lv);
@@ -658,7 +658,7 @@ size_t sast_postprocess_ws_bytes(int B, int anchors_total) {
 }
 
 int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, int class_agnostic,
-                     float* out, int32_t* n_out, void* ws, sast_stream_t stream) {
+                     float* out, int32_t* n_out, void* ws, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   const int A = anchors_total, words = (A + 63) / 64;
   if (!prediction || !out || !n_out || !ws || A < 1 || A > NMS_MAX || num_classes < 1) return SAST_EINVAL;

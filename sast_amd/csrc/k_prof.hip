@@ -46,8 +46,9 @@ void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, co
 }
 
 
+static double capped(double virt, double cap) { return (cap >= 0.0 && cap < virt) ? cap : virt; }
 void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st,
-                        hipEvent_t* e0, hipEvent_t* e1) {
+                        hipEvent_t* e0, hipEvent_t* e1, double a_cap, double b_cap) {
   ProfLaunch l;
   hipEventCreate(&l.e0);
   hipEventCreate(&l.e1);
@@ -55,7 +56,8 @@ void prof_kernel_events(const char* tag, int G, int M, int NJ, int R, const int*
   if (dM) { int v; hipMemcpyAsync(&v, dM, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < m) m = v; }
   if (dR) { int v; hipMemcpyAsync(&v, dR, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st); if (v < r) r = v; }
   l.flops = 2.0 * (double)m * (double)NJ * (double)G * (double)r;
-  l.bytes = 4.0 * ((double)m * r + (double)NJ * G * r + (double)m * NJ * G);   // A + B + C once each (operands read / written once)
+  // A + B + C once each (operands read / written once); a gathered operand (implicit-GEMM conv) at the size of its source tensor
+  l.bytes = capped(4.0 * (double)m * r, a_cap) + capped(4.0 * (double)NJ * G * r, b_cap) + 4.0 * (double)m * NJ * G;
   l.tag = tag;
   if (g_shapes) { char sh[96]; snprintf(sh, sizeof sh, " |M=%d N=%d R=%d", m, NJ * G, r); l.tag += sh; }
   g_launches.push_back(l);
@@ -72,13 +74,15 @@ static int dev_min(int v, const int* d, hipStream_t st) {
 }
 // one launch carrying two GEMMs (gemm_dual_kernel): the algorithmic FLOPs of both
 void prof_kernel_events2(const char* tag, double flops_static, int G1, int M1, int NJ1, int R1, const int* dM1, const int* dR1, int G2,
-                         int M2, int NJ2, int R2, const int* dM2, const int* dR2, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1) {
+                         int M2, int NJ2, int R2, const int* dM2, const int* dR2, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1,
+                         double a1_cap, double b1_cap, double a2_cap, double b2_cap) {
   ProfLaunch l;
   hipEventCreate(&l.e0);
   hipEventCreate(&l.e1);
   const double m1 = dev_min(M1, dM1, st), r1 = dev_min(R1, dR1, st), m2 = dev_min(M2, dM2, st), r2 = dev_min(R2, dR2, st);
   l.flops = flops_static + 2.0 * m1 * NJ1 * G1 * r1 + 2.0 * m2 * NJ2 * G2 * r2;
-  l.bytes = 4.0 * (m1 * r1 + (double)NJ1 * G1 * r1 + m1 * NJ1 * G1) + 4.0 * (m2 * r2 + (double)NJ2 * G2 * r2 + m2 * NJ2 * G2);
+  l.bytes = capped(4.0 * m1 * r1, a1_cap) + capped(4.0 * NJ1 * G1 * r1, b1_cap) + 4.0 * m1 * NJ1 * G1 +
+            capped(4.0 * m2 * r2, a2_cap) + capped(4.0 * NJ2 * G2 * r2, b2_cap) + 4.0 * m2 * NJ2 * G2;
   l.tag = tag;
   if (g_shapes) {
     char sh[160];

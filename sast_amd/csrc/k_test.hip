@@ -266,3 +266,25 @@ extern "C" int sast_test_launch_latch(int* scratch, int bad, sast_stream_t strea
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
+
+// ---- where do float atomics of MANY workgroups to the SAME buffer cost?  Every workgroup (2 waves) adds `nfloats` values into one
+// accumulation buffer, as the weight-gradient flush of a per-partition fused layer kernel would.  mode 0: one buffer shared by the
+// whole chip; mode 1: one private copy per XCD (HW_REG_XCC_ID), so a line is only ever owned by one L2; mode 2: plain stores to a
+// per-workgroup slice (the bandwidth floor); rot != 0: a workgroup starts at a rotated offset so that they do not hit the same
+// lines at the same time.  out_xcc[block] = the XCD the workgroup ran on.
+__device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)); }   // hwreg(HW_REG_XCC_ID, 0, 4)
+__global__ __launch_bounds__(128) void atomic_xcd_kernel(float* __restrict__ buf, int* __restrict__ out_xcc, int mode, int nfloats, int rot) {
+  const int x = xcc_id();
+  if (threadIdx.x == 0 && out_xcc) out_xcc[blockIdx.x] = x;
+  float* dst = buf + (mode == 1 ? (size_t)x * nfloats : mode == 2 ? (size_t)blockIdx.x * nfloats : 0);
+  const int start = rot ? (int)(((long long)blockIdx.x * 4099 * 128) % nfloats) : 0;
+  for (int i = threadIdx.x; i < nfloats; i += 128) {
+    int j = i + start; if (j >= nfloats) j -= nfloats;
+    if (mode == 2) dst[j] = 1.0f; else atomicAdd(dst + j, 1.0f);
+  }
+}
+extern "C" int sast_test_atomic_xcd(float* buf, int* out_xcc, int mode, int nfloats, int rot, int blocks, sast_stream_t stream) {
+  SAST_LAUNCH(atomic_xcd_kernel, dim3(blocks), dim3(128), 0, (hipStream_t)stream, buf, out_xcc, mode, nfloats, rot);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}

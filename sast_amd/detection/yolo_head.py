@@ -67,8 +67,8 @@ class YOLOXHead(nn.Module):
         if not hasattr(self, "_bn_floats"):
             self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
         ar = BnArena(self._bn_floats, feats[0].device)     # one memset / one counter update for the 15 BatchNorms
-        sync = self._sync_group is not None and self._sync_group.active()
-        if sync:
+        sync = self.training and self._sync_group is not None and self._sync_group.active()
+        if sync and not self._sync_group.reuse_batch(feats[0].shape[0]):
             self._sync_group.exchange_batch(feats[0].shape[0], feats[0].device)
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x, ar)

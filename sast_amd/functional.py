@@ -54,17 +54,24 @@ def _gbuf(p: Optional[torch.Tensor]):
     return g
 
 
-_SCRATCH_KEEP = collections.deque(maxlen=256)
+_SCRATCH_KEEP = collections.deque()
+_SCRATCH_KEEP_BYTES = 64 << 20     # a few launches' worth: same-stream reuse by the caching allocator is safe once the launch is enqueued
 
 
 def _scratch_grad(p: torch.Tensor):
     """for frozen parameters (and for the resident zero vectors standing in for absent biases) the kernels still need somewhere to
     accumulate: a throw-away buffer.  It must OUTLIVE the launch it is handed to: callers pass raw pointers, and a buffer freed before
     the launch is handed out again by the caching allocator -- to the next parameter's freshly created `.grad`, which the kernel would
-    then corrupt through the stale pointer (found with the attention_bias=False fixture).  The last 256 scratch buffers are kept alive
-    here; call sites that create several also hold them in a local until the launch is enqueued."""
+    then corrupt through the stale pointer (found with the attention_bias=False fixture).  Call sites hold their scratch buffers in a
+    local until the launch is enqueued (that alone is sufficient: the caching allocator only re-uses the memory on the same stream,
+    behind the launch); as a second line of defence the most recent ones are also kept alive here, bounded by BYTES so that a model
+    with large frozen weights (fine-tuning on a frozen backbone) does not pin hundreds of MB for the life of the process."""
     t = torch.zeros_like(p)
     _SCRATCH_KEEP.append(t)
+    total = sum(x.numel() * x.element_size() for x in _SCRATCH_KEEP)
+    while len(_SCRATCH_KEEP) > 1 and total > _SCRATCH_KEEP_BYTES:
+        old = _SCRATCH_KEEP.popleft()
+        total -= old.numel() * old.element_size()
     return t
 
 
@@ -762,9 +769,17 @@ class SyncBatchNormGroup:
     def __init__(self, process_group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._world = None          # resolved on first use: convert_sync_batchnorm may run before init_process_group
         self._ratio = None
         self.n_collectives = 0
+
+    @property
+    def world(self) -> int:
+        if self._world is None:
+            if not self.dist.is_initialized():
+                return 1            # not cached: a later init_process_group must still switch the group on
+            self._world = self.dist.get_world_size(self.group)
+        return self._world
 
     def active(self) -> bool:
         return self.world > 1
@@ -776,6 +791,15 @@ class SyncBatchNormGroup:
         self.dist.all_reduce(t, group=self.group)
         self.n_collectives += 1
         self._ratio = (int(round(float(t.item()))), int(n_local))
+        self._fresh = True
+
+    def reuse_batch(self, n_local: int) -> bool:
+        """the YOLOX head runs right behind the PAFPN on the same samples: it takes over the PAFPN's sample-count exchange of this pass
+        (one host sync less per step).  True = taken over; every rank takes the same branch (same model code, same call order)."""
+        if getattr(self, "_fresh", False) and self._ratio is not None and self._ratio[1] == int(n_local):
+            self._fresh = False
+            return True
+        return False
 
     def rows_total(self, m_local: int, batch_local: int) -> int:
         if self._ratio is None or self._ratio[1] != batch_local:

@@ -194,8 +194,12 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
         pipe = {"executed_as": "fp32 operands split exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate "
                                "(error <= 2^-23 |x||y| per product); SAST_MFMA_SPLIT3=0 builds the v_mfma_f32_32x32x2_f32 form",
                 "peak_of_executed_pipe": eff, "frac_of_executed_pipe": achieved / eff}
-    elif not is_gemm:
-        pipe = {"executed_as": "v_mfma_f32_32x32x2_f32 (f32-input MFMA), softmax in the MFMA C layout"}
+    elif split3:
+        # k_attn_mfma.hip / k_mswsa_fused.hip run the same bf16x3 split: six v_mfma_f32_32x32x16_bf16 per 32x32x16 product tile
+        eff = PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS
+        pipe = {"executed_as": "fp32 operands split exactly into 3 bf16 terms, 6 v_mfma_f32_32x32x16_bf16 per product tile, fp32 accumulate; "
+                               "softmax in the MFMA C layout",
+                "peak_of_executed_pipe": eff, "frac_of_executed_pipe": achieved / eff}
     # which roof is nearer for this kernel: time at the MFMA peak vs time at the HBM peak for its algorithmic work
     t_mfma, t_hbm = flops / (PEAK_F32_MFMA_TFLOPS * 1e12), nbytes / (PEAK_HBM_TBS * 1e12)
     bound = "mfma" if t_mfma >= t_hbm else "hbm"
@@ -208,6 +212,7 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
            "achieved_tflops": achieved, "frac_of_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
            "achieved_algorithmic_gbs": 1e3 * achieved_tbs, "frac_of_hbm_peak": achieved_tbs / PEAK_HBM_TBS,
            "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)",
+           "traffic_over_algorithmic": (pmc_traffic_bytes(name) / (nbytes / calls)) if (pmc_traffic_bytes(name) and nbytes) else None,
            "traffic_profile_csrc_sha": stamp, "traffic_stale": stamp != csrc_sha(), "kernel": name,
            "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
            "algorithmic_gflop_per_launch": flops / calls / 1e9, "algorithmic_mbytes_per_launch": nbytes / calls / 1e6,

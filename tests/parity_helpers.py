@@ -27,6 +27,7 @@ def grad_close(name, got, ref, rtol=None):
 
 
 KINK_BAND = 1e-5      # |z| < KINK_BAND * max|z|: a scoring pre-activation within rounding of the ReLU kink (SAST.py:110)
+KINK_MAX_PER_ROW = 4  # ambiguous elements allowed per output channel: the 0/1 fit below must not have the freedom to absorb a real error
 
 
 def scores_grads_close(prefix, gW, gb, rW, rb, records, rtol=None):
@@ -57,6 +58,8 @@ def scores_grads_close(prefix, gW, gb, rW, rb, records, rtol=None):
     gW_adj, gb_adj = gW.clone(), gb.clone()
     for c in torch.nonzero(amb.any(0)).view(-1).tolist():
         idx = torch.nonzero(amb[:, c]).view(-1)
+        assert idx.numel() <= KINK_MAX_PER_ROW, (f"{prefix}to_scores row {c}: {idx.numel()} pre-activations inside the kink band "
+                                                 f"(> {KINK_MAX_PER_ROW}): the kink-aware fit would have too much freedom -- use another seed")
         A = torch.cat([gs[idx, c, None] * xs[idx], gs[idx, c, None]], dim=1)            # (k, C_in + 1): contribution of each element
         res = torch.cat([gW[c] - rW_off[c], (gb[c] - rb_off[c]).view(1)])               # (C_in + 1,)
         if A.abs().max() == 0:
