@@ -163,7 +163,13 @@ typedef struct SastMswsaArgs {
   float *cb_m, *cb_sum;  /* cb_tps > 0 only: scratch [R,C] and [B*L/cb_tps, C] (fwd and bwd) */
   float* raw_ws;         /* optional fp32[sast_mswsa_raw_ws_floats()]: cleared by the forward, accumulated into by the backward of the
                             SAME call pair (saves the backward a clearing launch); NULL = backward clears its own scratch */
+  float* fused_ws;       /* optional fp32[sast_mswsa_fused_ws_floats()] (16-byte aligned): when non-NULL and that size is non-zero the
+                            layer runs as ONE kernel per direction (csrc/k_mswsa_fused.hip: one wave per partition, activations in
+                            registers from LN to the scatter, backward recomputes) and mean1..Hh, ws, raw_ws are NOT used (may be NULL).
+                            The forward fills it (bf16x3 weight planes), the backward of the same call pair reads it. */
 } SastMswsaArgs;
+/* 0 = this layer shape has no fused form (the caller passes fused_ws = NULL and the saved-activation buffers) */
+size_t sast_mswsa_fused_ws_floats(int C, int inner, int T, int dim_head, int cb_tps);
 size_t sast_mswsa_raw_ws_floats(int C, int inner);
 size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner);
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream);

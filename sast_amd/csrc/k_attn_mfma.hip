@@ -23,14 +23,12 @@
 //   * The backward needs P / dS in BOTH orientations (dQ reduces over keys, dV / dK over queries): instead of transposing through
 //     LDS it evaluates S and dP twice, once per orientation (the operands are already in LDS; 48 extra MFMAs per wave).
 // Padded keys are masked (P = 0), padded queries are never stored.  No padding work beyond rounding K_m up to 32.
-#include "gemm.cuh"
+#include "mfma_tiles.cuh"
 #include "kernels.h"
 
 namespace sast {
 
 constexpr int ADH = 32;    // plane row = maximum dim_head
-
-__device__ __forceinline__ int crow(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ---- LDS image of one staged matrix: 3 planes (h, m, l) of [KT][32] bf16
 __device__ __forceinline__ int plane_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -92,32 +90,6 @@ __device__ __forceinline__ Split3 tk_read(const char* mat, int t0, int lane) {
   }
   return Split3{r[0], r[1], r[2]};
 }
-// B operand from a C-layout tile (rows = reduce index, column = this lane's index): the 8 consecutive rows 16 u + 8 (lane / 32) + 0..7
-__device__ __forceinline__ Split3 c_tile_operand(const f32x16& c, int u) {
-  float v[8];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    // v_permlane32_swap(X, Y): r[0] = {low half: own X, high half: partner's Y}, r[1] = {low half: partner's X, high half: own Y}
-    // (common.cuh: lane_peer<32>): a lane of the low half ends with its own row 16u+e and the partner's 16u+4+e, a lane of the high
-    // half with the partner's 16u+8+e and its own 16u+12+e
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(c[8 * u + e]), __float_as_int(c[8 * u + 4 + e]), false, false);
-    v[e] = __int_as_float(r[0]);
-    v[4 + e] = __int_as_float(r[1]);
-  }
-  return split3(v);
-}
-// acc += A x B with both operands split: the six significant bf16 products, smallest terms first (gemm.cuh: compute)
-__device__ __forceinline__ f32x16 mfma6(const Split3& a, const Split3& b, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
-  return acc;
-}
-__device__ __forceinline__ float pair_sum(float v) { return v + lane_peer<32>(v); }
-__device__ __forceinline__ float pair_max(float v) { return fmaxf(v, lane_peer<32>(v)); }
 // the transposed result tile (rows = d, column = this lane's token): rows 8 q + 4 (lane / 32) + 0..3 are 4 consecutive floats
 __device__ __forceinline__ void store_rows_per_lane(float* __restrict__ dst, const f32x16& acc, float mul, int lane, int dh) {
 #pragma unroll

@@ -261,6 +261,12 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) { SAST_ENTR
 }
 
 // ------------------------------------------------------------------ MS-WSA
+size_t sast_mswsa_fused_ws_floats(int C, int inner, int T, int dim_head, int cb_tps) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("SAST_MSWSA_FUSED"); on = e ? atoi(e) : 1; }
+  if (!on || !mswsa_fused_supported(C, inner, T, dim_head > 0 ? dim_head : 32, cb_tps)) return 0;
+  return mswsa_fused_plane_floats(C, inner);
+}
 size_t sast_mswsa_raw_ws_floats(int C, int inner) { return (size_t)C * inner + (size_t)C * C + 2 * C; }
 
 size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
@@ -276,6 +282,12 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   if (T > ATTN_MAX_T) return SAST_EINVAL;
+  if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip)
+    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
+    int rc = mswsa_fused_planes_launch(a, a->fused_ws, st);
+    if (rc) return rc;
+    return mswsa_fused_fwd_launch(a, a->fused_ws, st);
+  }
   const int* dR = a->sel.counts;  // device-side number of kept tokens
   int rc = ln1_gather_fwd_launch(a->xin, a->out, a->S, a->sel.tok_slot, a->ln1_w, a->ln1_b, a->ln2_w, a->ln2_b, a->mean1,
                                  a->rstd1, a->mean2, a->rstd2, R, C, a->eps, a->raw_ws, sast_mswsa_raw_ws_floats(C, inner), st);

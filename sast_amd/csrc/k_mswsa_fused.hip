@@ -1,0 +1,550 @@
+// The MS-WSA layer (SAST.py:199-255 with LayerNorm, LayerScale ops.py:178-186 and the GLU-MLP ops.py:111-175) as ONE kernel per
+// direction: LN1 (+ LN2 and gather of the kept tokens) -> QKV -> per-head varlen attention -> proj + LayerScale 1 -> fc1 . GLU ->
+// fc2 + LayerScale 2 -> scatter, with no intermediate of the layer in HBM.  The unfused form (k_block.hip: seven launches) moves
+// 26 A bytes per layer forward where the operator reads A and writes A (A = 4 L C B bytes); at stages 1-2 it runs at the HBM rate of
+// that traffic.
+//
+// Work decomposition: ONE WAVE PER PARTITION (window / grid group of T <= 64 tokens), free-running -- no workgroup barrier and no
+// LDS in the forward.  Everything is kept TRANSPOSED in the MFMA C layout: a lane owns a token (column), the registers of a tile
+// own 32 channels (rows).  Then
+//   * a linear layer is  Y^T[j][t] = sum_c W[j][c] X^T[c][t]:  the weights are the A operand, streamed from L2 as bf16x3 planes that a
+//     prep kernel stores in MFMA operand order (one coalesced 16-byte load per lane, plane and 32x16 tile; no LDS, no split at use);
+//   * the output tile of one layer IS the B operand of the next: the C-layout registers of a tile, exchanged pairwise with
+//     lane ^ 32 (v_permlane32_swap), are the 8 consecutive reduce indices an MFMA operand needs (mfma_tiles.cuh: c_tile_operand) --
+//     the activations never leave the registers between LN and the final store;
+//   * attention runs on the same registers: S^T = K Q^T from the Q^T / K^T tiles, softmax over the rows of a lane's column (plus one
+//     exchange with lane ^ 32), O^T = V^T P^T with V produced in the [token][d] orientation (the X operand as A) so that its tile is the
+//     operand the product needs;
+//   * residuals (S for the attention branch, Y for the MLP) are the tiles still sitting in registers.
+// Products are evaluated like everywhere else in this library: fp32 operands split exactly into three bf16 terms, six
+// v_mfma_f32_32x32x16_bf16 per tile step, fp32 accumulation (error <= 2^-23 |x||y| per product).
+//
+// The hidden layer of the MLP is streamed in chunks of 32 channels: [u|g] chunk -> h chunk -> accumulated into Z, so the 2 x inner
+// pre-activations never exist at once.
+#include "mfma_tiles.cuh"
+#include "kernels.h"
+
+namespace sast {
+namespace fused {
+
+using Tile = f32x16;
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// ------------------------------------------------------------------------------------------------ weight planes
+// A weight matrix V[n][k] (n = output index, k = reduce index; N % 32 == 0, K % 16 == 0) is stored as tiles [nt = n / 32][ks = k / 16],
+// each tile 3 planes (h, m, l) x 64 lanes x 16 bytes: lane l holds V[32 nt + l % 32][16 ks + 8 (l / 32) + 0..7] as 8 bf16 -- the
+// register image of a v_mfma_f32_32x32x16_bf16 operand.
+constexpr int TILE_U4 = 3 * 64;
+
+// The kernels consume the tiles of all matrices of the layer in ONE fixed order ("stream"): tile n of a stream sits at byte 3072 n.
+// A wave prefetches the stream through a private LDS ring with LDS-DMA loads (global_load_lds_dwordx4: no staging registers), RING
+// tiles ahead of its MFMAs -- one wave per SIMD has nobody else to hide the L2 latency behind.
+struct TileRef { int mat, nt, ks; };   // mat: 0 qkv [3C][C], 1 proj [C][C], 2 fc1 [2 inner][C], 3 fc2 [C][inner]
+// forward order: per head { per ks: q, k, v tile; per (ct, u): proj tile }, then per hidden chunk { per ks: u, g tile; per (ct, u): fc2 tile }
+__host__ __device__ inline int fwd_stream_tiles(int C, int inner) { return (C / 32) * (3 * (C / 16) + 2 * (C / 32)) + (inner / 32) * (2 * (C / 16) + 2 * (C / 32)); }
+__host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
+  const int KS = C / 16, CT = C / 32, H = C / 32, IT = inner / 32, per_head = 3 * KS + 2 * CT, per_chunk = 2 * KS + 2 * CT;
+  if (n < H * per_head) {
+    const int h = n / per_head, j = n - h * per_head;
+    if (j < 3 * KS) return TileRef{0, 3 * h + j % 3, j / 3};
+    const int jj = j - 3 * KS;
+    return TileRef{1, jj / 2, 2 * h + (jj & 1)};
+  }
+  n -= H * per_head;
+  const int kc = n / per_chunk, j = n - kc * per_chunk;
+  if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc, j / 2};
+  const int jj = j - 2 * KS;
+  return TileRef{3, jj / 2, 2 * kc + (jj & 1)};
+}
+
+struct PlaneArgs { const float* w[4]; int ld[4]; int C, inner, ntiles; };
+// dir 0: forward stream (operand = the weight as stored: index = output channel, reduce = input channel)
+__global__ __launch_bounds__(256) void weight_planes_kernel(PlaneArgs a, u4* __restrict__ dst) {
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= a.ntiles * 64) return;
+  const int tile = item >> 6, lane = item & 63;
+  const TileRef t = fwd_stream_tile(tile, a.C, a.inner);
+  const float* src = a.w[t.mat] + (size_t)(t.nt * 32 + (lane & 31)) * a.ld[t.mat] + t.ks * 16 + 8 * (lane >> 5);
+  const float4 lo = ld4(src), hi = ld4(src + 4);
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const Split3 s = split3(v);
+  u4* d = dst + (size_t)tile * TILE_U4 + lane;
+  d[0] = __builtin_bit_cast(u4, s.h);
+  d[64] = __builtin_bit_cast(u4, s.m);
+  d[128] = __builtin_bit_cast(u4, s.l);
+}
+
+constexpr int RING = 8;                 // tiles in flight per wave (power of two); 24 KB of LDS per wave
+constexpr int TILE_BYTES = 3 * 1024;
+// one 1 KB piece: lane l's 16 bytes land at lds_dst + 16 l (M0 = wave-uniform LDS byte address).  The statement first waits for the
+// wave's own LDS reads (the slot being overwritten was read just before); hipcc does not count an asm load: take_tile() does.
+template <int LGKM>   // LGKM >= 0: first wait until at most that many of the wave's LDS operations are outstanding
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (LGKM >= 0)
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(LGKM) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+struct WStream {
+  const char* src;      // this lane's 16 bytes of plane 0 of tile 0
+  unsigned ring_lds;    // wave-uniform LDS byte address of the wave's ring
+  const char* ring;     // the same ring + 16 lane, as a pointer for the reads
+  int next;             // next tile to consume (wave-uniform)
+  Split3 pre;           // tile `next`, already read from the ring (its LDS latency hides behind the MFMAs of the tile before)
+  template <int LGKM>
+  __device__ __forceinline__ void issue(int n) const {
+    const char* g = src + (size_t)n * TILE_BYTES;
+    const unsigned d = ring_lds + (unsigned)(n & (RING - 1)) * TILE_BYTES;
+    dma16<LGKM>(g, d); dma16<-1>(g + 1024, d + 1024); dma16<-1>(g + 2048, d + 2048);
+  }
+  __device__ __forceinline__ Split3 read(int n) const {
+    const char* p = ring + (n & (RING - 1)) * TILE_BYTES;
+    return Split3{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 1024), *reinterpret_cast<const bf16x8*>(p + 2048)};
+  }
+  __device__ __forceinline__ void start() {
+    next = 0;
+    for (int n = 0; n < RING; ++n) issue<-1>(n);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RING - 1)) : "memory");
+    pre = read(0);
+  }
+  // the next tile of the stream.  Tile next + 1 is read from the ring for the following call, then the slot of tile `next` (read one
+  // call ago: lgkmcnt(3) = everything older than the three reads just issued has returned) is refilled with tile next + RING; the
+  // stream is padded by RING tiles.  hipcc does not count an asm load: the vmcnt waits here are the only ones the ring has.
+  __device__ __forceinline__ Split3 take() {
+    const Split3 cur = pre;
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RING - 2)) : "memory");
+    pre = read(next + 1);
+    issue<3>(next + RING);
+    ++next;
+    return cur;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ tile helpers (lane = token)
+__device__ __forceinline__ Tile tzero() {
+  Tile t;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) t[e] = 0.f;
+  return t;
+}
+// a per-channel vector as the rows of tile ct: register 4 q + i <-> channel 32 ct + 8 q + 4 hf + i
+__device__ __forceinline__ void rowvec(const float* __restrict__ v, int ct, int hf, float (&o)[16]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 x = ld4(v + ct * 32 + 8 * q + 4 * hf);
+    o[4 * q] = x.x; o[4 * q + 1] = x.y; o[4 * q + 2] = x.z; o[4 * q + 3] = x.w;
+  }
+}
+__device__ __forceinline__ void rowvec_or(const float* __restrict__ v, int ct, int hf, float dflt, float (&o)[16]) {
+  if (v) { rowvec(v, ct, hf, o); return; }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) o[e] = dflt;
+}
+// rows of a token (image layout [token][C]) <-> the column of this lane in tiles ct = 0 .. CT-1
+template <int CT>
+__device__ __forceinline__ void load_token(const float* __restrict__ row, int hf, Tile (&x)[CT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = ld4(row + ct * 32 + 8 * q + 4 * hf);
+      x[ct][4 * q] = v.x; x[ct][4 * q + 1] = v.y; x[ct][4 * q + 2] = v.z; x[ct][4 * q + 3] = v.w;
+    }
+}
+template <int CT>
+__device__ __forceinline__ void store_token(float* __restrict__ row, int hf, const Tile (&x)[CT]) {
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      st4(row + ct * 32 + 8 * q + 4 * hf, make_float4(x[ct][4 * q], x[ct][4 * q + 1], x[ct][4 * q + 2], x[ct][4 * q + 3]));
+}
+// LayerNorm over the channels of this lane's token: its own CT x 16 values and its partner's (lane ^ 32)
+template <int CT>
+__device__ __forceinline__ void ln_token(Tile (&x)[CT], const float* __restrict__ w, const float* __restrict__ b, float eps, int hf,
+                                         float& mean, float& rstd) {
+  constexpr float INV = 1.0f / (32 * CT);
+  float s = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) s += (x[ct][e] + x[ct][e + 1]) + (x[ct][e + 2] + x[ct][e + 3]);
+  mean = pair_sum(s) * INV;
+  float ss = 0.f;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+      const float d0 = x[ct][e] - mean, d1 = x[ct][e + 1] - mean, d2 = x[ct][e + 2] - mean, d3 = x[ct][e + 3] - mean;
+      x[ct][e] = d0; x[ct][e + 1] = d1; x[ct][e + 2] = d2; x[ct][e + 3] = d3;
+      ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  rstd = 1.0f / sqrtf(pair_sum(ss) * INV + eps);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float wv[16], bv[16];
+    rowvec(w, ct, hf, wv);
+    rowvec(b, ct, hf, bv);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[ct][e] = x[ct][e] * rstd * wv[e] + bv[e];
+  }
+}
+
+// per-channel vectors of the layer, copied to LDS once per workgroup (an ordinary global load in the steady state would make hipcc
+// drain the whole LDS-DMA queue at its use): offsets in floats
+template <int C, int INNER> struct Vec {
+  static constexpr int LN1W = 0, LN1B = C, LN2W = 2 * C, LN2B = 3 * C, QKVB = 4 * C, PROJB = 7 * C, LS1 = 8 * C, FC2B = 9 * C, LS2 = 10 * C, FC1B = 11 * C,
+                       FLOATS = 11 * C + 2 * INNER;
+};
+// in-kernel timeline (tools builds only, -DSAST_FUSED_TL): lane 0 of every wave stamps the shader clock at phase boundaries
+#ifdef SAST_FUSED_TL
+constexpr int FTL_SLOTS = 24, FTL_WAVES = 4096;
+__device__ unsigned long long fused_tl[FTL_WAVES * FTL_SLOTS];
+#define FTL(k) do { const int wv_ = blockIdx.x * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); } while (0)
+#else
+#define FTL(k)
+#endif
+struct FwdArgs {
+  const float* xin; float* out;
+  const int* Kw; const int* row_off; const int* row_tok; const unsigned long long* mask;
+  const char* wstream;     // forward tile stream (fwd_stream_tile order), padded by RING tiles
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *ls1, *fc1_b, *fc2_b, *ls2;
+  PartMap pm; int L, NG; float eps, scale;
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+// LN1 of the tokens of partition g that are NOT kept (they leave the layer as LN1(x), SAST.py:206,252): C / 4 lanes per token row
+// (one float4 each: whole rows are read and written contiguously), 256 / C rows per wave instruction; the loads of ALL rows of the
+// partition are issued before the first is used (one wave per SIMD: a load -> reduce -> store loop would run at one latency per row group)
+template <int C>
+__device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __restrict__ vec_w, const float* __restrict__ vec_b, int g, int lane) {
+  constexpr int GL = C / 4, RPI = 64 / GL, NIT = 64 / RPI;      // lanes per row, rows per iteration, iterations for T <= 64
+  const int T = a.pm.T(), N = a.pm.N();
+  const unsigned long long m0 = a.mask[2 * (size_t)g];
+  const int b = g / N, n = g - b * N;
+  const int gl = lane % GL, sub = lane / GL;
+  const float4 w = ld4(vec_w + 4 * gl), bb = ld4(vec_b + 4 * gl);
+  float4 v[NIT];
+  size_t row[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int t = it * RPI + sub;
+    row[it] = (size_t)b * a.L + a.pm.token(n, min(t, T - 1));
+    v[it] = ld4(a.xin + row[it] * C + 4 * gl);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int t = it * RPI + sub;
+    const bool act = t < T && !((m0 >> t) & 1ull);
+    float4 x = v[it];
+    const float mean = group_sum<GL>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
+    x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
+    const float rstd = 1.0f / sqrtf(group_sum<GL>((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w)) * (1.0f / C) + a.eps);
+    if (act) st4(a.out + row[it] * C + 4 * gl, make_float4(x.x * rstd * w.x + bb.x, x.y * rstd * w.y + bb.y, x.z * rstd * w.z + bb.z, x.w * rstd * w.w + bb.w));
+  }
+}
+
+// the kept tokens of one partition: NTT tiles of 32 tokens in this wave
+template <int C, int INNER, int NTT>
+__device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restrict__ vec, WStream& ws, int K, int r0, int lane) {
+  constexpr int CT = C / 32, KS = C / 16, H = C / 32, IT = INNER / 32;
+  using V = Vec<C, INNER>;
+  const int l31 = lane & 31, hf = lane >> 5;
+  int tok[NTT];
+  bool valid[NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const int i = tt * 32 + l31;
+    valid[tt] = i < K;
+    tok[tt] = a.row_tok[r0 + min(i, K - 1)];       // clamped: lanes past K recompute a real token, never stored, masked as keys
+  }
+  FTL(0);
+  // ---- S = LN2(LN1(x)) of the kept tokens, transposed tiles S^T[c][t]
+  Tile s[NTT][CT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    load_token<CT>(a.xin + (size_t)tok[tt] * C, hf, s[tt]);
+    float mean, rstd;
+    ln_token<CT>(s[tt], vec + V::LN1W, vec + V::LN1B, a.eps, hf, mean, rstd);
+    ln_token<CT>(s[tt], vec + V::LN2W, vec + V::LN2B, a.eps, hf, mean, rstd);
+  }
+  FTL(1);
+  Split3 sop[NTT][KS];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sop[tt][ks] = c_tile_operand(s[tt][ks >> 1], ks & 1);
+
+  FTL(2);
+  // ---- attention branch, head by head; the projection accumulates over the heads
+  Tile y[NTT][CT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) y[tt][ct] = tzero();
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    Tile q[NTT], k[NTT], v[NTT];
+    {
+      float bq[16], bk[16];
+      rowvec(vec + V::QKVB + h * 96, 0, hf, bq);
+      rowvec(vec + V::QKVB + h * 96 + 32, 0, hf, bk);
+      const float bv = vec[V::QKVB + h * 96 + 64 + l31];
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { q[tt][e] = bq[e]; k[tt][e] = bk[e]; v[tt][e] = bv; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const Split3 wq = ws.take(), wk = ws.take(), wv = ws.take();
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        q[tt] = mfma6(wq, sop[tt][ks], q[tt]);      // Q^T[d][t]
+        k[tt] = mfma6(wk, sop[tt][ks], k[tt]);      // K^T[d][t]
+        v[tt] = mfma6(sop[tt][ks], wv, v[tt]);      // V[t][d]
+      }
+    }
+    FTL(3 + 4 * h);
+    Split3 qop[NTT][2], kop[NTT][2], vop[NTT][2];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) q[tt][e] *= a.scale;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        qop[tt][u] = c_tile_operand(q[tt], u);       // index = token, reduce = d
+        kop[tt][u] = c_tile_operand(k[tt], u);
+        vop[tt][u] = c_tile_operand(v[tt], u);       // index = d, reduce = token
+      }
+    }
+    FTL(4 + 4 * h);
+    Tile o[NTT];
+#pragma unroll
+    for (int ti = 0; ti < NTT; ++ti) {
+      // S^T[j][i]: rows = keys of tile tj, column = this lane's query
+      Tile st[NTT];
+#pragma unroll
+      for (int tj = 0; tj < NTT; ++tj) {
+        st[tj] = tzero();
+#pragma unroll
+        for (int u = 0; u < 2; ++u) st[tj] = mfma6(kop[tj][u], qop[ti][u], st[tj]);
+      }
+      float mloc = -INFINITY;
+#pragma unroll
+      for (int tj = 0; tj < NTT; ++tj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool kv = tj * 32 + crow(e, lane) < K;
+          st[tj][e] = kv ? st[tj][e] : -INFINITY;
+          mloc = fmaxf(mloc, st[tj][e]);
+        }
+      const float m = pair_max(mloc);
+      float ploc = 0.f;
+#pragma unroll
+      for (int tj = 0; tj < NTT; ++tj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float pt = (tj * 32 + crow(e, lane) < K) ? __expf(st[tj][e] - m) : 0.f;
+          st[tj][e] = pt;
+          ploc += pt;
+        }
+      const float inv = 1.0f / pair_sum(ploc);
+      o[ti] = tzero();
+#pragma unroll
+      for (int tj = 0; tj < NTT; ++tj)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) o[ti] = mfma6(vop[tj][u], c_tile_operand(st[tj], u), o[ti]);   // O^T[d][i]
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[ti][e] *= inv;
+    }
+    FTL(5 + 4 * h);
+    // proj: Y^T[c][t] += sum_d Wp[c][32 h + d] O^T[d][t]
+    Split3 oop[NTT][2];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) oop[tt][u] = c_tile_operand(o[tt], u);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const Split3 w = ws.take();
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) y[tt][ct] = mfma6(w, oop[tt][u], y[tt][ct]);
+      }
+    FTL(6 + 4 * h);
+  }
+  FTL(11);
+  // ---- Y = S + ls1 * (proj + b)      (SAST.py:235)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float bp[16], g1[16];
+    rowvec(vec + V::PROJB, ct, hf, bp);
+    rowvec(vec + V::LS1, ct, hf, g1);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[tt][ct][e] = s[tt][ct][e] + g1[e] * (y[tt][ct][e] + bp[e]);
+  }
+  Split3 yop[NTT][KS];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) yop[tt][ks] = c_tile_operand(y[tt][ks >> 1], ks & 1);
+  FTL(12);
+  // ---- MLP, streamed over chunks of 32 hidden channels: [u|g] = W1 Y + b1, h = u * gelu(g), Z += W2[:, chunk] h   (ops.py:136-137)
+  Tile z[NTT][CT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) z[tt][ct] = tzero();
+#pragma unroll 1
+  for (int kc = 0; kc < IT; ++kc) {
+    Tile uu[NTT], gg[NTT];
+    {
+      float bu[16], bg[16];
+      rowvec(vec + V::FC1B + kc * 32, 0, hf, bu);
+      rowvec(vec + V::FC1B + INNER + kc * 32, 0, hf, bg);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { uu[tt][e] = bu[e]; gg[tt][e] = bg[e]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const Split3 wu = ws.take(), wg = ws.take();
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) {
+        uu[tt] = mfma6(wu, yop[tt][ks], uu[tt]);
+        gg[tt] = mfma6(wg, yop[tt][ks], gg[tt]);
+      }
+    }
+    Split3 hop[NTT][2];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) uu[tt][e] *= gelu_erf(gg[tt][e]);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) hop[tt][u] = c_tile_operand(uu[tt], u);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const Split3 w = ws.take();
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) z[tt][ct] = mfma6(w, hop[tt][u], z[tt][ct]);
+      }
+    FTL(13 + kc);
+  }
+  FTL(19);
+  // ---- out = Y + ls2 * (Z + b2), scattered to the image rows of the kept tokens   (SAST.py:248-253)
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    float b2[16], g2[16];
+    rowvec(vec + V::FC2B, ct, hf, b2);
+    rowvec(vec + V::LS2, ct, hf, g2);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) z[tt][ct][e] = y[tt][ct][e] + g2[e] * (z[tt][ct][e] + b2[e]);
+  }
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+    if (valid[tt]) store_token<CT>(a.out + (size_t)tok[tt] * C, hf, z[tt]);
+  FTL(20);
+}
+
+template <int C, int INNER>
+__global__ __launch_bounds__(256) void mswsa_fused_fwd_kernel(FwdArgs a) {
+  using V = Vec<C, INNER>;
+  __shared__ __attribute__((aligned(16))) char ring_s[4 * RING * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) float vec[V::FLOATS];
+  {   // the layer's vectors -> LDS (LayerScale disabled = ones)
+    const int i = threadIdx.x;
+    const auto cp = [&](int off, const float* src, int n, float dflt) { for (int j = i; j < n; j += 256) vec[off + j] = src ? src[j] : dflt; };
+    cp(V::LN1W, a.ln1_w, C, 1.f); cp(V::LN1B, a.ln1_b, C, 0.f); cp(V::LN2W, a.ln2_w, C, 1.f); cp(V::LN2B, a.ln2_b, C, 0.f);
+    cp(V::QKVB, a.qkv_b, 3 * C, 0.f); cp(V::PROJB, a.proj_b, C, 0.f); cp(V::LS1, a.ls1, C, 1.f); cp(V::FC2B, a.fc2_b, C, 0.f);
+    cp(V::LS2, a.ls2, C, 1.f); cp(V::FC1B, a.fc1_b, 2 * INNER, 0.f);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.x * 4 + w;
+  if (g >= a.NG) return;
+  const int K = a.Kw[g];
+  if (K < a.pm.T()) ln1_unkept<C>(a, vec + V::LN1W, vec + V::LN1B, g, lane);
+  if (K == 0) return;
+  const int r0 = a.row_off[g];
+  WStream ws;
+  ws.src = a.wstream + lane * 16;
+  char* ring = ring_s + w * (RING * TILE_BYTES);
+  ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
+  ws.ring = ring + lane * 16;
+  ws.start();
+  if (K <= 32) fwd_body<C, INNER, 1>(a, vec, ws, K, r0, lane);
+  else fwd_body<C, INNER, 2>(a, vec, ws, K, r0, lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the RING tiles of padding still in flight must land before the LDS is released
+}
+
+}  // namespace fused
+#ifdef SAST_FUSED_TL
+extern "C" int sast_fused_tl_read(unsigned long long* host_out, int nwaves) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fused::fused_tl), sizeof(unsigned long long) * fused::FTL_SLOTS * nwaves, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
+// ------------------------------------------------------------------------------------------------ host side
+// which layers the fused kernels serve: dim 64 (stage 1 of every shipped model size with embed_dim 64), dim_head 32, partitions of at
+// most 64 tokens (1Mpx: 60), GLU inner a multiple of 32.  Everything else keeps the unfused path (k_block.hip).
+bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps) {
+  return C == 64 && inner == 160 && T <= 64 && dim_head == 32 && cb_tps == 0;
+}
+// fp32 words of the weight planes: the forward stream (+ RING tiles of padding the prefetcher reads past the end)
+size_t mswsa_fused_plane_floats(int C, int inner) {
+  return (size_t)(fused::fwd_stream_tiles(C, inner) + fused::RING) * fused::TILE_BYTES / 4;
+}
+
+int mswsa_fused_planes_launch(const SastMswsaArgs* a, float* planes, hipStream_t st) {
+  using namespace fused;
+  const int C = a->C, inner = a->inner;
+  PlaneArgs pa{};
+  pa.w[0] = a->qkv_w; pa.ld[0] = C; pa.w[1] = a->proj_w; pa.ld[1] = C; pa.w[2] = a->fc1_w; pa.ld[2] = C; pa.w[3] = a->fc2_w; pa.ld[3] = inner;
+  pa.C = C; pa.inner = inner; pa.ntiles = fwd_stream_tiles(C, inner);
+  SAST_LAUNCH(weight_planes_kernel, dim3((pa.ntiles * 64 + 255) / 256), dim3(256), 0, st, pa, reinterpret_cast<u4*>(planes));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+void prof_kernel_events_ex(const char* tag, double flops, double bytes, hipStream_t st, hipEvent_t* e0, hipEvent_t* e1);
+void prof_sum_k(const int* Kw, int W, hipStream_t st, double* sum_k, double* sum_k2);
+
+int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStream_t st) {
+  using namespace fused;
+  const int C = a->C, inner = a->inner, L = a->H * a->W, T = a->ph * a->pw;
+  FwdArgs f{};
+  f.xin = a->xin; f.out = a->out;
+  f.Kw = a->sel.K; f.row_off = a->sel.row_off; f.row_tok = a->sel.row_tok; f.mask = (const unsigned long long*)a->sel.mask;
+  f.wstream = reinterpret_cast<const char*>(planes);
+  f.ln1_w = a->ln1_w; f.ln1_b = a->ln1_b; f.ln2_w = a->ln2_w; f.ln2_b = a->ln2_b; f.qkv_b = a->qkv_b; f.proj_b = a->proj_b; f.ls1 = a->ls1;
+  f.fc1_b = a->fc1_b; f.fc2_b = a->fc2_b; f.ls2 = a->ls2;
+  f.pm = make_part_map(a->H, a->W, a->ph, a->pw, a->mode);
+  f.L = L; f.NG = a->B * (L / T); f.eps = a->eps; f.scale = 1.0f / sqrtf(32.f);
+  const dim3 grid((f.NG + 3) / 4), block(256);
+  if (prof_enabled()) {
+    double sk, sk2; hipEvent_t e0, e1;
+    prof_sum_k(f.Kw, f.NG, st, &sk, &sk2);
+    // 2 (4 C^2 + 3 C inner) flop per kept token + 4 C K_m^2 per partition; bytes: the layer reads its input once and writes its output once
+    prof_kernel_events_ex("mswsa_fused_fwd_kernel", 2.0 * (4.0 * C * C + 3.0 * C * inner) * sk + 4.0 * C * sk2, 8.0 * C * (double)a->B * L, st, &e0, &e1);
+    SAST_EXT_LAUNCH((mswsa_fused_fwd_kernel<64, 160>), grid, block, 0, st, e0, e1, 0, f);
+  } else {
+    SAST_LAUNCH((mswsa_fused_fwd_kernel<64, 160>), grid, block, 0, st, f);
+  }
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+}  // namespace sast

@@ -68,4 +68,10 @@ struct LsFinish;
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
                          int T, int C, int dh, hipStream_t st, const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
 
+// k_mswsa_fused.hip: the MS-WSA layer as one kernel per direction (one wave per partition)
+bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps);
+size_t mswsa_fused_plane_floats(int C, int inner);
+int mswsa_fused_planes_launch(const SastMswsaArgs* a, float* planes, hipStream_t st);
+int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStream_t st);
+
 }  // namespace sast

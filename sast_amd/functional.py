@@ -562,6 +562,10 @@ _MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w",
                  "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")
 
 
+_FUSED_BWD = False    # the fused backward kernel exists: training steps may take the fused path too
+_FUSED_ENABLE = True  # tools / tests switch the fused form off to compare the two forms of the layer in one process
+
+
 class _MSWSA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, *params):
@@ -576,6 +580,23 @@ class _MSWSA(torch.autograd.Function):
         heads = Cc // dim_head
         dev = xin.device
         out = torch.empty_like(xin)
+        a = L.SastMswsaArgs()
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, xin=xin, out=out)
+        sel.fill_struct(a.sel)
+        _fill(a, **{k: _ptr(v) for k, v in p.items()})
+        # the layer as ONE kernel per direction (csrc/k_mswsa_fused.hip) where the library has that form for the shape: nothing but
+        # the input is kept for the backward (it recomputes), the scratch holds the bf16x3 weight planes both kernels stream
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps)
+        needs_bwd = torch.is_grad_enabled() and (xin.requires_grad or any(t is not None and t.requires_grad for t in params))
+        if _FUSED_ENABLE and fused_floats and (_FUSED_BWD or not needs_bwd):
+            fws = torch.empty(fused_floats, device=dev)
+            _fill(a, fused_ws=fws)
+            L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd (fused)")
+            ctx.save_for_backward(xin, fws)
+            ctx.fused = True
+            ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
+            return out
+        ctx.fused = False
         stats = torch.empty(4, R, device=dev)
         big = torch.empty(R, Cc * 6 + 3 * inner + heads, device=dev)  # one allocation for all saved activations
         # carve [R, width] blocks out of `big` as separate contiguous buffers
@@ -590,16 +611,12 @@ class _MSWSA(torch.autograd.Function):
 
         S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
         raw = torch.empty(L.lib().sast_mswsa_raw_ws_floats(Cc, inner), device=dev)   # cleared by the forward, used by the backward
-        a = L.SastMswsaArgs()
-        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, xin=xin, out=out,
-              raw_ws=raw, mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
+        _fill(a, raw_ws=raw, mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh)
         if cb_tps:
             if R % cb_tps:
                 raise RuntimeError(f"sast_amd: Context Broadcasting needs rows ({R}) divisible by tokens per sample ({cb_tps})")
             cb_m, cb_sum = torch.empty(R, Cc, device=dev), torch.empty(R // cb_tps, Cc, device=dev)
             _fill(a, cb_tps=cb_tps, cb_m=cb_m, cb_sum=cb_sum)
-        sel.fill_struct(a.sel)
-        _fill(a, **{k: _ptr(v) for k, v in p.items()})
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
         ctx.save_for_backward(xin, stats, big, raw)
         ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
