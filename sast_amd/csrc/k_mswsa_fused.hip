@@ -74,7 +74,10 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(PlaneArgs a, u4* __r
   d[128] = __builtin_bit_cast(u4, s.l);
 }
 
-constexpr int RING = 8;                 // tiles in flight per wave (power of two); 24 KB of LDS per wave
+#ifndef SAST_FUSED_RING
+#define SAST_FUSED_RING 2
+#endif
+constexpr int RING = SAST_FUSED_RING;   // tiles in flight per wave (power of two); 3 KB of LDS per tile and wave
 constexpr int TILE_BYTES = 3 * 1024;
 // one 1 KB piece: lane l's 16 bytes land at lds_dst + 16 l (M0 = wave-uniform LDS byte address).  The statement first waits for the
 // wave's own LDS reads (the slot being overwritten was read just before); hipcc does not count an asm load: take_tile() does.
@@ -201,9 +204,10 @@ template <int C, int INNER> struct Vec {
 };
 // in-kernel timeline (tools builds only, -DSAST_FUSED_TL): lane 0 of every wave stamps the shader clock at phase boundaries
 #ifdef SAST_FUSED_TL
-constexpr int FTL_SLOTS = 24, FTL_WAVES = 4096;
+constexpr int FTL_SLOTS = 24, FTL_WAVES = 4096;   // (the timeline tool reads the waves of the first 2048 workgroups)
 __device__ unsigned long long fused_tl[FTL_WAVES * FTL_SLOTS];
-#define FTL(k) do { const int wv_ = blockIdx.x * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); } while (0)
+#define FTL(k) do { const int wv_ = blockIdx.x * 2 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) { fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); \
+    if ((k) == 0) fused_tl[wv_ * FTL_SLOTS + 21] = wall_clock64(); if ((k) == 20) fused_tl[wv_ * FTL_SLOTS + 22] = wall_clock64(); } } while (0)
 #else
 #define FTL(k)
 #endif
@@ -220,8 +224,8 @@ struct FwdArgs {
 // (one float4 each: whole rows are read and written contiguously), 256 / C rows per wave instruction; the loads of ALL rows of the
 // partition are issued before the first is used (one wave per SIMD: a load -> reduce -> store loop would run at one latency per row group)
 template <int C>
-__device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __restrict__ vec_w, const float* __restrict__ vec_b, int g, int lane) {
-  constexpr int GL = C / 4, RPI = 64 / GL, NIT = 64 / RPI;      // lanes per row, rows per iteration, iterations for T <= 64
+__device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __restrict__ vec_w, const float* __restrict__ vec_b, int g, int wv, int lane) {
+  constexpr int GL = C / 4, RPI = 64 / GL, NIT = 32 / RPI;      // lanes per row, rows per iteration, iterations of ONE of the two waves for T <= 64
   const int T = a.pm.T(), N = a.pm.N();
   const unsigned long long m0 = a.mask[2 * (size_t)g];
   const int b = g / N, n = g - b * N;
@@ -231,13 +235,13 @@ __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __rest
   size_t row[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int t = it * RPI + sub;
+    const int t = (2 * it + wv) * RPI + sub;
     row[it] = (size_t)b * a.L + a.pm.token(n, min(t, T - 1));
     v[it] = ld4(a.xin + row[it] * C + 4 * gl);
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int t = it * RPI + sub;
+    const int t = (2 * it + wv) * RPI + sub;
     const bool act = t < T && !((m0 >> t) & 1ull);
     float4 x = v[it];
     const float mean = group_sum<GL>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
@@ -247,135 +251,120 @@ __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __rest
   }
 }
 
-// the kept tokens of one partition: NTT tiles of 32 tokens in this wave
-template <int C, int INNER, int NTT>
-__device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restrict__ vec, WStream& ws, int K, int r0, int lane) {
+// K / V operands of the partition's token tiles, shared by its waves through LDS: [tile][u][plane][lane] x 16 bytes (lane-linear: every
+// access is a conflict-free ds_write_b128 / ds_read_b128)
+__device__ __forceinline__ void xput(char* buf, int tile, int u, int lane, const Split3& v) {
+  char* p = buf + ((tile * 2 + u) * 3) * 1024 + lane * 16;
+  *reinterpret_cast<bf16x8*>(p) = v.h; *reinterpret_cast<bf16x8*>(p + 1024) = v.m; *reinterpret_cast<bf16x8*>(p + 2048) = v.l;
+}
+__device__ __forceinline__ Split3 xget(const char* buf, int tile, int u, int lane) {
+  const char* p = buf + ((tile * 2 + u) * 3) * 1024 + lane * 16;
+  return Split3{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 1024), *reinterpret_cast<const bf16x8*>(p + 2048)};
+}
+constexpr int XBUF_BYTES = 2 * 2 * 3 * 1024;     // one matrix (K or V) of a partition: 2 tiles x 2 k-steps x 3 planes
+
+// the kept tokens [32 w, 32 w + 32) of one partition in wave w; NT = token tiles (= waves) the partition needs
+template <int C, int INNER, int NT>
+__device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restrict__ vec, char* xk, char* xv, WStream& ws, int K, int r0, int w, int lane) {
   constexpr int CT = C / 32, KS = C / 16, H = C / 32, IT = INNER / 32;
   using V = Vec<C, INNER>;
   const int l31 = lane & 31, hf = lane >> 5;
-  int tok[NTT];
-  bool valid[NTT];
-#pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) {
-    const int i = tt * 32 + l31;
-    valid[tt] = i < K;
-    tok[tt] = a.row_tok[r0 + min(i, K - 1)];       // clamped: lanes past K recompute a real token, never stored, masked as keys
-  }
+  const int i = w * 32 + l31;
+  const bool valid = i < K;
+  const int tok = a.row_tok[r0 + min(i, K - 1)];       // clamped: lanes past K recompute a real token, never stored, masked as keys
   FTL(0);
   // ---- S = LN2(LN1(x)) of the kept tokens, transposed tiles S^T[c][t]
-  Tile s[NTT][CT];
-#pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) {
-    load_token<CT>(a.xin + (size_t)tok[tt] * C, hf, s[tt]);
+  Tile s[CT];
+  {
+    load_token<CT>(a.xin + (size_t)tok * C, hf, s);
     float mean, rstd;
-    ln_token<CT>(s[tt], vec + V::LN1W, vec + V::LN1B, a.eps, hf, mean, rstd);
-    ln_token<CT>(s[tt], vec + V::LN2W, vec + V::LN2B, a.eps, hf, mean, rstd);
+    ln_token<CT>(s, vec + V::LN1W, vec + V::LN1B, a.eps, hf, mean, rstd);
+    ln_token<CT>(s, vec + V::LN2W, vec + V::LN2B, a.eps, hf, mean, rstd);
   }
   FTL(1);
-  Split3 sop[NTT][KS];
+  Split3 sop[KS];
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) sop[tt][ks] = c_tile_operand(s[tt][ks >> 1], ks & 1);
-
+  for (int ks = 0; ks < KS; ++ks) sop[ks] = c_tile_operand(s[ks >> 1], ks & 1);
   FTL(2);
   // ---- attention branch, head by head; the projection accumulates over the heads
-  Tile y[NTT][CT];
+  Tile y[CT];
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) y[tt][ct] = tzero();
+  for (int ct = 0; ct < CT; ++ct) y[ct] = tzero();
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    Tile q[NTT], k[NTT], v[NTT];
+    Tile q, k, v;
     {
       float bq[16], bk[16];
       rowvec(vec + V::QKVB + h * 96, 0, hf, bq);
       rowvec(vec + V::QKVB + h * 96 + 32, 0, hf, bk);
       const float bv = vec[V::QKVB + h * 96 + 64 + l31];
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { q[tt][e] = bq[e]; k[tt][e] = bk[e]; v[tt][e] = bv; }
+      for (int e = 0; e < 16; ++e) { q[e] = bq[e]; k[e] = bk[e]; v[e] = bv; }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const Split3 wq = ws.take(), wk = ws.take(), wv = ws.take();
-#pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) {
-        q[tt] = mfma6(wq, sop[tt][ks], q[tt]);      // Q^T[d][t]
-        k[tt] = mfma6(wk, sop[tt][ks], k[tt]);      // K^T[d][t]
-        v[tt] = mfma6(sop[tt][ks], wv, v[tt]);      // V[t][d]
-      }
+      q = mfma6(wq, sop[ks], q);      // Q^T[d][t]
+      k = mfma6(wk, sop[ks], k);      // K^T[d][t]
+      v = mfma6(sop[ks], wv, v);      // V[t][d]
     }
     FTL(3 + 4 * h);
-    Split3 qop[NTT][2], kop[NTT][2], vop[NTT][2];
+    if (NT > 1 && h > 0) __syncthreads();      // the other wave has finished reading the previous head's K / V
+    Split3 qop[2];
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) {
+    for (int e = 0; e < 16; ++e) q[e] *= a.scale;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) q[tt][e] *= a.scale;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        qop[tt][u] = c_tile_operand(q[tt], u);       // index = token, reduce = d
-        kop[tt][u] = c_tile_operand(k[tt], u);
-        vop[tt][u] = c_tile_operand(v[tt], u);       // index = d, reduce = token
-      }
+    for (int u = 0; u < 2; ++u) {
+      qop[u] = c_tile_operand(q, u);           // index = token, reduce = d
+      xput(xk, w, u, lane, c_tile_operand(k, u));
+      xput(xv, w, u, lane, c_tile_operand(v, u));     // index = d, reduce = token
     }
+    if (NT > 1) __syncthreads(); else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     FTL(4 + 4 * h);
-    Tile o[NTT];
+    // S^T[j][i]: rows = keys of tile tj, column = this lane's query
+    Tile st[NT];
 #pragma unroll
-    for (int ti = 0; ti < NTT; ++ti) {
-      // S^T[j][i]: rows = keys of tile tj, column = this lane's query
-      Tile st[NTT];
+    for (int tj = 0; tj < NT; ++tj) {
+      st[tj] = tzero();
 #pragma unroll
-      for (int tj = 0; tj < NTT; ++tj) {
-        st[tj] = tzero();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) st[tj] = mfma6(kop[tj][u], qop[ti][u], st[tj]);
-      }
-      float mloc = -INFINITY;
-#pragma unroll
-      for (int tj = 0; tj < NTT; ++tj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const bool kv = tj * 32 + crow(e, lane) < K;
-          st[tj][e] = kv ? st[tj][e] : -INFINITY;
-          mloc = fmaxf(mloc, st[tj][e]);
-        }
-      const float m = pair_max(mloc);
-      float ploc = 0.f;
-#pragma unroll
-      for (int tj = 0; tj < NTT; ++tj)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float pt = (tj * 32 + crow(e, lane) < K) ? __expf(st[tj][e] - m) : 0.f;
-          st[tj][e] = pt;
-          ploc += pt;
-        }
-      const float inv = 1.0f / pair_sum(ploc);
-      o[ti] = tzero();
-#pragma unroll
-      for (int tj = 0; tj < NTT; ++tj)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) o[ti] = mfma6(vop[tj][u], c_tile_operand(st[tj], u), o[ti]);   // O^T[d][i]
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[ti][e] *= inv;
+      for (int u = 0; u < 2; ++u) st[tj] = mfma6(xget(xk, tj, u, lane), qop[u], st[tj]);
     }
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const bool kv = tj * 32 + crow(e, lane) < K;
+        st[tj][e] = kv ? st[tj][e] : -INFINITY;
+        mloc = fmaxf(mloc, st[tj][e]);
+      }
+    const float m = pair_max(mloc);
+    float ploc = 0.f;
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pt = (tj * 32 + crow(e, lane) < K) ? __expf(st[tj][e] - m) : 0.f;
+        st[tj][e] = pt;
+        ploc += pt;
+      }
+    const float inv = 1.0f / pair_sum(ploc);
+    Tile o = tzero();
+#pragma unroll
+    for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) o = mfma6(xget(xv, tj, u, lane), c_tile_operand(st[tj], u), o);   // O^T[d][i]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] *= inv;
     FTL(5 + 4 * h);
     // proj: Y^T[c][t] += sum_d Wp[c][32 h + d] O^T[d][t]
-    Split3 oop[NTT][2];
+    Split3 oop[2];
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) oop[tt][u] = c_tile_operand(o[tt], u);
+    for (int u = 0; u < 2; ++u) oop[u] = c_tile_operand(o, u);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const Split3 w = ws.take();
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) y[tt][ct] = mfma6(w, oop[tt][u], y[tt][ct]);
-      }
+      for (int u = 0; u < 2; ++u) y[ct] = mfma6(ws.take(), oop[u], y[ct]);
     FTL(6 + 4 * h);
   }
   FTL(11);
@@ -386,59 +375,41 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     rowvec(vec + V::PROJB, ct, hf, bp);
     rowvec(vec + V::LS1, ct, hf, g1);
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) y[tt][ct][e] = s[tt][ct][e] + g1[e] * (y[tt][ct][e] + bp[e]);
+    for (int e = 0; e < 16; ++e) y[ct][e] = s[ct][e] + g1[e] * (y[ct][e] + bp[e]);
   }
-  Split3 yop[NTT][KS];
+  Split3 yop[KS];
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) yop[tt][ks] = c_tile_operand(y[tt][ks >> 1], ks & 1);
+  for (int ks = 0; ks < KS; ++ks) yop[ks] = c_tile_operand(y[ks >> 1], ks & 1);
   FTL(12);
   // ---- MLP, streamed over chunks of 32 hidden channels: [u|g] = W1 Y + b1, h = u * gelu(g), Z += W2[:, chunk] h   (ops.py:136-137)
-  Tile z[NTT][CT];
+  Tile z[CT];
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) z[tt][ct] = tzero();
+  for (int ct = 0; ct < CT; ++ct) z[ct] = tzero();
 #pragma unroll 1
   for (int kc = 0; kc < IT; ++kc) {
-    Tile uu[NTT], gg[NTT];
+    Tile uu, gg;
     {
       float bu[16], bg[16];
       rowvec(vec + V::FC1B + kc * 32, 0, hf, bu);
       rowvec(vec + V::FC1B + INNER + kc * 32, 0, hf, bg);
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { uu[tt][e] = bu[e]; gg[tt][e] = bg[e]; }
+      for (int e = 0; e < 16; ++e) { uu[e] = bu[e]; gg[e] = bg[e]; }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const Split3 wu = ws.take(), wg = ws.take();
-#pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) {
-        uu[tt] = mfma6(wu, yop[tt][ks], uu[tt]);
-        gg[tt] = mfma6(wg, yop[tt][ks], gg[tt]);
-      }
+      uu = mfma6(wu, yop[ks], uu);
+      gg = mfma6(wg, yop[ks], gg);
     }
-    Split3 hop[NTT][2];
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) {
+    for (int e = 0; e < 16; ++e) uu[e] *= gelu_erf(gg[e]);
+    Split3 hop[2];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) uu[tt][e] *= gelu_erf(gg[tt][e]);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) hop[tt][u] = c_tile_operand(uu[tt], u);
-    }
+    for (int u = 0; u < 2; ++u) hop[u] = c_tile_operand(uu, u);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const Split3 w = ws.take();
-#pragma unroll
-        for (int tt = 0; tt < NTT; ++tt) z[tt][ct] = mfma6(w, hop[tt][u], z[tt][ct]);
-      }
+      for (int u = 0; u < 2; ++u) z[ct] = mfma6(ws.take(), hop[u], z[ct]);
     FTL(13 + kc);
   }
   FTL(19);
@@ -449,35 +420,33 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     rowvec(vec + V::FC2B, ct, hf, b2);
     rowvec(vec + V::LS2, ct, hf, g2);
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) z[tt][ct][e] = y[tt][ct][e] + g2[e] * (z[tt][ct][e] + b2[e]);
+    for (int e = 0; e < 16; ++e) z[ct][e] = y[ct][e] + g2[e] * (z[ct][e] + b2[e]);
   }
-#pragma unroll
-  for (int tt = 0; tt < NTT; ++tt)
-    if (valid[tt]) store_token<CT>(a.out + (size_t)tok[tt] * C, hf, z[tt]);
+  if (valid) store_token<CT>(a.out + (size_t)tok * C, hf, z);
   FTL(20);
 }
 
+// one workgroup = one partition, one wave per tile of 32 kept tokens (T <= 64: two waves)
 template <int C, int INNER>
-__global__ __launch_bounds__(256) void mswsa_fused_fwd_kernel(FwdArgs a) {
+__global__ __launch_bounds__(128, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
   using V = Vec<C, INNER>;
-  __shared__ __attribute__((aligned(16))) char ring_s[4 * RING * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char ring_s[2 * RING * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char xk[XBUF_BYTES];
+  __shared__ __attribute__((aligned(16))) char xv[XBUF_BYTES];
   __shared__ __attribute__((aligned(16))) float vec[V::FLOATS];
   {   // the layer's vectors -> LDS (LayerScale disabled = ones)
     const int i = threadIdx.x;
-    const auto cp = [&](int off, const float* src, int n, float dflt) { for (int j = i; j < n; j += 256) vec[off + j] = src ? src[j] : dflt; };
+    const auto cp = [&](int off, const float* src, int n, float dflt) { for (int j = i; j < n; j += 128) vec[off + j] = src ? src[j] : dflt; };
     cp(V::LN1W, a.ln1_w, C, 1.f); cp(V::LN1B, a.ln1_b, C, 0.f); cp(V::LN2W, a.ln2_w, C, 1.f); cp(V::LN2B, a.ln2_b, C, 0.f);
     cp(V::QKVB, a.qkv_b, 3 * C, 0.f); cp(V::PROJB, a.proj_b, C, 0.f); cp(V::LS1, a.ls1, C, 1.f); cp(V::FC2B, a.fc2_b, C, 0.f);
     cp(V::LS2, a.ls2, C, 1.f); cp(V::FC1B, a.fc1_b, 2 * INNER, 0.f);
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blockIdx.x * 4 + w;
-  if (g >= a.NG) return;
+  const int g = blockIdx.x;
   const int K = a.Kw[g];
-  if (K < a.pm.T()) ln1_unkept<C>(a, vec + V::LN1W, vec + V::LN1B, g, lane);
-  if (K == 0) return;
+  if (K < a.pm.T()) ln1_unkept<C>(a, vec + V::LN1W, vec + V::LN1B, g, w, lane);
+  if (K <= 32 * w) return;                   // K <= 32: one wave runs the partition alone (no barrier below); K == 0: nothing kept
   const int r0 = a.row_off[g];
   WStream ws;
   ws.src = a.wstream + lane * 16;
@@ -485,8 +454,8 @@ __global__ __launch_bounds__(256) void mswsa_fused_fwd_kernel(FwdArgs a) {
   ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
   ws.ring = ring + lane * 16;
   ws.start();
-  if (K <= 32) fwd_body<C, INNER, 1>(a, vec, ws, K, r0, lane);
-  else fwd_body<C, INNER, 2>(a, vec, ws, K, r0, lane);
+  if (K <= 32) fwd_body<C, INNER, 1>(a, vec, xk, xv, ws, K, r0, w, lane);
+  else fwd_body<C, INNER, 2>(a, vec, xk, xv, ws, K, r0, w, lane);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the RING tiles of padding still in flight must land before the LDS is released
 }
 
@@ -533,7 +502,7 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
   f.fc1_b = a->fc1_b; f.fc2_b = a->fc2_b; f.ls2 = a->ls2;
   f.pm = make_part_map(a->H, a->W, a->ph, a->pw, a->mode);
   f.L = L; f.NG = a->B * (L / T); f.eps = a->eps; f.scale = 1.0f / sqrtf(32.f);
-  const dim3 grid((f.NG + 3) / 4), block(256);
+  const dim3 grid(f.NG), block(128);
   if (prof_enabled()) {
     double sk, sk2; hipEvent_t e0, e1;
     prof_sum_k(f.Kw, f.NG, st, &sk, &sk2);

@@ -288,3 +288,51 @@ extern "C" int sast_test_atomic_xcd(float* buf, int* out_xcc, int mode, int nflo
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
+
+// ---- do the matrix pipe and the VALU of one SIMD overlap?  512 threads = two waves per SIMD (waves w and w + 4 share a SIMD).
+// mode 0: every wave runs MFMA chains only; 1: VALU only; 2: waves 0-3 MFMA, waves 4-7 VALU (the pair on a SIMD is complementary);
+// 3: every wave alternates 6 dependent MFMAs with NV independent VALU instructions (the shape of the fused layer kernels);
+// 4: as 3 with TWO accumulator chains interleaved.  out[block] = shader-clock cycles of wave 0.
+template <int MODE, int NV>
+__global__ __launch_bounds__(512) void overlap_probe_kernel(float* __restrict__ out, long long* __restrict__ cyc, int iters) {
+  using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
+  using f32x16_t = __attribute__((ext_vector_type(16))) float;
+  const int w = threadIdx.x >> 6;
+  f32x16_t acc0, acc1;
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+  bf16x8_t a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(float)(threadIdx.x & 7); b[e] = (__bf16)1.0f; }
+  float v[8];
+  for (int e = 0; e < 8; ++e) v[e] = (float)threadIdx.x + e;
+  const long long t0 = clock64();
+  const bool do_m = MODE == 0 || (MODE == 2 && w < 4) || MODE >= 3, do_v = MODE == 1 || (MODE == 2 && w >= 4) || MODE >= 3;
+  for (int it = 0; it < iters; ++it) {
+    if (do_m) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (MODE == 4 && (k & 1)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+      }
+    }
+    if (do_v) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k & 7] = fmaf(v[k & 7], 1.000001f, 0.5f);
+    }
+  }
+  const long long t1 = clock64();
+  float s = 0.f;
+  for (int e = 0; e < 16; ++e) s += acc0[e] + acc1[e];
+  for (int e = 0; e < 8; ++e) s += v[e];
+  if (s == 123.456f) out[0] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+extern "C" int sast_test_overlap_probe(float* out, long long* cyc, int mode, int nv, int blocks, int iters, sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+#define OVL(M, V) SAST_LAUNCH((overlap_probe_kernel<M, V>), dim3(blocks), dim3(512), 0, st, out, cyc, iters)
+  if (nv == 24) { switch (mode) { case 0: OVL(0, 24); break; case 1: OVL(1, 24); break; case 2: OVL(2, 24); break; case 3: OVL(3, 24); break; case 4: OVL(4, 24); break; default: return SAST_EINVAL; } }
+  else if (nv == 48) { switch (mode) { case 0: OVL(0, 48); break; case 1: OVL(1, 48); break; case 2: OVL(2, 48); break; case 3: OVL(3, 48); break; case 4: OVL(4, 48); break; default: return SAST_EINVAL; } }
+  else return SAST_EINVAL;
+#undef OVL
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}

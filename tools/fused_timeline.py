@@ -23,16 +23,21 @@ with torch.no_grad():
     for _ in range(3):
         SF.mswsa(x, sel, 1e-5, p)
 torch.cuda.synchronize()
-nw = B * (H // ph) * (W // pw)
+nw = 2 * B * (H // ph) * (W // pw)      # one wave per tile of 32 kept tokens, two per partition
 buf = (C.c_ulonglong * (24 * nw))()
 fn = L.lib().sast_fused_tl_read
 fn.restype = C.c_int; fn.argtypes = [C.c_void_p, C.c_int]
 assert fn(buf, nw) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 24).astype(np.int64)
+t = t[t[:, 20] > 0]
+nw = len(t)
 names = {0: "start", 1: "load+LN1+LN2", 2: "S operands", 3: "h0 QKV", 4: "h0 q/k/v operands", 5: "h0 attention", 6: "h0 proj", 7: "h1 QKV", 8: "h1 operands",
          9: "h1 attention", 10: "h1 proj", 11: "(heads done)", 12: "Y + Y operands", 13: "chunk 0", 14: "chunk 1", 15: "chunk 2", 16: "chunk 3", 17: "chunk 4",
          19: "(mlp done)", 20: "epilogue + store"}
 order = [k for k in sorted(names)]
+wall = (t[:, 22] - t[:, 21]) * 10.0      # s_memrealtime: 100 MHz
+print(f"wall clock per wave: mean {np.mean(wall):.0f} ns; launch span {(np.max(t[:, 22]) - np.min(t[:, 21])) * 10.0:.0f} ns; "
+      f"clock64 units per ns: {np.mean(t[:, 20] - t[:, 0]) / np.mean(wall):.3f}")
 print(f"waves {nw}; total cycles per wave mean {np.mean(t[:, 20] - t[:, 0]):.0f} (min {np.min(t[:, 20] - t[:, 0])}, max {np.max(t[:, 20] - t[:, 0])}); "
       f"launch span {np.max(t[:, 20]) - np.min(t[:, 0])} cycles")
 prev = 0
