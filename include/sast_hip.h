@@ -165,8 +165,9 @@ typedef struct SastMswsaArgs {
                             SAME call pair (saves the backward a clearing launch); NULL = backward clears its own scratch */
   float* fused_ws;       /* optional fp32[sast_mswsa_fused_ws_floats()] (16-byte aligned): when non-NULL and that size is non-zero the
                             layer runs as ONE kernel per direction (csrc/k_mswsa_fused.hip: one wave per partition, activations in
-                            registers from LN to the scatter, backward recomputes) and mean1..Hh, ws, raw_ws are NOT used (may be NULL).
-                            The forward fills it (bf16x3 weight planes), the backward of the same call pair reads it. */
+                            registers from LN to the scatter).  With S == NULL (inference) nothing else is written; with the saved-activation
+                            buffers mean1 .. Hh present the same kernel also writes them, so that sast_mswsa_bwd runs unchanged.  The forward
+                            fills fused_ws with the bf16x3 weight planes its kernel streams. */
 } SastMswsaArgs;
 /* 0 = this layer shape has no fused form (the caller passes fused_ws = NULL and the saved-activation buffers) */
 size_t sast_mswsa_fused_ws_floats(int C, int inner, int T, int dim_head, int cb_tps);

@@ -217,6 +217,9 @@ struct FwdArgs {
   const char* wstream;     // forward tile stream (fwd_stream_tile order), padded by RING tiles
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *ls1, *fc1_b, *fc2_b, *ls2;
   PartMap pm; int L, NG; float eps, scale;
+  // training: the activations the (unfused) backward reads, compact rows; all NULL = inference
+  float *S, *QKV, *O, *lse, *Y, *UG, *Hh, *mean1, *rstd1, *mean2, *rstd2;
+  float* zero_ptr; int zero_n4;      // the backward's gamma-free accumulators (raw_ws), cleared here as a side job
 };
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -247,7 +250,10 @@ __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __rest
     const float mean = group_sum<GL>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
     x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
     const float rstd = 1.0f / sqrtf(group_sum<GL>((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w)) * (1.0f / C) + a.eps);
-    if (act) st4(a.out + row[it] * C + 4 * gl, make_float4(x.x * rstd * w.x + bb.x, x.y * rstd * w.y + bb.y, x.z * rstd * w.z + bb.z, x.w * rstd * w.w + bb.w));
+    if (act) {
+      st4(a.out + row[it] * C + 4 * gl, make_float4(x.x * rstd * w.x + bb.x, x.y * rstd * w.y + bb.y, x.z * rstd * w.z + bb.z, x.w * rstd * w.w + bb.w));
+      if (a.mean1 && gl == 0) { a.mean1[row[it]] = mean; a.rstd1[row[it]] = rstd; }
+    }
   }
 }
 
@@ -272,6 +278,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
   const int i = w * 32 + l31;
   const bool valid = i < K;
   const int tok = a.row_tok[r0 + min(i, K - 1)];       // clamped: lanes past K recompute a real token, never stored, masked as keys
+  const bool save = a.S != nullptr && valid;           // training: this lane's compact row r0 + i of the saved activations
+  const size_t crow_g = (size_t)(r0 + min(i, K - 1));
   FTL(0);
   // ---- S = LN2(LN1(x)) of the kept tokens, transposed tiles S^T[c][t]
   Tile s[CT];
@@ -279,7 +287,12 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     load_token<CT>(a.xin + (size_t)tok * C, hf, s);
     float mean, rstd;
     ln_token<CT>(s, vec + V::LN1W, vec + V::LN1B, a.eps, hf, mean, rstd);
+    if (save && hf == 0) { a.mean1[tok] = mean; a.rstd1[tok] = rstd; }
     ln_token<CT>(s, vec + V::LN2W, vec + V::LN2B, a.eps, hf, mean, rstd);
+    if (save) {
+      if (hf == 0) { a.mean2[crow_g] = mean; a.rstd2[crow_g] = rstd; }
+      store_token<CT>(a.S + crow_g * C, hf, s);
+    }
   }
   FTL(1);
   Split3 sop[KS];
@@ -309,6 +322,21 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
       v = mfma6(sop[ks], wv, v);      // V[t][d]
     }
     FTL(3 + 4 * h);
+    if (a.S) {   // raw q, k, v of head h: channels [96 h, 96 h + 96) of the saved QKV rows (SAST.py:219: [head][q|k|v])
+      float* qrow = a.QKV + crow_g * (3 * C) + h * 96;
+      if (save) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          st4(qrow + 8 * qd + 4 * hf, make_float4(q[4 * qd], q[4 * qd + 1], q[4 * qd + 2], q[4 * qd + 3]));
+          st4(qrow + 32 + 8 * qd + 4 * hf, make_float4(k[4 * qd], k[4 * qd + 1], k[4 * qd + 2], k[4 * qd + 3]));
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {   // the V tile is [token][d]: register e = token row crow(e), this lane's d = l31
+        const int ti = w * 32 + crow(e, lane);
+        if (ti < K) a.QKV[(size_t)(r0 + ti) * (3 * C) + h * 96 + 64 + l31] = v[e];
+      }
+    }
     if (NT > 1 && h > 0) __syncthreads();      // the other wave has finished reading the previous head's K / V
     Split3 qop[2];
 #pragma unroll
@@ -348,7 +376,9 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
         st[tj][e] = pt;
         ploc += pt;
       }
-    const float inv = 1.0f / pair_sum(ploc);
+    const float psum = pair_sum(ploc);
+    const float inv = 1.0f / psum;
+    if (save && hf == 0) a.lse[crow_g * H + h] = m + logf(psum);
     Tile o = tzero();
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj)
@@ -356,6 +386,10 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
       for (int u = 0; u < 2; ++u) o = mfma6(xget(xv, tj, u, lane), c_tile_operand(st[tj], u), o);   // O^T[d][i]
 #pragma unroll
     for (int e = 0; e < 16; ++e) o[e] *= inv;
+    if (save) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) st4(a.O + crow_g * C + h * 32 + 8 * qd + 4 * hf, make_float4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]));
+    }
     FTL(5 + 4 * h);
     // proj: Y^T[c][t] += sum_d Wp[c][32 h + d] O^T[d][t]
     Split3 oop[2];
@@ -377,6 +411,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) y[ct][e] = s[ct][e] + g1[e] * (y[ct][e] + bp[e]);
   }
+  if (save) store_token<CT>(a.Y + crow_g * C, hf, y);
   Split3 yop[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) yop[ks] = c_tile_operand(y[ks >> 1], ks & 1);
@@ -401,8 +436,20 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
       uu = mfma6(wu, yop[ks], uu);
       gg = mfma6(wg, yop[ks], gg);
     }
+    if (save && a.UG) {
+      float* ug = a.UG + crow_g * (2 * INNER) + kc * 32;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        st4(ug + 8 * qd + 4 * hf, make_float4(uu[4 * qd], uu[4 * qd + 1], uu[4 * qd + 2], uu[4 * qd + 3]));
+        st4(ug + INNER + 8 * qd + 4 * hf, make_float4(gg[4 * qd], gg[4 * qd + 1], gg[4 * qd + 2], gg[4 * qd + 3]));
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) uu[e] *= gelu_erf(gg[e]);
+    if (save && a.Hh) {
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) st4(a.Hh + crow_g * INNER + kc * 32 + 8 * qd + 4 * hf, make_float4(uu[4 * qd], uu[4 * qd + 1], uu[4 * qd + 2], uu[4 * qd + 3]));
+    }
     Split3 hop[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) hop[u] = c_tile_operand(uu, u);
@@ -441,6 +488,7 @@ __global__ __launch_bounds__(128, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
     cp(V::QKVB, a.qkv_b, 3 * C, 0.f); cp(V::PROJB, a.proj_b, C, 0.f); cp(V::LS1, a.ls1, C, 1.f); cp(V::FC2B, a.fc2_b, C, 0.f);
     cp(V::LS2, a.ls2, C, 1.f); cp(V::FC1B, a.fc1_b, 2 * INNER, 0.f);
   }
+  for (int i4 = blockIdx.x * 128 + threadIdx.x; i4 < a.zero_n4; i4 += gridDim.x * 128) st4(a.zero_ptr + 4 * (size_t)i4, zero4());
   __syncthreads();
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x;
@@ -500,6 +548,10 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
   f.wstream = reinterpret_cast<const char*>(planes);
   f.ln1_w = a->ln1_w; f.ln1_b = a->ln1_b; f.ln2_w = a->ln2_w; f.ln2_b = a->ln2_b; f.qkv_b = a->qkv_b; f.proj_b = a->proj_b; f.ls1 = a->ls1;
   f.fc1_b = a->fc1_b; f.fc2_b = a->fc2_b; f.ls2 = a->ls2;
+  f.S = a->S; f.QKV = a->QKV; f.O = a->O; f.lse = a->lse; f.Y = a->Y; f.UG = a->UG; f.Hh = a->Hh;
+  f.mean1 = a->mean1; f.rstd1 = a->rstd1; f.mean2 = a->mean2; f.rstd2 = a->rstd2;
+  if (f.S && (!f.QKV || !f.O || !f.lse || !f.Y || !f.mean1 || !f.rstd1 || !f.mean2 || !f.rstd2)) return SAST_EINVAL;
+  f.zero_ptr = a->raw_ws; f.zero_n4 = a->raw_ws ? (int)(sast_mswsa_raw_ws_floats(C, inner) / 4) : 0;
   f.pm = make_part_map(a->H, a->W, a->ph, a->pw, a->mode);
   f.L = L; f.NG = a->B * (L / T); f.eps = a->eps; f.scale = 1.0f / sqrtf(32.f);
   const dim3 grid(f.NG), block(128);

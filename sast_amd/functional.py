@@ -562,7 +562,6 @@ _MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w",
                  "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")
 
 
-_FUSED_BWD = False    # the fused backward kernel exists: training steps may take the fused path too
 _FUSED_ENABLE = True  # tools / tests switch the fused form off to compare the two forms of the layer in one process
 
 
@@ -584,19 +583,17 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, xin=xin, out=out)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
-        # the layer as ONE kernel per direction (csrc/k_mswsa_fused.hip) where the library has that form for the shape: nothing but
-        # the input is kept for the backward (it recomputes), the scratch holds the bf16x3 weight planes both kernels stream
-        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps)
-        needs_bwd = torch.is_grad_enabled() and (xin.requires_grad or any(t is not None and t.requires_grad for t in params))
-        if _FUSED_ENABLE and fused_floats and (_FUSED_BWD or not needs_bwd):
+        # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
+        # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if _FUSED_ENABLE else 0
+        needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
+        fws = None
+        if fused_floats:
             fws = torch.empty(fused_floats, device=dev)
             _fill(a, fused_ws=fws)
-            L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd (fused)")
-            ctx.save_for_backward(xin, fws)
-            ctx.fused = True
-            ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
-            return out
-        ctx.fused = False
+            if not needs_bwd:       # inference: the layer writes nothing but its output
+                L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd (fused)")
+                return out
         stats = torch.empty(4, R, device=dev)
         big = torch.empty(R, Cc * 6 + 3 * inner + heads, device=dev)  # one allocation for all saved activations
         # carve [R, width] blocks out of `big` as separate contiguous buffers
