@@ -131,7 +131,16 @@ typedef struct SastSel {
   int32_t* counts;     /* [4] sum K (= len(asy_index)), M (= len(index_window)), sumK / B, 0 */
   int32_t* tok_slot;   /* [B*L] compact row of a token or -1 */
   int32_t* row_tok;    /* [B*L] token (b*L + y*W + x) of a compact row */
+  /* PACKS (round 4): the kept rows of consecutive groups are contiguous, so several small groups can share the 32-token tiles of one
+   * workgroup of the fused MS-WSA layer kernel (its cost follows kept tokens, not kept groups x tiles).  A pack = the largest aligned
+   * block of 1, 2, 4, 8 or 16 consecutive groups whose kept rows fit one 32-token tile (SAST_ATTN_PACKS overrides the budget, at most
+   * 64 rows for T <= 64); attention inside a pack is masked to the rows of the query's own group. */
+  int32_t* pack_rows;  /* [B*N] rows of the pack this group LEADS (first group of its block), 0 for every other group */
+  int32_t* row_seg;    /* [B*L] per compact row: lo | hi << 16 = the rows [lo, hi) of its own group, relative to the pack's first row */
 } SastSel;
+/* fills pack_rows / row_seg from K / row_off (sast_select and sast_select_pair do it themselves; hosts that build a SastSel from
+ * index lists call this).  W = number of groups, T = tokens per group. */
+int sast_select_packs(const SastSel* sel, int W, int T, sast_stream_t stream);
 /* mode 0: window partition (ops.py:189-195), 1: grid partition (ops.py:206-212) */
 int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode, double bounce, const SastSel* sel,
                 sast_stream_t stream);

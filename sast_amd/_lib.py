@@ -39,7 +39,7 @@ SastScoreArgs = _struct("SastScoreArgs", [
     (I32, "B L C r_stride"), (F32, "amp"),
     (P, "xp r ws_w ws_b wc scale s xw tok dxw dxp d_ws_w d_ws_b d_wc ws dscale_ws"),
 ])
-SastSel = _struct("SastSel", [(P, "win_keep mask K row_off win_rank counts tok_slot row_tok")])
+SastSel = _struct("SastSel", [(P, "win_keep mask K row_off win_rank counts tok_slot row_tok pack_rows row_seg")])
 SastMswsaArgs = _struct("SastMswsaArgs", [
     (I32, "B H W C ph pw mode inner"), (F32, "eps"), (I32, "cb_tps dim_head"),
     (P, "xin out"), (SastSel, "sel"),
@@ -91,6 +91,7 @@ _SIGNATURES = {
     "sast_score_stp_fwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
     "sast_score_stp_bwd": (C.c_int, [C.POINTER(SastScoreArgs), P]),
     "sast_select": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(SastSel), P]),
+    "sast_select_packs": (C.c_int, [C.POINTER(SastSel), C.c_int, C.c_int, P]),
     "sast_head_pred_decode": (C.c_int, [P] * 9 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, P]),
     "sast_head_pred_fwd": (C.c_int, [P] * 10 + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_int, C.c_int, P]),
     "sast_head_pred_bwd": (C.c_int, [P] * 14 + [C.c_int] * 7 + [P]),

@@ -213,8 +213,11 @@ int sast_select(const float* tok, int B, int H, int W, int ph, int pw, int mode,
   // `x >= d / (1 + b)` tensor-vs-python-scalar compare (SAST.py:264,272)
   const float thr_w = (float)((1.0 / N) / (1.0 + bounce));
   const float thr_t = (float)((1.0 / T) / (1.0 + bounce));
-  return select_launch(tok, B, H, W, ph, pw, mode, thr_w, thr_t, s->win_keep, (unsigned long long*)s->mask, s->K, s->row_off,
-                       s->win_rank, s->counts, s->tok_slot, s->row_tok, (hipStream_t)stream);
+  return select_launch(tok, B, H, W, ph, pw, mode, thr_w, thr_t, s, (hipStream_t)stream);
+}
+int sast_select_packs(const SastSel* s, int W, int T, sast_stream_t stream) { SAST_ENTRY();
+  if (!s || !s->K || !s->row_off || !s->pack_rows || !s->row_seg || W < 1 || T < 1 || T > ATTN_MAX_T) return SAST_EINVAL;
+  return select_packs_launch(s, W, T, (hipStream_t)stream);
 }
 
 int sast_select_pair(const float* tok, int B, int H, int W, int ph, int pw, double bounce, const SastSel* win, const SastSel* grid,
@@ -294,7 +297,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
-  rc = attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
+  rc = attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, a->sel.pack_rows, a->sel.row_seg, NW, T, C, dh, st);
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
   if (rc) return rc;
@@ -389,7 +392,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   {
     const LsFinish f2{a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner};
     const LsFinish f1{a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C};
-    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C);
+    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, a->sel.pack_rows, a->sel.row_seg, NW, T, C, dh, st, &f2, &f1, C);
   }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv

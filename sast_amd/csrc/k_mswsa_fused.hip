@@ -213,7 +213,7 @@ __device__ unsigned long long fused_tl[FTL_WAVES * FTL_SLOTS];
 #endif
 struct FwdArgs {
   const float* xin; float* out;
-  const int* Kw; const int* row_off; const int* row_tok; const unsigned long long* mask;
+  const int* Kw; const int* row_off; const int* row_tok; const unsigned long long* mask; const int* pack_rows; const int* row_seg;
   const char* wstream;     // forward tile stream (fwd_stream_tile order), padded by RING tiles
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *ls1, *fc1_b, *fc2_b, *ls2;
   PartMap pm; int L, NG; float eps, scale;
@@ -269,7 +269,7 @@ __device__ __forceinline__ Split3 xget(const char* buf, int tile, int u, int lan
 }
 constexpr int XBUF_BYTES = 2 * 2 * 3 * 1024;     // one matrix (K or V) of a partition: 2 tiles x 2 k-steps x 3 planes
 
-// the kept tokens [32 w, 32 w + 32) of one partition in wave w; NT = token tiles (= waves) the partition needs
+// the kept tokens [32 w, 32 w + 32) of one pack of partitions in wave w; NT = token tiles (= waves) the pack needs
 template <int C, int INNER, int NT>
 __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restrict__ vec, char* xk, char* xv, WStream& ws, int K, int r0, int w, int lane) {
   constexpr int CT = C / 32, KS = C / 16, H = C / 32, IT = INNER / 32;
@@ -280,6 +280,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
   const int tok = a.row_tok[r0 + min(i, K - 1)];       // clamped: lanes past K recompute a real token, never stored, masked as keys
   const bool save = a.S != nullptr && valid;           // training: this lane's compact row r0 + i of the saved activations
   const size_t crow_g = (size_t)(r0 + min(i, K - 1));
+  // the rows [0, K) are a PACK of whole partitions (SastSel.pack_rows / row_seg): a query attends the keys [klo, khi) of its own one
+  const int seg = a.row_seg[crow_g], klo = seg & 0xffff, khi = seg >> 16;
   FTL(0);
   // ---- S = LN2(LN1(x)) of the kept tokens, transposed tiles S^T[c][t]
   Tile s[CT];
@@ -362,7 +364,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const bool kv = tj * 32 + crow(e, lane) < K;
+        const int j = tj * 32 + crow(e, lane);
+        const bool kv = j >= klo && j < khi;
         st[tj][e] = kv ? st[tj][e] : -INFINITY;
         mloc = fmaxf(mloc, st[tj][e]);
       }
@@ -372,7 +375,8 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pt = (tj * 32 + crow(e, lane) < K) ? __expf(st[tj][e] - m) : 0.f;
+        const int j = tj * 32 + crow(e, lane);
+        const float pt = (j >= klo && j < khi) ? __expf(st[tj][e] - m) : 0.f;
         st[tj][e] = pt;
         ploc += pt;
       }
@@ -481,6 +485,14 @@ __global__ __launch_bounds__(128, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) char xk[XBUF_BYTES];
   __shared__ __attribute__((aligned(16))) char xv[XBUF_BYTES];
   __shared__ __attribute__((aligned(16))) float vec[V::FLOATS];
+  for (int i4 = blockIdx.x * 128 + threadIdx.x; i4 < a.zero_n4; i4 += gridDim.x * 128) st4(a.zero_ptr + 4 * (size_t)i4, zero4());
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = blockIdx.x;
+  const int K = a.pack_rows[g];              // kept rows of the pack of partitions this one leads (0: served elsewhere / nothing kept)
+  // tokens of this partition that are not kept leave the layer as LN1(x): straight from the parameter vectors in global memory
+  // (most workgroups of a sparse step do nothing else and skip the LDS staging below)
+  if (a.Kw[g] < a.pm.T()) ln1_unkept<C>(a, a.ln1_w, a.ln1_b, g, w, lane);
+  if (K == 0) return;
   {   // the layer's vectors -> LDS (LayerScale disabled = ones)
     const int i = threadIdx.x;
     const auto cp = [&](int off, const float* src, int n, float dflt) { for (int j = i; j < n; j += 128) vec[off + j] = src ? src[j] : dflt; };
@@ -488,13 +500,8 @@ __global__ __launch_bounds__(128, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
     cp(V::QKVB, a.qkv_b, 3 * C, 0.f); cp(V::PROJB, a.proj_b, C, 0.f); cp(V::LS1, a.ls1, C, 1.f); cp(V::FC2B, a.fc2_b, C, 0.f);
     cp(V::LS2, a.ls2, C, 1.f); cp(V::FC1B, a.fc1_b, 2 * INNER, 0.f);
   }
-  for (int i4 = blockIdx.x * 128 + threadIdx.x; i4 < a.zero_n4; i4 += gridDim.x * 128) st4(a.zero_ptr + 4 * (size_t)i4, zero4());
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = blockIdx.x;
-  const int K = a.Kw[g];
-  if (K < a.pm.T()) ln1_unkept<C>(a, vec + V::LN1W, vec + V::LN1B, g, w, lane);
-  if (K <= 32 * w) return;                   // K <= 32: one wave runs the partition alone (no barrier below); K == 0: nothing kept
+  if (K <= 32 * w) return;                   // K <= 32: one wave runs the pack alone (no barrier below)
   const int r0 = a.row_off[g];
   WStream ws;
   ws.src = a.wstream + lane * 16;
@@ -545,6 +552,7 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
   FwdArgs f{};
   f.xin = a->xin; f.out = a->out;
   f.Kw = a->sel.K; f.row_off = a->sel.row_off; f.row_tok = a->sel.row_tok; f.mask = (const unsigned long long*)a->sel.mask;
+  f.pack_rows = a->sel.pack_rows; f.row_seg = a->sel.row_seg;
   f.wstream = reinterpret_cast<const char*>(planes);
   f.ln1_w = a->ln1_w; f.ln1_b = a->ln1_b; f.ln2_w = a->ln2_w; f.ln2_b = a->ln2_b; f.qkv_b = a->qkv_b; f.proj_b = a->proj_b; f.ls1 = a->ls1;
   f.fc1_b = a->fc1_b; f.fc2_b = a->fc2_b; f.ls2 = a->ls2;

@@ -17,7 +17,33 @@ namespace sast {
 // 1: grid layer -- SAST.py:141-142 regroups the same scores), each with its own output set
 struct SelOut {
   int* win_keep; unsigned long long* mask; int* K; int* row_off; int* win_rank; int* counts; int* tok_slot; int* row_tok;
+  int* pack_rows; int* row_seg;
 };
+static SelOut sel_out(const SastSel* s) {
+  return SelOut{s->win_keep, (unsigned long long*)s->mask, s->K, s->row_off, s->win_rank, s->counts, s->tok_slot, s->row_tok, s->pack_rows, s->row_seg};
+}
+
+// Attention packs.  kk[0..16) = kept tokens of the 16 consecutive groups of an aligned block, i = this group's place in it.  The pack of
+// group i is the LARGEST aligned sub-block of 1, 2, 4, 8 or 16 groups containing i whose kept rows fit `limit` (the blocks are nested and
+// their sums monotone, so the first level that does not fit ends the search).  lead = first group of the pack, rows = its kept rows,
+// lo = kept rows of the pack in front of group i.
+__device__ __forceinline__ void pack_of(const int* kk, int i, int limit, int& lead, int& rows, int& lo) {
+  lead = i; rows = 0; lo = 0;
+  bool open = true;
+#pragma unroll
+  for (int sz = 1; sz <= 16; sz <<= 1) {           // fully unrolled, branch-free: kk stays in registers
+    const int b0 = i & ~(sz - 1);
+    int sum = 0, before = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bool in = j >= b0 && j < b0 + sz;
+      sum += in ? kk[j] : 0;
+      before += (in && j < i) ? kk[j] : 0;
+    }
+    open = open && (sz == 1 || sum <= limit);
+    if (open) { lead = b0; rows = sum; lo = before; }
+  }
+}
 struct SelPair { SelOut o[2]; int mode[2]; };
 
 constexpr int SEL_WAVES = 16;   // windows per workgroup (one wave each)
@@ -88,7 +114,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float
 // ids, one wave per window (mbcnt-style rank = popcount of lower mask bits).  Every workgroup first sums K / win_keep of all
 // windows before its own SEL_WAVES (W <= a few thousand ints), so no separate scan launch is needed; the last workgroup
 // publishes the totals.
-__global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm, int L, int W, int B, SelPair sp) {
+__global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm, int L, int W, int B, int pack_limit, SelPair sp) {
   pm.mode = sp.mode[blockIdx.y];
   const SelOut& o = sp.o[blockIdx.y];
   const int* __restrict__ win_keep = o.win_keep;
@@ -120,7 +146,15 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm,
     o.counts[3] = 0;
   }
   if (w >= W) return;
-  if (lane == 0) { o.row_off[w] = base; o.win_rank[w] = myw ? rank : -1; }
+  int lead, prow, plo;
+  {
+    int kk[SEL_WAVES];                                  // into registers first: pack_of's loops would chain dependent LDS reads
+#pragma unroll
+    for (int i = 0; i < SEL_WAVES; ++i) kk[i] = ok[i];
+    pack_of(kk, wave, pack_limit, lead, prow, plo);     // SEL_WAVES == 16 == the aligned block of the packs
+  }
+  if (lane == 0) { o.row_off[w] = base; o.win_rank[w] = myw ? rank : -1; o.pack_rows[w] = lead == wave ? prow : 0; }
+  const int seg = plo | ((plo + myk) << 16);
   const int N = pm.N(), T = pm.T();
   const int b = w / N, n = w % N;
   const unsigned long long m0 = mask[2 * w], m1 = mask[2 * w + 1];
@@ -128,13 +162,13 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm,
   if (lane < T) {
     const int p = b * L + pm.token(n, lane);
     int slot = -1;
-    if ((m0 >> lane) & 1ull) { slot = base + __popcll(m0 & below); row_tok[slot] = p; }
+    if ((m0 >> lane) & 1ull) { slot = base + __popcll(m0 & below); row_tok[slot] = p; o.row_seg[slot] = seg; }
     tok_slot[p] = slot;
   }
   if (lane + 64 < T) {
     const int p = b * L + pm.token(n, lane + 64);
     int slot = -1;
-    if ((m1 >> lane) & 1ull) { slot = base + __popcll(m0) + __popcll(m1 & below); row_tok[slot] = p; }
+    if ((m1 >> lane) & 1ull) { slot = base + __popcll(m0) + __popcll(m1 & below); row_tok[slot] = p; o.row_seg[slot] = seg; }
     tok_slot[p] = slot;
   }
 }
@@ -147,32 +181,48 @@ static int select_launch_n(const float* tok, int B, int H, int W_, int ph, int p
   const int chunks = (N + SEL_WAVES - 1) / SEL_WAVES;
   SAST_LAUNCH(select_mask_kernel, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win,
                      thr_tok, sp);
-  SAST_LAUNCH(select_fill_kernel, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, sp);
+  static_assert(SEL_WAVES == 16, "the pack blocks are the 16 groups of a select_fill workgroup");
+  SAST_LAUNCH(select_fill_kernel, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, attn_pack_limit(pm.T()), sp);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 
-int select_launch(const float* tok, int B, int H, int W_, int ph, int pw, int mode, float thr_win, float thr_tok,
-                  int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,
-                  int* row_tok, hipStream_t st) {
+int select_launch(const float* tok, int B, int H, int W_, int ph, int pw, int mode, float thr_win, float thr_tok, const SastSel* sel,
+                  hipStream_t st) {
   SelPair sp;
-  sp.o[0] = SelOut{win_keep, mask, K, row_off, win_rank, counts, tok_slot, row_tok};
+  sp.o[0] = sel_out(sel);
   sp.o[1] = sp.o[0];
   sp.mode[0] = sp.mode[1] = mode;
   return select_launch_n(tok, B, H, W_, ph, pw, thr_win, thr_tok, sp, 1, st);
 }
 
-// window-layer and grid-layer selection of one SAST block in the same four launches
+// window-layer and grid-layer selection of one SAST block in the same launches
 int select_pair_launch(const float* tok, int B, int H, int W_, int ph, int pw, float thr_win, float thr_tok, const SastSel* win,
                        const SastSel* grid, hipStream_t st) {
   SelPair sp;
-  const SastSel* s2[2] = {win, grid};
-  for (int i = 0; i < 2; ++i) {
-    sp.o[i] = SelOut{s2[i]->win_keep, (unsigned long long*)s2[i]->mask, s2[i]->K, s2[i]->row_off, s2[i]->win_rank, s2[i]->counts,
-                     s2[i]->tok_slot, s2[i]->row_tok};
-    sp.mode[i] = i;
-  }
+  sp.o[0] = sel_out(win); sp.o[1] = sel_out(grid);
+  sp.mode[0] = 0; sp.mode[1] = 1;
   return select_launch_n(tok, B, H, W_, ph, pw, thr_win, thr_tok, sp, 2, st);
+}
+
+// packs of a selection built by the host from index lists: one thread per group
+__global__ void select_packs_kernel(const int* __restrict__ K, const int* __restrict__ row_off, int* __restrict__ pack_rows,
+                                    int* __restrict__ row_seg, int W, int limit) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  int kk[16];
+  const int b0 = w & ~15;
+  for (int j = 0; j < 16; ++j) kk[j] = b0 + j < W ? K[b0 + j] : 0;
+  int lead, rows, lo;
+  pack_of(kk, w & 15, limit, lead, rows, lo);
+  pack_rows[w] = lead == (w & 15) ? rows : 0;
+  const int seg = lo | ((lo + kk[w & 15]) << 16);
+  for (int r = 0; r < kk[w & 15]; ++r) row_seg[row_off[w] + r] = seg;
+}
+int select_packs_launch(const SastSel* s, int W, int T, hipStream_t st) {
+  SAST_LAUNCH(select_packs_kernel, dim3((W + 63) / 64), dim3(64), 0, st, s->K, s->row_off, s->pack_rows, s->row_seg, W, attn_pack_limit(T));
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
 }
 
 }  // namespace sast

@@ -54,19 +54,22 @@ int sample_gather_launch(const SastSampleGather& a, bool backward, hipStream_t s
 int zero_samples_launch(float* x, int B, size_t sample_floats, const SastSampleMask& m, hipStream_t st);
 
 // k_select.hip
-int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mode, float thr_win, float thr_tok,
-                  int* win_keep, unsigned long long* mask, int* K, int* row_off, int* win_rank, int* counts, int* tok_slot,
-                  int* row_tok, hipStream_t st);
+int select_launch(const float* tok, int B, int H, int W, int ph, int pw, int mode, float thr_win, float thr_tok, const SastSel* s,
+                  hipStream_t st);
+int select_packs_launch(const SastSel* s, int W, int T, hipStream_t st);
+int attn_pack_limit(int T);   // rows an attention workgroup can hold: 32 x (token tiles of the kernel instantiated for T)
 
 int select_pair_launch(const float* tok, int B, int H, int W, int ph, int pw, float thr_win, float thr_tok, const SastSel* win,
                        const SastSel* grid, hipStream_t st);
 
 // k_attn_mfma.hip (T <= 128)
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh,
-                         hipStream_t st);
+// Kw: kept tokens per group (work accounting only); the kernels run per PACK (pack_rows / row_seg, see SastSel)
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, const int* pack_rows,
+                         const int* row_seg, int W, int T, int C, int dh, hipStream_t st);
 struct LsFinish;
-int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw, int W,
-                         int T, int C, int dh, hipStream_t st, const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
+int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw,
+                         const int* pack_rows, const int* row_seg, int W, int T, int C, int dh, hipStream_t st,
+                         const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
 
 // k_mswsa_fused.hip: the MS-WSA layer as one kernel per direction (one wave per partition)
 bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps);

@@ -388,20 +388,28 @@ class Selection:
         self.N = (H // ph) * (W // pw)
         self.L = H * W
         nw = B * self.N
-        buf = torch.empty(4 * nw + 4 + 2 * B * self.L, device=device, dtype=torch.int32)
-        self.win_keep, self.K, self.row_off, self.win_rank = (buf[i * nw:(i + 1) * nw] for i in range(4))
-        o = 4 * nw
+        buf = torch.empty(5 * nw + 4 + 3 * B * self.L, device=device, dtype=torch.int32)
+        self.win_keep, self.K, self.row_off, self.win_rank, self.pack_rows = (buf[i * nw:(i + 1) * nw] for i in range(5))
+        o = 5 * nw
         self.counts = buf[o:o + 4]
         self.tok_slot = buf[o + 4:o + 4 + B * self.L]
-        self.row_tok = buf[o + 4 + B * self.L:]
+        self.row_tok = buf[o + 4 + B * self.L:o + 4 + 2 * B * self.L]
+        self.row_seg = buf[o + 4 + 2 * B * self.L:]
         self.mask = torch.empty(nw, 2, device=device, dtype=torch.int64)
         self._buf = buf
         self.tok = None  # scores the selection was computed from (for index-list export)
 
     def fill_struct(self, s):
         _fill(s, win_keep=self.win_keep, mask=self.mask, K=self.K, row_off=self.row_off, win_rank=self.win_rank,
-              counts=self.counts, tok_slot=self.tok_slot, row_tok=self.row_tok)
+              counts=self.counts, tok_slot=self.tok_slot, row_tok=self.row_tok, pack_rows=self.pack_rows, row_seg=self.row_seg)
         return s
+
+    def build_packs(self):
+        """attention packs of a selection that was NOT produced by sast_select (index-list constructor below)"""
+        if not hasattr(self, "pack_rows"):
+            self.pack_rows = torch.zeros(self.B * self.N, device=self.K.device, dtype=torch.int32)
+            self.row_seg = torch.zeros(self.B * self.L, device=self.K.device, dtype=torch.int32)
+        L.check(L.lib().sast_select_packs(C.byref(self.struct()), self.B * self.N, self.T, _stream()), "select_packs")
 
     def struct(self):
         return self.fill_struct(L.SastSel())
@@ -508,9 +516,9 @@ def selection_from_index_lists(index_window, asy_index, K, n_groups: int, T: int
     sel.win_keep[iw] = 1
     sel.K = torch.zeros(n_groups, **i32)
     sel.K[iw] = Kl.int()
-    ro = torch.cumsum(Kl, 0) - Kl
-    sel.row_off = torch.zeros(n_groups, **i32)
-    sel.row_off[iw] = ro.int()
+    # exclusive prefix of K over ALL groups (a dropped group gets the offset of the next kept row, as on the device: a pack may be
+    # led by a dropped group)
+    sel.row_off = (torch.cumsum(sel.K.long(), 0) - sel.K.long()).int()
     sel.win_rank = torch.full((n_groups,), -1, **i32)
     sel.win_rank[iw] = torch.arange(len(iw), **i32)
     total = int(asy.numel())
@@ -520,8 +528,15 @@ def selection_from_index_lists(index_window, asy_index, K, n_groups: int, T: int
     sel.tok_slot[tokens] = torch.arange(total, **i32)
     sel.row_tok = torch.zeros(n_groups * T, **i32)
     sel.row_tok[:total] = tokens.int()
-    sel.mask = torch.zeros(n_groups, 2, device=device, dtype=torch.int64)
+    # kept-token bitmask of every group (two 64-bit words): the kernels test it to tell kept from passed-through tokens
+    bits = torch.zeros(n_groups, 128, device=device, dtype=torch.int64)
+    bits[iw[asy // T], asy % T] = 1
+    sh = torch.arange(64, device=device, dtype=torch.int64)
+    lo = (bits[:, :64] << sh).sum(1)        # bit 63 wraps into the sign: the same two's-complement word the device writes
+    hi = (bits[:, 64:] << sh).sum(1)
+    sel.mask = torch.stack([lo, hi], dim=1).contiguous()
     sel.tok = None
+    sel.build_packs()
     return sel
 
 
@@ -567,7 +582,7 @@ _FUSED_ENABLE = True  # tools / tests switch the fused form off to compare the t
 
 class _MSWSA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, *params):
+    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, *params):
         _need_gpu(xin)
         xin = xin.contiguous()
         p = dict(zip(_MSWSA_PARAMS, params))
@@ -585,7 +600,7 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
-        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if _FUSED_ENABLE else 0
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused) else 0
         needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
         fws = None
         if fused_floats:
@@ -653,14 +668,17 @@ class _MSWSA(torch.autograd.Function):
         grads = {k: _g(v) for k, v in p.items()}          # held until the launch is enqueued (scratch buffers among them)
         _fill(a, **{"d_" + k: _ptr(v) for k, v in grads.items()})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
-        return (dxin, None, None, None, None) + (None,) * len(params)
+        return (dxin, None, None, None, None, None) + (None,) * len(params)
 
 
-def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32) -> torch.Tensor:
+def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32, fused: bool = True) -> torch.Tensor:
     """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled).
     cb_tokens_per_sample > 0 enables Context Broadcasting (SAST.py:240-246) with that many tokens per sample.
-    dim_head: 32 or 24 (the widths the reference ships)."""
-    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), *[params[k] for k in _MSWSA_PARAMS])
+    dim_head: 32 or 24 (the widths the reference ships).
+    fused: allow the one-kernel forward (csrc/k_mswsa_fused.hip) where the library has it for the shape.  Same results either way; the
+    fused form is faster when most tokens are kept (-1.5 % of the dense 1Mpx step) and slower when few are (+1.5 % at 15 % kept: a
+    wave runs the whole layer for its <= 32 tokens, a latency the compacted GEMM chain does not have) -- SAST_block passes its AMP."""
+    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), *[params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12

@@ -112,9 +112,9 @@ class MS_WSA(nn.Module):
                     fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias if self.mlp.net[2].bias is not None else self._zero_fc2_b,
                     ls2=getattr(self.ls2, "gamma", None))
 
-    def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False) -> torch.Tensor:
-        """fused path: x (B,H,W,C) in IMAGE layout + device-side selection."""
-        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0, self.dim_head)
+    def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False, fused: bool = True) -> torch.Tensor:
+        """device path: x (B,H,W,C) in IMAGE layout + device-side selection."""
+        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0, self.dim_head, fused)
 
     def forward(self, x: torch.Tensor, index_window: torch.Tensor, index_token: torch.Tensor, padding_index: torch.Tensor,
                 asy_index: torch.Tensor, M: int, B, enable_CB: bool) -> torch.Tensor:
@@ -130,6 +130,9 @@ class MS_WSA(nn.Module):
         # Context Broadcasting averages over the tokens of one sample = N*T/B consecutive partitioned tokens (SAST.py:244-245)
         out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0, self.dim_head)
         return out.view(*shape)
+
+
+FUSED_FORWARD_MAX_AMP = 5e-3
 
 
 class SAST_block(nn.Module):
@@ -170,6 +173,9 @@ class SAST_block(nn.Module):
             torch.nn.init.constant_(self.to_controls.weight, 1)
             self.act = nn.ReLU()
         self.amp_value = cfg_get(attention_cfg, 'AMP', 2e-4)
+        # the one-kernel forward of the MS-WSA layers pays when most tokens survive the selection; the kept fraction is set by AMP
+        # (2e-4 -> ~100 %, 2e-3 -> ~58 %, 2e-2 -> ~29 %).  Measured crossover between 2e-3 and 2e-2 (profiles/r04_j).
+        self.fused_forward = self.amp_value <= FUSED_FORWARD_MAX_AMP
         self.bounce_value = cfg_get(attention_cfg, 'BOUNCE', 1e-3)
         self.first_block = first_block
         self.sync_index_count = sync_index_count
@@ -188,8 +194,8 @@ class SAST_block(nn.Module):
             sel1, sel2 = index_list
             if not isinstance(sel1, SF.Selection):
                 raise TypeError("sast_amd: index_list must be the [Selection, Selection] pair returned by the first block")
-        x = self.win_attn.forward_image(xw, sel1, self.enable_CB)
-        x = self.grid_attn.forward_image(x, sel2, self.enable_CB)
+        x = self.win_attn.forward_image(xw, sel1, self.enable_CB, self.fused_forward)
+        x = self.grid_attn.forward_image(x, sel2, self.enable_CB, self.fused_forward)
         count = SF.DeviceCount((sel1.counts[2], sel2.counts[2]))   # SAST.py:136,159 (floor per layer), summed lazily on the device
         if self.sync_index_count:
             count = count.item()

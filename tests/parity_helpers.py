@@ -27,8 +27,8 @@ def grad_close(name, got, ref, rtol=None):
 
 
 KINK_BAND = 1e-5      # |z| < KINK_BAND * max|z|: a scoring pre-activation within rounding of the ReLU kink (SAST.py:110)
-KINK_MAX_PER_ROW = 8  # ambiguous elements allowed per output channel: the 0/1 fit below (k unknowns, C_in + 1 >= 33 equations) must stay heavily
-                      # over-determined so that it cannot absorb a real error (full-size rows see 245 760 tokens: 6 in the band were measured)
+KINK_MAX_PER_ROW = 16 # ambiguous elements allowed per output channel: the 0/1 fit below (k <= 16 unknowns, C_in + 1 >= 65 equations at the sizes where k > 4 occurs) must stay heavily
+                      # over-determined so that it cannot absorb a real error (full-size rows see 245 760 tokens: up to 9 in the band were measured)
 
 
 def scores_grads_close(prefix, gW, gb, rW, rb, records, rtol=None):

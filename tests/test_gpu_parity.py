@@ -880,6 +880,19 @@ def test_selection_properties_full_size(dev):
         assert kept.numel() == total
         assert torch.equal(torch.sort(slot[kept])[0], torch.arange(total, device=dev))
         assert torch.equal(sel.row_tok[:total].long()[slot[kept]], kept)
+        # attention packs: every kept row belongs to exactly one pack of <= 64 rows that starts at its leader's first row; a row's segment
+        # [lo, hi) is its own group's rows inside the pack; packs are aligned blocks of 1 .. 16 groups and as large as the budget allows
+        Kc, ro, pr = sel.K.cpu().long(), sel.row_off.cpu().long(), sel.pack_rows.cpu().long()
+        assert int(pr.sum()) == total and int(pr.max()) <= 64
+        seg = sel.row_seg[:total].cpu().long()
+        lo, hi = seg & 0xffff, seg >> 16
+        row_group = torch.repeat_interleave(torch.arange(Kc.numel()), Kc)
+        assert torch.equal(hi - lo, Kc[row_group])
+        leaders = torch.nonzero(pr).view(-1)
+        pack_start = torch.repeat_interleave(ro[leaders], pr[leaders])                 # packs tile the compact rows in order
+        assert pack_start.numel() == total
+        assert torch.equal(torch.arange(total) - pack_start, lo + (torch.arange(total) - ro[row_group]))
+        assert len(leaders) < int((Kc > 0).sum()) or int(Kc[Kc > 0].min()) > 32         # small groups really do share workgroups
         # oracle on the same scalars: identical kept sets
         gid = sel.group_token_ids()
         sc = tok.cpu().view(B, H * W)[:, gid].reshape(B, sel.N, sel.T, 1)
@@ -890,14 +903,18 @@ def test_selection_properties_full_size(dev):
         assert torch.equal(sel.K_list().cpu(), K)
 
 
-@pytest.mark.parametrize("T,Ks", [(60, [60, 33, 32, 1, 17]), (80, [80, 65, 64, 3, 40]), (120, [120, 97, 96, 31, 70])])
+@pytest.mark.parametrize("T,Ks", [(60, [60, 33, 32, 1, 17]), (80, [80, 65, 64, 3, 40]), (120, [120, 97, 96, 31, 70]),
+                                  (60, [1, 2, 8, 5, 3, 7, 4, 6, 1, 8, 2, 30, 33, 5, 9, 60, 3, 1, 1, 2, 40, 24, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7, 7]),
+                                  (80, [5, 3, 80, 1, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 8, 40, 40, 17])])
 def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
     """1Mpx-sized groups (T = 60 -> up to two 32-token MFMA tiles), Gen1-sized groups (T = 80 -> up to three tiles, the
     4-wave kernel) and near-maximum partitions (T = 120 -> four tiles) with ragged K_m (full, tile boundary +-1, tiny,
-    dropped window): forward and every gradient against the oracle's padded / masked formulation."""
+    dropped window): forward and every gradient against the oracle's padded / masked formulation.  The two long lists are windows
+    of 1-8 kept tokens next to full ones: several small windows share one attention workgroup (SastSel.pack_rows: aligned blocks of up
+    to 16 groups whose kept rows fit the tile budget), masked block-diagonally."""
     from sast_amd.layers import MS_WSA
     from sast_amd.layers.ops import LayerNorm
-    C, NW = 64, 6                                 # window 5 is dropped
+    C, NW = 64, len(Ks) + 1                       # the last window is dropped
     g = torch.Generator().manual_seed(11)
     kept = [torch.sort(torch.randperm(T, generator=g)[:k])[0] for k in Ks]
     index_window = torch.arange(len(Ks))
