@@ -332,6 +332,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        # proof that the collective backend really spans `world` ranks (not just that WORLD_SIZE says so): every rank contributes a one
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks_verified = int(round(float(ones.item())))
+        if ranks_verified != world:
+            raise SystemExit(f"all-reduce of ones returned {ranks_verified}, expected {world} ranks")
+    else:
+        ranks_verified = 1
 
     # Everything below runs on an explicit (non-default) HIP stream.  Measured on ROCm 7.2 / MI355X: a hipGraph launched on
     # the legacy NULL stream is NOT ordered after kernels enqueued on the NULL stream just before it, so with the optimizer
@@ -365,12 +373,13 @@ def main():
         el = float(t.item())
     # N > 1: how much of the gradient exchange is NOT hidden behind the backward -- a few extra, un-timed steps on every rank with
     # event pairs (main stream idle, side stream done); max over ranks
-    exposed_ms = None
+    exposed_ms, bucket_ms = None, None
     if (world > 1 or tr.segmented) and not tr.fwd_only:
         tr.ts.measure_exposed = True
         for _ in range(20):
             tr.step()
         exposed_ms = tr.ts.exposed_ms()
+        bucket_ms = tr.ts.bucket_ms()
         tr.ts.measure_exposed = False
         if world > 1:
             t = torch.tensor([exposed_ms if exposed_ms is not None else -1.0], device=dev, dtype=torch.float64)
@@ -407,9 +416,12 @@ def main():
                        "library": os.path.relpath(__import__("sast_amd._lib", fromlist=["lib"]).loaded_path(), ROOT),
                        "product_library": __import__("sast_amd._lib", fromlist=["lib"]).is_product_library(),
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
-                       "collective_ranks": world, "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "collective_ranks": world, "collective_ranks_verified": ranks_verified,
+                       "collective_backend": (dist.get_backend() if world > 1 else None),
                        "gradient_bytes_per_rank": 4 * int(tr.flat.numel),
                        "allreduce_exposed_ms": exposed_ms,
+                       # rank 0's all-reduce + AdamW time per gradient bucket (PAFPN[+head], stage 4, stages 3-1), on the stream that ran it
+                       "allreduce_update_ms_per_bucket": ({str(k): round(v, 4) for k, v in bucket_ms.items()} if bucket_ms else None),
                        # the reference's DDP runs convert BatchNorm to SyncBatchNorm (train.py:167); false = per-rank batch statistics
                        "sync_batchnorm": bool(tr.sync_bn),
                        "event_dtype": args.event_dtype,

@@ -622,12 +622,18 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
             "assign": assigns, "outputs": out}
 
 
-# ---- post-processing: yolox/utils/boxes.py:32-76.  The reference calls torchvision.ops.batched_nms, which is
-# not installed here (and not part of /root/reference): greedy NMS is restated from its published definition -- sort by score
-# descending, keep a box unless its IoU with an already kept box OF THE SAME CLASS exceeds the threshold.  (torchvision realises
-# the class separation by shifting the boxes of class c by c * (max coordinate + 1); the decision is the same up to rounding.)
-# Parity for this function is therefore pinned by definition, not by a run of torchvision.
+# ---- post-processing: yolox/utils/boxes.py:32-76.  The reference calls torchvision.ops.nms / batched_nms
+# (boxes.py:57-69); torchvision is not installed here and is not part of /root/reference, so its PUBLISHED algorithm (torchvision 0.15,
+# the version the reference's README pins with pytorch 2.0: torchvision/ops/boxes.py `batched_nms`, csrc/ops/cpu/nms_kernel.cpp) is
+# restated: parity for this function is pinned to that restatement, not to a run of torchvision ("parity unpinned").
+#   nms: boxes by decreasing score; a box is kept unless an already kept box has IoU > thr with it, IoU = inter / (a_i + a_j - inter),
+#        inter = max(0, min(x2) - max(x1)) * max(0, min(y2) - max(y1)), areas (x2 - x1) * (y2 - y1), all in fp32.
+#   batched_nms: with at most 4000 box COORDINATES on the CPU (20000 on a GPU) the "coordinate trick": every box is shifted by
+#        class * (max coordinate of all boxes + 1) and ONE class-agnostic nms runs on the shifted boxes -- the fp32 rounding of the
+#        shifted corners moves intersections and areas by ~1e-7 relative to the unshifted per-class evaluation, which can flip a decision
+#        that sits on the threshold; above that size a per-class loop over the unshifted boxes ("vanilla"), result sorted by score.
 def _nms_greedy(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float, class_agnostic: bool = False) -> Tensor:
+    """plain greedy NMS on the boxes as given; class-aware = only boxes of the same class suppress each other (the vanilla form)"""
     order = torch.sort(scores, descending=True, stable=True).indices
     keep: List[int] = []
     area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
@@ -647,6 +653,20 @@ def _nms_greedy(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float, clas
     return torch.tensor(keep, dtype=torch.long)
 
 
+BATCHED_NMS_TRICK_MAX_COORDS = 4000      # torchvision 0.15 batched_nms, CPU tensors (the oracle's device)
+
+
+def _batched_nms(boxes: Tensor, scores: Tensor, classes: Tensor, thr: float) -> Tensor:
+    """torchvision.ops.batched_nms as published (see above): coordinate trick up to 4000 coordinates, per-class loop beyond"""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.long)
+    if boxes.numel() > BATCHED_NMS_TRICK_MAX_COORDS:
+        return _nms_greedy(boxes, scores, classes, thr, class_agnostic=False)
+    max_coordinate = boxes.max()
+    offsets = classes.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return _nms_greedy(boxes + offsets[:, None], scores, classes, thr, class_agnostic=True)
+
+
 def postprocess(prediction: Tensor, num_classes: int, conf_thre: float = 0.7, nms_thre: float = 0.45, class_agnostic: bool = False):
     """boxes.py:32-76 (class-aware branch, or torchvision.ops.nms over all boxes with class_agnostic): prediction (B, A, 5+nc) with (cx, cy, w, h, obj, cls...) -> list of (n_i, 7) tensors
     (x1, y1, x2, y2, obj_conf, class_conf, class_pred) sorted by decreasing score, or None."""
@@ -662,7 +682,10 @@ def postprocess(prediction: Tensor, num_classes: int, conf_thre: float = 0.7, nm
         det = torch.cat((ip[:, :5], class_conf, class_pred.float()), 1)[mask]
         if not det.size(0):
             continue
-        keep = _nms_greedy(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thre, class_agnostic)
+        if class_agnostic:
+            keep = _nms_greedy(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thre, True)      # torchvision.ops.nms (boxes.py:58-62)
+        else:
+            keep = _batched_nms(det[:, :4], det[:, 4] * det[:, 5], det[:, 6], nms_thre)            # torchvision.ops.batched_nms (:64-69)
         out[i] = det[keep]
     return out
 

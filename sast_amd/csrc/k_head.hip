@@ -436,13 +436,17 @@ __global__ void yolox_loss_finish_kernel(const float* __restrict__ acc, const in
 }
 
 // ---------------------------------------------------------------- post-processing: confidence filter + class-aware NMS
-// reference: yolox/utils/boxes.py:32-76 (torchvision.ops.batched_nms = greedy NMS per class, boxes by decreasing score).
+// reference: yolox/utils/boxes.py:32-76 -> torchvision.ops.nms / batched_nms (torchvision 0.15, restated in oracle/sast_oracle.py:
+// _batched_nms): greedy NMS by decreasing score; class-aware with at most NMS_TRICK_MAX_COORDS box coordinates = the "coordinate
+// trick" (boxes shifted by class * (max coordinate + 1), one class-agnostic pass: the fp32 rounding of the shifted corners is part of
+// the result), above that a per-class evaluation of the unshifted boxes.
+constexpr int NMS_TRICK_MAX_COORDS = 4000;
 // det rows: (x1, y1, x2, y2, obj_conf, class_conf, class_pred, score)
 constexpr int NMS_MAX = 8192;           // anchors per image the sort kernel holds in LDS
 
 // one workgroup per image: candidates (score >= conf_thre), sorted by score descending (ties: lower anchor index first)
 __global__ __launch_bounds__(1024) void nms_candidates_kernel(const float* __restrict__ pred, int A, int nc, float conf_thre,
-                                                              float* __restrict__ det, int* __restrict__ ncand) {
+                                                              float* __restrict__ det, int* __restrict__ ncand, float* __restrict__ maxc) {
   __shared__ float key[NMS_MAX];
   __shared__ unsigned short idx[NMS_MAX];
   const int b = blockIdx.x, no = 5 + nc;
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(1024) void nms_candidates_kernel(const float* __res
   const int n = cnt;
   if (threadIdx.x == 0) ncand[b] = n;
   float* db = det + (size_t)b * A * 8;
+  float mx = -INFINITY;                  // max coordinate over the candidate boxes (batched_nms: boxes.max())
   for (int i = threadIdx.x; i < n; i += 1024) {
     const float* p = pb + (size_t)idx[i] * no;
     float cmax = p[5]; int carg = 0;
@@ -496,29 +501,46 @@ __global__ __launch_bounds__(1024) void nms_candidates_kernel(const float* __res
     float* d = db + (size_t)i * 8;
     d[0] = p[0] - p[2] / 2; d[1] = p[1] - p[3] / 2; d[2] = p[0] + p[2] / 2; d[3] = p[1] + p[3] / 2;
     d[4] = p[4]; d[5] = cmax; d[6] = (float)carg; d[7] = key[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(d[0], d[1])), fmaxf(d[2], d[3]));
+  }
+  __syncthreads();                       // key[] is free now: fold the per-wave maxima through it
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) key[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = key[0];
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, key[w]);
+    maxc[b] = m;
   }
 }
-// suppression bit matrix: bit j of mask[i][j/64] set when sorted box j > i has the same class (or class_agnostic) and IoU(i, j) > thr
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ det, const int* __restrict__ ncand, int A, float thr,
-                                                      unsigned long long* __restrict__ mask, int words, int class_agnostic) {
+// suppression bit matrix: bit j of mask[i][j/64] set when sorted box j > i has IoU(i, j) > thr and (class_agnostic, or the same class in
+// the per-class form, or -- coordinate trick -- whatever the boxes shifted by class * (max coordinate + 1) say)
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ det, const int* __restrict__ ncand, const float* __restrict__ maxc,
+                                                      int A, float thr, unsigned long long* __restrict__ mask, int words, int class_agnostic) {
   const int b = blockIdx.z, n = ncand[b];
   const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
   if (i0 >= n || j0 >= n || j0 + 63 < i0) return;
   __shared__ float bj[64][5];
   const float* db = det + (size_t)b * A * 8;
+  const bool trick = !class_agnostic && 4 * n <= NMS_TRICK_MAX_COORDS;
+  // offsets = class * (max_coordinate + 1), boxes + offsets: separately rounded fp32 operations (no fused multiply-add), as torch evaluates them
+  const float step = __fadd_rn(maxc[b], 1.0f);
   if (j0 + threadIdx.x < n) {
     const float* d = db + (size_t)(j0 + threadIdx.x) * 8;
-    bj[threadIdx.x][0] = d[0]; bj[threadIdx.x][1] = d[1]; bj[threadIdx.x][2] = d[2]; bj[threadIdx.x][3] = d[3]; bj[threadIdx.x][4] = d[6];
+    const float off = trick ? __fmul_rn(d[6], step) : 0.f;
+    bj[threadIdx.x][0] = __fadd_rn(d[0], off); bj[threadIdx.x][1] = __fadd_rn(d[1], off); bj[threadIdx.x][2] = __fadd_rn(d[2], off);
+    bj[threadIdx.x][3] = __fadd_rn(d[3], off); bj[threadIdx.x][4] = d[6];
   }
   __syncthreads();
   const int i = i0 + threadIdx.x;
   if (i >= n) return;
   const float* d = db + (size_t)i * 8;
-  const float x1 = d[0], y1 = d[1], x2 = d[2], y2 = d[3], cl = d[6], ai = (x2 - x1) * (y2 - y1);
+  const float cl = d[6], offi = trick ? __fmul_rn(cl, step) : 0.f;
+  const float x1 = __fadd_rn(d[0], offi), y1 = __fadd_rn(d[1], offi), x2 = __fadd_rn(d[2], offi), y2 = __fadd_rn(d[3], offi), ai = (x2 - x1) * (y2 - y1);
   unsigned long long bits = 0ull;
   for (int t = 0; t < 64; ++t) {
     const int j = j0 + t;
-    if (j <= i || j >= n || (!class_agnostic && bj[t][4] != cl)) continue;
+    if (j <= i || j >= n || (!class_agnostic && !trick && bj[t][4] != cl)) continue;
     const float w = fmaxf(fminf(x2, bj[t][2]) - fmaxf(x1, bj[t][0]), 0.f), h = fmaxf(fminf(y2, bj[t][3]) - fmaxf(y1, bj[t][1]), 0.f);
     const float inter = w * h, aj = (bj[t][2] - bj[t][0]) * (bj[t][3] - bj[t][1]);
     if (inter / (ai + aj - inter) > thr) bits |= 1ull << t;
@@ -654,7 +676,7 @@ int sast_yolox_loss(const float* train_out, const float* labels, const SastHeadG
 
 size_t sast_postprocess_ws_bytes(int B, int anchors_total) {
   const size_t A = (size_t)anchors_total, words = (A + 63) / 64;
-  return (size_t)B * A * 8 * sizeof(float) + (size_t)B * A * words * sizeof(unsigned long long) + (size_t)B * sizeof(int) + 64;
+  return (size_t)B * A * 8 * sizeof(float) + (size_t)B * A * words * sizeof(unsigned long long) + (size_t)B * (sizeof(int) + sizeof(float)) + 64;
 }
 
 int sast_postprocess(const float* prediction, int B, int anchors_total, int num_classes, float conf_thre, float nms_thre, int class_agnostic,
@@ -665,9 +687,10 @@ int sast_postprocess(const float* prediction, int B, int anchors_total, int num_
   float* det = (float*)ws;
   unsigned long long* mask = (unsigned long long*)(det + (size_t)B * A * 8);
   int* ncand = (int*)(mask + (size_t)B * A * words);
+  float* maxc = (float*)(ncand + B);
   zero_fill(mask, sizeof(unsigned long long) * (size_t)B * A * words, st);
-  SAST_LAUNCH(nms_candidates_kernel, dim3(B), dim3(1024), 0, st, prediction, A, num_classes, conf_thre, det, ncand);
-  SAST_LAUNCH(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, A, nms_thre, mask, words, class_agnostic);
+  SAST_LAUNCH(nms_candidates_kernel, dim3(B), dim3(1024), 0, st, prediction, A, num_classes, conf_thre, det, ncand, maxc);
+  SAST_LAUNCH(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, det, ncand, maxc, A, nms_thre, mask, words, class_agnostic);
   SAST_LAUNCH(nms_scan_kernel, dim3(B), dim3(64), 0, st, det, ncand, A, mask, words, out, n_out);
   SAST_CHECK_LAUNCH();
   return SAST_OK;

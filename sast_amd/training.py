@@ -74,6 +74,7 @@ class TrainStep:
         # last bucket's all-reduce + update AFTER its own backward has finished (bench.py: `allreduce_exposed_ms`)
         self.measure_exposed = False
         self._exposed = []
+        self._bucket_ev = {}       # bucket -> [(start, end)] event pairs on the stream that runs its all-reduce + update (measure_exposed)
 
     # ---------------------------------------------------------------- forward + backward segments
     def forward(self, xs: Sequence[torch.Tensor], states=None, labels=None, indices=None, token_masks=None):
@@ -143,8 +144,22 @@ class TrainStep:
     # ---------------------------------------------------------------- reduce + update
     def _reduce_update(self, buckets: List[int]):
         for b in buckets:
+            if self.measure_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.flat.all_reduce(self.group, bucket=b)
             self.opt.update(grad_scale=1.0 / self.world, bucket=b)
+            if self.measure_exposed:
+                e1.record()
+                self._bucket_ev.setdefault(b, []).append((e0, e1))
+
+    def bucket_ms(self):
+        """mean duration of each bucket's all-reduce + AdamW on the stream that ran it (measure_exposed steps): with the segmented step
+        all but the last run beside the remaining backward, so their sum minus `exposed_ms` is what the overlap hid"""
+        torch.cuda.synchronize()
+        out = {b: sum(a.elapsed_time(e) for a, e in v) / len(v) for b, v in sorted(self._bucket_ev.items()) if v}
+        self._bucket_ev = {}
+        return out
 
     def _after_segment(self, i: int, first: bool):
         """all-reduce + AdamW of the buckets that segment i completed; on the side stream when the step is segmented"""

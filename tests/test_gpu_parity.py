@@ -526,6 +526,48 @@ def test_postprocess_nms(dev, A, thr, agnostic):
         assert torch.allclose(got[b].cpu(), ref[b], atol=1e-5, rtol=1e-6), b
 
 
+def _near_threshold_detections(seed=0, n=24, thr=0.45):
+    """n boxes in pairs whose IoU sits on the NMS threshold (a horizontal shift by w (1 - thr) / (1 + thr)), 3 classes: whether the second of
+    a pair survives depends on the last bits of the intersection -- which the coordinate shift of torchvision's batched_nms changes"""
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.randint(0, 3, (n,), generator=g)
+    xy = torch.rand(n, 2, generator=g) * 500 + 20
+    wh = torch.rand(n, 2, generator=g) * 80 + 20
+    boxes = torch.cat([xy, xy + wh], 1)
+    for k in range(0, n, 2):
+        d = float(wh[k, 0] * (1 - thr) / (1 + thr))
+        boxes[k + 1] = boxes[k] + torch.tensor([d, 0, d, 0])
+        cls[k + 1] = cls[k]
+    pred = torch.zeros(1, n, 8)
+    pred[0, :, 0], pred[0, :, 1] = (boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2
+    pred[0, :, 2], pred[0, :, 3] = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    pred[0, :, 4] = 0.75 + 0.25 * torch.rand(n, generator=g)
+    pred[0, torch.arange(n), 5 + cls] = 1.0
+    return pred
+
+
+def test_postprocess_nms_coordinate_trick(dev):
+    """torchvision.ops.batched_nms (the call of boxes.py:64-69) shifts the boxes of class c by c * (max coordinate + 1) and runs ONE
+    class-agnostic pass while the set is small (<= 4000 coordinates); the rounding of the shifted corners is part of its result.  On
+    detections whose pairs sit on the threshold the shifted and the per-class evaluation keep different sets (17 vs 15 here): the kernel
+    must follow the shifted form, as the oracle's restatement of torchvision does.  Above the size limit both are the per-class form."""
+    from sast_amd import functional as SF
+    pred = _near_threshold_detections()
+    ref = O.postprocess(pred, 3, conf_thre=0.5, nms_thre=0.45)
+    ip = pred[0]
+    det = torch.cat((ip[:, 0:1] - ip[:, 2:3] / 2, ip[:, 1:2] - ip[:, 3:4] / 2, ip[:, 0:1] + ip[:, 2:3] / 2, ip[:, 1:2] + ip[:, 3:4] / 2), 1)
+    cc, cp = torch.max(ip[:, 5:8], 1)
+    per_class = O._nms_greedy(det, ip[:, 4] * cc, cp.float(), 0.45, False)
+    assert len(per_class) != ref[0].shape[0], "the fixture no longer separates the two forms"
+    got = SF.postprocess(pred.to(dev), 3, conf_thre=0.5, nms_thre=0.45)
+    assert got[0].shape == ref[0].shape and torch.allclose(got[0].cpu(), ref[0], atol=1e-5, rtol=1e-6)
+    # the same detections replicated beyond the size limit (1250 boxes = 5000 coordinates): per-class form on both sides
+    big = torch.cat([pred + torch.tensor([0.0, 700.0 * k, 0, 0, 0, 0, 0, 0]) for k in range(53)], 1)[:, :1250]
+    ref_b = O.postprocess(big, 3, conf_thre=0.5, nms_thre=0.45)
+    got_b = SF.postprocess(big.to(dev), 3, conf_thre=0.5, nms_thre=0.45)
+    assert got_b[0].shape == ref_b[0].shape and torch.allclose(got_b[0].cpu(), ref_b[0], atol=1e-4, rtol=1e-6)
+
+
 def test_unpadded_uint8_input(dev):
     """the reference pads the uint8 event tensor to in_res_hw before the backbone (modules/detection.py:143-144); here the
     unpadded tensor is accepted directly -- bit-identical to feeding the explicitly padded one, and equal to the oracle."""

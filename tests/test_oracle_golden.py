@@ -298,3 +298,18 @@ def test_conv_lstm_depthwise(golden_dir, mode):
         assert torch.allclose(x.grad, torch.from_numpy(g[pre + "dx"]), atol=1e-6, rtol=1e-4)
         for k, v in po.items():
             assert torch.allclose(v.grad, torch.from_numpy(g[pre + "g_" + k[len("lstm."):]]), atol=1e-5, rtol=1e-4), (tag, k)
+
+
+def test_oracle_batched_nms_forms_differ_on_threshold_pairs():
+    """the oracle restates torchvision.ops.batched_nms with its coordinate trick (oracle/sast_oracle.py:_batched_nms); on detections whose
+    pairs sit on the IoU threshold it keeps a different set than the per-class evaluation of the unshifted boxes -- the case the GPU test
+    test_postprocess_nms_coordinate_trick pins the kernel to"""
+    from test_gpu_parity import _near_threshold_detections
+    pred = _near_threshold_detections()
+    out = O.postprocess(pred, 3, conf_thre=0.5, nms_thre=0.45)
+    ip = pred[0]
+    det = torch.cat((ip[:, 0:1] - ip[:, 2:3] / 2, ip[:, 1:2] - ip[:, 3:4] / 2, ip[:, 0:1] + ip[:, 2:3] / 2, ip[:, 1:2] + ip[:, 3:4] / 2), 1)
+    cc, cp = torch.max(ip[:, 5:8], 1)
+    assert len(O._nms_greedy(det, ip[:, 4] * cc, cp.float(), 0.45, False)) == 17 and out[0].shape[0] == 15
+    # torchvision.ops.nms (class_agnostic) does not shift: at most what the per-class evaluation keeps
+    assert O.postprocess(pred, 3, conf_thre=0.5, nms_thre=0.45, class_agnostic=True)[0].shape[0] <= 17
