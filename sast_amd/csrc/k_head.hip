@@ -436,8 +436,8 @@ __global__ void yolox_loss_finish_kernel(const float* __restrict__ acc, const in
 }
 
 // ---------------------------------------------------------------- post-processing: confidence filter + class-aware NMS
-// reference: yolox/utils/boxes.py:32-76 -> torchvision.ops.nms / batched_nms (torchvision 0.15, restated in oracle/sast_oracle.py:
-// _batched_nms): greedy NMS by decreasing score; class-aware with at most NMS_TRICK_MAX_COORDS box coordinates = the "coordinate
+// reference: yolox/utils/boxes.py:32-76 -> torchvision.ops.nms / batched_nms (torchvision 0.15: torchvision/ops/boxes.py `batched_nms`,
+// csrc/ops/cpu/nms_kernel.cpp): greedy NMS by decreasing score; class-aware with at most NMS_TRICK_MAX_COORDS box coordinates = the "coordinate
 // trick" (boxes shifted by class * (max coordinate + 1), one class-agnostic pass: the fp32 rounding of the shifted corners is part of
 // the result), above that a per-class evaluation of the unshifted boxes.
 constexpr int NMS_TRICK_MAX_COORDS = 4000;

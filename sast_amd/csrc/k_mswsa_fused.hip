@@ -206,7 +206,7 @@ template <int C, int INNER> struct Vec {
 #ifdef SAST_FUSED_TL
 constexpr int FTL_SLOTS = 24, FTL_WAVES = 4096;   // (the timeline tool reads the waves of the first 2048 workgroups)
 __device__ unsigned long long fused_tl[FTL_WAVES * FTL_SLOTS];
-#define FTL(k) do { const int wv_ = blockIdx.x * 2 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) { fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); \
+#define FTL(k) do { const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) { fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); \
     if ((k) == 0) fused_tl[wv_ * FTL_SLOTS + 21] = wall_clock64(); if ((k) == 20) fused_tl[wv_ * FTL_SLOTS + 22] = wall_clock64(); } } while (0)
 #else
 #define FTL(k)
@@ -226,11 +226,11 @@ struct FwdArgs {
 // LN1 of the tokens of partition g that are NOT kept (they leave the layer as LN1(x), SAST.py:206,252): C / 4 lanes per token row
 // (one float4 each: whole rows are read and written contiguously), 256 / C rows per wave instruction; the loads of ALL rows of the
 // partition are issued before the first is used (one wave per SIMD: a load -> reduce -> store loop would run at one latency per row group)
-template <int C>
+template <int C, int NTW>
 __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __restrict__ vec_w, const float* __restrict__ vec_b, int g, int wv, int lane) {
-  constexpr int GL = C / 4, RPI = 64 / GL, NIT = 32 / RPI;      // lanes per row, rows per iteration, iterations of ONE of the two waves for T <= 64
+  constexpr int GL = C / 4, RPI = 64 / GL, NIT = 32 / RPI;      // lanes per row, rows per iteration, iterations of ONE of the NTW waves (T <= 32 NTW)
   const int T = a.pm.T(), N = a.pm.N();
-  const unsigned long long m0 = a.mask[2 * (size_t)g];
+  const unsigned long long m0 = a.mask[2 * (size_t)g], m1 = a.mask[2 * (size_t)g + 1];
   const int b = g / N, n = g - b * N;
   const int gl = lane % GL, sub = lane / GL;
   const float4 w = ld4(vec_w + 4 * gl), bb = ld4(vec_b + 4 * gl);
@@ -238,14 +238,14 @@ __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __rest
   size_t row[NIT];
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int t = (2 * it + wv) * RPI + sub;
+    const int t = (NTW * it + wv) * RPI + sub;
     row[it] = (size_t)b * a.L + a.pm.token(n, min(t, T - 1));
     v[it] = ld4(a.xin + row[it] * C + 4 * gl);
   }
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    const int t = (2 * it + wv) * RPI + sub;
-    const bool act = t < T && !((m0 >> t) & 1ull);
+    const int t = (NTW * it + wv) * RPI + sub;
+    const bool act = t < T && !(((t < 64 ? m0 : m1) >> (t & 63)) & 1ull);
     float4 x = v[it];
     const float mean = group_sum<GL>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
     x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
@@ -257,17 +257,17 @@ __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __rest
   }
 }
 
+constexpr int XTILE_BYTES = 2 * 3 * 1024;        // one token tile of one matrix (K or V): 2 k-steps x 3 planes
 // K / V operands of the partition's token tiles, shared by its waves through LDS: [tile][u][plane][lane] x 16 bytes (lane-linear: every
 // access is a conflict-free ds_write_b128 / ds_read_b128)
 __device__ __forceinline__ void xput(char* buf, int tile, int u, int lane, const Split3& v) {
-  char* p = buf + ((tile * 2 + u) * 3) * 1024 + lane * 16;
+  char* p = buf + tile * XTILE_BYTES + u * 3 * 1024 + lane * 16;
   *reinterpret_cast<bf16x8*>(p) = v.h; *reinterpret_cast<bf16x8*>(p + 1024) = v.m; *reinterpret_cast<bf16x8*>(p + 2048) = v.l;
 }
 __device__ __forceinline__ Split3 xget(const char* buf, int tile, int u, int lane) {
-  const char* p = buf + ((tile * 2 + u) * 3) * 1024 + lane * 16;
+  const char* p = buf + tile * XTILE_BYTES + u * 3 * 1024 + lane * 16;
   return Split3{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + 1024), *reinterpret_cast<const bf16x8*>(p + 2048)};
 }
-constexpr int XBUF_BYTES = 2 * 2 * 3 * 1024;     // one matrix (K or V) of a partition: 2 tiles x 2 k-steps x 3 planes
 
 // the kept tokens [32 w, 32 w + 32) of one pack of partitions in wave w; NT = token tiles (= waves) the pack needs
 template <int C, int INNER, int NT>
@@ -477,31 +477,48 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
   FTL(20);
 }
 
-// one workgroup = one partition, one wave per tile of 32 kept tokens (T <= 64: two waves)
-template <int C, int INNER>
-__global__ __launch_bounds__(128, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
+// the waves of a workgroup that have no token tile of their own (the pack needs NT < NTW tiles) still owe the barriers of fwd_body
+template <int H, int NT>
+__device__ __forceinline__ void barriers_only() {
+  if (NT > 1)
+    for (int h = 0; h < H; ++h) { if (h > 0) __syncthreads(); __syncthreads(); }
+}
+
+// one workgroup = one partition (its LN1-only tokens) + the pack of partitions it leads, one wave per tile of 32 kept tokens;
+// NTW = ceil(T / 32) waves (1Mpx T = 60: two, Gen1 T = 80: three)
+template <int C, int INNER, int NTW>
+__global__ __launch_bounds__(64 * NTW, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
   using V = Vec<C, INNER>;
-  __shared__ __attribute__((aligned(16))) char ring_s[2 * RING * TILE_BYTES];
-  __shared__ __attribute__((aligned(16))) char xk[XBUF_BYTES];
-  __shared__ __attribute__((aligned(16))) char xv[XBUF_BYTES];
+  __shared__ __attribute__((aligned(16))) char ring_s[NTW * RING * TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char xk[NTW * XTILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char xv[NTW * XTILE_BYTES];
   __shared__ __attribute__((aligned(16))) float vec[V::FLOATS];
-  for (int i4 = blockIdx.x * 128 + threadIdx.x; i4 < a.zero_n4; i4 += gridDim.x * 128) st4(a.zero_ptr + 4 * (size_t)i4, zero4());
+  constexpr int NTH = 64 * NTW;
+  for (int i4 = blockIdx.x * NTH + threadIdx.x; i4 < a.zero_n4; i4 += gridDim.x * NTH) st4(a.zero_ptr + 4 * (size_t)i4, zero4());
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = blockIdx.x;
   const int K = a.pack_rows[g];              // kept rows of the pack of partitions this one leads (0: served elsewhere / nothing kept)
   // tokens of this partition that are not kept leave the layer as LN1(x): straight from the parameter vectors in global memory
   // (most workgroups of a sparse step do nothing else and skip the LDS staging below)
-  if (a.Kw[g] < a.pm.T()) ln1_unkept<C>(a, a.ln1_w, a.ln1_b, g, w, lane);
+  if (a.Kw[g] < a.pm.T()) ln1_unkept<C, NTW>(a, a.ln1_w, a.ln1_b, g, w, lane);
   if (K == 0) return;
   {   // the layer's vectors -> LDS (LayerScale disabled = ones)
     const int i = threadIdx.x;
-    const auto cp = [&](int off, const float* src, int n, float dflt) { for (int j = i; j < n; j += 128) vec[off + j] = src ? src[j] : dflt; };
+    const auto cp = [&](int off, const float* src, int n, float dflt) { for (int j = i; j < n; j += NTH) vec[off + j] = src ? src[j] : dflt; };
     cp(V::LN1W, a.ln1_w, C, 1.f); cp(V::LN1B, a.ln1_b, C, 0.f); cp(V::LN2W, a.ln2_w, C, 1.f); cp(V::LN2B, a.ln2_b, C, 0.f);
     cp(V::QKVB, a.qkv_b, 3 * C, 0.f); cp(V::PROJB, a.proj_b, C, 0.f); cp(V::LS1, a.ls1, C, 1.f); cp(V::FC2B, a.fc2_b, C, 0.f);
     cp(V::LS2, a.ls2, C, 1.f); cp(V::FC1B, a.fc1_b, 2 * INNER, 0.f);
   }
   __syncthreads();
-  if (K <= 32 * w) return;                   // K <= 32: one wave runs the pack alone (no barrier below)
+  const int nt = (K + 31) >> 5;              // token tiles of the pack (workgroup-uniform)
+  if (w >= nt) {                             // no tile for this wave: only the barriers the working waves count on
+    switch (nt) {
+      case 2: barriers_only<C / 32, 2>(); break;
+      case 3: barriers_only<C / 32, 3>(); break;
+      default: break;
+    }
+    return;
+  }
   const int r0 = a.row_off[g];
   WStream ws;
   ws.src = a.wstream + lane * 16;
@@ -509,8 +526,12 @@ __global__ __launch_bounds__(128, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
   ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
   ws.ring = ring + lane * 16;
   ws.start();
-  if (K <= 32) fwd_body<C, INNER, 1>(a, vec, xk, xv, ws, K, r0, w, lane);
-  else fwd_body<C, INNER, 2>(a, vec, xk, xv, ws, K, r0, w, lane);
+  switch (nt) {
+    case 1: fwd_body<C, INNER, 1>(a, vec, xk, xv, ws, K, r0, w, lane); break;
+    case 2: fwd_body<C, INNER, 2>(a, vec, xk, xv, ws, K, r0, w, lane); break;
+    case 3: if constexpr (NTW >= 3) fwd_body<C, INNER, 3>(a, vec, xk, xv, ws, K, r0, w, lane); break;
+    case 4: if constexpr (NTW >= 4) fwd_body<C, INNER, 4>(a, vec, xk, xv, ws, K, r0, w, lane); break;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the RING tiles of padding still in flight must land before the LDS is released
 }
 
@@ -522,10 +543,10 @@ extern "C" int sast_fused_tl_read(unsigned long long* host_out, int nwaves) {
 #endif
 
 // ------------------------------------------------------------------------------------------------ host side
-// which layers the fused kernels serve: dim 64 (stage 1 of every shipped model size with embed_dim 64), dim_head 32, partitions of at
-// most 64 tokens (1Mpx: 60), GLU inner a multiple of 32.  Everything else keeps the unfused path (k_block.hip).
+// which layers the fused kernels serve: dim 64 (stage 1 of the models with embed_dim 64), dim_head 32, partitions of at most 128 tokens
+// (1Mpx: 60, Gen1: 80), GLU inner 160.  Everything else keeps the unfused path (k_block.hip).
 bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps) {
-  return C == 64 && inner == 160 && T <= 64 && dim_head == 32 && cb_tps == 0;
+  return C == 64 && inner == 160 && T <= 128 && dim_head == 32 && cb_tps == 0;
 }
 // fp32 words of the weight planes: the forward stream (+ RING tiles of padding the prefetcher reads past the end)
 size_t mswsa_fused_plane_floats(int C, int inner) {
@@ -562,15 +583,22 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
   f.zero_ptr = a->raw_ws; f.zero_n4 = a->raw_ws ? (int)(sast_mswsa_raw_ws_floats(C, inner) / 4) : 0;
   f.pm = make_part_map(a->H, a->W, a->ph, a->pw, a->mode);
   f.L = L; f.NG = a->B * (L / T); f.eps = a->eps; f.scale = 1.0f / sqrtf(32.f);
-  const dim3 grid(f.NG), block(128);
+  const int ntw = T <= 64 ? 2 : (T <= 96 ? 3 : 4);
+  const dim3 grid(f.NG), block(64 * ntw);
+#define SAST_FUSED_FWD_LAUNCH(LAUNCH, ...)                                                                   \
+  do {                                                                                                       \
+    if (ntw == 2) LAUNCH((mswsa_fused_fwd_kernel<64, 160, 2>), grid, block, 0, st, __VA_ARGS__);              \
+    else if (ntw == 3) LAUNCH((mswsa_fused_fwd_kernel<64, 160, 3>), grid, block, 0, st, __VA_ARGS__);         \
+    else LAUNCH((mswsa_fused_fwd_kernel<64, 160, 4>), grid, block, 0, st, __VA_ARGS__);                       \
+  } while (0)
   if (prof_enabled()) {
     double sk, sk2; hipEvent_t e0, e1;
     prof_sum_k(f.Kw, f.NG, st, &sk, &sk2);
     // 2 (4 C^2 + 3 C inner) flop per kept token + 4 C K_m^2 per partition; bytes: the layer reads its input once and writes its output once
     prof_kernel_events_ex("mswsa_fused_fwd_kernel", 2.0 * (4.0 * C * C + 3.0 * C * inner) * sk + 4.0 * C * sk2, 8.0 * C * (double)a->B * L, st, &e0, &e1);
-    SAST_EXT_LAUNCH((mswsa_fused_fwd_kernel<64, 160>), grid, block, 0, st, e0, e1, 0, f);
+    SAST_FUSED_FWD_LAUNCH(SAST_EXT_LAUNCH, e0, e1, 0, f);
   } else {
-    SAST_LAUNCH((mswsa_fused_fwd_kernel<64, 160>), grid, block, 0, st, f);
+    SAST_FUSED_FWD_LAUNCH(SAST_LAUNCH, f);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;

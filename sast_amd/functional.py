@@ -578,6 +578,10 @@ _MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w",
 
 
 _FUSED_ENABLE = True  # tools / tests switch the fused form off to compare the two forms of the layer in one process
+# rows (B * L tokens of the layer) from which the one-kernel forward is used: a wave of it runs the whole layer for 32 tokens (~50 us of
+# dependent work), which only pays once the rows give every SIMD of the chip about two such waves.  Measured: 1Mpx B = 4 (61 440 rows)
+# -1.5 % of the training step, -4.2 % forward only; Gen1 B = 4 (20 480 rows) +1.9 % forward only (profiles/r04_k).  Tests set 0.
+_FUSED_MIN_ROWS = int(os.environ.get("SAST_MSWSA_FUSED_MIN_ROWS", "49152"))
 
 
 class _MSWSA(torch.autograd.Function):
@@ -600,7 +604,7 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
-        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused) else 0
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and R >= _FUSED_MIN_ROWS) else 0
         needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
         fws = None
         if fused_floats:

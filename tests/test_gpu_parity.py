@@ -34,6 +34,11 @@ LIST_NAMES = ("index_window", "index_token", "padding_index", "asy_index", "K")
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "these tests need the MI355X"
+    # the one-kernel forward of the dim-64 MS-WSA layers is a throughput choice the product makes from the row count
+    # (functional._FUSED_MIN_ROWS); here every eligible layer takes it, whatever its size, so that the golden fixtures pin THAT kernel --
+    # the launch chain it replaces is pinned by test_fused_forward_matches_the_launch_chain and by every layer of another width
+    from sast_amd import functional as SF
+    SF._FUSED_MIN_ROWS = 0
     return torch.device("cuda:0")
 
 
@@ -524,6 +529,44 @@ def test_postprocess_nms(dev, A, thr, agnostic):
     for b in range(2):
         assert got[b] is not None and got[b].shape == ref[b].shape, (b, None if got[b] is None else got[b].shape, ref[b].shape)
         assert torch.allclose(got[b].cpu(), ref[b], atol=1e-5, rtol=1e-6), b
+
+
+@pytest.mark.parametrize("T,B,Hh,Ww,ph,pw", [(60, 2, 48, 80, 6, 10), (80, 2, 32, 40, 8, 10)])
+def test_fused_forward_matches_the_launch_chain(dev, T, B, Hh, Ww, ph, pw):
+    """the one-kernel MS-WSA forward (csrc/k_mswsa_fused.hip) against the seven-launch chain of k_block.hip on the same inputs: output,
+    input gradient and every parameter gradient (the fused forward writes the activations the chain's backward reads), window and grid
+    partition, dense / half / few tokens kept, partitions of 60 tokens (two waves) and of 80 (three waves, Gen1)."""
+    from sast_amd import functional as SF
+    C, inner = 64, 160
+    g = torch.Generator().manual_seed(7)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(dev)
+    p = dict(ln1_w=1 + r(C, sc=0.1), ln1_b=r(C, sc=0.1), ln2_w=1 + r(C, sc=0.1), ln2_b=r(C, sc=0.1), qkv_w=r(3 * C, C, sc=C ** -0.5), qkv_b=r(3 * C, sc=0.1),
+             proj_w=r(C, C, sc=C ** -0.5), proj_b=r(C, sc=0.1), ls1=0.5 + r(C, sc=0.1), fc1_w=r(2 * inner, C, sc=C ** -0.5), fc1_b=r(2 * inner, sc=0.1),
+             fc2_w=r(C, inner, sc=inner ** -0.5), fc2_b=r(C, sc=0.1), ls2=0.5 + r(C, sc=0.1))
+    x, wgt = r(B, Hh, Ww, C), r(B, Hh, Ww, C)
+    try:
+        for mode in (0, 1):
+            for sharp in (0.0, 0.3, 0.8):
+                tok = (torch.randn(B, Hh * Ww, generator=g) * sharp).exp().to(dev).contiguous()
+                sel = SF.select(tok, B, Hh, Ww, ph, pw, mode, 0.0)
+                res = {}
+                for fused in (False, True):
+                    SF._FUSED_ENABLE = fused
+                    xs = x.clone().requires_grad_(True)
+                    ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+                    out = SF.mswsa(xs, sel, 1e-5, ps)
+                    (out * wgt).sum().backward()
+                    with torch.no_grad():
+                        out_inf = SF.mswsa(x, sel, 1e-5, p)           # the inference form of the same kernel (writes nothing but the output)
+                    res[fused] = (out.detach(), xs.grad, {k: v.grad for k, v in ps.items()}, out_inf)
+                tag = f"T{T} mode{mode} sharp{sharp}"
+                abs_close(res[True][0].cpu(), res[False][0].cpu(), FWD_ATOL, tag + " out")
+                abs_close(res[True][3].cpu(), res[False][0].cpu(), FWD_ATOL, tag + " out (inference form)")
+                maxnorm_close(res[True][1], res[False][1], 1e-5, tag + " dx")
+                for k in p:
+                    maxnorm_close(res[True][2][k], res[False][2][k], 1e-5, tag + " d" + k)
+    finally:
+        SF._FUSED_ENABLE = True
 
 
 def _near_threshold_detections(seed=0, n=24, thr=0.45):
