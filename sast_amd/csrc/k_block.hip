@@ -359,6 +359,11 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     dz = a->cb_m;
     dz_tok = nullptr;
   }
+  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
+    // MLP backward as one kernel (k_mswsa_fused.hip): dY and dW1 / db1 / raw dW2 / colsum(dZ) from the saved Y, [u|g] recomputed
+    rc = mswsa_fused_mlp_bwd_launch(a, a->fused_ws, dY, raw2, s2, R, st);
+    if (rc) return rc;
+  } else {
   // Every (weight gradient, activation gradient) pair below consumes the same dY and goes out as ONE launch (gemm_pair).
   // fc2: raw dW2 / db2 (LayerScale applied in the finish kernel) need dZ (= dout rows) and H;  dH = (gamma2 * dZ) W2 fused
   // with the GLU backward: dUG from the saved pre-activations
@@ -377,6 +382,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
                  LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
   if (rc) return rc;
+  }
   // proj: raw dWp / dbp, and dO = (gamma1 * dY) Wp
   if (a->ls1) {
     rc = gemm_pair(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1,

@@ -76,5 +76,7 @@ bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps);
 size_t mswsa_fused_plane_floats(int C, int inner);
 int mswsa_fused_planes_launch(const SastMswsaArgs* a, float* planes, hipStream_t st);
 int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStream_t st);
+bool mswsa_fused_mlp_bwd_enabled();
+int mswsa_fused_mlp_bwd_launch(const SastMswsaArgs* a, const float* planes, float* dY, float* raw2, float* s2, int rows_max, hipStream_t st);
 
 }  // namespace sast

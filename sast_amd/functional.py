@@ -634,13 +634,13 @@ class _MSWSA(torch.autograd.Function):
             cb_m, cb_sum = torch.empty(R, Cc, device=dev), torch.empty(R // cb_tps, Cc, device=dev)
             _fill(a, cb_tps=cb_tps, cb_m=cb_m, cb_sum=cb_sum)
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
-        ctx.save_for_backward(xin, stats, big, raw)
+        ctx.save_for_backward(xin, stats, big, raw, fws)      # fws: the weight planes the fused kernels of this call pair stream (or None)
         ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        xin, stats, big, raw = ctx.saved_tensors
+        xin, stats, big, raw, fws = ctx.saved_tensors
         _consume(ctx, "mswsa")
         sel, params, inner = ctx.sel, ctx.params, ctx.inner
         p = dict(zip(_MSWSA_PARAMS, params))
@@ -664,6 +664,8 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, dim_head=ctx.dim_head, xin=xin,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh,
               dout=dout, dxin=dxin, ws=ws, raw_ws=raw)
+        if fws is not None:
+            _fill(a, fused_ws=fws)
         if ctx.cb_tps:
             cb_m, cb_sum = torch.empty(R, Cc, device=xin.device), torch.empty(R // ctx.cb_tps, Cc, device=xin.device)
             _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
