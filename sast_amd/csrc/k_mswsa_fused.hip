@@ -47,7 +47,7 @@ constexpr int STREAM_PAD = 8;           // tiles of padding behind every stream 
 // A wave prefetches the stream through a private LDS ring with LDS-DMA loads (global_load_lds_dwordx4: no staging registers), RING
 // tiles ahead of its MFMAs -- one wave per SIMD has nobody else to hide the L2 latency behind.
 struct TileRef { int mat, nt, ks, tr; };   // mat: 0 qkv [3C][C], 1 proj [C][C], 2 fc1 [2 inner][C], 3 fc2 [C][inner]; tr: tile of the TRANSPOSED matrix
-// forward order: per head { per ks: q, k, v tile; per (ct, u): proj tile }, then per hidden chunk { per ks: u, g tile; per (ct, u): fc2 tile }
+// forward order: per head { per ks: q, k, v tile; per (u, ct): proj tile }, then per hidden chunk { per ks: u, g tile; per (u, ct): fc2 tile }
 __host__ __device__ inline int fwd_stream_tiles(int C, int inner) { return (C / 32) * (3 * (C / 16) + 2 * (C / 32)) + (inner / 32) * (2 * (C / 16) + 2 * (C / 32)); }
 __host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
   const int KS = C / 16, CT = C / 32, H = C / 32, IT = inner / 32, per_head = 3 * KS + 2 * CT, per_chunk = 2 * KS + 2 * CT;
@@ -55,13 +55,13 @@ __host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
     const int h = n / per_head, j = n - h * per_head;
     if (j < 3 * KS) return TileRef{0, 3 * h + j % 3, j / 3, 0};
     const int jj = j - 3 * KS;
-    return TileRef{1, jj / 2, 2 * h + (jj & 1), 0};
+    return TileRef{1, jj % CT, 2 * h + jj / CT, 0};       // (half u, channel tile ct): the two ct tiles of a half are consumed together
   }
   n -= H * per_head;
   const int kc = n / per_chunk, j = n - kc * per_chunk;
   if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc, j / 2, 0};
   const int jj = j - 2 * KS;
-  return TileRef{3, jj / 2, 2 * kc + (jj & 1), 0};
+  return TileRef{3, jj % CT, 2 * kc + jj / CT, 0};
 }
 // MLP-backward order, per hidden chunk kc: { per ks: W1 u, g tile (recompute of [u|g]) } { per ks: W2^T tile (dH = (ls2 dZ) W2: index = hidden
 // channel of the chunk, reduce = c) } { per ct, per part (u, g), per half: W1^T tile (dY += dUG W1: index = c, reduce = hidden row) }
@@ -345,9 +345,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const Split3 wq = ws.take(), wk = ws.take(), wv = ws.take();
-      q = mfma6(wq, sop[ks], q);      // Q^T[d][t]
-      k = mfma6(wk, sop[ks], k);      // K^T[d][t]
-      v = mfma6(sop[ks], wv, v);      // V[t][d]
+      mfma6x3(wq, sop[ks], q, wk, sop[ks], k, sop[ks], wv, v);      // Q^T[d][t], K^T[d][t], V[t][d]: three chains interleaved
     }
     FTL(3 + 4 * h);
     if (a.S) {   // raw q, k, v of head h: channels [96 h, 96 h + 96) of the saved QKV rows (SAST.py:219: [head][q|k|v])
@@ -380,10 +378,12 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     // S^T[j][i]: rows = keys of tile tj, column = this lane's query
     Tile st[NT];
 #pragma unroll
-    for (int tj = 0; tj < NT; ++tj) {
-      st[tj] = tzero();
+    for (int tj = 0; tj < NT; ++tj) st[tj] = tzero();
 #pragma unroll
-      for (int u = 0; u < 2; ++u) st[tj] = mfma6(xget(xk, tj, u, lane), qop[u], st[tj]);
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int tj = 0; tj + 1 < NT; tj += 2) mfma6x2(xget(xk, tj, u, lane), qop[u], st[tj], xget(xk, tj + 1, u, lane), qop[u], st[tj + 1]);
+      if (NT & 1) st[NT - 1] = mfma6(xget(xk, NT - 1, u, lane), qop[u], st[NT - 1]);
     }
     float mloc = -INFINITY;
 #pragma unroll
@@ -409,13 +409,12 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     const float psum = pair_sum(ploc);
     const float inv = 1.0f / psum;
     if (save && hf == 0) a.lse[crow_g * H + h] = m + logf(psum);
-    Tile o = tzero();
+    Tile o = tzero(), o2 = tzero();                     // O^T[d][i], over two accumulator chains
 #pragma unroll
     for (int tj = 0; tj < NT; ++tj)
+      mfma6x2(xget(xv, tj, 0, lane), c_tile_operand(st[tj], 0), o, xget(xv, tj, 1, lane), c_tile_operand(st[tj], 1), o2);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) o = mfma6(xget(xv, tj, u, lane), c_tile_operand(st[tj], u), o);   // O^T[d][i]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) o[e] *= inv;
+    for (int e = 0; e < 16; ++e) o[e] = (o[e] + o2[e]) * inv;
     if (save) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) st4(a.O + crow_g * C + h * 32 + 8 * qd + 4 * hf, make_float4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]));
@@ -425,10 +424,14 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     Split3 oop[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) oop[u] = c_tile_operand(o, u);
+    static_assert(CT == 2, "the interleaved projection / fc2 products below are written for two channel tiles");
+    {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) y[ct] = mfma6(ws.take(), oop[u], y[ct]);
+      for (int u = 0; u < 2; ++u) {                      // stream order (u, ct)
+        const Split3 w0 = ws.take(), w1 = ws.take();
+        mfma6x2(w0, oop[u], y[0], w1, oop[u], y[1]);
+      }
+    }
     FTL(6 + 4 * h);
   }
   FTL(11);
@@ -483,10 +486,13 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     Split3 hop[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) hop[u] = c_tile_operand(uu, u);
+    {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) z[ct] = mfma6(ws.take(), hop[u], z[ct]);
+      for (int u = 0; u < 2; ++u) {                      // stream order (u, ct)
+        const Split3 w0 = ws.take(), w1 = ws.take();
+        mfma6x2(w0, hop[u], z[0], w1, hop[u], z[1]);
+      }
+    }
     FTL(13 + kc);
   }
   FTL(19);
@@ -778,12 +784,14 @@ size_t mswsa_fused_plane_floats(int C, int inner) {
   return (size_t)(fused::fwd_stream_tiles(C, inner) + fused::mlpb_stream_tiles(C, inner) + 2 * fused::STREAM_PAD) * fused::TILE_BYTES / 4;
 }
 
+bool mswsa_fused_mlp_bwd_enabled();
 int mswsa_fused_planes_launch(const SastMswsaArgs* a, float* planes, hipStream_t st) {
   using namespace fused;
   const int C = a->C, inner = a->inner;
   PlaneArgs pa{};
   pa.w[0] = a->qkv_w; pa.ld[0] = C; pa.w[1] = a->proj_w; pa.ld[1] = C; pa.w[2] = a->fc1_w; pa.ld[2] = C; pa.w[3] = a->fc2_w; pa.ld[3] = inner;
-  pa.C = C; pa.inner = inner; pa.ntiles_fwd = fwd_stream_tiles(C, inner); pa.ntiles = pa.ntiles_fwd + mlpb_stream_tiles(C, inner);
+  pa.C = C; pa.inner = inner; pa.ntiles_fwd = fwd_stream_tiles(C, inner);
+  pa.ntiles = pa.ntiles_fwd + (mswsa_fused_mlp_bwd_enabled() ? mlpb_stream_tiles(C, inner) : 0);      // the backward stream only when its kernel will run
   SAST_LAUNCH(weight_planes_kernel, dim3((pa.ntiles * 64 + 255) / 256), dim3(256), 0, st, pa, reinterpret_cast<u4*>(planes));
   SAST_CHECK_LAUNCH();
   return SAST_OK;

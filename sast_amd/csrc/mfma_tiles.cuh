@@ -33,6 +33,31 @@ __device__ __forceinline__ f32x16 mfma6(const Split3& a, const Split3& b, f32x16
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, acc, 0, 0, 0);
   return acc;
 }
+// two (three) independent products with their terms issued alternately: a dependent v_mfma chain on ONE accumulator issues every ~42
+// cycles, the pipe takes one every 32 (tools/overlap_probe.py) -- interleaved chains fill the gap without a second wave
+__device__ __forceinline__ void mfma6x2(const Split3& a0, const Split3& b0, f32x16& c0, const Split3& a1, const Split3& b1, f32x16& c1) {
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.l, b0.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.l, b1.h, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.l, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.l, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.m, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.m, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.m, b0.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.m, b1.h, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.m, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.m, c1, 0, 0, 0);
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.h, b0.h, c0, 0, 0, 0);
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.h, b1.h, c1, 0, 0, 0);
+}
+__device__ __forceinline__ void mfma6x3(const Split3& a0, const Split3& b0, f32x16& c0, const Split3& a1, const Split3& b1, f32x16& c1,
+                                        const Split3& a2, const Split3& b2, f32x16& c2) {
+#define SAST_M3(T0, T1)                                                          \
+  c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.T0, b0.T1, c0, 0, 0, 0);       \
+  c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.T0, b1.T1, c1, 0, 0, 0);       \
+  c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2.T0, b2.T1, c2, 0, 0, 0);
+  SAST_M3(l, h) SAST_M3(h, l) SAST_M3(m, m) SAST_M3(m, h) SAST_M3(h, m) SAST_M3(h, h)
+#undef SAST_M3
+}
 __device__ __forceinline__ float pair_sum(float v) { return v + lane_peer<32>(v); }
 __device__ __forceinline__ float pair_max(float v) { return fmaxf(v, lane_peer<32>(v)); }
 
