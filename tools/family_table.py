@@ -4,7 +4,8 @@ the 8 TB/s HBM peak.  usage: python tools/family_table.py <kernel_trace_stats.tx
 import json, re, sys, collections
 
 stats, pmc, nstep, npmc = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-FAM = [("GEMM template (all linears, convs, dW/dX pairs)", r"gemm_kernel|gemm_dual_kernel"),
+FAM = [("fused MS-WSA layer kernels (stage 1: forward, weight planes)", r"mswsa_fused|weight_planes"),
+       ("GEMM template (all linears, convs, dW/dX pairs)", r"gemm_kernel|gemm_dual_kernel"),
        ("attention fwd/bwd (MFMA, per window)", r"attn_"),
        ("BatchNorm apply / backward passes (FPN)", r"bn_"),
        ("LayerNorm / STP / gather rows", r"ln_|ln1_|stp_"),
