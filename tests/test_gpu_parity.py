@@ -531,8 +531,8 @@ def test_postprocess_nms(dev, A, thr, agnostic):
         assert torch.allclose(got[b].cpu(), ref[b], atol=1e-5, rtol=1e-6), b
 
 
-@pytest.mark.parametrize("T,B,Hh,Ww,ph,pw", [(60, 2, 48, 80, 6, 10), (80, 2, 32, 40, 8, 10)])
-def test_fused_forward_matches_the_launch_chain(dev, T, B, Hh, Ww, ph, pw):
+@pytest.mark.parametrize("T,B,Hh,Ww,ph,pw,layer_scale", [(60, 2, 48, 80, 6, 10, True), (80, 2, 32, 40, 8, 10, True), (60, 1, 24, 40, 6, 10, False)])
+def test_fused_forward_matches_the_launch_chain(dev, T, B, Hh, Ww, ph, pw, layer_scale):
     """the one-kernel MS-WSA forward (csrc/k_mswsa_fused.hip) against the seven-launch chain of k_block.hip on the same inputs: output,
     input gradient and every parameter gradient (the fused forward writes the activations the chain's backward reads), window and grid
     partition, dense / half / few tokens kept, partitions of 60 tokens (two waves) and of 80 (three waves, Gen1)."""
@@ -543,6 +543,8 @@ def test_fused_forward_matches_the_launch_chain(dev, T, B, Hh, Ww, ph, pw):
     p = dict(ln1_w=1 + r(C, sc=0.1), ln1_b=r(C, sc=0.1), ln2_w=1 + r(C, sc=0.1), ln2_b=r(C, sc=0.1), qkv_w=r(3 * C, C, sc=C ** -0.5), qkv_b=r(3 * C, sc=0.1),
              proj_w=r(C, C, sc=C ** -0.5), proj_b=r(C, sc=0.1), ls1=0.5 + r(C, sc=0.1), fc1_w=r(2 * inner, C, sc=C ** -0.5), fc1_b=r(2 * inner, sc=0.1),
              fc2_w=r(C, inner, sc=inner ** -0.5), fc2_b=r(C, sc=0.1), ls2=0.5 + r(C, sc=0.1))
+    if not layer_scale:                     # ls_init_value <= 0 (SAST.py:187): no LayerScale parameters at all
+        p["ls1"] = p["ls2"] = None
     x, wgt = r(B, Hh, Ww, C), r(B, Hh, Ww, C)
     try:
         for mode in (0, 1):
@@ -556,17 +558,17 @@ def test_fused_forward_matches_the_launch_chain(dev, T, B, Hh, Ww, ph, pw):
                     junk = torch.full((64 << 20,), float('nan'), device=dev)      # whatever scratch is handed out next holds NaN, not
                     del junk                                                         # the other form's leftovers
                     xs = x.clone().requires_grad_(True)
-                    ps = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+                    ps = {k: (v.clone().requires_grad_(True) if v is not None else None) for k, v in p.items()}
                     out = SF.mswsa(xs, sel, 1e-5, ps)
                     (out * wgt).sum().backward()
                     with torch.no_grad():
                         out_inf = SF.mswsa(x, sel, 1e-5, p)           # the inference form of the same kernel (writes nothing but the output)
-                    res[fused] = (out.detach(), xs.grad, {k: v.grad for k, v in ps.items()}, out_inf)
+                    res[fused] = (out.detach(), xs.grad, {k: v.grad for k, v in ps.items() if v is not None}, out_inf)
                 tag = f"T{T} mode{mode} sharp{sharp}"
                 abs_close(res[True][0].cpu(), res[False][0].cpu(), FWD_ATOL, tag + " out")
                 abs_close(res[True][3].cpu(), res[False][0].cpu(), FWD_ATOL, tag + " out (inference form)")
                 maxnorm_close(res[True][1], res[False][1], 1e-5, tag + " dx")
-                for k in p:
+                for k in res[True][2]:
                     maxnorm_close(res[True][2][k], res[False][2][k], 1e-5, tag + " d" + k)
     finally:
         SF._FUSED_ENABLE = True
