@@ -278,6 +278,14 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False, tr=None):
                       f"oracle/sast_oracle.py, torch {torch.__version__} CPU, {cores} threads, no optimizer step"}
 
 
+def _fused_forward_in_use(amp):
+    from sast_amd import functional as SF, _lib as SL
+    from sast_amd.layers.sast import FUSED_FORWARD_MAX_AMP
+    rows = BATCH * (HW[0] // 4) * (HW[1] // 4)
+    T = PART[0] * PART[1]
+    return bool(SF._FUSED_ENABLE and amp <= FUSED_FORWARD_MAX_AMP and rows >= SF._FUSED_MIN_ROWS and SL.lib().sast_mswsa_fused_ws_floats(64, 160, T, 32, 0) > 0)
+
+
 def main():
     global BATCH, HW, PART
     ap = argparse.ArgumentParser()
@@ -416,6 +424,9 @@ def main():
                        "library": os.path.relpath(__import__("sast_amd._lib", fromlist=["lib"]).loaded_path(), ROOT),
                        "product_library": __import__("sast_amd._lib", fromlist=["lib"]).is_product_library(),
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
+                       # the dim-64 MS-WSA layers (stage 1) run their forward as ONE kernel (csrc/k_mswsa_fused.hip) when the rows and the
+                       # block's AMP allow it (sast_amd/functional.py: _FUSED_MIN_ROWS, layers/sast.py: FUSED_FORWARD_MAX_AMP)
+                       "fused_mswsa_forward": _fused_forward_in_use(args.amp),
                        "collective_ranks": world, "collective_ranks_verified": ranks_verified,
                        "collective_backend": (dist.get_backend() if world > 1 else None),
                        "gradient_bytes_per_rank": 4 * int(tr.flat.numel),
