@@ -579,9 +579,9 @@ __global__ __launch_bounds__(64 * NTW, 2) void mswsa_fused_fwd_kernel(FwdArgs a)
 //   * dW path: a weight gradient reduces over the ROWS, which sit in the lanes of every tile: the tiles of dZ, Y (once) and h, dU, dG
 //     (per chunk) go through a wave-private LDS scratch ([channel][32 rows], written by row, read by channel: 16 ds_write_b32 + 4
 //     ds_read_b128 per tile) and come back as operands with the rows as reduce index; their row sums are the bias gradients;
-//   * the partial products of the waves are added in LDS (ds_add_f32): dW1 stays there for the whole workgroup, the dW2 block of a chunk
-//     is flushed (one float atomic per element and workgroup) while the next chunk computes.  Atomic adds run at ~1.2 TB/s chip-wide
-//     whatever their addresses (profiles/r04_a): one flush per 128 rows keeps them at 58 MB per launch.
+//   * the six partial dW tiles of a chunk are summed over the four waves by an owner wave each (the others park theirs in LDS with plain
+//     stores) and leave as one float atomic per element and workgroup.  Atomic adds run at ~1.2 TB/s chip-wide whatever their addresses
+//     (profiles/r04_a): one flush per 128 rows keeps them at 58 MB per launch.
 constexpr int TR_LD = 36;                          // scratch row: 32 rows of the tile + 4 floats (16-byte aligned, conflict-free b128 reads)
 constexpr int TR_FLOATS = 32 * TR_LD;
 
@@ -629,15 +629,15 @@ __global__ __launch_bounds__(256) void mswsa_fused_mlp_bwd_kernel(MlpBwdArgs a) 
   constexpr int CT = C / 32, KS = C / 16, IT = INNER / 32;
   __shared__ __attribute__((aligned(16))) char ring_s[4 * RINGB * TILE_BYTES];
   __shared__ __attribute__((aligned(16))) float trs[4 * TR_FLOATS];
-  __shared__ __attribute__((aligned(16))) float dw1[2 * INNER * C];           // [2 inner][C], the layout of fc1.weight
-  __shared__ __attribute__((aligned(16))) float dw2[C * 32];                   // [c][hidden channel of the chunk]
+  // the six dW tiles of a chunk (0, 1: dW2 ct 0 / 1; 2, 3: dW1 u-rows ct 0 / 1; 4, 5: dW1 g-rows) are summed over the four waves by an
+  // OWNER wave (tile i: wave i & 3): the other three park their partial tiles here (lane-linear float4 stores), the owner adds them to its
+  // own and issues the global atomics.  (LDS float atomics into shared accumulators cost ~760 cycles per wave instruction: r04_m.)
+  __shared__ __attribute__((aligned(16))) float stage[6 * 3 * 64 * 16];
   __shared__ float db1[2 * INNER], s2s[C], vb1[2 * INNER], vg2[C];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hf = lane >> 5;
   const int count = min(*a.count, a.rows_max);
   const int wg_row0 = blockIdx.x * 128;
   if (wg_row0 >= count) return;                                               // workgroup-uniform
-  for (int i = threadIdx.x; i < 2 * INNER * C; i += 256) dw1[i] = 0.f;
-  for (int i = threadIdx.x; i < C * 32; i += 256) dw2[i] = 0.f;
   for (int i = threadIdx.x; i < 2 * INNER; i += 256) { db1[i] = 0.f; vb1[i] = a.fc1_b[i]; }
   if (threadIdx.x < C) { s2s[threadIdx.x] = 0.f; vg2[threadIdx.x] = a.ls2 ? a.ls2[threadIdx.x] : 1.f; }
   __syncthreads();
@@ -682,6 +682,7 @@ __global__ __launch_bounds__(256) void mswsa_fused_mlp_bwd_kernel(MlpBwdArgs a) 
     }
   }
   FTLB(1);
+  Tile own0, own1;                           // this wave's own partial of the dW tiles it owns (w, w + 4)
 #pragma unroll 1
   for (int kc = 0; kc < IT; ++kc) {
     if (wave_on) {
@@ -727,29 +728,58 @@ __global__ __launch_bounds__(256) void mswsa_fused_mlp_bwd_kernel(MlpBwdArgs a) 
       tr_operands(tr, du, lane, duT, su);
       tr_operands(tr, dg, lane, dgT, sg);
       if (hf == 0) { lds_add(db1 + kc * 32 + l31, su); lds_add(db1 + INNER + kc * 32 + l31, sg); }
+      Tile pt[6];
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
-        Tile t = tzero();                                                     // raw dW2[c][k] = sum_t dZ[t][c] h[t][k]
-        t = mfma6(dzT[ct][0], hT[0], t);
-        t = mfma6(dzT[ct][1], hT[1], t);
-        lds_add_tile(&dw2[ct * 32 * 32], 32, t, lane);
-        Tile tu = tzero(), tg = tzero();                                      // dW1[j][c] = sum_t dUG[t][j] Y[t][c]
-        tu = mfma6(duT[0], yT[ct][0], tu);
-        tu = mfma6(duT[1], yT[ct][1], tu);
-        tg = mfma6(dgT[0], yT[ct][0], tg);
-        tg = mfma6(dgT[1], yT[ct][1], tg);
-        lds_add_tile(dw1 + (size_t)(kc * 32) * C + ct * 32, C, tu, lane);
-        lds_add_tile(dw1 + (size_t)(INNER + kc * 32) * C + ct * 32, C, tg, lane);
+        pt[ct] = tzero();                                                     // raw dW2[c][k] = sum_t dZ[t][c] h[t][k]
+        pt[2 + ct] = tzero(); pt[4 + ct] = tzero();                           // dW1[j][c] = sum_t dUG[t][j] Y[t][c]
+        mfma6x3(dzT[ct][0], hT[0], pt[ct], duT[0], yT[ct][0], pt[2 + ct], dgT[0], yT[ct][0], pt[4 + ct]);
+        mfma6x3(dzT[ct][1], hT[1], pt[ct], duT[1], yT[ct][1], pt[2 + ct], dgT[1], yT[ct][1], pt[4 + ct]);
       }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if ((i & 3) == w) { if (i < 4) own0 = pt[i]; else own1 = pt[i]; }
+        else {
+          float* sp = stage + ((i * 3 + ((w - (i & 3) - 1) & 3)) * 64 + lane) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) st4(sp + 4 * q, make_float4(pt[i][4 * q], pt[i][4 * q + 1], pt[i][4 * q + 2], pt[i][4 * q + 3]));
+        }
+      }
+    } else {                               // a wave past the last kept row: its partial tiles are zero
+      own0 = tzero(); own1 = tzero();
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        if ((i & 3) != w) {
+          float* sp = stage + ((i * 3 + ((w - (i & 3) - 1) & 3)) * 64 + lane) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) st4(sp + 4 * q, zero4());
+        }
     }
     FTLB(4 + 4 * kc);
-    __syncthreads();                       // every wave's share of this chunk's dW2 block is in
-    for (int i = threadIdx.x; i < C * 32; i += 256) {
-      const int c = i >> 5, k = i & 31;
-      atomicAdd(a.raw2 + (size_t)c * INNER + kc * 32 + k, dw2[i]);
-      dw2[i] = 0.f;
+    __syncthreads();                       // every wave's partial tiles of this chunk are parked
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int i = w + 4 * half;          // the tiles this wave owns: w, and w + 4 for waves 0 and 1
+      if (i < 6) {
+        Tile t = half ? own1 : own0;
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+          const float* sp = stage + ((i * 3 + sl) * 64 + lane) * 16;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = ld4(sp + 4 * q);
+            t[4 * q] += v.x; t[4 * q + 1] += v.y; t[4 * q + 2] += v.z; t[4 * q + 3] += v.w;
+          }
+        }
+        const int ct = i & 1;
+        float* dst = i < 2 ? a.raw2 + (size_t)(ct * 32) * INNER + kc * 32                       // [c][k]
+                           : a.d_fc1_w + (size_t)((i >= 4 ? INNER : 0) + kc * 32) * C + ct * 32;   // [j][c]
+        const int ld = i < 2 ? INNER : C;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(dst + (size_t)crow(e, lane) * ld + l31, t[e]);
+      }
     }
-    __syncthreads();                       // ... and cleared before the next chunk adds into it (LDS is full: no second buffer)
+    __syncthreads();                       // ... and read before the next chunk overwrites them
     FTLB(5 + 4 * kc);
   }
   if (wave_on) {
@@ -760,7 +790,6 @@ __global__ __launch_bounds__(256) void mswsa_fused_mlp_bwd_kernel(MlpBwdArgs a) 
   }
   __syncthreads();
   FTLB(22);
-  for (int i = threadIdx.x; i < 2 * INNER * C; i += 256) atomicAdd(a.d_fc1_w + i, dw1[i]);
   for (int i = threadIdx.x; i < 2 * INNER; i += 256) atomicAdd(a.d_fc1_b + i, db1[i]);
   if (threadIdx.x < C) atomicAdd(a.s2 + threadIdx.x, s2s[threadIdx.x]);
   FTLB(23);
@@ -840,12 +869,15 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
 }
 
 // OFF by default (SAST_MSWSA_FUSED_MLP_BWD=1 enables): correct (tests/test_gpu_parity.py: test_fused_mlp_backward_opt_in) but measured
-// SLOWER than the two (dW || dX) launch pairs it replaces -- 1Mpx B = 4 step 4.94 -> 5.58 ms (profiles/r04_l, r04_m):
-//   * a wave spends 73 000 of its 98 000 cycles per hidden chunk in the 96 ds_add_f32 that fold its six partial dW tiles into the
-//     workgroup's LDS accumulators (~760 cycles per LDS float-atomic wave instruction with four waves contending);
-//   * without them the kernel would still be ~170 us against the pairs' 93 us: one wave per SIMD (256 VGPRs + 252 AGPRs, 160 KB of LDS)
-//     runs the MFMA, VALU, transpose and barrier phases of a chunk strictly one after the other at ~25 % of the matrix pipe, while the
-//     pairs stream their 28 A bytes at 4.3-5.3 TB/s.
+// SLOWER than the two (dW || dX) launch pairs it replaces -- 1Mpx B = 4 step 4.955 -> 5.064 ms (profiles/r04_o), i.e. ~180 us per launch
+// against the pairs' 93 us + the 15 us the forward saves by not writing [u|g] and h:
+//   * a wave needs 174 kcycles (89 us at 1.95 GHz) for its 32 rows and the 1920 waves of a 1Mpx B = 4 layer are two rounds of the chip;
+//     per hidden chunk: fc1 recompute + dH 6-14 k, gelu + dY 6 k, transposes + dW MFMAs 8 k, the owner-wave reduction of the partial dW
+//     tiles with its atomics and two barriers 3-4 k -- for 32 tile steps = 6.1 kcycles of matrix-pipe time, ~20 % of the pipe with ONE wave
+//     per SIMD (256 VGPRs + 252 AGPRs, 147 KB of LDS) whose MFMA, VALU, LDS-transpose and barrier phases run strictly one after the other;
+//   * the pairs stream their 28 A bytes at 4.3-5.3 TB/s with four workgroups per CU.
+// (The first form folded the partial dW tiles into shared LDS accumulators with ds_add_f32: 73 of 98 kcycles per chunk, ~760 cycles per
+// LDS float-atomic wave instruction with four waves contending -- profiles/r04_m; the step was 5.58 ms.)
 // Kept as the measured record of the recomputing backward the round-3 verdict asked for (in-kernel weight gradients included).
 bool mswsa_fused_mlp_bwd_enabled() {
   static int on = -1;

@@ -27,8 +27,8 @@ print(f"waves {len(t)}; cycles per wave mean {np.mean(t[:, 23] - t[:, 0]):.0f}")
 names = {1: "prologue (loads, operands, transposes of Y / dZ)"}
 for kc in range(5):
     names[2 + 4 * kc] = f"chunk {kc}: fc1 recompute + dH MFMAs"; names[3 + 4 * kc] = f"chunk {kc}: gelu, dU dG, dY MFMAs"
-    names[4 + 4 * kc] = f"chunk {kc}: transposes, dW MFMAs, LDS adds"; names[5 + 4 * kc] = f"chunk {kc}: barrier, dW2 flush, barrier"
-names[22] = "dY store + barrier"; names[23] = "dW1 / db1 flush"
+    names[4 + 4 * kc] = f"chunk {kc}: transposes, dW MFMAs, partial tiles parked"; names[5 + 4 * kc] = f"chunk {kc}: barrier, owner sums + atomics, barrier"
+names[22] = "dY store + barrier"; names[23] = "db1 / colsum(dZ) flush"
 prev = 0
 for k in sorted(names):
     d = t[:, k] - t[:, prev]
