@@ -47,6 +47,11 @@ constexpr int STREAM_PAD = 8;           // tiles of padding behind every stream 
 // A wave prefetches the stream through a private LDS ring with LDS-DMA loads (global_load_lds_dwordx4: no staging registers), RING
 // tiles ahead of its MFMAs -- one wave per SIMD has nobody else to hide the L2 latency behind.
 struct TileRef { int mat, nt, ks, tr; };   // mat: 0 qkv [3C][C], 1 proj [C][C], 2 fc1 [2 inner][C], 3 fc2 [C][inner]; tr: tile of the TRANSPOSED matrix
+// SAST_FUSED_PIPELINED_MLP=1 (experiment): the MLP loop of the forward is software-pipelined -- the fc1 MFMAs of chunk k + 1 are issued
+// between slices of the GELU / split VALU work of chunk k -- and the tile stream carries fc1(k + 1) in front of fc2(k)
+#ifndef SAST_FUSED_PIPELINED_MLP
+#define SAST_FUSED_PIPELINED_MLP 0
+#endif
 // forward order: per head { per ks: q, k, v tile; per (u, ct): proj tile }, then per hidden chunk { per ks: u, g tile; per (u, ct): fc2 tile }
 __host__ __device__ inline int fwd_stream_tiles(int C, int inner) { return (C / 32) * (3 * (C / 16) + 2 * (C / 32)) + (inner / 32) * (2 * (C / 16) + 2 * (C / 32)); }
 __host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
@@ -58,10 +63,25 @@ __host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
     return TileRef{1, jj % CT, 2 * h + jj / CT, 0};       // (half u, channel tile ct): the two ct tiles of a half are consumed together
   }
   n -= H * per_head;
+#if SAST_FUSED_PIPELINED_MLP
+  // fc1(0) | { fc1(k + 1), fc2(k) } for k < IT - 1 | fc2(IT - 1)
+  if (n < 2 * KS) return TileRef{2, (n & 1) * IT, n / 2, 0};
+  n -= 2 * KS;
+  {
+    const int kc = n / per_chunk, j = n - kc * per_chunk;
+    if (kc < IT - 1) {
+      if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc + 1, j / 2, 0};
+      const int jj = j - 2 * KS;
+      return TileRef{3, jj % CT, 2 * kc + jj / CT, 0};
+    }
+    return TileRef{3, j % CT, 2 * (IT - 1) + j / CT, 0};
+  }
+#else
   const int kc = n / per_chunk, j = n - kc * per_chunk;
   if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc, j / 2, 0};
   const int jj = j - 2 * KS;
   return TileRef{3, jj % CT, 2 * kc + jj / CT, 0};
+#endif
 }
 // MLP-backward order, per hidden chunk kc: { per ks: W1 u, g tile (recompute of [u|g]) } { per ks: W2^T tile (dH = (ls2 dZ) W2: index = hidden
 // channel of the chunk, reduce = c) } { per ct, per part (u, g), per half: W1^T tile (dY += dUG W1: index = c, reduce = hidden row) }
@@ -453,6 +473,65 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
   Tile z[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) z[ct] = tzero();
+#if SAST_FUSED_PIPELINED_MLP
+  static_assert(KS == 4, "the pipelined MLP loop slices the 16 registers of a tile over the 4 k-steps of fc1");
+  const auto fc1_bias = [&](int kc, Tile& u_, Tile& g_) {
+    float bu[16], bg[16];
+    rowvec(vec + V::FC1B + kc * 32, 0, hf, bu);
+    rowvec(vec + V::FC1B + INNER + kc * 32, 0, hf, bg);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { u_[e] = bu[e]; g_[e] = bg[e]; }
+  };
+  Tile uu, gg;
+  fc1_bias(0, uu, gg);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const Split3 wu = ws.take(), wg = ws.take();
+    mfma6x2(wu, yop[ks], uu, wg, yop[ks], gg);
+  }
+#pragma unroll 1
+  for (int kc = 0; kc < IT; ++kc) {
+    Tile un, gn;
+    Split3 hop[2];
+    // slice q of the GELU / save / split work of chunk kc: registers 4 q .. 4 q + 3
+    const auto slice = [&](int q) {
+      if (save && a.UG) {
+        float* ug = a.UG + crow_g * (2 * INNER) + kc * 32;
+        st4(ug + 8 * q + 4 * hf, make_float4(uu[4 * q], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]));
+        st4(ug + INNER + 8 * q + 4 * hf, make_float4(gg[4 * q], gg[4 * q + 1], gg[4 * q + 2], gg[4 * q + 3]));
+      }
+#pragma unroll
+      for (int e = 4 * q; e < 4 * q + 4; ++e) uu[e] *= gelu_erf(gg[e]);
+      if (save && a.Hh) st4(a.Hh + crow_g * INNER + kc * 32 + 8 * q + 4 * hf, make_float4(uu[4 * q], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]));
+      if (q == 1) hop[0] = c_tile_operand(uu, 0);
+      if (q == 3) hop[1] = c_tile_operand(uu, 1);
+    };
+    if (kc + 1 < IT) {
+      fc1_bias(kc + 1, un, gn);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const Split3 wu = ws.take(), wg = ws.take();
+        mfma6x2(wu, yop[ks], un, wg, yop[ks], gn);       // chunk kc + 1 on the matrix pipe ...
+        slice(ks);                                         // ... under a quarter of chunk kc's VALU work
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {                     // one MFMA, then ~a twelfth of the slice's VALU instructions
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) slice(ks);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                          // stream order (u, ct)
+      const Split3 w0 = ws.take(), w1 = ws.take();
+      mfma6x2(w0, hop[u], z[0], w1, hop[u], z[1]);
+    }
+    uu = un; gg = gn;
+    FTL(13 + kc);
+  }
+#else
 #pragma unroll 1
   for (int kc = 0; kc < IT; ++kc) {
     Tile uu, gg;
@@ -495,6 +574,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     }
     FTL(13 + kc);
   }
+#endif
   FTL(19);
   // ---- out = Y + ls2 * (Z + b2), scattered to the image rows of the kept tokens   (SAST.py:248-253)
 #pragma unroll
