@@ -54,6 +54,14 @@ def synthetic_labels(B, hw, num_classes, max_labels=16, seed=0):
     return lab
 
 
+def _flush_c_stdio():
+    """RCCL prints a version banner through C stdio when its first communicator comes up; on a pipe that buffer is only written at
+    exit, i.e. BEHIND the JSON line.  Flushed after the process group is up (every rank) and again before rank 0 prints its line."""
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+
+
 class Trainer:
     """bench harness around sast_amd.training.TrainStep (the reference's step is Lightning's, modules/detection.py:113-221)."""
 
@@ -90,14 +98,16 @@ class Trainer:
         self.fpn.to(dev)
         self.world = world
         # --sync-bn: the reference's DDP runs use SyncBatchNorm (train.py:167).  The statistics all-reduces sit between the two phases of
-        # every conv + BatchNorm unit and are not captured into hipGraphs: the step then runs eagerly (training.TrainStep.capture refuses)
-        self.sync_bn = bool(sync_bn) and world > 1 and not infer
+        # every conv + BatchNorm unit; on RCCL they are captured into the step's hipGraphs, on a host-side backend (gloo) the step runs
+        # eagerly (training.TrainStep.capture refuses).  SAST_SYNC_BN_FORCE=1: the same two-phase path with ONE rank (single-GPU check)
+        force = os.environ.get("SAST_SYNC_BN_FORCE", "0") == "1"
+        self.sync_bn = bool(sync_bn) and (world > 1 or force) and not infer
         if self.sync_bn:
             from sast_amd.detection import convert_sync_batchnorm
-            convert_sync_batchnorm(self.fpn)
-            if self.head is not None:
-                convert_sync_batchnorm(self.head)
-            use_graph = False
+            # one group for PAFPN + head: the head takes over the PAFPN's sample-count exchange of the pass
+            convert_sync_batchnorm(torch.nn.ModuleList([self.fpn] + ([self.head] if self.head is not None else [])), force=force)
+            if not self.fpn._sync_group.capturable():
+                use_graph = False
         self.segmented = ((world > 1) and os.environ.get("SAST_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
         self.ts = TrainStep(self.net, self.fpn, self.head if yolox_loss else None, lr=2e-4, weight_decay=0.0, clip_value=1.0, world=world,
                             segmented=self.segmented)
@@ -150,7 +160,10 @@ class Trainer:
                     # the same weights and input and reports the disagreement in the JSON line (`parity`)
                     self.fwd_bwd()
                     self.step0 = {"loss": float(self.loss), "P": [int(p) for p in self.P], "grad": self.flat.grad.detach().cpu().clone()}
+                n0 = self.fpn._sync_group.n_collectives if self.sync_bn else 0
                 self.eager_step()
+                if self.sync_bn:       # statistics all-reduces of ONE step (PAFPN + head share the group)
+                    self.sync_collectives_per_step = self.fpn._sync_group.n_collectives - n0
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.loss_first = float(self.loss)
@@ -309,7 +322,7 @@ def main():
                     "built reduced-precision library (GEMM operands rounded to bf16, fp32 accumulate; the arithmetic class of the reference's AMP-16 "
                     "experiments) -- reported as a different metric, index decisions differ from the fp32 reference's")
     ap.add_argument("--sync-bn", action="store_true", help="N > 1: SyncBatchNorm in the PAFPN / head like the reference's DDP runs (train.py:167); "
-                    "eager step (the statistics all-reduces are not captured into hipGraphs).  Default: per-rank batch statistics")
+                    "the statistics all-reduces are captured into the hipGraphs on RCCL, eager step on gloo.  Default: per-rank batch statistics")
     ap.add_argument("--event-dtype", choices=["int32", "uint8"], default="int32", help="int32: the reference's benchmark.py protocol (`.int()`); "
                     "uint8: the dataset's storage type -- the event tensor stays bytes up to the stem conv's loaders")
     ap.add_argument("--no-graph", action="store_true")
@@ -333,6 +346,13 @@ def main():
     local = local % max(ndev, 1)          # (test rigs with fewer GPUs than ranks share a device; the driver gives one GPU per rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # SAST_SYNC_BN_FORCE=1 with --sync-bn and one rank: a ONE-rank RCCL group, so that the captured statistics all-reduces are real
+    # RCCL calls (single-GPU check of the capture path; the collectives then move no data)
+    one_rank_group = world == 1 and args.sync_bn and os.environ.get("SAST_SYNC_BN_FORCE", "0") == "1"
+    if one_rank_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SAST_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo only for plumbing tests
@@ -344,6 +364,7 @@ def main():
         ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ones)
         ranks_verified = int(round(float(ones.item())))
+        _flush_c_stdio()
         if ranks_verified != world:
             raise SystemExit(f"all-reduce of ones returned {ranks_verified}, expected {world} ranks")
     else:
@@ -428,13 +449,14 @@ def main():
                        # block's AMP allow it (sast_amd/functional.py: _FUSED_MIN_ROWS, layers/sast.py: FUSED_FORWARD_MAX_AMP)
                        "fused_mswsa_forward": _fused_forward_in_use(args.amp),
                        "collective_ranks": world, "collective_ranks_verified": ranks_verified,
-                       "collective_backend": (dist.get_backend() if world > 1 else None),
+                       "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "gradient_bytes_per_rank": 4 * int(tr.flat.numel),
                        "allreduce_exposed_ms": exposed_ms,
                        # rank 0's all-reduce + AdamW time per gradient bucket (PAFPN[+head], stage 4, stages 3-1), on the stream that ran it
                        "allreduce_update_ms_per_bucket": ({str(k): round(v, 4) for k, v in bucket_ms.items()} if bucket_ms else None),
                        # the reference's DDP runs convert BatchNorm to SyncBatchNorm (train.py:167); false = per-rank batch statistics
                        "sync_batchnorm": bool(tr.sync_bn),
+                       "sync_batchnorm_collectives_per_step": (tr.sync_collectives_per_step if tr.sync_bn else None),
                        "event_dtype": args.event_dtype,
                        "kept_token_fraction_per_stage": [round(k / (2 * l), 4) for k, l in zip(kept, L)],
                        "loss_first_step": loss_first, "loss": float(tr.loss),
@@ -447,9 +469,12 @@ def main():
             parity, res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only, tr=tr)
             if parity is not None:
                 res["parity"] = parity
-        print(json.dumps(res))
     if world > 1:
         dist.barrier()       # rank 0 may still be in its (rank-local) roofline leg: leave the group together
+    _flush_c_stdio()         # RCCL's version banner sits in the C library's stdout buffer: out with it BEFORE the one JSON line
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

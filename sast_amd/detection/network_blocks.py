@@ -49,12 +49,13 @@ def sync_active(conv: "BaseConv") -> bool:
     return conv.sync_bn is not None and conv.sync_bn.active()
 
 
-def convert_sync_batchnorm(module: nn.Module, process_group=None):
+def convert_sync_batchnorm(module: nn.Module, process_group=None, force: bool = False):
     """the reference's Trainer(sync_batchnorm=True) under DDP (train.py:167; torch.nn.SyncBatchNorm.convert_sync_batchnorm): every
     conv + BatchNorm + SiLU unit below `module` takes its training-mode batch statistics over the rows of ALL ranks of `process_group`.
     The BatchNorm2d modules stay what they are (same parameters, buffers and state_dict keys); one functional.SyncBatchNormGroup is shared
-    by the units and issues the all-reduces between the two phases of the fused op.  Returns `module`."""
-    grp = SF.SyncBatchNormGroup(process_group)
+    by the units and issues the all-reduces between the two phases of the fused op.  `force`: keep the two-phase path on with one rank
+    (functional.SyncBatchNormGroup).  Returns `module`."""
+    grp = SF.SyncBatchNormGroup(process_group, force=force)
     for m in module.modules():
         if isinstance(m, BaseConv):
             m.sync_bn = grp

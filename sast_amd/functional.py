@@ -801,14 +801,17 @@ class SyncBatchNormGroup:
     """SyncBatchNorm for the conv + BatchNorm + SiLU units: the reference trains with `sync_batchnorm=True` whenever it runs DDP
     (train.py:167 -> torch.nn.SyncBatchNorm: batch statistics over the rows of ALL ranks, affine gradients local).  One object is shared
     by the BaseConvs of a model (`sast_amd.detection.convert_sync_batchnorm`); the C entry points are called in two phases around the
-    all-reduces issued here (include/sast_hip.h: SastConvBnArgs.sync_phase).  Collectives cannot be captured into a hipGraph by this
-    design (training.py keeps every RCCL call outside the graphs), so a model converted with it runs its PAFPN / head eagerly."""
+    all-reduces issued here (include/sast_hip.h: SastConvBnArgs.sync_phase).  On the RCCL backend ("nccl") the statistics all-reduces
+    are captured INTO the step's hipGraph like any kernel node (`capturable()`, training.TrainStep.capture); a host-side backend (gloo:
+    plumbing tests) cannot be captured and runs its PAFPN / head eagerly.  `force=True` keeps the two-phase path on with ONE rank (the
+    all-reduce is then the identity): the captured path can be exercised on a single GPU."""
 
-    def __init__(self, process_group=None):
+    def __init__(self, process_group=None, force: bool = False):
         import torch.distributed as dist
         self.dist, self.group = dist, process_group
         self._world = None          # resolved on first use: convert_sync_batchnorm may run before init_process_group
         self._ratio = None
+        self.force = bool(force)
         self.n_collectives = 0
 
     @property
@@ -820,15 +823,34 @@ class SyncBatchNormGroup:
         return self._world
 
     def active(self) -> bool:
-        return self.world > 1
+        return self.world > 1 or self.force
+
+    def capturable(self) -> bool:
+        """True when every collective of a pass can sit inside a stream capture: RCCL enqueues its kernels on a HIP stream (torch's
+        ProcessGroupNCCL is capture-aware); without a process group (forced, one rank) there is nothing to enqueue"""
+        if not self.dist.is_initialized():
+            return True
+        return self.dist.get_backend(self.group) == "nccl"
 
     def exchange_batch(self, n_local: int, device):
         """once per pass over a model: every BatchNorm of the pass sees rows = samples * H_out * W_out, so the rows of all ranks follow
-        from the SAMPLE counts (they differ between ranks when a step keeps only the labelled samples, modules/detection.py:161-171)"""
-        t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-        self.dist.all_reduce(t, group=self.group)
-        self.n_collectives += 1
-        self._ratio = (int(round(float(t.item()))), int(n_local))
+        from the SAMPLE counts (they differ between ranks when a step keeps only the labelled samples, modules/detection.py:161-171).
+        Inside a stream capture the counts are those of the eager pass that preceded it: a replayed graph has static shapes on every
+        rank, and reading the sum back is a host synchronisation a capture does not allow."""
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            if self._ratio is None or self._ratio[1] != int(n_local):
+                raise RuntimeError("sast_amd: SyncBatchNormGroup inside a hipGraph capture needs one eager pass with the same per-rank "
+                                   "batch first (it fixes the sample counts of all ranks)")
+            self._fresh = True
+            return
+        if self.world > 1:
+            t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+            self.dist.all_reduce(t, group=self.group)
+            self.n_collectives += 1
+            total = int(round(float(t.item())))
+        else:
+            total = int(n_local)
+        self._ratio = (total, int(n_local))
         self._fresh = True
 
     def reuse_batch(self, n_local: int) -> bool:
@@ -845,7 +867,8 @@ class SyncBatchNormGroup:
         return m_local // batch_local * self._ratio[0]
 
     def all_reduce(self, t):
-        self.dist.all_reduce(t, group=self.group)
+        if self.dist.is_initialized():
+            self.dist.all_reduce(t, group=self.group)
         self.n_collectives += 1
 
 

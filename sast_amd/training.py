@@ -13,7 +13,9 @@ The parameters / gradients of a bucket are one contiguous slice of the flat buff
 main stream records an event; a side stream waits for it, all-reduces that bucket over RCCL (torch.distributed "nccl") and runs
 the AdamW update of the bucket, while the main stream continues with the next segment (the later segments never read the
 parameters of an earlier bucket again).  The next step's forward waits for the side stream.  Each segment can be a captured
-hipGraph (three graphs sharing one memory pool); the collectives stay OUTSIDE the graphs, so no RCCL call is ever captured.
+hipGraph (three graphs sharing one memory pool); the GRADIENT collectives stay outside the graphs (they run on the side stream
+between them).  The only captured RCCL calls are SyncBatchNorm's statistics all-reduces (functional.SyncBatchNormGroup), which sit
+in the middle of the PAFPN / head passes.
 With world == 1 the all-reduce is a no-op and everything else is identical, so a single-GPU run exercises the same path.
 
 For sequences (seq_len > 1, BPTT) the backbone gradients only become final at the end of the backward: segments B and C merge.
@@ -216,9 +218,10 @@ class TrainStep:
         self.flat.check_views()
         for m in (self.fpn, self.head):
             grp = getattr(m, "_sync_group", None)
-            if grp is not None and grp.active():
-                raise RuntimeError("sast_amd.TrainStep.capture: the model was converted with convert_sync_batchnorm; its statistics "
-                                   "all-reduces sit inside the PAFPN / head passes and are not captured into hipGraphs -- run step()")
+            if grp is not None and grp.active() and not grp.capturable():
+                raise RuntimeError("sast_amd.TrainStep.capture: the model was converted with convert_sync_batchnorm and the process group's "
+                                   f"backend ({dist.get_backend(grp.group)}) runs its collectives on the host; the statistics all-reduces "
+                                   "inside the PAFPN / head passes can only be captured into hipGraphs on RCCL (\"nccl\") -- run step()")
         if not self.segmented:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):

@@ -1579,6 +1579,93 @@ print(f"ok rank {rank} worst grad err {worst:.2e}")
 '''
 
 
+_SYNC_BN_CAPTURE_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from oracle import sast_oracle as O                      # the checker's parameter initialiser only
+from sast_amd.detection import YOLOPAFPN, convert_sync_batchnorm
+from test_gpu_parity import load_params
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # RCCL with ONE rank: the collectives are real calls, the sums unchanged
+chans, hw, B = (64, 128, 256), (32, 40), 3
+params = O.init_pafpn_params(chans, seed=5)
+gen = torch.Generator().manual_seed(77)
+full = {k: torch.randn(B, c, hw[0] >> i, hw[1] >> i, generator=gen) for i, (k, c) in enumerate(zip((2, 3, 4), chans))}
+def build(sync):
+    net = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev)
+    if sync:
+        convert_sync_batchnorm(net, force=True)
+    load_params(net, params)
+    return net.train()
+def run(net, feats):
+    outs = net(feats)
+    sum((o ** 2).mean() for o in outs).backward()
+    return outs
+plain, net = build(False), build(True)
+fp = {k: v.to(dev).requires_grad_(True) for k, v in full.items()}
+ref_out = [o.detach().clone() for o in run(plain, fp)]
+ref_g = {k: p.grad.clone() for k, p in plain.named_parameters()}
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    feats = {k: v.to(dev).requires_grad_(True) for k, v in full.items()}
+    run(net, feats)                                       # the eager pass: fixes the sample counts, allocates the gradient buffers
+    n_eager = net._sync_group.n_collectives
+    assert n_eager == 2 * 32, n_eager                     # one per conv + BatchNorm unit and direction; the count exchange needs no call with one rank
+    sd0 = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        outs = run(net, feats)
+    assert net._sync_group.n_collectives == 2 * n_eager, "the statistics all-reduces were not issued inside the capture"
+torch.cuda.current_stream().wait_stream(s)
+torch.cuda.synchronize()
+for rep in range(2):                                      # replays: clear what the pass accumulates into, run the graph
+    for p in net.parameters():
+        p.grad.zero_()
+    for v in feats.values():
+        v.grad.zero_()
+    for o in outs:
+        o.detach().fill_(float("nan"))
+    g.replay()
+    torch.cuda.synchronize()
+    for o, r in zip(outs, ref_out):
+        err = float((o.detach() - r).abs().max())
+        assert err <= 1e-6 * float(r.abs().max()), f"replay {rep} forward: {err:.3e}"
+    worst = 0.0
+    for k, p in net.named_parameters():
+        err = float((p.grad - ref_g[k]).abs().max()) / (float(ref_g[k].abs().max()) + 1e-30)
+        worst = max(worst, err)
+        assert err <= 2e-5, f"replay {rep} {k}: {err:.3e}"
+    for k in (2, 3, 4):
+        err = float((feats[k].grad - fp[k].grad).abs().max()) / float(fp[k].grad.abs().max())
+        assert err <= 2e-5, f"replay {rep} din{k}: {err:.3e}"
+sd = net.state_dict()
+for k, v in sd0.items():                                  # the running statistics moved with every replay (they are graph state too)
+    if "running_var" in k:
+        assert not torch.equal(sd[k], v), k
+dist.destroy_process_group()
+print(f"ok captured worst grad err {worst:.2e}")
+'''
+
+
+def test_sync_batchnorm_statistics_allreduces_captured_into_hipgraph(dev, tmp_path):
+    """SyncBatchNorm inside the replayed step (the reference's DDP default, train.py:167): on RCCL the statistics all-reduces between the
+    two phases of every conv + BatchNorm unit are stream-captured with the kernels around them.  One rank is what a one-GPU box can run:
+    a ONE-rank RCCL group with the two-phase path forced on (`convert_sync_batchnorm(force=True)`) -- 32 + 32 real collective calls inside
+    `torch.cuda.graph`, replayed twice -- must reproduce the unconverted PAFPN's outputs and gradients (one rank: the global statistics ARE
+    the local ones; the two forms differ only in where the fp64 sums are finished)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_SYNC_BN_CAPTURE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "ok captured" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("split", ["even", "ragged"])
 def test_sync_batchnorm_two_ranks_match_whole_batch(dev, tmp_path, split):
     """the reference trains with SyncBatchNorm under DDP (train.py:167).  Two ranks (gloo, sharing the GPU), each with its part of a
