@@ -155,6 +155,9 @@ typedef struct SastMswsaArgs {
   float eps;
   int32_t cb_tps;        /* Context Broadcasting (enable_CB, SAST.py:240-246): tokens per sample, 0 = off */
   int32_t dim_head;      /* attention head width (SAST.py:171-181): 32 (default when 0) or 24; heads = C / dim_head */
+  int32_t mlp_act;       /* gate activation of the GLU-MLP (attention_cfg.mlp_activation, SAST.py:38,55 -> ops.py:133-137):
+                            0 gelu (erf form; every shipped config)  1 relu  2 silu / swish  3 sigmoid  4 tanh; the one-kernel form
+                            (fused_ws) exists for 0 only */
   const float* xin;      /* [B*L, C] image layout */
   float* out;            /* [B*L, C] */
   SastSel sel;

@@ -41,6 +41,7 @@ class AttnCfg:
     amp: float = 2e-4
     bounce: float = 1e-3
     enable_cb: bool = False
+    mlp_activation: str = "gelu"     # attention_cfg.mlp_activation (SAST.py:38,55 -> layers/create_act.py:62-79)
 
 
 @dataclass
@@ -180,11 +181,15 @@ def selection_margins(scores: Tensor, B: int, N: int, T: int, bounce: float):
 
 
 # --------------------------------------------------------------------------- a9
-def mlp_glu(x: Tensor, p: Params, pre: str) -> Tensor:
-    """ops.py:111-175: Linear(C->2*inner) -> value * GELU_erf(gate) -> Linear(inner->C)."""
+# layers/create_act.py:62-79 (_ACT_LAYER_DEFAULT; torch >= 1.7 has nn.SiLU): the names the build implements
+GLU_ACTS = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, "swish": F.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+
+
+def mlp_glu(x: Tensor, p: Params, pre: str, act: str = "gelu") -> Tensor:
+    """ops.py:111-175: Linear(C->2*inner) -> value * act(gate) (GELU_erf in every shipped config) -> Linear(inner->C)."""
     y = F.linear(x, p[pre + "net.0.proj.weight"], p.get(pre + "net.0.proj.bias"))       # (mlp_bias: False -> no bias keys)
     val, gate = torch.tensor_split(y, 2, dim=-1)
-    return F.linear(val * F.gelu(gate), p[pre + "net.2.weight"], p.get(pre + "net.2.bias"))
+    return F.linear(val * GLU_ACTS[act](gate), p[pre + "net.2.weight"], p.get(pre + "net.2.bias"))
 
 
 def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: AttnCfg) -> Tensor:
@@ -220,7 +225,7 @@ def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: A
     x = XX[asy_index]
     x = shortcut + x * p[pre + "ls1.gamma"]
     shortcut = x
-    x = mlp_glu(x, p, pre + "mlp.")
+    x = mlp_glu(x, p, pre + "mlp.", cfg.mlp_activation)
     if cfg.enable_cb:  # SAST.py:240-246
         tX, tXX = torch.zeros_like(X), torch.zeros_like(XX)
         tXX[asy_index] = x

@@ -41,7 +41,7 @@ SastScoreArgs = _struct("SastScoreArgs", [
 ])
 SastSel = _struct("SastSel", [(P, "win_keep mask K row_off win_rank counts tok_slot row_tok pack_rows row_seg")])
 SastMswsaArgs = _struct("SastMswsaArgs", [
-    (I32, "B H W C ph pw mode inner"), (F32, "eps"), (I32, "cb_tps dim_head"),
+    (I32, "B H W C ph pw mode inner"), (F32, "eps"), (I32, "cb_tps dim_head mlp_act"),
     (P, "xin out"), (SastSel, "sel"),
     (P, "ln1_w ln1_b ln2_w ln2_b qkv_w qkv_b proj_w proj_b ls1 fc1_w fc1_b fc2_w fc2_b ls2"),
     (P, "mean1 rstd1 mean2 rstd2 S QKV O lse Y UG Hh"),

@@ -107,6 +107,30 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// gate activation of the GLU-MLP (ops.py:111-137, act_layer from layers/create_act.py:62-79): SastMswsaArgs.mlp_act
+//   0 gelu (erf form: GeGLU, every shipped config)  1 relu (ReGLU)  2 silu / swish (SwiGLU)  3 sigmoid (GLU)  4 tanh
+// the code is wave-uniform (one layer per launch): the switch is a scalar branch
+constexpr int GLU_ACT_COUNT = 5;
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float glu_act(float g, int act) {
+  switch (act) {
+    case 1: return fmaxf(g, 0.0f);
+    case 2: return g * sigmoid_f(g);
+    case 3: return sigmoid_f(g);
+    case 4: return tanhf(g);
+    default: return gelu_erf(g);
+  }
+}
+__device__ __forceinline__ float glu_act_grad(float g, int act) {
+  switch (act) {
+    case 1: return g > 0.0f ? 1.0f : 0.0f;                  // torch: relu'(0) = 0
+    case 2: { const float s = sigmoid_f(g); return s * (1.0f + g * (1.0f - s)); }
+    case 3: { const float s = sigmoid_f(g); return s * (1.0f - s); }
+    case 4: { const float t = tanhf(g); return 1.0f - t * t; }
+    default: return gelu_erf_grad(g);
+  }
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -55,8 +55,11 @@ struct EpResidualLSScatter {  // out[row_tok[m]] = res + gamma * (v + bias)
     out[(size_t)x.row * C + j] = x.r + k.g * (v[0] + k.b);
   }
 };
-struct EpGlu {  // ops.py:136-137: value = first half, gate = second half, exact-erf GELU
-  float* ug; float* h; const float* bias; int inner;
+// ANY = false: exact-erf GELU (every shipped config) compiled in; ANY = true: the gate activation is the run-time code `act`
+// (common.cuh glu_act) -- a separate instantiation, so that the GELU kernels do not carry the switch (measured: +2 / +7 us per launch)
+template <bool ANY>
+struct EpGluT {  // ops.py:136-137: value = first half, gate = second half
+  float* ug; float* h; const float* bias; int inner; int act;
   struct Col { float bu, bg; };
   using Aux = EpNone;
   __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[inner + j]}; }
@@ -65,18 +68,25 @@ struct EpGlu {  // ops.py:136-137: value = first half, gate = second half, exact
     const float u = v[0] + k.bu, g = v[1] + k.bg;
     ug[(size_t)m * 2 * inner + j] = u;
     ug[(size_t)m * 2 * inner + inner + j] = g;
-    h[(size_t)m * inner + j] = u * gelu_erf(g);
+    if constexpr (ANY) h[(size_t)m * inner + j] = u * glu_act(g, act);
+    else h[(size_t)m * inner + j] = u * gelu_erf(g);
   }
 };
-struct EpDGlu {  // v = dH -> d(value), d(gate)
-  const float* ug; float* dug; int inner;
+template <bool ANY>
+struct EpDGluT {  // v = dH -> d(value), d(gate)
+  const float* ug; float* dug; int inner; int act;
   using Col = EpNone;
   struct Aux { float u, g; };
   __device__ __forceinline__ Col col(int) const { return Col{}; }
   __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{ug[(size_t)m * 2 * inner + j], ug[(size_t)m * 2 * inner + inner + j]}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
-    dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(x.g);
-    dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * gelu_erf_grad(x.g);
+    if constexpr (ANY) {
+      dug[(size_t)m * 2 * inner + j] = v[0] * glu_act(x.g, act);
+      dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * glu_act_grad(x.g, act);
+    } else {
+      dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(x.g);
+      dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * gelu_erf_grad(x.g);
+    }
   }
 };
 struct EpAddGather {  // c[m,j] = v + src[idx[m], j]
@@ -284,9 +294,9 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   if (a->C % dh) return SAST_EINVAL;
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
-  if (T > ATTN_MAX_T) return SAST_EINVAL;
-  if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip)
-    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
+  if (T > ATTN_MAX_T || a->mlp_act < 0 || a->mlp_act >= GLU_ACT_COUNT) return SAST_EINVAL;
+  if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip: GeGLU only)
+    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || a->mlp_act != 0 || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
     int rc = mswsa_fused_planes_launch(a, a->fused_ws, st);
     if (rc) return rc;
     return mswsa_fused_fwd_launch(a, a->fused_ws, st);
@@ -304,13 +314,15 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   {
     const LdRows la{a->Y, C, nullptr};
     const LdWeightNT lb{a->fc1_w, C, inner};
-    const EpGlu ep{a->UG, a->Hh, a->fc1_b, inner};
     const long nb = (long)((R + 63) / 64) * ((inner + 63) / 64);
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("SAST_GLU_TILE"); mode = e ? atoi(e) : 0; }
-    if (mode && C >= 256 && nb <= 2 * pair_thin_nb()) rc = launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
-    else if (mode && C >= 256) rc = launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
-    else rc = launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    auto fc1 = [&](auto ep) {
+      if (mode && C >= 256 && nb <= 2 * pair_thin_nb()) return launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
+      if (mode && C >= 256) return launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+      return launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
+    };
+    rc = a->mlp_act ? fc1(EpGluT<true>{a->UG, a->Hh, a->fc1_b, inner, a->mlp_act}) : fc1(EpGluT<false>{a->UG, a->Hh, a->fc1_b, inner, 0});
     if (rc) return rc;
   }
   if (a->cb_tps <= 0)
@@ -331,7 +343,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   const int dh = a->dim_head > 0 ? a->dim_head : 32;
-  if (T > ATTN_MAX_T) return SAST_EINVAL;
+  if (T > ATTN_MAX_T || a->mlp_act < 0 || a->mlp_act >= GLU_ACT_COUNT) return SAST_EINVAL;
   const int* dR = a->sel.counts;
   const int* row_tok = a->sel.row_tok;
   float* dUG = a->ws;
@@ -359,7 +371,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     dz = a->cb_m;
     dz_tok = nullptr;
   }
-  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
+  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && a->mlp_act == 0 && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
     // MLP backward as one kernel (k_mswsa_fused.hip): dY and dW1 / db1 / raw dW2 / colsum(dZ) from the saved Y, [u|g] recomputed
     rc = mswsa_fused_mlp_bwd_launch(a, a->fused_ws, dY, raw2, s2, R, st);
     if (rc) return rc;
@@ -367,16 +379,18 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   // Every (weight gradient, activation gradient) pair below consumes the same dY and goes out as ONE launch (gemm_pair).
   // fc2: raw dW2 / db2 (LayerScale applied in the finish kernel) need dZ (= dout rows) and H;  dH = (gamma2 * dZ) W2 fused
   // with the GLU backward: dUG from the saved pre-activations
-  if (dz_tok && a->ls2) {
-    rc = gemm_pair(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2,
-                   LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
-  } else {   // Context Broadcasting (compact dZ') or LayerScale disabled: the rarely used combinations stay two launches
-    rc = dz_tok ? gemm_tn(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st)
-                : gemm_tn(LdRowsT{dz, C}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st);
-    if (rc) return rc;
-    rc = a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st)
-                : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, EpDGlu{a->UG, dUG, inner}, R, inner, C, dR, st);
-  }
+  auto fc2_bwd = [&](auto ep) {
+    if (dz_tok && a->ls2)
+      return gemm_pair(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2,
+                       LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, ep, R, inner, C, dR, st);
+    // Context Broadcasting (compact dZ') or LayerScale disabled: the rarely used combinations stay two launches
+    int r = dz_tok ? gemm_tn(LdRowsTG{dz, C, dz_tok}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st)
+                   : gemm_tn(LdRowsT{dz, C}, LdRowsT{a->Hh, inner}, raw2, inner, C, inner, R, dR, s2, st);
+    if (r) return r;
+    return a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, ep, R, inner, C, dR, st)
+                  : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, ep, R, inner, C, dR, st);
+  };
+  rc = a->mlp_act ? fc2_bwd(EpDGluT<true>{a->UG, dUG, inner, a->mlp_act}) : fc2_bwd(EpDGluT<false>{a->UG, dUG, inner, 0});
   if (rc) return rc;
   // fc1: dW1 / db1, and dY = dZ + dUG W1
   rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,

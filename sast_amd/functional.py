@@ -586,7 +586,7 @@ _FUSED_MIN_ROWS = int(os.environ.get("SAST_MSWSA_FUSED_MIN_ROWS", "49152"))
 
 class _MSWSA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, *params):
+    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, mlp_act, *params):
         _need_gpu(xin)
         xin = xin.contiguous()
         p = dict(zip(_MSWSA_PARAMS, params))
@@ -599,12 +599,12 @@ class _MSWSA(torch.autograd.Function):
         dev = xin.device
         out = torch.empty_like(xin)
         a = L.SastMswsaArgs()
-        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, xin=xin, out=out)
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, mlp_act=mlp_act, xin=xin, out=out)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
-        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and R >= _FUSED_MIN_ROWS) else 0
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and R >= _FUSED_MIN_ROWS) else 0
         needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
         fws = None
         if fused_floats:
@@ -635,7 +635,7 @@ class _MSWSA(torch.autograd.Function):
             _fill(a, cb_tps=cb_tps, cb_m=cb_m, cb_sum=cb_sum)
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
         ctx.save_for_backward(xin, stats, big, raw, fws)      # fws: the weight planes the fused kernels of this call pair stream (or None)
-        ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head = sel, params, eps, inner, cb_tps, dim_head
+        ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head, ctx.mlp_act = sel, params, eps, inner, cb_tps, dim_head, mlp_act
         return out
 
     @staticmethod
@@ -661,7 +661,7 @@ class _MSWSA(torch.autograd.Function):
         S, QKV, O, Y, UG, Hh, lse = carve(Cc), carve(3 * Cc), carve(Cc), carve(Cc), carve(2 * inner), carve(inner), carve(heads)
         ws = torch.empty(L.lib().sast_mswsa_bwd_ws_floats(R, Cc, inner), device=xin.device)
         a = L.SastMswsaArgs()
-        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, dim_head=ctx.dim_head, xin=xin,
+        _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=ctx.eps, dim_head=ctx.dim_head, mlp_act=ctx.mlp_act, xin=xin,
               mean1=stats[0], rstd1=stats[1], mean2=stats[2], rstd2=stats[3], S=S, QKV=QKV, O=O, lse=lse, Y=Y, UG=UG, Hh=Hh,
               dout=dout, dxin=dxin, ws=ws, raw_ws=raw)
         if fws is not None:
@@ -674,17 +674,26 @@ class _MSWSA(torch.autograd.Function):
         grads = {k: _g(v) for k, v in p.items()}          # held until the launch is enqueued (scratch buffers among them)
         _fill(a, **{"d_" + k: _ptr(v) for k, v in grads.items()})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
-        return (dxin, None, None, None, None, None) + (None,) * len(params)
+        return (dxin, None, None, None, None, None, None) + (None,) * len(params)
 
 
-def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32, fused: bool = True) -> torch.Tensor:
+GLU_ACTIVATIONS = {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4}     # include/sast_hip.h: SastMswsaArgs.mlp_act
+
+
+def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32, fused: bool = True,
+          mlp_activation: str = "gelu") -> torch.Tensor:
     """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled).
     cb_tokens_per_sample > 0 enables Context Broadcasting (SAST.py:240-246) with that many tokens per sample.
     dim_head: 32 or 24 (the widths the reference ships).
     fused: allow the one-kernel forward (csrc/k_mswsa_fused.hip) where the library has it for the shape.  Same results either way; the
     fused form is faster when most tokens are kept (-1.5 % of the dense 1Mpx step) and slower when few are (+1.5 % at 15 % kept: a
-    wave runs the whole layer for its <= 32 tokens, a latency the compacted GEMM chain does not have) -- SAST_block passes its AMP."""
-    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), *[params[k] for k in _MSWSA_PARAMS])
+    wave runs the whole layer for its <= 32 tokens, a latency the compacted GEMM chain does not have) -- SAST_block passes its AMP.
+    mlp_activation: the gate activation of the GLU-MLP (attention_cfg.mlp_activation, layers/create_act.py:62-79): one of
+    GLU_ACTIVATIONS; the one-kernel forward exists for "gelu"."""
+    if mlp_activation not in GLU_ACTIVATIONS:
+        raise NotImplementedError(f"sast_amd: mlp_activation {mlp_activation!r}: the GLU epilogues implement {sorted(GLU_ACTIVATIONS)}")
+    return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), GLU_ACTIVATIONS[mlp_activation],
+                        *[params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12

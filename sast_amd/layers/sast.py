@@ -69,6 +69,19 @@ def get_score_index_with_padding(x: torch.Tensor, d: float, b: float):
     return (top + base).view(-1), nz[:, 0] * x.shape[-1] + nz[:, 1], K
 
 
+def _glu_activation_name(act) -> str:
+    """the reference hands MS_WSA an activation CLASS (get_act_layer(name), SAST.py:55); here a name, such a class, or None (= gelu)"""
+    if act is None:
+        return "gelu"
+    if isinstance(act, str):
+        name = act
+    else:
+        name = {nn.GELU: "gelu", nn.ReLU: "relu", nn.SiLU: "silu", nn.Sigmoid: "sigmoid", nn.Tanh: "tanh"}.get(act)
+    if name not in SF.GLU_ACTIVATIONS:
+        raise NotImplementedError(f"sast_amd: MLP activation {act!r}: the GLU epilogues implement {sorted(SF.GLU_ACTIVATIONS)}")
+    return name
+
+
 class MS_WSA(nn.Module):
     """Masked Sparse Window multi-head Self-Attention, channels-last (SAST.py:167-255)."""
 
@@ -85,6 +98,7 @@ class MS_WSA(nn.Module):
         ls_init_value, drop_path, mlp_expand_ratio, mlp_act_layer, mlp_bias, drop_mlp = sub_layer_params
         if drop_path > 0:
             raise NotImplementedError("sast_amd: drop_path > 0 is not implemented (reference default 0)")
+        self.mlp_activation = _glu_activation_name(mlp_act_layer)
         self.ls1 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop1 = nn.Identity()
         self.norm2 = norms[1]
@@ -114,7 +128,8 @@ class MS_WSA(nn.Module):
 
     def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False, fused: bool = True) -> torch.Tensor:
         """device path: x (B,H,W,C) in IMAGE layout + device-side selection."""
-        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0, self.dim_head, fused)
+        return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0, self.dim_head, fused,
+                        self.mlp_activation)
 
     def forward(self, x: torch.Tensor, index_window: torch.Tensor, index_token: torch.Tensor, padding_index: torch.Tensor,
                 asy_index: torch.Tensor, M: int, B, enable_CB: bool) -> torch.Tensor:
@@ -128,7 +143,8 @@ class MS_WSA(nn.Module):
             else torch.zeros(0, dtype=torch.long, device=x.device)
         sel = SF.selection_from_index_lists(index_window, asy_index, K, N, T, x.device)
         # Context Broadcasting averages over the tokens of one sample = N*T/B consecutive partitioned tokens (SAST.py:244-245)
-        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0, self.dim_head)
+        out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0, self.dim_head,
+                       mlp_activation=self.mlp_activation)
         return out.view(*shape)
 
 
@@ -150,8 +166,8 @@ class SAST_block(nn.Module):
         drop_path = cfg_get(attention_cfg, 'drop_path', 0.0)
         drop_mlp = cfg_get(attention_cfg, 'drop_mlp', 0.0)
         ls_init_value = cfg_get(attention_cfg, 'ls_init_value', 1e-5)
-        if mlp_act_string != 'gelu':
-            raise NotImplementedError("sast_amd: the fused GLU epilogue implements mlp_activation='gelu' (erf form) only")
+        if mlp_act_string not in SF.GLU_ACTIVATIONS:       # layers/create_act.py:62-79 knows 17 names; the GLU epilogues implement these
+            raise NotImplementedError(f"sast_amd: mlp_activation {mlp_act_string!r}: the GLU epilogues implement {sorted(SF.GLU_ACTIVATIONS)}")
         if isinstance(partition_size, int):
             partition_size = (partition_size, partition_size)
         else:
@@ -160,7 +176,7 @@ class SAST_block(nn.Module):
         self.partition_size = partition_size
         if partition_size[0] * partition_size[1] > 128:
             raise NotImplementedError("sast_amd: partitions of more than 128 tokens are not supported by the selection kernels")
-        sub_layer_params = (ls_init_value, drop_path, mlp_expand_ratio, None, mlp_bias, drop_mlp)
+        sub_layer_params = (ls_init_value, drop_path, mlp_expand_ratio, mlp_act_string, mlp_bias, drop_mlp)
         self.enable_CB = cfg_get(attention_cfg, 'enable_CB', False)
         mk_norm = lambda: LayerNorm(dim, eps=norm_eps)
         self.win_attn = MS_WSA(dim, dim_head=dim_head, bias=attention_bias, sub_layer_params=sub_layer_params,

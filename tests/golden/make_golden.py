@@ -84,12 +84,13 @@ def run_ref_block(ref, params, x, r, pe_mod, acfg, first=True, index_list=None, 
     return blk, xx, out, cnt, lists
 
 
-def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bias=True):
-    """bias=False: attention_bias: False and mlp_bias: False (qkv / proj / MLP linears without bias vectors, SAST.py:180-181)"""
+def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bias=True, act="gelu"):
+    """bias=False: attention_bias: False and mlp_bias: False (qkv / proj / MLP linears without bias vectors, SAST.py:180-181);
+    act: attention_cfg.mlp_activation (SAST.py:38,55: get_act_layer(name) -> the GLU's gate activation, ops.py:133-137)"""
     H, W, part = 16, 20, (4, 5)
-    acfg = dict(partition_size=part, dim_head=dim_head, attention_bias=bias, mlp_activation="gelu", mlp_bias=bias,
+    acfg = dict(partition_size=part, dim_head=dim_head, attention_bias=bias, mlp_activation=act, mlp_bias=bias,
                 mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=0.5, enable_CB=enable_cb, AMP=amp, BOUNCE=1e-3)
-    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb, dim_head=dim_head)
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb, dim_head=dim_head, mlp_activation=act)
     pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     pe = O.position_embedding_sine(H, W, C)
     assert torch.equal(pe, pe_mod.pos_embedding)
@@ -128,7 +129,7 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
     assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
     d = dict(x=np_(x), r=np_(r), out=np_(out), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)),
-             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head), bias=np.int64(bias))
+             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head), bias=np.int64(bias), act=np.array(act))
     d.update(lists_to_np(lists, ""))
     named = dict(blk.named_parameters())
     for k, v in named.items():
@@ -141,6 +142,11 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
         d[gk] = np_(gv)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
     print(f"{name}: seed {seed} margin {margin:.2e} kept {kept} of {B * H * W} count {cnt}")
+
+
+def gen_acts(ref):
+    for act in ("relu", "silu", "sigmoid", "tanh"):
+        gen_block(ref, "block_act_" + act, 1, 2e-2, C=32, act=act)
 
 
 def gen_two_blocks(ref):
@@ -550,6 +556,9 @@ def main():
     if "--nobias-only" in sys.argv:
         gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
         return
+    if "--acts-only" in sys.argv:    # the gate activations beside gelu (B=1, C=32: small fixtures)
+        gen_acts(ref)
+        return
     if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
         gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
         gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
@@ -563,6 +572,7 @@ def main():
     gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
     gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
     gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
+    gen_acts(ref)
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)

@@ -129,7 +129,8 @@ def test_input_prep_one_launch(golden_dir, dev):
 
 
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
-                                  "block_large_c96", "block_nobias"])
+                                  "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
+                                  "block_act_tanh"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
@@ -142,8 +143,9 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     bias = bool(int(g["bias"])) if "bias" in g else True    # False: attention_bias / mlp_bias False (linears without bias vectors)
     if not bias:
         params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
+    act = str(g["act"]) if "act" in g else "gelu"           # attention_cfg.mlp_activation: the GLU's gate activation
     acfg = attn_cfg((4, 5), float(g["amp"]), cb=cb, dim_head=dh)
-    acfg.update(attention_bias=bias, mlp_bias=bias)
+    acfg.update(attention_bias=bias, mlp_bias=bias, mlp_activation=act)
     blk = SAST_block(C, acfg, first_block=True).to(dev)
     load_params(blk, params, "att_blocks.0.att.")
     pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
@@ -164,7 +166,7 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     kl = {}
     po = {("att_blocks.0.att." + k): v.clone().requires_grad_(True) for k, v in {kk[len("att_blocks.0.att."):]: vv for kk, vv in params.items()}.items()}
     oo, _c, _l = O.sast_block(x.clone(), O.position_embedding_sine(H, W, C), r, po, "att_blocks.0.att.",
-                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), enable_cb=cb, dim_head=dh), kink_log=kl)
+                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), enable_cb=cb, dim_head=dh, mlp_activation=act), kink_log=kl)
     (oo ** 2).mean().backward()
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
 

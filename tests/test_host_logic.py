@@ -329,6 +329,42 @@ def test_convert_sync_batchnorm_marks_every_unit_and_is_inert_on_one_rank():
         g.rows_total(3 * 40 * 50, 3)                       # a pass with another local batch needs its own exchange
 
 
+def test_sync_batchnorm_group_forced_and_capturable():
+    """round 4: the statistics all-reduces are captured into the step's hipGraphs on RCCL.  Host logic of the group: `force` keeps the
+    two-phase path on with one rank (the single-GPU check of the capture), a group without a process group is capturable (nothing to
+    enqueue), and with one rank the sample-count exchange needs no collective"""
+    from sast_amd.functional import SyncBatchNormGroup
+    g = SyncBatchNormGroup()
+    assert not g.active() and g.capturable()
+    f = SyncBatchNormGroup(force=True)
+    assert f.active() and f.world == 1 and f.capturable()
+    f.exchange_batch(3, torch.device("cpu"))
+    assert f.n_collectives == 0 and f.rows_total(3 * 8 * 10, 3) == 3 * 8 * 10
+    assert f.reuse_batch(3) and not f.reuse_batch(3)       # the head takes over the PAFPN's exchange once per pass
+    t = torch.ones(4, dtype=torch.float64)
+    f.all_reduce(t)                                        # no process group: the identity, but counted
+    assert f.n_collectives == 1 and torch.equal(t, torch.ones(4, dtype=torch.float64))
+
+
+def test_glu_activation_names():
+    """attention_cfg.mlp_activation (SAST.py:38,55): the reference resolves the name through layers/create_act.py:62-79 and hands MS_WSA
+    the activation CLASS; the mirror accepts the name, such a class, or None (= gelu), and refuses what the GLU epilogues do not implement"""
+    from sast_amd.layers.sast import _glu_activation_name, SAST_block
+    from sast_amd.functional import GLU_ACTIVATIONS
+    assert GLU_ACTIVATIONS == {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4}
+    assert _glu_activation_name(None) == "gelu" and _glu_activation_name("swish") == "swish"
+    assert [_glu_activation_name(c) for c in (torch.nn.GELU, torch.nn.ReLU, torch.nn.SiLU, torch.nn.Sigmoid, torch.nn.Tanh)] == \
+        ["gelu", "relu", "silu", "sigmoid", "tanh"]
+    with pytest.raises(NotImplementedError):
+        _glu_activation_name(torch.nn.Mish)
+    cfg = dict(partition_size=(4, 5), dim_head=32, attention_bias=True, mlp_activation="relu", mlp_bias=True, mlp_ratio=4, drop_mlp=0,
+               drop_path=0, ls_init_value=1e-5, enable_CB=False, AMP=2e-4, BOUNCE=1e-3)
+    blk = SAST_block(64, cfg, first_block=True)
+    assert blk.win_attn.mlp_activation == blk.grid_attn.mlp_activation == "relu"
+    with pytest.raises(NotImplementedError):
+        SAST_block(64, dict(cfg, mlp_activation="mish"), first_block=True)
+
+
 def test_struct_sizes_and_offsets_match_a_c_compiler(tmp_path):
     """the boundary is a C ABI: the header must compile as plain C (gcc, no HIP), and every struct the Python host fills must have the
     size and field offsets the C compiler gives it (the ctypes mirrors are written by hand: an appended or reordered field that the

@@ -42,7 +42,8 @@ def test_non_zero_ratio(golden_dir):
 
 
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
-                                  "block_large_c96", "block_nobias"])
+                                  "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
+                                  "block_act_tanh"])
 def test_sast_block(golden_dir, name):
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
@@ -51,7 +52,8 @@ def test_sast_block(golden_dir, name):
         params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
     cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]),
-                    dim_head=int(g["dim_head"]) if "dim_head" in g else 32)
+                    dim_head=int(g["dim_head"]) if "dim_head" in g else 32,
+                    mlp_activation=str(g["act"]) if "act" in g else "gelu")     # mlp_activation: relu / silu / sigmoid / tanh fixtures
     pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])
     xo = x.clone().requires_grad_(True)
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
