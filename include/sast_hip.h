@@ -261,6 +261,10 @@ typedef struct SastConvBnArgs {
               other gradient) -- and then all-reduces (SUM) the block;
        bwd 2  the rest (BatchNorm-backward apply with 1 / m_total, dW, dX, producer folding); d_bn_w / d_bn_b NULL. */
   int32_t sync_phase, m_total;
+  int32_t groups;        /* 0 / 1: dense conv.  == Cin == Cout: depth-wise conv -- the `dconv` of YOLOX's DWConv (network_blocks.py:57-76:
+                            BaseConv(in, in, ksize, stride, groups=in), used for Bottleneck.conv2, bu_conv* and the head towers when the
+                            model is built with depthwise=True); w is [C][ksize*ksize] (torch's (C,1,k,k)), single dense input (x2 NULL,
+                            ldx == Cin), no producer folding (p_* NULL); BatchNorm / SiLU / sync_phase as for the dense conv */
 } SastConvBnArgs;
 int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream);
 int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream);

@@ -425,7 +425,7 @@ def backbone(x: Tensor, prev_states, p: Params, cfg: BackboneCfg, pre: str = "",
 def base_conv(x: Tensor, p: Params, pre: str, stride: int, training: bool, bufs: Optional[Params] = None):
     """network_blocks.py:29-54: conv(no bias, same pad) + BatchNorm2d(eps 1e-5, mom 0.1) + SiLU."""
     w = p[pre + "conv.weight"]
-    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2)
+    y = F.conv2d(x, w, None, stride=stride, padding=(w.shape[-1] - 1) // 2, groups=x.shape[1] // w.shape[1])   # groups > 1: DWConv.dconv
     src = bufs if bufs is not None else p
     rm, rv = src.get(pre + "bn.running_mean"), src.get(pre + "bn.running_var")
     if training and bufs is None:  # do not mutate the caller's buffers unless asked to
@@ -435,12 +435,20 @@ def base_conv(x: Tensor, p: Params, pre: str, stride: int, training: bool, bufs:
     return F.silu(y)
 
 
+def conv_unit(x: Tensor, p: Params, pre: str, stride: int, training: bool, bufs: Optional[Params] = None):
+    """`Conv = DWConv if depthwise else BaseConv` (network_blocks.py:93, yolo_pafpn.py:37, yolo_head.py:42): which one a unit is follows
+    from its parameter names -- DWConv (network_blocks.py:57-76) holds `dconv` (depth-wise, carries the stride) and `pconv` (1x1)."""
+    if pre + "dconv.conv.weight" in p:
+        return base_conv(base_conv(x, p, pre + "dconv.", stride, training, bufs), p, pre + "pconv.", 1, training, bufs)
+    return base_conv(x, p, pre, stride, training, bufs)
+
+
 def csp_layer(x: Tensor, p: Params, pre: str, n: int, training: bool, bufs=None):
     """network_blocks.py:104-141 with shortcut=False, expansion 0.5, Bottleneck expansion 1.0."""
     x1 = base_conv(x, p, pre + "conv1.", 1, training, bufs)
     x2 = base_conv(x, p, pre + "conv2.", 1, training, bufs)
     for i in range(n):
-        x1 = base_conv(base_conv(x1, p, f"{pre}m.{i}.conv1.", 1, training, bufs), p,
+        x1 = conv_unit(base_conv(x1, p, f"{pre}m.{i}.conv1.", 1, training, bufs), p,
                        f"{pre}m.{i}.conv2.", 1, training, bufs)
     return base_conv(torch.cat((x1, x2), dim=1), p, pre + "conv3.", 1, training, bufs)
 
@@ -455,9 +463,9 @@ def pafpn(feats: Dict[int, Tensor], p: Params, pre: str = "", depth: float = 0.6
     f0 = csp_layer(torch.cat([up(fpn0), x1], 1), p, pre + "C3_p4.", n, training, bufs)
     fpn1 = base_conv(f0, p, pre + "reduce_conv1.", 1, training, bufs)
     pan2 = csp_layer(torch.cat([up(fpn1), x2], 1), p, pre + "C3_p3.", n, training, bufs)
-    d1 = base_conv(pan2, p, pre + "bu_conv2.", 2, training, bufs)
+    d1 = conv_unit(pan2, p, pre + "bu_conv2.", 2, training, bufs)
     pan1 = csp_layer(torch.cat([d1, fpn1], 1), p, pre + "C3_n3.", n, training, bufs)
-    d0 = base_conv(pan1, p, pre + "bu_conv1.", 2, training, bufs)
+    d0 = conv_unit(pan1, p, pre + "bu_conv1.", 2, training, bufs)
     pan0 = csp_layer(torch.cat([d0, fpn0], 1), p, pre + "C3_n4.", n, training, bufs)
     return pan2, pan1, pan0
 
@@ -478,8 +486,8 @@ def yolox_head_eval(feats: Sequence[Tensor], p: Params, strides=(8, 16, 32), pre
         cf = x
         rf = x
         for i in range(2):
-            cf = base_conv(cf, p, f"{pre}cls_convs.{k}.{i}.", 1, False)
-            rf = base_conv(rf, p, f"{pre}reg_convs.{k}.{i}.", 1, False)
+            cf = conv_unit(cf, p, f"{pre}cls_convs.{k}.{i}.", 1, False)
+            rf = conv_unit(rf, p, f"{pre}reg_convs.{k}.{i}.", 1, False)
         cls = F.conv2d(cf, p[f"{pre}cls_preds.{k}.weight"], p[f"{pre}cls_preds.{k}.bias"])
         reg = F.conv2d(rf, p[f"{pre}reg_preds.{k}.weight"], p[f"{pre}reg_preds.{k}.bias"])
         obj = F.conv2d(rf, p[f"{pre}obj_preds.{k}.weight"], p[f"{pre}obj_preds.{k}.bias"])
@@ -574,8 +582,8 @@ def yolox_head_train(feats: Sequence[Tensor], labels: Tensor, p: Params, strides
         x = base_conv(x, p, f"{pre}stems.{k}.", 1, True, bufs)
         cf, rf = x, x
         for i in range(2):
-            cf = base_conv(cf, p, f"{pre}cls_convs.{k}.{i}.", 1, True, bufs)
-            rf = base_conv(rf, p, f"{pre}reg_convs.{k}.{i}.", 1, True, bufs)
+            cf = conv_unit(cf, p, f"{pre}cls_convs.{k}.{i}.", 1, True, bufs)
+            rf = conv_unit(rf, p, f"{pre}reg_convs.{k}.{i}.", 1, True, bufs)
         cls = F.conv2d(cf, p[f"{pre}cls_preds.{k}.weight"], p[f"{pre}cls_preds.{k}.bias"])
         reg = F.conv2d(rf, p[f"{pre}reg_preds.{k}.weight"], p[f"{pre}reg_preds.{k}.bias"])
         obj = F.conv2d(rf, p[f"{pre}obj_preds.{k}.weight"], p[f"{pre}obj_preds.{k}.bias"])
@@ -710,7 +718,8 @@ def synthetic_labels(B: int, hw: Tuple[int, int], num_classes: int, max_labels: 
     return lab
 
 
-def init_head_params(in_channels=(128, 256, 512), num_classes: int = 3, seed: int = 2, prior_prob: float = 0.01) -> Params:
+def init_head_params(in_channels=(128, 256, 512), num_classes: int = 3, seed: int = 2, prior_prob: float = 0.01,
+                     depthwise: bool = False) -> Params:
     """seeded stand-in for YOLOXHead.__init__ (names / shapes of yolo_head.py:58-133; biases as initialize_biases :154-163);
     BatchNorm running statistics are randomised so that the eval path is exercised with non-trivial statistics."""
     g = torch.Generator().manual_seed(seed)
@@ -728,8 +737,12 @@ def init_head_params(in_channels=(128, 256, 512), num_classes: int = 3, seed: in
     for k, ci in enumerate(in_channels):
         conv_bn(f"stems.{k}", ci, hid, 1)
         for i in range(2):
-            conv_bn(f"cls_convs.{k}.{i}", hid, hid, 3)
-            conv_bn(f"reg_convs.{k}.{i}", hid, hid, 3)
+            for tower in ("cls_convs", "reg_convs"):
+                if depthwise:          # DWConv (yolo_head.py:42): depth-wise 3x3 (weight (C,1,3,3)) + point-wise 1x1
+                    conv_bn(f"{tower}.{k}.{i}.dconv", 1, hid, 3)
+                    conv_bn(f"{tower}.{k}.{i}.pconv", hid, hid, 1)
+                else:
+                    conv_bn(f"{tower}.{k}.{i}", hid, hid, 3)
         for name, co in (("cls_preds", num_classes), ("reg_preds", 4), ("obj_preds", 1)):
             p[f"{name}.{k}.weight"] = (torch.rand((co, hid, 1, 1), generator=g) * 2 - 1) / math.sqrt(hid)
             if name == "reg_preds":
@@ -796,34 +809,41 @@ def init_backbone_params(cfg: BackboneCfg, seed: int = 0, ls_init: float = 1e-5,
     return p
 
 
-def pafpn_conv_list(in_channels=(128, 256, 512), depth: float = 0.67):
-    """(name, cin, cout, ksize, stride) for all conv-BN-SiLU units of YOLOPAFPN (yolo_pafpn.py:50-98)."""
+def pafpn_conv_list(in_channels=(128, 256, 512), depth: float = 0.67, depthwise: bool = False):
+    """(name, cin, cout, ksize, stride) for all conv-BN-SiLU units of YOLOPAFPN (yolo_pafpn.py:50-98).  depthwise: the 3x3 units
+    (Bottleneck.conv2, bu_conv*) are DWConvs (network_blocks.py:57-76) = `<name>.dconv` (depth-wise: cin listed as 1, the weight's
+    second dimension) + `<name>.pconv` (1x1)."""
     c0, c1, c2 = in_channels
     n = round(3 * depth)
     out = [("lateral_conv0", c2, c1, 1, 1)]
+
+    def conv3(name, ci, co, stride):
+        if depthwise:
+            return [(f"{name}.dconv", 1, ci, 3, stride), (f"{name}.pconv", ci, co, 1, 1)]
+        return [(name, ci, co, 3, stride)]
 
     def csp(name, ci, co):
         hid = int(co * 0.5)
         l = [(f"{name}.conv1", ci, hid, 1, 1), (f"{name}.conv2", ci, hid, 1, 1)]
         for i in range(n):
-            l += [(f"{name}.m.{i}.conv1", hid, hid, 1, 1), (f"{name}.m.{i}.conv2", hid, hid, 3, 1)]
+            l += [(f"{name}.m.{i}.conv1", hid, hid, 1, 1)] + conv3(f"{name}.m.{i}.conv2", hid, hid, 1)
         l.append((f"{name}.conv3", 2 * hid, co, 1, 1))
         return l
 
     out += csp("C3_p4", 2 * c1, c1)
     out.append(("reduce_conv1", c1, c0, 1, 1))
     out += csp("C3_p3", 2 * c0, c0)
-    out.append(("bu_conv2", c0, c0, 3, 2))
+    out += conv3("bu_conv2", c0, c0, 2)
     out += csp("C3_n3", 2 * c0, c1)
-    out.append(("bu_conv1", c1, c1, 3, 2))
+    out += conv3("bu_conv1", c1, c1, 2)
     out += csp("C3_n4", 2 * c1, c2)
     return out
 
 
-def init_pafpn_params(in_channels=(128, 256, 512), depth: float = 0.67, seed: int = 1):
+def init_pafpn_params(in_channels=(128, 256, 512), depth: float = 0.67, seed: int = 1, depthwise: bool = False):
     g = torch.Generator().manual_seed(seed)
     p: Params = {}
-    for name, ci, co, k, _s in pafpn_conv_list(in_channels, depth):
+    for name, ci, co, k, _s in pafpn_conv_list(in_channels, depth, depthwise):
         b = 1.0 / math.sqrt(ci * k * k)
         p[name + ".conv.weight"] = (torch.rand((co, ci, k, k), generator=g) * 2 - 1) * b
         p[name + ".bn.weight"] = torch.ones(co)

@@ -64,7 +64,7 @@ SastConvBnArgs = _struct("SastConvBnArgs", [
     (I32, "B H W Cin Cout ksize stride training ldx ldy lddy lddx bn_ws_zeroed bn_red_done Cin1 ldx2"), (F32, "momentum eps"),
     (P, "x w bn_w bn_b run_mean run_var conv_out stats y dy dx dw d_bn_w d_bn_b bn_ws ws x2 dx2 "
         "p_conv_out p_stats p_bn_w p_bn_b p_bn_ws p2_conv_out p2_stats p2_bn_w p2_bn_b p2_bn_ws dy2"),
-    (I32, "sync_phase m_total"),
+    (I32, "sync_phase m_total groups"),
 ])
 
 SastSampleGather = _struct("SastSampleGather", [

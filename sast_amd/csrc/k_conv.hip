@@ -471,6 +471,11 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
   const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->stride, pad, 0, a->ldx);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin, C = a->Cout;
   if ((unsigned long long)M * (C / 4) >= (1ull << 31)) return SAST_EINVAL;   // element indices of the BatchNorm passes are 31-bit
+  // groups == Cin == Cout: the depth-wise half of YOLOX's DWConv (network_blocks.py:57-76) -- a stencil, not a GEMM (k_dwconv.hip);
+  // the BatchNorm + SiLU passes around it are the dense conv's
+  const bool dw = a->groups > 1;
+  if (dw && (a->groups != a->Cin || a->Cin != a->Cout || a->x2 || a->ldx != a->Cin)) return SAST_EINVAL;
+  const DwGeom dg{a->H, a->W, g.Ho, g.Wo, C, k, a->stride};
   double* sums = (double*)a->bn_ws;
   // SyncBatchNorm (include/sast_hip.h: sync_phase): 1 = conv + this process's column sums, 2 = BatchNorm + SiLU from the sums the host
   // all-reduced in between, over the m_total rows of all ranks
@@ -485,12 +490,28 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
   const LdRows2 la2{a->x, a->ldx, a->Cin1, a->x2, a->ldx2};    // virtual channel concat [x | x2]
   if (!a->training && !a->conv_out) {   // inference: one launch, nothing kept for a backward
     if (!a->run_mean || !a->run_var) return SAST_EINVAL;
+    if (dw) {
+      if (a->ldy != C) return SAST_EINVAL;
+      const DwBnSilu bn{a->run_mean, a->run_var, a->bn_w, a->bn_b, a->eps};
+      rc = dwconv_fwd_launch(a->x, a->w, nullptr, a->y, a->B, dg, &bn, st);
+      if (rc) return rc;
+      SAST_CHECK_LAUNCH();
+      return SAST_OK;
+    }
     const EpBnSilu ep{a->y, a->ldy, a->run_mean, a->run_var, a->bn_w, a->bn_b, a->eps};
     return one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
                         : gemm_auto(LdRows{a->x, a->ldx, nullptr}, LdWeightNT{a->w, K, 0}, ep, M, C, K, st))
                : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (phase == 2) {            // the conv and its sums are phase 1's
+  } else if (dw) {             // the stencil, then (training) its column sums as a row-strip pass
+    rc = dwconv_fwd_launch(a->x, a->w, nullptr, a->conv_out, a->B, dg, nullptr, st);
+    if (!rc && a->training) {
+      int rpb = (M + 127) / 128;
+      rpb = rpb < 8 ? 8 : rpb;
+      const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
+      SAST_LAUNCH(bn_stats_kernel, dim3((M + rpb - 1) / rpb), dim3(256), sizeof(double) * 2 * RP * C, st, a->conv_out, M, C, sums, rpb);
+    }
   } else if (a->training && !sep) {   // conv + per-channel sum / sum-of-squares in one pass
     const EpStoreStats ep{a->conv_out, C, sums};
     rc = one ? (a->x2 ? gemm_auto(la2, LdWeightNT{a->w, K, 0}, ep, M, C, K, st)
@@ -503,7 +524,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
              : conv_gemm(a->x, g, LdWeightNT{a->w, K, 0}, ep, M, C, K, st);
   }
   if (rc) return rc;
-  if (a->training && sep && phase != 2) {
+  if (a->training && sep && phase != 2 && !dw) {
     int rpb = (M + sep - 1) / sep;
     rpb = rpb < 8 ? 8 : rpb;
     const int c4n = C / 4, RP = 256 / c4n > 0 ? 256 / c4n : 1;
@@ -546,6 +567,13 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
   BnProducer p1{a->p_conv_out, a->p_stats, a->p_bn_w, a->p_bn_b, a->p_bn_ws ? a->p_bn_ws + 4 * BN_STAT_COPIES * a->Cin1 : nullptr, a->Cin1};
   BnProducer p2{a->p2_conv_out, a->p2_stats, a->p2_bn_w, a->p2_bn_b, a->p2_bn_ws ? a->p2_bn_ws + 4 * BN_STAT_COPIES * C2 : nullptr, C2};
   const bool fold = a->training && a->dx && (p1.x || p2.x);
+  if (a->groups > 1) {       // depth-wise unit (see the forward): dX / dW of the stencil; no producer folding, no virtual concat
+    if (a->groups != a->Cin || a->Cin != C || a->x2 || fold || a->ldx != a->Cin || (a->dx && a->lddx != a->Cin)) return SAST_EINVAL;
+    int rc = dwconv_bwd_launch(a->x, a->w, dconv, a->dx, a->dw, nullptr, a->B, DwGeom{a->H, a->W, g.Ho, g.Wo, C, k, a->stride}, st);
+    if (rc) return rc;
+    SAST_CHECK_LAUNCH();
+    return SAST_OK;
+  }
   if (fold && (a->stride != 1 || (p1.x && !(p1.stats && p1.gamma && p1.beta && p1.sums)) || (p2.x && !(a->x2 && p2.stats && p2.gamma && p2.beta && p2.sums))))
     return SAST_EINVAL;
   if (k == 1 && a->stride == 1 && a->x2) {   // virtual concat input: dW over [x | x2], dX split into the two gradients

@@ -71,6 +71,12 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
                          const int* pack_rows, const int* row_seg, int W, int T, int C, int dh, hipStream_t st,
                          const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
 
+// k_dwconv.hip: depth-wise k x k convolution, zero padding k/2, stride 1 / 2 (input Hi x Wi -> output Ho x Wo)
+struct DwGeom { int Hi, Wi, Ho, Wo, C, k, stride; };
+struct DwBnSilu { const float* mean; const float* var; const float* gamma; const float* beta; float eps; };   // inference epilogue
+int dwconv_fwd_launch(const float* x, const float* w, const float* bias, float* y, int B, DwGeom g, const DwBnSilu* bn, hipStream_t st);
+int dwconv_bwd_launch(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int B, DwGeom g, hipStream_t st);
+
 // k_mswsa_fused.hip: the MS-WSA layer as one kernel per direction (one wave per partition)
 bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps);
 size_t mswsa_fused_plane_floats(int C, int inner);

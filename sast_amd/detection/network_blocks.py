@@ -13,11 +13,13 @@ class BaseConv(nn.Module):
 
     def __init__(self, in_channels, out_channels, ksize, stride, groups=1, bias=False, act="silu"):
         super().__init__()
-        if groups != 1 or bias or act != "silu" or ksize not in (1, 3):
-            raise NotImplementedError("sast_amd: BaseConv implements groups=1, bias=False, act='silu', ksize in {1,3}")
-        self.ksize, self.stride = ksize, stride
+        depthwise = groups > 1 and groups == in_channels == out_channels      # DWConv.dconv (network_blocks.py:63-70)
+        if (groups != 1 and not depthwise) or bias or act != "silu" or ksize not in (1, 3):
+            raise NotImplementedError("sast_amd: BaseConv implements groups=1 or groups=in=out (depth-wise), bias=False, act='silu', "
+                                      "ksize in {1,3}")
+        self.ksize, self.stride, self.groups = ksize, stride, groups
         self.conv = nn.Module()
-        self.conv.weight = channels_last_conv_weight(out_channels, in_channels, ksize)
+        self.conv.weight = channels_last_conv_weight(out_channels, in_channels // groups, ksize)
         self.bn = nn.BatchNorm2d(out_channels)
         self.sync_bn = None       # a functional.SyncBatchNormGroup after convert_sync_batchnorm: batch statistics over all ranks
 
@@ -41,6 +43,23 @@ class BaseConv(nn.Module):
     def forward(self, x):
         if isinstance(x, (tuple, list)):
             raise TypeError("sast_amd: the two-source (virtual concat) input is an internal NHWC feature; use forward_nhwc")
+        return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
+
+
+class DWConv(nn.Module):
+    """Depthwise Conv + Conv (network_blocks.py:57-76): BaseConv(in, in, ksize, stride, groups=in) then BaseConv(in, out, 1)."""
+
+    def __init__(self, in_channels, out_channels, ksize, stride=1, act="silu"):
+        super().__init__()
+        self.dconv = BaseConv(in_channels, in_channels, ksize=ksize, stride=stride, groups=in_channels, act=act)
+        self.pconv = BaseConv(in_channels, out_channels, ksize=1, stride=1, groups=1, act=act)
+
+    def forward_nhwc(self, x, arena=None, sole=False, two_outputs=False):
+        """same contract as BaseConv.forward_nhwc; the depth-wise stencil has no dX epilogue, so a producer of x keeps its own
+        BatchNorm-backward reduction (`sole` is not passed on), while the point-wise conv is the only consumer of the stencil's output"""
+        return self.pconv.forward_nhwc(self.dconv.forward_nhwc(x, arena), arena, sole=True, two_outputs=two_outputs)
+
+    def forward(self, x):
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
 
 
@@ -90,11 +109,10 @@ class Bottleneck(nn.Module):
 
     def __init__(self, in_channels, out_channels, shortcut=True, expansion=0.5, depthwise=False, act="silu"):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError("sast_amd: depthwise PAFPN is not implemented (shipped config: depthwise False)")
         hidden = int(out_channels * expansion)
+        Conv = DWConv if depthwise else BaseConv
         self.conv1 = BaseConv(in_channels, hidden, 1, stride=1, act=act)
-        self.conv2 = BaseConv(hidden, out_channels, 3, stride=1, act=act)
+        self.conv2 = Conv(hidden, out_channels, 3, stride=1, act=act)
         self.use_add = shortcut and in_channels == out_channels
 
     def forward_nhwc(self, x, arena=None, sole_input=False):

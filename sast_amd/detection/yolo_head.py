@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import functional as SF
-from .network_blocks import BaseConv, BnArena
+from .network_blocks import BaseConv, BnArena, DWConv
 
 
 class _PredConv(nn.Module):
@@ -34,8 +34,8 @@ class YOLOXHead(nn.Module):
     def __init__(self, num_classes=80, strides=(8, 16, 32), in_channels=(256, 512, 1024), act="silu", depthwise=False,
                  compile_cfg: Optional[Dict] = None):
         super().__init__()
-        if depthwise:
-            raise NotImplementedError("sast_amd: depthwise head convs are not implemented (every shipped config has depthwise: False)")
+        Conv = DWConv if depthwise else BaseConv      # yolo_head.py:42: the 3x3 tower convs
+        self.depthwise = bool(depthwise)
         self.num_classes = num_classes
         self.decode_in_inference = True
         self.strides = tuple(strides)
@@ -45,8 +45,8 @@ class YOLOXHead(nn.Module):
         self.cls_preds, self.reg_preds, self.obj_preds, self.stems = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.ModuleList()
         for c in in_channels:
             self.stems.append(BaseConv(int(c), hidden, 1, stride=1, act=act))
-            self.cls_convs.append(nn.Sequential(BaseConv(hidden, hidden, 3, stride=1, act=act), BaseConv(hidden, hidden, 3, stride=1, act=act)))
-            self.reg_convs.append(nn.Sequential(BaseConv(hidden, hidden, 3, stride=1, act=act), BaseConv(hidden, hidden, 3, stride=1, act=act)))
+            self.cls_convs.append(nn.Sequential(Conv(hidden, hidden, 3, stride=1, act=act), Conv(hidden, hidden, 3, stride=1, act=act)))
+            self.reg_convs.append(nn.Sequential(Conv(hidden, hidden, 3, stride=1, act=act), Conv(hidden, hidden, 3, stride=1, act=act)))
             self.cls_preds.append(_PredConv(hidden, num_classes))
             self.reg_preds.append(_PredConv(hidden, 4))
             self.obj_preds.append(_PredConv(hidden, 1))
@@ -72,7 +72,7 @@ class YOLOXHead(nn.Module):
             self._sync_group.exchange_batch(feats[0].shape[0], feats[0].device)
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x, ar)
-            if SF.CONV_PAIR and not sync:
+            if SF.CONV_PAIR and not sync and not self.depthwise:
                 # the first conv of both towers reads the stem output: one stacked 3x3 GEMM + shared BatchNorm launches, and (sole
                 # consumer of the stem output) the stem's BatchNorm-backward reduction in the pair's dX epilogue
                 c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]
@@ -115,7 +115,7 @@ class YOLOXHead(nn.Module):
         off = 0
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x)
-            if SF.CONV_PAIR:     # the first conv of both towers reads the stem output: one launch over the stacked 3x3 weights
+            if SF.CONV_PAIR and not self.depthwise:     # the first conv of both towers reads the stem output: one launch over the stacked 3x3 weights
                 c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]
                 cf, rf = SF.conv_bn_silu2_infer(x, *[(c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var,
                                                      c.bn.momentum, c.bn.eps) for c in (c0, r0)], ksize=3)

@@ -6,7 +6,7 @@ from typing import Dict, Optional, Tuple
 import torch.nn as nn
 
 from .. import functional as SF
-from .network_blocks import BaseConv, BnArena, CSPLayer
+from .network_blocks import BaseConv, BnArena, CSPLayer, DWConv
 
 
 class YOLOPAFPN(nn.Module):
@@ -16,20 +16,19 @@ class YOLOPAFPN(nn.Module):
                  depthwise: bool = False, act: str = "silu", compile_cfg: Optional[Dict] = None):
         super().__init__()
         assert len(in_stages) == len(in_channels) == 3, 'Current implementation only for 3 feature maps'
-        if depthwise:
-            raise NotImplementedError("sast_amd: depthwise PAFPN is not implemented")
         if compile_cfg is not None and compile_cfg.get('enable', False):
             raise NotImplementedError("sast_amd: torch.compile is not used; capture the step in a hipGraph instead")
         self.in_features, self.in_channels = in_stages, in_channels
         c0, c1, c2 = in_channels
         n = round(3 * depth)
+        Conv = DWConv if depthwise else BaseConv      # yolo_pafpn.py:37: the two bottom-up convs (and every Bottleneck.conv2)
         self.lateral_conv0 = BaseConv(c2, c1, 1, 1, act=act)
         self.C3_p4 = CSPLayer(2 * c1, c1, n, False, depthwise=depthwise, act=act)
         self.reduce_conv1 = BaseConv(c1, c0, 1, 1, act=act)
         self.C3_p3 = CSPLayer(2 * c0, c0, n, False, depthwise=depthwise, act=act)
-        self.bu_conv2 = BaseConv(c0, c0, 3, 2, act=act)
+        self.bu_conv2 = Conv(c0, c0, 3, 2, act=act)
         self.C3_n3 = CSPLayer(2 * c0, c1, n, False, depthwise=depthwise, act=act)
-        self.bu_conv1 = BaseConv(c1, c1, 3, 2, act=act)
+        self.bu_conv1 = Conv(c1, c1, 3, 2, act=act)
         self.C3_n4 = CSPLayer(2 * c1, c2, n, False, depthwise=depthwise, act=act)
         self._sync_group = None      # set by network_blocks.convert_sync_batchnorm
 

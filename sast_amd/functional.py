@@ -904,6 +904,7 @@ class _ConvBnSilu(torch.autograd.Function):
             x2 = x2.contiguous()
             Cin = Cin1 + x2.shape[-1]
         Cout = w.shape[0]
+        groups = _conv_groups(w, Cin, x2)
         pad = (ksize - 1) // 2
         Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
         M = B * Ho * Wo
@@ -915,7 +916,7 @@ class _ConvBnSilu(torch.autograd.Function):
             bn_ws = torch.zeros(bn_ws_floats(Cout), device=dev)
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin1,
                   ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
-                  run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1)
+                  run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1, groups=groups)
         m_total = 0
         if sync is not None and training and sync.active():
             a.sync_phase = 1
@@ -928,8 +929,9 @@ class _ConvBnSilu(torch.autograd.Function):
         ctx.save_for_backward(x, x2, conv_out, stats, bn_ws)
         ctx.params = (w, bn_w, bn_b)
         ctx.meta = (B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M)
+        ctx.groups = groups
         ctx.handle = handle.fill(conv_out, stats, bn_w, bn_b, bn_ws, Cout) if (training and handle is not None) else None
-        p1, p2 = producers if (training and stride == 1) else (None, None)
+        p1, p2 = producers if (training and stride == 1 and groups == 1) else (None, None)   # (the depth-wise stencil has no dX epilogue to fold into)
         if p1 is not None and p1.cout != Cin1:
             p1 = None
         if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
@@ -968,7 +970,8 @@ class _ConvBnSilu(torch.autograd.Function):
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
                   ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
                   eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w),
-                  d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2), **pk)
+                  d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2),
+                  groups=ctx.groups, **pk)
         if ctx.sync is not None:
             sync, m_total = ctx.sync
             a.sync_phase = 1
@@ -986,6 +989,16 @@ class _ConvBnSilu(torch.autograd.Function):
             if h is not None:
                 h.red_done = True
         return (dx, dx2) + (None,) * 15
+
+
+def _conv_groups(w, cin: int, x2=None) -> int:
+    """1 for a dense conv weight (Cout, Cin, k, k); Cin for the depth-wise weight (C, 1, k, k) of YOLOX's DWConv.dconv
+    (network_blocks.py:57-76).  Other group counts do not occur in the reference."""
+    if w.shape[1] == cin:
+        return 1
+    if w.shape[1] == 1 and w.shape[0] == cin and x2 is None:
+        return cin
+    raise RuntimeError(f"sast_amd: conv weight {tuple(w.shape)} fits neither a dense conv of {cin} input channels nor a depth-wise one")
 
 
 def bn_ws_floats(cout: int) -> int:
@@ -1174,7 +1187,7 @@ def _conv_bn_silu_infer(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, 
     y = torch.empty(B, Ho, Wo, Cout, device=x.device)
     a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=0, ldx=Cin1, ldy=Cout,
               bn_ws_zeroed=1, momentum=0.0, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=run_mean, run_var=run_var, y=y,
-              x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1)
+              x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1, groups=_conv_groups(w, Cin, x2))
     L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
     return y
 

@@ -254,6 +254,67 @@ def gen_pafpn(ref):
     print("pafpn ok")
 
 
+def gen_depthwise(ref):
+    """depthwise=True (yolo_pafpn.py:37, network_blocks.py:93, yolo_head.py:42): Bottleneck.conv2, bu_conv* and the head's tower convs
+    are DWConvs (depth-wise 3x3 + BN + SiLU, then 1x1 + BN + SiLU).  PAFPN in train and eval mode, head in eval mode, reference modules."""
+    chans, nc, strides = (32, 64, 128), 2, (8, 16, 32)
+    params = O.init_pafpn_params(chans, seed=41, depthwise=True)
+    net = ref.yolo_pafpn.YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans, depthwise=True, act="silu")
+    sd0 = net.state_dict()
+    assert set(params) <= set(sd0), sorted(set(params) - set(sd0))[:5]
+    assert {k for k in sd0 if not k.endswith("num_batches_tracked")} == set(params)
+    net.load_state_dict({k: (params[k].clone() if not k.endswith("num_batches_tracked") else v) for k, v in sd0.items()})
+    g = torch.Generator().manual_seed(42)
+    feats = {2: torch.randn(2, chans[0], 16, 20, generator=g), 3: torch.randn(2, chans[1], 8, 10, generator=g),
+             4: torch.randn(2, chans[2], 4, 5, generator=g)}
+    fin = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    net.train()
+    outs = net(fin)
+    sum((o ** 2).mean() for o in outs).backward()
+    po = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in params.items()}
+    fo = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    oo = O.pafpn(fo, po, training=True)
+    for a, b in zip(outs, oo):
+        assert torch.equal(a, b)
+    sum((o ** 2).mean() for o in oo).backward()
+    d = dict(seed=np.int64(41), param_checksum=np.float64(param_checksum(params)))
+    for k, v in feats.items():
+        d[f"in{k}"] = np_(v)
+        d[f"din{k}"] = np_(fin[k].grad)
+        assert torch.allclose(fo[k].grad, fin[k].grad, atol=1e-7, rtol=1e-4)
+    for i, o in enumerate(outs):
+        d[f"train_out{i}"] = np_(o)
+    named = dict(net.named_parameters())
+    for k, v in named.items():
+        assert torch.allclose(po[k].grad, v.grad, atol=1e-7, rtol=1e-3), k
+    d["grad_stats_json"] = np.array(json.dumps({k: [float(v.grad.double().norm()), float(v.grad.double().sum())] for k, v in named.items()}))
+    for k in ("bu_conv2.dconv.conv.weight", "bu_conv2.pconv.conv.weight", "C3_p3.m.0.conv2.dconv.conv.weight", "bu_conv1.dconv.bn.weight"):
+        d["g_" + k] = np_(named[k].grad)
+    d["rm_bu_dconv"] = np_(net.bu_conv2.dconv.bn.running_mean)
+    d["rv_bu_dconv"] = np_(net.bu_conv2.dconv.bn.running_var)
+    net.eval()
+    with torch.no_grad():
+        eo = net(feats)
+    bufs = {k: v.clone() for k, v in net.state_dict().items()}
+    for i, (a, b) in enumerate(zip(eo, O.pafpn(feats, bufs, training=False))):
+        assert torch.equal(a, b)
+        d[f"eval_out{i}"] = np_(a)
+    # the head on the PAFPN's eval outputs
+    hp = O.init_head_params(chans, num_classes=nc, seed=43, depthwise=True)
+    head = ref.yolo_head.YOLOXHead(num_classes=nc, strides=strides, in_channels=chans, depthwise=True)
+    hsd = head.state_dict()
+    assert {k for k in hsd if not k.endswith("num_batches_tracked")} == set(hp), sorted(set(hp) ^ {k for k in hsd if not k.endswith("num_batches_tracked")})[:6]
+    head.load_state_dict({k: (v if k.endswith("num_batches_tracked") else hp[k]) for k, v in hsd.items()}, strict=True)
+    head.eval()
+    with torch.no_grad():
+        hout, _ = head(tuple(eo))
+    mine = O.yolox_head_eval(list(eo), hp, strides)
+    assert torch.allclose(mine, hout, atol=1e-5, rtol=1e-5), float((mine - hout).abs().max())
+    d.update(head_out=np_(hout), head_seed=np.int64(43), num_classes=np.int64(nc))
+    np.savez_compressed(os.path.join(HERE, "depthwise.npz"), **d)
+    print("depthwise ok: head oracle max abs diff", float((mine - hout).abs().max()))
+
+
 def gen_full_stats(ref):
     """F-7: full-size M1 / G1 statistics (tensors too large to commit)."""
     res = {}
@@ -556,6 +617,9 @@ def main():
     if "--nobias-only" in sys.argv:
         gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
         return
+    if "--depthwise-only" in sys.argv:
+        gen_depthwise(ref)
+        return
     if "--acts-only" in sys.argv:    # the gate activations beside gelu (B=1, C=32: small fixtures)
         gen_acts(ref)
         return
@@ -576,6 +640,7 @@ def main():
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)
+    gen_depthwise(ref)
     gen_head_eval(ref)
     gen_head_train(ref)
     gen_masked_backbone(ref)

@@ -847,6 +847,75 @@ def test_pafpn_vs_golden(golden_dir, dev):
         abs_close(a, b.detach(), 1e-6, "")
 
 
+def test_depthwise_pafpn_and_head_vs_golden(golden_dir, dev):
+    """depthwise=True (yolo_pafpn.py:37, network_blocks.py:57-76,93, yolo_head.py:42): Bottleneck.conv2, the two bottom-up convs and the
+    head's tower convs are DWConvs -- a depth-wise 3x3 stencil (stride 1 / 2, `SastConvBnArgs.groups`) + BatchNorm + SiLU, then a 1x1 unit.
+    Against the reference modules' numbers (depthwise.npz): PAFPN in train mode (outputs, running statistics of a depth-wise BatchNorm, input
+    gradients, the norm of every parameter gradient, four gradient tensors) and eval mode, the head in eval mode; then the head's training
+    branch with depth-wise towers against the oracle (whose DWConv units the same fixture pins)."""
+    from sast_amd.detection import YOLOPAFPN, YOLOXHead, DWConv
+    g = _load(golden_dir, "depthwise")
+    chans, nc = (32, 64, 128), int(g["num_classes"])
+    params = O.init_pafpn_params(chans, seed=int(g["seed"]), depthwise=True)
+    net = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans, depthwise=True).to(dev)
+    assert isinstance(net.bu_conv2, DWConv) and isinstance(net.C3_p3.m[0].conv2, DWConv)
+    assert {k for k in net.state_dict() if not k.endswith("num_batches_tracked")} == set(params)     # the reference's state_dict keys
+    load_params(net, params)
+    feats = {k: torch.from_numpy(g[f"in{k}"]).to(dev).requires_grad_(True) for k in (2, 3, 4)}
+    net.train()
+    outs = net(feats)
+    for i, o in enumerate(outs):
+        abs_close(o.detach().cpu(), torch.from_numpy(g[f"train_out{i}"]), FWD_ATOL, str(i))
+    maxnorm_close(net.bu_conv2.dconv.bn.running_mean, torch.from_numpy(g["rm_bu_dconv"]), 1e-5, "running_mean")
+    maxnorm_close(net.bu_conv2.dconv.bn.running_var, torch.from_numpy(g["rv_bu_dconv"]), 1e-5, "running_var")
+    sum((o ** 2).mean() for o in outs).backward()
+    for k in (2, 3, 4):
+        maxnorm_close(feats[k].grad, torch.from_numpy(g[f"din{k}"]), GRAD_RTOL, f"din{k}")
+    named = dict(net.named_parameters())
+    for k, (nrm, _s) in json.loads(str(g["grad_stats_json"])).items():
+        got = float(named[k].grad.double().norm())
+        assert abs(got - nrm) <= GRAD_RTOL * nrm + 1e-9, (k, got, nrm)
+    for k in ("bu_conv2.dconv.conv.weight", "bu_conv2.pconv.conv.weight", "C3_p3.m.0.conv2.dconv.conv.weight", "bu_conv1.dconv.bn.weight"):
+        maxnorm_close(named[k].grad, torch.from_numpy(g["g_" + k]), GRAD_RTOL, k)
+    net.eval()
+    with torch.no_grad():
+        ev = net({k: v.detach() for k, v in feats.items()})
+    for i, o in enumerate(ev):
+        abs_close(o.cpu(), torch.from_numpy(g[f"eval_out{i}"]), 1e-4, str(i))
+    ev_grad = net({k: v.detach() for k, v in feats.items()})          # eval with autograd on: the conv output is kept, same values
+    for a, b in zip(ev, ev_grad):
+        abs_close(a, b.detach(), 1e-6, "")
+    # head, eval mode, on the reference's PAFPN outputs
+    hp = O.init_head_params(chans, num_classes=nc, seed=int(g["head_seed"]), depthwise=True)
+    head = YOLOXHead(num_classes=nc, strides=(8, 16, 32), in_channels=chans, depthwise=True).to(dev)
+    assert {k for k in head.state_dict() if not k.endswith("num_batches_tracked")} == set(hp)
+    load_params(head, hp)
+    head.eval()
+    fin = tuple(torch.from_numpy(g[f"eval_out{i}"]).to(dev) for i in range(3))
+    hout, _ = head(fin)
+    ref_out = torch.from_numpy(g["head_out"])
+    assert float((hout.cpu() - ref_out).abs().max()) <= 1e-4 * float(ref_out.abs().max())
+    # head, training branch (SimOTA loss): the oracle on the same inputs
+    head.train()
+    labels = O.synthetic_labels(2, (128, 160), nc, max_labels=5, seed=12)
+    labels[:, 0, :] = torch.tensor([1.0, 60.0, 50.0, 40.0, 30.0])          # every image has at least one box
+    ft = tuple(f.clone().requires_grad_(True) for f in fin)
+    _o, losses = head(ft, labels.to(dev))
+    losses["loss"].backward()
+    fo = [torch.from_numpy(g[f"eval_out{i}"]).requires_grad_(True) for i in range(3)]
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in hp.items()}
+    ref = O.yolox_head_train(fo, labels, po, num_classes=nc)
+    ref["loss"].backward()
+    for k in ("loss", "iou_loss", "conf_loss", "cls_loss", "num_fg"):
+        assert abs(float(losses[k]) - float(ref[k])) <= 2e-5 * max(1.0, abs(float(ref[k]))), (k, float(losses[k]), float(ref[k]))
+    for a, b in zip(ft, fo):
+        maxnorm_close(a.grad, b.grad, GRAD_RTOL, "head din")
+    hn = dict(head.named_parameters())
+    for k, v in po.items():
+        if v.requires_grad and v.grad is not None:
+            maxnorm_close(hn[k].grad, v.grad, GRAD_RTOL, k)
+
+
 @pytest.mark.parametrize("tag,hw,part", [("G1", (256, 320), (8, 10)), ("M1", (384, 640), (6, 10))])
 def test_full_size_backbone(golden_dir, dev, tag, hw, part):
     """BASELINE configs at full size: kept-token counts and P identical to the reference run
@@ -1590,12 +1659,14 @@ from test_gpu_parity import load_params
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)     # RCCL with ONE rank: the collectives are real calls, the sums unchanged
+dwise = sys.argv[2] == "depthwise"                     # DWConv units (depth-wise stencil + stats pass) through the same two phases
 chans, hw, B = (64, 128, 256), (32, 40), 3
-params = O.init_pafpn_params(chans, seed=5)
+params = O.init_pafpn_params(chans, seed=5, depthwise=dwise)
+n_units = len(params) // 5
 gen = torch.Generator().manual_seed(77)
 full = {k: torch.randn(B, c, hw[0] >> i, hw[1] >> i, generator=gen) for i, (k, c) in enumerate(zip((2, 3, 4), chans))}
 def build(sync):
-    net = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev)
+    net = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans, depthwise=dwise).to(dev)
     if sync:
         convert_sync_batchnorm(net, force=True)
     load_params(net, params)
@@ -1614,7 +1685,7 @@ with torch.cuda.stream(s):
     feats = {k: v.to(dev).requires_grad_(True) for k, v in full.items()}
     run(net, feats)                                       # the eager pass: fixes the sample counts, allocates the gradient buffers
     n_eager = net._sync_group.n_collectives
-    assert n_eager == 2 * 32, n_eager                     # one per conv + BatchNorm unit and direction; the count exchange needs no call with one rank
+    assert n_eager == 2 * n_units and n_units == (42 if dwise else 32), n_eager    # one per conv + BatchNorm unit and direction; the count exchange needs no call with one rank
     sd0 = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -1651,19 +1722,20 @@ print(f"ok captured worst grad err {worst:.2e}")
 '''
 
 
-def test_sync_batchnorm_statistics_allreduces_captured_into_hipgraph(dev, tmp_path):
+@pytest.mark.parametrize("convs", ["dense", "depthwise"])
+def test_sync_batchnorm_statistics_allreduces_captured_into_hipgraph(dev, tmp_path, convs):
     """SyncBatchNorm inside the replayed step (the reference's DDP default, train.py:167): on RCCL the statistics all-reduces between the
     two phases of every conv + BatchNorm unit are stream-captured with the kernels around them.  One rank is what a one-GPU box can run:
     a ONE-rank RCCL group with the two-phase path forced on (`convert_sync_batchnorm(force=True)`) -- 32 + 32 real collective calls inside
     `torch.cuda.graph`, replayed twice -- must reproduce the unconverted PAFPN's outputs and gradients (one rank: the global statistics ARE
-    the local ones; the two forms differ only in where the fp64 sums are finished)."""
+    the local ones; the two forms differ only in where the fp64 sums are finished).  "depthwise": the same with DWConv units (42 + 42)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "worker.py"
     script.write_text(_SYNC_BN_CAPTURE_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=600)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743" if convs == "dense" else "29744", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, str(script), root, convs], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "ok captured" in r.stdout, r.stdout[-2000:]
 

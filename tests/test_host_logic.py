@@ -365,6 +365,24 @@ def test_glu_activation_names():
         SAST_block(64, dict(cfg, mlp_activation="mish"), first_block=True)
 
 
+def test_depthwise_modules_have_the_reference_state_dict_keys():
+    """depthwise=True: DWConv = dconv (depth-wise, weight (C,1,k,k) stored [C][k*k]) + pconv (network_blocks.py:57-76); the key sets are
+    the oracle's, which tests/golden/depthwise.npz was generated against with strict loading into the reference modules"""
+    from sast_amd.detection import YOLOPAFPN, YOLOXHead, DWConv, BaseConv
+    from oracle import sast_oracle as O
+    chans = (32, 64, 128)
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans, depthwise=True)
+    assert {k for k in fpn.state_dict() if not k.endswith("num_batches_tracked")} == set(O.init_pafpn_params(chans, depthwise=True))
+    head = YOLOXHead(num_classes=2, strides=(8, 16, 32), in_channels=chans, depthwise=True)
+    assert {k for k in head.state_dict() if not k.endswith("num_batches_tracked")} == set(O.init_head_params(chans, num_classes=2, depthwise=True))
+    d = fpn.bu_conv1
+    assert isinstance(d, DWConv) and d.dconv.groups == 64 and d.dconv.stride == 2 and d.pconv.groups == 1
+    w = d.dconv.conv.weight
+    assert tuple(w.shape) == (64, 1, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+    with pytest.raises(NotImplementedError):
+        BaseConv(64, 64, 3, 1, groups=2)
+
+
 def test_struct_sizes_and_offsets_match_a_c_compiler(tmp_path):
     """the boundary is a C ABI: the header must compile as plain C (gcc, no HIP), and every struct the Python host fills must have the
     size and field offsets the C compiler gives it (the ctypes mirrors are written by hand: an appended or reordered field that the

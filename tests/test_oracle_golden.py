@@ -134,6 +134,38 @@ def test_pafpn(golden_dir):
         assert torch.allclose(o, torch.from_numpy(g[f"eval_out{i}"]), atol=ATOL, rtol=0)
 
 
+def test_depthwise_pafpn_and_head(golden_dir):
+    """depthwise=True (yolo_pafpn.py:37, network_blocks.py:57-76,93, yolo_head.py:42): the oracle's DWConv units against the reference
+    modules' numbers -- PAFPN train mode (outputs, running statistics of a depth-wise BatchNorm, input gradients, every parameter gradient
+    norm, four gradient tensors), PAFPN eval mode, head eval mode on the PAFPN's outputs."""
+    g = _load(golden_dir, "depthwise")
+    chans = (32, 64, 128)
+    params = O.init_pafpn_params(chans, seed=int(g["seed"]), depthwise=True)
+    assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    assert params["bu_conv2.dconv.conv.weight"].shape == (32, 1, 3, 3) and "bu_conv2.conv.weight" not in params
+    feats = {k: torch.from_numpy(g[f"in{k}"]).requires_grad_(True) for k in (2, 3, 4)}
+    po = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in params.items()}
+    outs = O.pafpn(feats, po, training=True, bufs=po)
+    for i, o in enumerate(outs):
+        assert torch.allclose(o.detach(), torch.from_numpy(g[f"train_out{i}"]), atol=ATOL, rtol=0)
+    assert torch.allclose(po["bu_conv2.dconv.bn.running_mean"], torch.from_numpy(g["rm_bu_dconv"]), atol=1e-7)
+    assert torch.allclose(po["bu_conv2.dconv.bn.running_var"], torch.from_numpy(g["rv_bu_dconv"]), atol=1e-7)
+    sum((o ** 2).mean() for o in outs).backward()
+    for k in (2, 3, 4):
+        assert torch.allclose(feats[k].grad, torch.from_numpy(g[f"din{k}"]), atol=1e-7, rtol=1e-3)
+    for k, (nrm, _sm) in json.loads(str(g["grad_stats_json"])).items():
+        assert abs(float(po[k].grad.double().norm()) - nrm) <= 1e-4 * nrm + 1e-10, k
+    for k in ("bu_conv2.dconv.conv.weight", "bu_conv2.pconv.conv.weight", "C3_p3.m.0.conv2.dconv.conv.weight", "bu_conv1.dconv.bn.weight"):
+        assert torch.allclose(po[k].grad, torch.from_numpy(g["g_" + k]), atol=1e-7, rtol=1e-3), k
+    with torch.no_grad():
+        ev = O.pafpn({k: v.detach() for k, v in feats.items()}, po, training=False)
+    for i, o in enumerate(ev):
+        assert torch.allclose(o, torch.from_numpy(g[f"eval_out{i}"]), atol=ATOL, rtol=0)
+    hp = O.init_head_params(chans, num_classes=int(g["num_classes"]), seed=int(g["head_seed"]), depthwise=True)
+    hout = O.yolox_head_eval([torch.from_numpy(g[f"eval_out{i}"]) for i in range(3)], hp)
+    assert torch.allclose(hout, torch.from_numpy(g["head_out"]), atol=1e-5, rtol=1e-5)
+
+
 def test_yolox_head_eval(golden_dir):
     """YOLOX head inference path: oracle restatement vs the reference module's outputs (decoded and raw)."""
     g = _load(golden_dir, "head_eval")
