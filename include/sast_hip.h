@@ -201,6 +201,8 @@ typedef struct SastLstmArgs {
   float* dw; float* db;
   float* ws;             /* fp32[B*L*4C] */
   const float* dh1b;     /* bwd, optional: a second gradient of h1 (h1 consumed by two ops), added to dh1 on the fly */
+  const float* drop;     /* fwd + bwd, optional: fp32[B*L, C] = the keep mask of `cell_update_dropout` divided by (1 - p) (rnn.py:34,64:
+                            nn.Dropout on tanh(cell_input)); the caller draws it (torch's RNG), NULL = no dropout (p = 0 or eval mode) */
 } SastLstmArgs;
 int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream);
 int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream);

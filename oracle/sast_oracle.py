@@ -345,9 +345,12 @@ def sast_block(x: Tensor, pe: Tensor, r: Tensor, p: Params, pre: str, cfg: AttnC
 
 
 # --------------------------------------------------------------------------- a12
-def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: str):
+def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: str, cell_update_dropout: float = 0.0, training: bool = True,
+              drop_mask: Optional[Tensor] = None):
     """rnn.py:36-69.  NCHW.  dws_conv=True <=> the dict holds `<pre>conv3x3_dws.weight`: [C,1,k,k] = on the previous hidden state
-    (dws_conv_only_hidden=True, :52-53), [2C,1,k,k] = on cat(x, h) (:55-56)."""
+    (dws_conv_only_hidden=True, :52-53), [2C,1,k,k] = on cat(x, h) (:55-56).  cell_update_dropout (:34,64): nn.Dropout on the tanh of
+    the cell input -- the same torch call, so under the same RNG state it draws the reference's mask; drop_mask (NCHW, keep / (1 - p))
+    replaces the draw (fixture tests/golden/lstm_dropout.npz)."""
     C = x.shape[1]
     if hc is None:
         hc = (torch.zeros_like(x), torch.zeros_like(x))
@@ -361,7 +364,8 @@ def conv_lstm(x: Tensor, hc: Optional[Tuple[Tensor, Tensor]], p: Params, pre: st
     mix = F.conv2d(xh, p[pre + "conv1x1.weight"], p[pre + "conv1x1.bias"])
     gates, cin = torch.tensor_split(mix, [C * 3], dim=1)
     f, i, o = torch.tensor_split(torch.sigmoid(gates), 3, dim=1)
-    c1 = f * c0 + i * torch.tanh(cin)
+    cell_in = torch.tanh(cin) * drop_mask if drop_mask is not None else F.dropout(torch.tanh(cin), cell_update_dropout, training)
+    c1 = f * c0 + i * cell_in
     h1 = o * torch.tanh(c1)
     return h1, c1
 

@@ -58,7 +58,7 @@ SastConvBn2Args = _struct("SastConvBn2Args", [
 SastHeadGeom = _struct("SastHeadGeom", [(I32, "n_levels"), (I32 * 4, "H"), (I32 * 4, "W"), (F32 * 4, "stride")])
 SastLstmArgs = _struct("SastLstmArgs", [
     (I32, "B L C"),
-    (P, "x h0 c0 w b h1 c1 gates dh1 dc1 dx dh0 dc0 dw db ws dh1b"),
+    (P, "x h0 c0 w b h1 c1 gates dh1 dc1 dx dh0 dc0 dw db ws dh1b drop"),
 ])
 SastConvBnArgs = _struct("SastConvBnArgs", [
     (I32, "B H W Cin Cout ksize stride training ldx ldy lddy lddx bn_ws_zeroed bn_red_done Cin1 ldx2"), (F32, "momentum eps"),

@@ -101,14 +101,15 @@ struct EpAddGather {  // c[m,j] = v + src[idx[m], j]
 };
 struct EpLstm {  // rnn.py:57-67
   const float* bias; const float* c0; float* h1; float* c1; float* gates; int C;
+  const float* drop;   // cell_update_dropout (rnn.py:34,64): the dropout's keep mask / (1 - p) on the cell input, NULL = none
   struct Col { float bf, bi, bo, bg; };
-  struct Aux { float c; };
+  struct Aux { float c, d; };
   __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[C + j], bias[2 * C + j], bias[3 * C + j]}; }
-  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{c0 ? c0[(size_t)m * C + j] : 0.f}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{c0 ? c0[(size_t)m * C + j] : 0.f, drop ? drop[(size_t)m * C + j] : 1.f}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[4], const Col& k, const Aux& x) const {
     const float f = sigmoid_exact(v[0] + k.bf), i = sigmoid_exact(v[1] + k.bi);
     const float o = sigmoid_exact(v[2] + k.bo), g = tanhf(v[3] + k.bg);
-    const float c = f * x.c + i * g;
+    const float c = f * x.c + i * (g * x.d);
     c1[(size_t)m * C + j] = c;
     h1[(size_t)m * C + j] = o * tanhf(c);
     float* gp = gates + (size_t)m * 4 * C + j;
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
                                                                  const float* __restrict__ c1, const float* __restrict__ dh1,
                                                                  const float* __restrict__ dh1b, const float* __restrict__ dc1,
                                                                  float* __restrict__ dmix,
-                                                                 float* __restrict__ dc0, size_t n, int C, unsigned c_mul) {
+                                                                 float* __restrict__ dc0, size_t n, int C, unsigned c_mul,
+                                                                 const float* __restrict__ drop) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   const size_t m = fast_div((int)e, C, c_mul); const int j = (int)(e - m * C);   // n < 2^31 (launcher)
@@ -132,9 +134,10 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
   const float cp = c0 ? c0[e] : 0.f;
   float* dp = dmix + m * 4 * C + j;
   dp[0] = dc * cp * f * (1.f - f);
-  dp[C] = dc * g * i * (1.f - i);
+  const float d = drop ? drop[e] : 1.f;           // cell input = dropout(tanh(.)) = g * d (the saved g is the tanh itself)
+  dp[C] = dc * (g * d) * i * (1.f - i);
   dp[2 * C] = dh * tc * o * (1.f - o);
-  dp[3 * C] = dc * i * (1.f - g * g);
+  dp[3 * C] = dc * i * d * (1.f - g * g);
   if (dc0) dc0[e] = dc * f;
 }
 
@@ -433,7 +436,7 @@ int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const int Kred = a->h0 ? 2 * C : C;   // zero hidden state: skip the h half of the reduction
   const LdRows2 la{a->x, C, C, a->h0, C};
   const LdWeightNT lb{a->w, 2 * C, C};
-  const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C};
+  const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C, a->drop};
   static int mode = -1;
   if (mode < 0) { const char* e = getenv("SAST_LSTM_TILE"); mode = e ? atoi(e) : 0; }
   if (mode && Kred >= 256 && (long)((M + 63) / 64) * ((C + 31) / 32) <= 2 * pair_thin_nb())
@@ -449,7 +452,7 @@ int sast_lstm_bwd(const SastLstmArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const size_t n = (size_t)M * C;
   if (n >= (1ull << 31)) return SAST_EINVAL;
   SAST_LAUNCH(lstm_bwd_pointwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a->gates, a->c0, a->c1, a->dh1,
-                     a->dh1b, a->dc1, dmix, a->dc0, n, C, div_mul_of((unsigned)C, n));
+                     a->dh1b, a->dc1, dmix, a->dc0, n, C, div_mul_of((unsigned)C, n), a->drop);
   const int NJ = (a->h0 && a->dh0) ? 2 * C : C;
   return gemm_pair(LdRowsT{dmix, 4 * C}, LdRowsT2{a->x, C, C, a->h0, C}, a->dw, 2 * C, 4 * C, a->h0 ? 2 * C : C, M, nullptr, a->db,
                    LdRows{dmix, 4 * C, nullptr}, LdWeightNN{a->w, 2 * C}, EpSplit2{a->dx, a->dh0, C, C}, M, NJ, 4 * C, nullptr, st);

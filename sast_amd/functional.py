@@ -699,7 +699,7 @@ def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: i
 # ---------------------------------------------------------------------------------------------- a12
 class _LSTM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, h0, c0, w, b):
+    def forward(ctx, x, h0, c0, w, b, drop=None):
         _need_gpu(x, w)
         ctx.set_materialize_grads(False)
         x = x.contiguous()
@@ -710,9 +710,13 @@ class _LSTM(torch.autograd.Function):
         Lt = x.numel() // (B * Cc)
         h1, c1 = torch.empty_like(x), torch.empty_like(x)
         gates = torch.empty(B * Lt, 4 * Cc, device=x.device)
-        a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, h1=h1, c1=c1, gates=gates)
+        if drop is not None:
+            if drop.shape != x.shape or drop.dtype != torch.float32:
+                raise RuntimeError("sast_amd: the cell-update dropout mask must be fp32 of the input's NHWC shape")
+            drop = drop.contiguous()
+        a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, h1=h1, c1=c1, gates=gates, drop=_ptr(drop))
         L.check(L.lib().sast_lstm_fwd(C.byref(a), _stream()), "lstm_fwd")
-        ctx.save_for_backward(x, h0, c0, c1, gates)
+        ctx.save_for_backward(x, h0, c0, c1, gates, drop)
         ctx.params = (w, b)
         ctx.meta = (B, Lt, Cc)
         # h1 twice: a stage's output feeds the next stage AND the FPN / the next time step; handing the two consumers two
@@ -721,7 +725,7 @@ class _LSTM(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dh1, dh1b, dc1):
-        x, h0, c0, c1, gates = ctx.saved_tensors
+        x, h0, c0, c1, gates, drop = ctx.saved_tensors
         w, b = ctx.params
         B, Lt, Cc = ctx.meta
         if dh1 is None:
@@ -738,15 +742,16 @@ class _LSTM(torch.autograd.Function):
         dc0 = torch.empty_like(x) if need_c else None
         ws = torch.empty(B * Lt * 4 * Cc, device=x.device)
         a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, c1=c1, gates=gates, dh1=dh1,
-                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=_g(w), db=_g(b), ws=ws, dh1b=_ptr(dh1b))
+                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=_g(w), db=_g(b), ws=ws, dh1b=_ptr(dh1b), drop=_ptr(drop))
         L.check(L.lib().sast_lstm_bwd(C.byref(a), _stream()), "lstm_bwd")
-        return dx, dh0, dc0, None, None
+        return dx, dh0, dc0, None, None, None
 
 
-def conv_lstm(x_nhwc, h0, c0, w, b, two_h=False):
+def conv_lstm(x_nhwc, h0, c0, w, b, two_h=False, drop_mask=None):
     """-> (h1, c1), or with two_h (h1, h1_alias, c1): two handles on the same h1 for its two consumers (their gradients
-    are then summed inside the backward kernel instead of by an autograd add launch)"""
-    h1, h1b, c1 = _LSTM.apply(x_nhwc, h0, c0, w, b)
+    are then summed inside the backward kernel instead of by an autograd add launch).
+    drop_mask: fp32 NHWC tensor of x's shape, keep mask / (1 - p) of `cell_update_dropout` (rnn.py:64), None = no dropout"""
+    h1, h1b, c1 = _LSTM.apply(x_nhwc, h0, c0, w, b, drop_mask)
     return (h1, h1b if TWO_OUT else h1, c1) if two_h else (h1, c1)
 
 

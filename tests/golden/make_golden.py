@@ -446,6 +446,51 @@ def gen_lstm_dws(ref):
     print("lstm_dws ok")
 
 
+def gen_lstm_dropout(ref):
+    """a12 with cell_update_dropout > 0 (rnn.py:34,64; reference default 0): DWSConvLSTM2d of the reference in training mode under a fixed
+    RNG state.  The fixture holds the keep mask the reference drew (recovered from an identical nn.Dropout call under the same RNG state, and
+    proven by the oracle reproducing the reference's outputs with it), outputs and every gradient."""
+    B, C, H, W, pdrop = 2, 32, 8, 10, 0.3
+    cfgp = O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=C)
+    full = O.init_backbone_params(cfgp, seed=81)
+    params = {k[len("stages.0.lstm."):]: v for k, v in full.items() if k.startswith("stages.0.lstm.")}
+    m = ref.rnn.DWSConvLSTM2d(C, dws_conv=False, cell_update_dropout=pdrop)
+    m.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    m.train()
+    g = torch.Generator().manual_seed(82)
+    x = torch.randn(B, C, H, W, generator=g)
+    h0, c0 = torch.randn(B, C, H, W, generator=g) * 0.5, torch.randn(B, C, H, W, generator=g) * 0.5
+    wh, wc = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    xx, hh, cc = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    torch.manual_seed(83)
+    h1, c1 = m(xx, (hh, cc))
+    ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+    torch.manual_seed(83)
+    mask = torch.nn.functional.dropout(torch.ones(B, C, H, W), pdrop, True)          # keep / (1 - p), NCHW like the reference's cell input
+    assert 0.2 < float((mask == 0).float().mean()) < 0.4
+    po = {"lstm." + k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo, ho, co = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    torch.manual_seed(83)
+    oh, oc = O.conv_lstm(xo, (ho, co), po, "lstm.", cell_update_dropout=pdrop, training=True)
+    assert torch.equal(oh, h1) and torch.equal(oc, c1)
+    # the recovered mask is the one in use: c1 = f c0 + i tanh(.) mask  <=>  zero mask entries leave c1 = f c0
+    ((oh * wh).sum() + (oc * wc).sum()).backward()
+    for k, v in m.named_parameters():
+        assert torch.allclose(po["lstm." + k].grad, v.grad, atol=1e-6, rtol=1e-5), k
+    m.eval()
+    with torch.no_grad():
+        eh, ec = m(x, (h0, c0))
+        oe = O.conv_lstm(x, (h0, c0), {"lstm." + k: v for k, v in params.items()}, "lstm.", cell_update_dropout=pdrop, training=False)
+    assert torch.equal(eh, oe[0]) and torch.equal(ec, oe[1])
+    d = dict(x=np_(x), h0=np_(h0), c0=np_(c0), wh=np_(wh), wc=np_(wc), mask=np_(mask), p=np.float64(pdrop), seed=np.int64(81),
+             rng_seed=np.int64(83), h1=np_(h1), c1=np_(c1), dx=np_(xx.grad), dh0=np_(hh.grad), dc0=np_(cc.grad), eval_h1=np_(eh), eval_c1=np_(ec),
+             param_checksum=np.float64(param_checksum(params)))
+    for k, v in m.named_parameters():
+        d["g_" + k] = np_(v.grad)
+    np.savez_compressed(os.path.join(HERE, "lstm_dropout.npz"), **d)
+    print("lstm_dropout ok: dropped", float((mask == 0).float().mean()))
+
+
 def gen_head_eval(ref):
     """YOLOX head, inference path: the oracle restatement against the reference module in eval mode."""
     if ref.yolo_head is None:
@@ -617,6 +662,9 @@ def main():
     if "--nobias-only" in sys.argv:
         gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
         return
+    if "--lstm-dropout-only" in sys.argv:
+        gen_lstm_dropout(ref)
+        return
     if "--depthwise-only" in sys.argv:
         gen_depthwise(ref)
         return
@@ -646,6 +694,7 @@ def main():
     gen_masked_backbone(ref)
     gen_full_stats(ref)
     gen_lstm_dws(ref)
+    gen_lstm_dropout(ref)
     gen_sequence_gather(ref)
 
 

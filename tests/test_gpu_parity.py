@@ -1162,6 +1162,52 @@ def test_conv_lstm_depthwise_vs_golden(golden_dir, dev, mode):
             grad_close(pre + k, v.grad, torch.from_numpy(g[pre + "g_" + k]))
 
 
+def test_conv_lstm_cell_update_dropout_vs_golden(golden_dir, dev):
+    """a12 with cell_update_dropout > 0 (rnn.py:34,64; the shipped YAML leaves it 0): nn.Dropout on the tanh of the cell input.  The
+    fixture holds the reference module's training-mode outputs and gradients under a fixed RNG state together with the keep mask it drew;
+    with that mask injected the fused gates epilogue (`SastLstmArgs.drop`) reproduces them.  Then the module's own draw: a fraction p of the
+    cell inputs dropped, the survivors scaled by 1 / (1 - p), eval mode untouched."""
+    from sast_amd.layers import DWSConvLSTM2d
+    g = _load(golden_dir, "lstm_dropout")
+    C, pdrop = g["x"].shape[1], float(g["p"])
+    full = O.init_backbone_params(O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=C), seed=int(g["seed"]))
+    params = {k[len("stages.0.lstm."):]: v for k, v in full.items() if k.startswith("stages.0.lstm.")}
+    m = DWSConvLSTM2d(C, dws_conv=False, cell_update_dropout=pdrop).to(dev)
+    m.load_state_dict({k: v.clone() for k, v in params.items()}, strict=True)
+    m.train()
+    m.drop_mask_override = torch.from_numpy(g["mask"]).permute(0, 2, 3, 1).contiguous().to(dev)     # the reference's mask, NCHW -> NHWC
+    wh, wc = torch.from_numpy(g["wh"]).to(dev), torch.from_numpy(g["wc"]).to(dev)
+    x = torch.from_numpy(g["x"]).to(dev).requires_grad_(True)
+    h0, c0 = torch.from_numpy(g["h0"]).to(dev).requires_grad_(True), torch.from_numpy(g["c0"]).to(dev).requires_grad_(True)
+    h1, c1 = m(x, (h0, c0))
+    abs_close(h1, torch.from_numpy(g["h1"]), FWD_ATOL, "h1")
+    abs_close(c1, torch.from_numpy(g["c1"]), FWD_ATOL, "c1")
+    ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+    maxnorm_close(x.grad, torch.from_numpy(g["dx"]), GRAD_RTOL, "dx")
+    maxnorm_close(h0.grad, torch.from_numpy(g["dh0"]), GRAD_RTOL, "dh0")
+    maxnorm_close(c0.grad, torch.from_numpy(g["dc0"]), GRAD_RTOL, "dc0")
+    for k, v in m.named_parameters():
+        grad_close(k, v.grad, torch.from_numpy(g["g_" + k]))
+    # the module's own draw (device RNG): c1 - f c0 = i tanh(.) mask, so the dropped positions are where c1 equals the no-input cell
+    m.drop_mask_override = None
+    torch.manual_seed(5)
+    with torch.no_grad():
+        xs, hs, cs = x.detach(), h0.detach(), c0.detach()
+        _h, c_drop = m(xs, (hs, cs))
+        m.eval()
+        he, ce = m(xs, (hs, cs))
+        m.train()
+    abs_close(he, torch.from_numpy(g["eval_h1"]), FWD_ATOL, "eval h1")
+    abs_close(ce, torch.from_numpy(g["eval_c1"]), FWD_ATOL, "eval c1")
+    ref = O.conv_lstm(torch.from_numpy(g["x"]), (torch.from_numpy(g["h0"]), torch.from_numpy(g["c0"])), {"lstm." + k: v for k, v in params.items()},
+                      "lstm.", drop_mask=torch.zeros_like(torch.from_numpy(g["mask"])))[1]              # every cell input dropped: c1 = f c0
+    dropped = ((c_drop.cpu() - ref).abs() <= 1e-6).float().mean()
+    assert abs(float(dropped) - pdrop) < 0.05, float(dropped)
+    scale = (c_drop.cpu() - ref) / (torch.from_numpy(g["eval_c1"]) - ref)                              # survivors: exactly 1 / (1 - p) of the eval update
+    keep = ((c_drop.cpu() - ref).abs() > 1e-4) & ((torch.from_numpy(g["eval_c1"]) - ref).abs() > 1e-3)
+    assert float((scale[keep] - 1.0 / (1.0 - pdrop)).abs().max()) < 1e-2
+
+
 def test_backbone_with_depthwise_lstm(dev):
     """the whole backbone with lstm.dws_conv: True (the reference's class default; the shipped YAML sets False), two timesteps with
     the recurrent state carried, forward and backward against the oracle"""

@@ -134,6 +134,33 @@ def test_pafpn(golden_dir):
         assert torch.allclose(o, torch.from_numpy(g[f"eval_out{i}"]), atol=ATOL, rtol=0)
 
 
+def test_lstm_cell_update_dropout(golden_dir):
+    """cell_update_dropout > 0 (rnn.py:34,64): the fixture holds the reference DWSConvLSTM2d's training-mode numbers under a fixed RNG state
+    and the keep mask it drew.  The oracle with that mask, and the oracle drawing its own under the same RNG state (the same nn.Dropout call
+    on a tensor of the same shape), both reproduce them; eval mode ignores the dropout."""
+    g = _load(golden_dir, "lstm_dropout")
+    cfgp = O.BackboneCfg(in_res_hw=(128, 160), partition_size=(4, 5), embed_dim=32)
+    full = O.init_backbone_params(cfgp, seed=int(g["seed"]))
+    params = {k[len("stages.0."):]: v for k, v in full.items() if k.startswith("stages.0.lstm.")}
+    x, h0, c0, mask = (torch.from_numpy(g[k]) for k in ("x", "h0", "c0", "mask"))
+    wh, wc, pdrop = torch.from_numpy(g["wh"]), torch.from_numpy(g["wc"]), float(g["p"])
+    assert set(torch.unique(mask).tolist()) == {0.0, float(np.float32(1.0 / (1.0 - pdrop)))}
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo, ho, co = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    h1, c1 = O.conv_lstm(xo, (ho, co), po, "lstm.", drop_mask=mask)
+    assert torch.allclose(h1, torch.from_numpy(g["h1"]), atol=1e-6, rtol=0) and torch.allclose(c1, torch.from_numpy(g["c1"]), atol=1e-6, rtol=0)
+    ((h1 * wh).sum() + (c1 * wc).sum()).backward()
+    for got, key in ((xo.grad, "dx"), (ho.grad, "dh0"), (co.grad, "dc0")):
+        assert torch.allclose(got, torch.from_numpy(g[key]), atol=1e-6, rtol=1e-4), key
+    for k, v in po.items():
+        assert torch.allclose(v.grad, torch.from_numpy(g["g_" + k[len("lstm."):]]), atol=1e-5, rtol=1e-4), k
+    torch.manual_seed(int(g["rng_seed"]))
+    h1b, c1b = O.conv_lstm(x, (h0, c0), params, "lstm.", cell_update_dropout=pdrop, training=True)
+    assert torch.equal(h1b, h1.detach()) and torch.equal(c1b, c1.detach())
+    he, ce = O.conv_lstm(x, (h0, c0), params, "lstm.", cell_update_dropout=pdrop, training=False)
+    assert torch.allclose(he, torch.from_numpy(g["eval_h1"]), atol=1e-6, rtol=0) and torch.allclose(ce, torch.from_numpy(g["eval_c1"]), atol=1e-6, rtol=0)
+
+
 def test_depthwise_pafpn_and_head(golden_dir):
     """depthwise=True (yolo_pafpn.py:37, network_blocks.py:57-76,93, yolo_head.py:42): the oracle's DWConv units against the reference
     modules' numbers -- PAFPN train mode (outputs, running statistics of a depth-wise BatchNorm, input gradients, every parameter gradient
