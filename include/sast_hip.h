@@ -175,6 +175,10 @@ typedef struct SastMswsaArgs {
   float *cb_m, *cb_sum;  /* cb_tps > 0 only: scratch [R,C] and [B*L/cb_tps, C] (fwd and bwd) */
   float* raw_ws;         /* optional fp32[sast_mswsa_raw_ws_floats()]: cleared by the forward, accumulated into by the backward of the
                             SAME call pair (saves the backward a clearing launch); NULL = backward clears its own scratch */
+  const float *drop1, *drop2;  /* DropPath (`drop_path > 0`, SAST.py:188,193,232,248; reference default 0): fp32[R] each, per KEPT ROW (compact
+                            order = asy_index order) keep / keep_prob of the attention branch (drop1) and of the MLP branch (drop2); the caller
+                            draws them.  Both or neither; NULL = no DropPath (p = 0 or eval).  Not with cb_tps > 0, not with fused_ws. */
+  float* drop_ws;        /* bwd with drop1 / drop2: fp32[2 * R * C] scratch (the scaled branch gradients) */
   float* fused_ws;       /* optional fp32[sast_mswsa_fused_ws_floats()] (16-byte aligned): when non-NULL and that size is non-zero the
                             layer runs as ONE kernel per direction (csrc/k_mswsa_fused.hip: one wave per partition, activations in
                             registers from LN to the scatter).  With S == NULL (inference) nothing else is written; with the saved-activation

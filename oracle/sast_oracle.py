@@ -42,6 +42,10 @@ class AttnCfg:
     bounce: float = 1e-3
     enable_cb: bool = False
     mlp_activation: str = "gelu"     # attention_cfg.mlp_activation (SAST.py:38,55 -> layers/create_act.py:62-79)
+    drop_path: float = 0.0           # attention_cfg.drop_path (SAST.py:42,188,193): DropPath on the two residual branches, training mode only
+    training: bool = True
+    drop_log: Optional[list] = None    # test plumbing: every DropPath factor vector drawn is appended (call order: layer 1 attention, MLP, layer 2 ...)
+    drop_masks: Optional[list] = None  # test plumbing: factor vectors to USE instead of drawing, consumed in the same order
 
 
 @dataclass
@@ -185,6 +189,23 @@ def selection_margins(scores: Tensor, B: int, N: int, T: int, bounce: float):
 GLU_ACTS = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, "swish": F.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
 
 
+def drop_path(x: Tensor, cfg: "AttnCfg") -> Tensor:
+    """layers/drop.py:137-154 as MS_WSA applies it (SAST.py:232,248) to (kept rows, C): one Bernoulli(keep_prob) factor per row, divided by
+    keep_prob.  The same torch calls as the reference: under the same RNG state it draws the same factors."""
+    if cfg.drop_path == 0.0 or not cfg.training:
+        return x
+    keep = 1.0 - cfg.drop_path
+    if cfg.drop_masks is not None:
+        rt = cfg.drop_masks.pop(0).view(-1, 1).to(x.dtype)
+    else:
+        rt = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0:
+            rt.div_(keep)
+    if cfg.drop_log is not None:
+        cfg.drop_log.append(rt.view(-1).clone())
+    return x * rt
+
+
 def mlp_glu(x: Tensor, p: Params, pre: str, act: str = "gelu") -> Tensor:
     """ops.py:111-175: Linear(C->2*inner) -> value * act(gate) (GELU_erf in every shipped config) -> Linear(inner->C)."""
     y = F.linear(x, p[pre + "net.0.proj.weight"], p.get(pre + "net.0.proj.bias"))       # (mlp_bias: False -> no bias keys)
@@ -223,7 +244,7 @@ def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: A
 
     XX[index_token] = x.view(-1, C)
     x = XX[asy_index]
-    x = shortcut + x * p[pre + "ls1.gamma"]
+    x = shortcut + drop_path(x * p[pre + "ls1.gamma"], cfg)
     shortcut = x
     x = mlp_glu(x, p, pre + "mlp.", cfg.mlp_activation)
     if cfg.enable_cb:  # SAST.py:240-246
@@ -233,7 +254,7 @@ def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: A
         tX = tX.view(B, -1, C)
         tX = (0.5 * tX + (1 - 0.5) * tX.mean(dim=1, keepdim=True)).view(*shape)
         x = tX[index_window].view(-1, C)[asy_index]
-    x = shortcut + x * p[pre + "ls2.gamma"]
+    x = shortcut + drop_path(x * p[pre + "ls2.gamma"], cfg)
     XX[asy_index] = x.view(-1, C)
     XX[padding_index] = X[index_window].view(-1, C)[padding_index]
     X[index_window] = XX.view(M, -1, C)

@@ -35,24 +35,30 @@ struct EpStoreAddCtl : EpStoreAdd {
   ControlsJob k; int side_blocks;
   __device__ __forceinline__ void side(int sb) const { if (threadIdx.x < 256) controls_bwd_elem(k, sb * 256 + threadIdx.x); }
 };
-struct EpResidualLS {  // y = res + gamma * (v + bias)
-  float* y; const float* res; const float* bias; const float* gamma; int C;
+// RS: DropPath (SAST.py:188,193,232,248; reference default drop_path 0): the LayerScale'd branch of row m is multiplied by rs[m] =
+// keep / keep_prob before it joins the shortcut.  A separate instantiation: the shipped path carries neither the load nor the multiply.
+template <bool RS>
+struct EpResidualLST {  // y = res + [rs[m] *] gamma * (v + bias)
+  float* y; const float* res; const float* bias; const float* gamma; int C; const float* rs;
   struct Col { float b, g; };
-  struct Aux { float r; };
+  struct Aux { float r, d; };
   __device__ __forceinline__ Col col(int j) const { return Col{bias[j], gamma ? gamma[j] : 1.f}; }
-  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{res[(size_t)m * C + j]}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{res[(size_t)m * C + j], RS ? rs[m] : 1.f}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux& x) const {
-    y[(size_t)m * C + j] = x.r + k.g * (v[0] + k.b);
+    if constexpr (RS) y[(size_t)m * C + j] = x.r + (k.g * (v[0] + k.b)) * x.d;
+    else y[(size_t)m * C + j] = x.r + k.g * (v[0] + k.b);
   }
 };
-struct EpResidualLSScatter {  // out[row_tok[m]] = res + gamma * (v + bias)
-  float* out; const float* res; const float* bias; const float* gamma; const int* row_tok; int C;
+template <bool RS>
+struct EpResidualLSScatterT {  // out[row_tok[m]] = res + [rs[m] *] gamma * (v + bias)
+  float* out; const float* res; const float* bias; const float* gamma; const int* row_tok; int C; const float* rs;
   struct Col { float b, g; };
-  struct Aux { float r; int row; };
+  struct Aux { float r, d; int row; };
   __device__ __forceinline__ Col col(int j) const { return Col{bias[j], gamma ? gamma[j] : 1.f}; }
-  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{res[(size_t)m * C + j], row_tok[m]}; }
+  __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{res[(size_t)m * C + j], RS ? rs[m] : 1.f, row_tok[m]}; }
   __device__ __forceinline__ void post(int, int j, const float (&v)[1], const Col& k, const Aux& x) const {
-    out[(size_t)x.row * C + j] = x.r + k.g * (v[0] + k.b);
+    if constexpr (RS) out[(size_t)x.row * C + j] = x.r + (k.g * (v[0] + k.b)) * x.d;
+    else out[(size_t)x.row * C + j] = x.r + k.g * (v[0] + k.b);
   }
 };
 // ANY = false: exact-erf GELU (every shipped config) compiled in; ANY = true: the gate activation is the run-time code `act`
@@ -297,9 +303,9 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   if (a->C % dh) return SAST_EINVAL;
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
-  if (T > ATTN_MAX_T || a->mlp_act < 0 || a->mlp_act >= GLU_ACT_COUNT) return SAST_EINVAL;
-  if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip: GeGLU only)
-    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || a->mlp_act != 0 || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
+  if (T > ATTN_MAX_T || a->mlp_act < 0 || a->mlp_act >= GLU_ACT_COUNT || (!a->drop1) != (!a->drop2)) return SAST_EINVAL;
+  if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip: GeGLU, no DropPath)
+    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || a->mlp_act != 0 || a->drop1 || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
     int rc = mswsa_fused_planes_launch(a, a->fused_ws, st);
     if (rc) return rc;
     return mswsa_fused_fwd_launch(a, a->fused_ws, st);
@@ -312,7 +318,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   if (rc) return rc;
   rc = attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, a->sel.pack_rows, a->sel.row_seg, NW, T, C, dh, st);
   if (rc) return rc;
-  rc = gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLS{a->Y, a->S, a->proj_b, a->ls1, C}, R, C, C, dR, st);
+  rc = a->drop1 ? gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLST<true>{a->Y, a->S, a->proj_b, a->ls1, C, a->drop1}, R, C, C, dR, st)
+                : gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLST<false>{a->Y, a->S, a->proj_b, a->ls1, C, nullptr}, R, C, C, dR, st);
   if (rc) return rc;
   {
     const LdRows la{a->Y, C, nullptr};
@@ -329,8 +336,11 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     if (rc) return rc;
   }
   if (a->cb_tps <= 0)
-    return gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
-                     EpResidualLSScatter{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C}, R, C, inner, dR, st);
+    return a->drop2 ? gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
+                                EpResidualLSScatterT<true>{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C, a->drop2}, R, C, inner, dR, st)
+                    : gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
+                                EpResidualLSScatterT<false>{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C, nullptr}, R, C, inner, dR, st);
+  if (a->drop2) return SAST_EINVAL;     // DropPath together with Context Broadcasting is not built
   // Context Broadcasting (SAST.py:240-246): the MLP output is mixed with its per-sample mean over ALL L tokens before LayerScale
   if (!a->cb_m || !a->cb_sum || R % a->cb_tps) return SAST_EINVAL;
   rc = gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0}, EpStore{a->cb_m, C, a->fc2_b}, R, C, inner, dR, st);
@@ -374,7 +384,16 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     dz = a->cb_m;
     dz_tok = nullptr;
   }
-  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && a->mlp_act == 0 && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
+  // DropPath (drop1 / drop2: per kept row keep / keep_prob): what enters a residual BRANCH is the row factor times the gradient of the
+  // sum -- a scaled compact copy for the branch GEMMs, the unscaled gradient for the identity path
+  if ((!a->drop1) != (!a->drop2) || (a->drop1 && (!a->drop_ws || a->cb_tps > 0))) return SAST_EINVAL;
+  if (a->drop2) {
+    rc = row_scale_launch(a->dout, row_tok, a->drop2, a->drop_ws, dR, R, C, st);
+    if (rc) return rc;
+    dz = a->drop_ws;
+    dz_tok = nullptr;
+  }
+  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && a->mlp_act == 0 && !a->drop1 && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
     // MLP backward as one kernel (k_mswsa_fused.hip): dY and dW1 / db1 / raw dW2 / colsum(dZ) from the saved Y, [u|g] recomputed
     rc = mswsa_fused_mlp_bwd_launch(a, a->fused_ws, dY, raw2, s2, R, st);
     if (rc) return rc;
@@ -400,14 +419,21 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
                  LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
   if (rc) return rc;
   }
-  // proj: raw dWp / dbp, and dO = (gamma1 * dY) Wp
-  if (a->ls1) {
-    rc = gemm_pair(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1,
-                   LdRows{dY, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
-  } else {
-    rc = gemm_tn(LdRowsT{dY, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, st);
+  // proj: raw dWp / dbp, and dO = (gamma1 * dY) Wp   (DropPath: the branch sees drop1 (.) dY, the identity path below the plain dY)
+  const float* dYb = dY;
+  if (a->drop1) {
+    float* scaled = a->drop_ws + (size_t)R * C;
+    rc = row_scale_launch(dY, nullptr, a->drop1, scaled, dR, R, C, st);
     if (rc) return rc;
-    rc = gemm_auto(LdRows{dY, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+    dYb = scaled;
+  }
+  if (a->ls1) {
+    rc = gemm_pair(LdRowsT{dYb, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1,
+                   LdRows{dYb, C, nullptr}, LdWeightNNS{a->proj_w, C, a->ls1}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
+  } else {
+    rc = gemm_tn(LdRowsT{dYb, C}, LdRowsT{a->O, C}, raw1, C, C, C, R, dR, s1, st);
+    if (rc) return rc;
+    rc = gemm_auto(LdRows{dYb, C, nullptr}, LdWeightNN{a->proj_w, C}, EpStore{dO, C, nullptr}, R, C, C, dR, st);
   }
   if (rc) return rc;
   // raw (gamma-free) fc2 and proj gradients -> parameter gradients incl. the LayerScale gammas: side workgroups of the attention

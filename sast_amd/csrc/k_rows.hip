@@ -763,6 +763,26 @@ int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, i
   return SAST_OK;
 }
 
+// ============================================================ dst[m] = rs[m] * src[idx ? idx[m] : m] for the first *nrows_dev rows
+// (DropPath, SAST.py:188,193,232,248: the gradient that enters a dropped residual branch is the row's keep factor times the gradient
+// of the sum; the identity path keeps the unscaled one)
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ src, const int* __restrict__ idx, const float* __restrict__ rs,
+                                                        float* __restrict__ dst, const int* __restrict__ nrows_dev, int C4) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t row = e / C4; const int c = (int)(e % C4);
+  if (row >= (size_t)*nrows_dev) return;
+  const size_t from = idx ? (size_t)idx[row] : row;
+  const float4 v = ld4(src + (from * C4 + c) * 4);
+  const float d = rs[row];
+  st4(dst + e * 4, make_float4(v.x * d, v.y * d, v.z * d, v.w * d));
+}
+int row_scale_launch(const float* src, const int* idx, const float* rs, float* dst, const int* nrows_dev, int rows_max, int C, hipStream_t st) {
+  const size_t n4 = (size_t)rows_max * (C / 4);
+  SAST_LAUNCH(row_scale_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, src, idx, rs, dst, nrows_dev, C / 4);
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
 // ============================================================ mask token (sast_rnn.py:271-273): x[token_mask] = mask_token
 // Forward works in place on the LayerNorm output that already carries the first block's position embedding, so a masked row
 // becomes mask_token + pos_emb[row % L].  Backward: masked rows pass no gradient to x, their gradient sums go to the token.

@@ -32,6 +32,7 @@ int stp_fwd_launch(const float* xp, const float* s, const float* scale, float am
 int stp_bwd_launch(const float* xp, const float* s, const float* scale, const float* g, float* direct, float* dz,
                    float* dscale, int B, int L, int C, hipStream_t st);
 int add_rows_launch(const float* x, const float* t, float* y, int rows, int C, int table_rows, hipStream_t st);
+int row_scale_launch(const float* src, const int* idx, const float* rs, float* dst, const int* nrows_dev, int rows_max, int C, hipStream_t st);
 int mask_token_fwd_launch(float* x, const unsigned char* mask, const float* token, const float* pe, int rows, int C, int L, hipStream_t st);
 int mask_token_bwd_launch(const float* dy, const unsigned char* mask, float* dx, float* dtoken, int rows, int C, hipStream_t st);
 int colsum_launch(const float* x, int ld, const int* idx, int rows, const int* drows, int C, float* out, hipStream_t st);

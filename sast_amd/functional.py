@@ -586,7 +586,7 @@ _FUSED_MIN_ROWS = int(os.environ.get("SAST_MSWSA_FUSED_MIN_ROWS", "49152"))
 
 class _MSWSA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, mlp_act, *params):
+    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, mlp_act, drop, *params):
         _need_gpu(xin)
         xin = xin.contiguous()
         p = dict(zip(_MSWSA_PARAMS, params))
@@ -602,9 +602,16 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, mlp_act=mlp_act, xin=xin, out=out)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
+        if drop is not None:       # DropPath: per kept row keep / keep_prob of the two residual branches (include/sast_hip.h: drop1 / drop2)
+            if cb_tps:
+                raise NotImplementedError("sast_amd: drop_path > 0 together with enable_CB is not implemented")
+            drop = tuple(d.contiguous() for d in drop)
+            if any(d.dtype != torch.float32 or d.numel() < R for d in drop):
+                raise RuntimeError("sast_amd: the DropPath factors must be fp32 with one entry per row upper bound")
+            _fill(a, drop1=drop[0], drop2=drop[1])
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
-        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and R >= _FUSED_MIN_ROWS) else 0
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and drop is None and R >= _FUSED_MIN_ROWS) else 0
         needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
         fws = None
         if fused_floats:
@@ -636,6 +643,7 @@ class _MSWSA(torch.autograd.Function):
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
         ctx.save_for_backward(xin, stats, big, raw, fws)      # fws: the weight planes the fused kernels of this call pair stream (or None)
         ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head, ctx.mlp_act = sel, params, eps, inner, cb_tps, dim_head, mlp_act
+        ctx.drop = drop
         return out
 
     @staticmethod
@@ -666,6 +674,9 @@ class _MSWSA(torch.autograd.Function):
               dout=dout, dxin=dxin, ws=ws, raw_ws=raw)
         if fws is not None:
             _fill(a, fused_ws=fws)
+        if ctx.drop is not None:
+            drop_ws = torch.empty(2 * R * Cc, device=xin.device)
+            _fill(a, drop1=ctx.drop[0], drop2=ctx.drop[1], drop_ws=drop_ws)
         if ctx.cb_tps:
             cb_m, cb_sum = torch.empty(R, Cc, device=xin.device), torch.empty(R // ctx.cb_tps, Cc, device=xin.device)
             _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
@@ -674,14 +685,14 @@ class _MSWSA(torch.autograd.Function):
         grads = {k: _g(v) for k, v in p.items()}          # held until the launch is enqueued (scratch buffers among them)
         _fill(a, **{"d_" + k: _ptr(v) for k, v in grads.items()})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
-        return (dxin, None, None, None, None, None, None) + (None,) * len(params)
+        return (dxin, None, None, None, None, None, None, None) + (None,) * len(params)
 
 
 GLU_ACTIVATIONS = {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4}     # include/sast_hip.h: SastMswsaArgs.mlp_act
 
 
 def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32, fused: bool = True,
-          mlp_activation: str = "gelu") -> torch.Tensor:
+          mlp_activation: str = "gelu", drop_path=None) -> torch.Tensor:
     """params: dict with the keys of _MSWSA_PARAMS (ls1/ls2 may be None = LayerScale disabled).
     cb_tokens_per_sample > 0 enables Context Broadcasting (SAST.py:240-246) with that many tokens per sample.
     dim_head: 32 or 24 (the widths the reference ships).
@@ -689,11 +700,13 @@ def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: i
     fused form is faster when most tokens are kept (-1.5 % of the dense 1Mpx step) and slower when few are (+1.5 % at 15 % kept: a
     wave runs the whole layer for its <= 32 tokens, a latency the compacted GEMM chain does not have) -- SAST_block passes its AMP.
     mlp_activation: the gate activation of the GLU-MLP (attention_cfg.mlp_activation, layers/create_act.py:62-79): one of
-    GLU_ACTIVATIONS; the one-kernel forward exists for "gelu"."""
+    GLU_ACTIVATIONS; the one-kernel forward exists for "gelu".
+    drop_path: None, or (d1, d2) -- fp32 vectors with one entry per row (upper bound B*L; entry m belongs to the m-th KEPT row in
+    asy_index order): keep / keep_prob of timm's DropPath on the attention and on the MLP branch (SAST.py:188,193,232,248)."""
     if mlp_activation not in GLU_ACTIVATIONS:
         raise NotImplementedError(f"sast_amd: mlp_activation {mlp_activation!r}: the GLU epilogues implement {sorted(GLU_ACTIVATIONS)}")
     return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), GLU_ACTIVATIONS[mlp_activation],
-                        *[params[k] for k in _MSWSA_PARAMS])
+                        drop_path, *[params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12

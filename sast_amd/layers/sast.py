@@ -69,6 +69,23 @@ def get_score_index_with_padding(x: torch.Tensor, d: float, b: float):
     return (top + base).view(-1), nz[:, 0] * x.shape[-1] + nz[:, 1], K
 
 
+class DropPath(nn.Module):
+    """layers/drop.py:157-169 (stochastic depth): in MS_WSA it acts on (kept rows, C) tensors, i.e. per kept TOKEN.  No parameters; the
+    scaling lives in the kernels (include/sast_hip.h: SastMswsaArgs.drop1 / drop2), this module only draws the row factors."""
+
+    def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
+
+    def row_factors(self, rows: int, device) -> torch.Tensor:
+        keep = 1.0 - self.drop_prob
+        f = torch.empty(rows, device=device).bernoulli_(keep)
+        return f.div_(keep) if (keep > 0.0 and self.scale_by_keep) else f
+
+    def extra_repr(self):
+        return f'drop_prob={round(self.drop_prob, 3):0.3f}'
+
+
 def _glu_activation_name(act) -> str:
     """the reference hands MS_WSA an activation CLASS (get_act_layer(name), SAST.py:55); here a name, such a class, or None (= gelu)"""
     if act is None:
@@ -96,16 +113,17 @@ class MS_WSA(nn.Module):
         self.proj = nn.Linear(dim, dim, bias=bias)
         self.norm1 = norms[0]
         ls_init_value, drop_path, mlp_expand_ratio, mlp_act_layer, mlp_bias, drop_mlp = sub_layer_params
-        if drop_path > 0:
-            raise NotImplementedError("sast_amd: drop_path > 0 is not implemented (reference default 0)")
+        if not 0.0 <= drop_path < 1.0:
+            raise ValueError(f"drop_path must be in [0, 1), got {drop_path}")
         self.mlp_activation = _glu_activation_name(mlp_act_layer)
         self.ls1 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
-        self.drop1 = nn.Identity()
+        self.drop1 = DropPath(drop_path) if drop_path > 0 else nn.Identity()
         self.norm2 = norms[1]
         self.mlp = MLP(dim=dim, channel_last=True, expansion_ratio=mlp_expand_ratio, act_layer=mlp_act_layer, bias=mlp_bias,
                        drop_prob=drop_mlp)
         self.ls2 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
-        self.drop2 = nn.Identity()
+        self.drop2 = DropPath(drop_path) if drop_path > 0 else nn.Identity()
+        self.drop_path_override = None     # tests: fixed (d1, d2) row factors instead of a fresh draw
         # aliased container, same state_dict duplicates as the reference (SAST.py:194)
         self.sub_layers = nn.ModuleList([self.ls1, self.drop1, self.norm2, self.mlp, self.ls2, self.drop2])
         self.eps = 1e-6
@@ -126,10 +144,19 @@ class MS_WSA(nn.Module):
                     fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias if self.mlp.net[2].bias is not None else self._zero_fc2_b,
                     ls2=getattr(self.ls2, "gamma", None))
 
+    def _drop_path_factors(self, rows: int, device):
+        """DropPath in training mode (SAST.py:232,248 -> layers/drop.py): one Bernoulli(keep_prob) draw per KEPT ROW and branch, divided by
+        keep_prob.  The number of kept rows lives on the device, so the draw covers the row upper bound; entry m serves the m-th kept row."""
+        if not self.training or not isinstance(self.drop1, DropPath):
+            return None
+        if self.drop_path_override is not None:
+            return self.drop_path_override
+        return self.drop1.row_factors(rows, device), self.drop2.row_factors(rows, device)
+
     def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False, fused: bool = True) -> torch.Tensor:
         """device path: x (B,H,W,C) in IMAGE layout + device-side selection."""
         return SF.mswsa(x, sel, self.norm1.eps, self.kernel_params(), x.shape[1] * x.shape[2] if enable_CB else 0, self.dim_head, fused,
-                        self.mlp_activation)
+                        self.mlp_activation, self._drop_path_factors(x.numel() // x.shape[-1], x.device))
 
     def forward(self, x: torch.Tensor, index_window: torch.Tensor, index_token: torch.Tensor, padding_index: torch.Tensor,
                 asy_index: torch.Tensor, M: int, B, enable_CB: bool) -> torch.Tensor:
@@ -144,7 +171,7 @@ class MS_WSA(nn.Module):
         sel = SF.selection_from_index_lists(index_window, asy_index, K, N, T, x.device)
         # Context Broadcasting averages over the tokens of one sample = N*T/B consecutive partitioned tokens (SAST.py:244-245)
         out = SF.mswsa(x3.reshape(1, N * T, 1, C), sel, self.norm1.eps, self.kernel_params(), N * T // int(B) if enable_CB else 0, self.dim_head,
-                       mlp_activation=self.mlp_activation)
+                       mlp_activation=self.mlp_activation, drop_path=self._drop_path_factors(N * T, x.device))
         return out.view(*shape)
 
 

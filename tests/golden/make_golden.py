@@ -144,6 +144,66 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
     print(f"{name}: seed {seed} margin {margin:.2e} kept {kept} of {B * H * W} count {cnt}")
 
 
+def gen_block_drop_path(ref):
+    """drop_path > 0 (SAST.py:42,188,193,232,248; shipped YAML: 0): DropPath on both residual branches of both MS-WSA layers, training mode,
+    fixed RNG state.  The oracle (same torch calls in the same order) reproduces the reference bit for bit and records the four factor
+    vectors it drew (= the reference's); the fixture holds them next to the reference's outputs and gradients."""
+    H, W, part, C, B, amp, pdrop = 16, 20, (4, 5), 32, 2, 2e-2, 0.25
+    acfg = dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
+                mlp_ratio=4, drop_mlp=0, drop_path=pdrop, ls_init_value=0.5, enable_CB=False, AMP=amp, BOUNCE=1e-3)
+    pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    pe = O.position_embedding_sine(H, W, C)
+    T, N = part[0] * part[1], H * W // (part[0] * part[1])
+    for seed in range(0, 200):
+        g = torch.Generator().manual_seed(3000 + seed)
+        x = torch.randn(B, H, W, C, generator=g)
+        r = torch.rand(B, 20, generator=g) * 0.05
+        params = block_params(C, seed, 0.5)
+        ocfg0 = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3)
+        _o, _c, _l, sc = O.sast_block(x, pe, r, params, "att_blocks.0.att.", ocfg0, return_scores=True)
+        mw, mt = O.selection_margins(sc, B, N, T, 1e-3)
+        scg = O.grid_partition(O.window_reverse(sc.view(B * N, part[0], part[1], C), part, (H, W)), part).view(B, N, -1, C)
+        mw2, mt2 = O.selection_margins(scg, B, N, T, 1e-3)
+        margin = float(min(mw.min(), mt.min(), mw2.min(), mt2.min()))
+        if margin >= MIN_MARGIN:
+            break
+    else:
+        raise RuntimeError("no seed with a safe margin")
+    blk = ref.SAST.SAST_block(C, RI.to_cfg(acfg), first_block=True)       # a fresh module is in training mode
+    load_into(blk, params, "att_blocks.0.att.")
+    xx = x.clone().requires_grad_(True)
+    torch.manual_seed(91)                                                  # (the constructor's parameter init consumed the generator)
+    out, cnt, lists = blk(xx, pe_mod, r, None)
+    (out ** 2).mean().backward()
+    log = []
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, drop_path=pdrop, training=True, drop_log=log)
+    xo = x.clone().requires_grad_(True)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    torch.manual_seed(91)
+    oo, oc, ol = O.sast_block(xo, pe, r, po, "att_blocks.0.att.", ocfg)
+    assert oc == cnt and torch.equal(oo, out), float((oo - out).abs().max())
+    assert len(log) == 4 and all(0.1 < float((m == 0).float().mean()) < 0.4 for m in log)
+    (oo ** 2).mean().backward()
+    assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
+    blk.eval()
+    with torch.no_grad():
+        eout, _ec, _el = blk(x, pe_mod, r, None)
+    d = dict(x=np_(x), r=np_(r), out=np_(out), eval_out=np_(eout), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
+             margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)), p=np.float64(pdrop),
+             rng_seed=np.int64(91))
+    for i, m in enumerate(log):
+        d[f"drop{i}"] = np_(m)
+    d.update(lists_to_np(lists, ""))
+    for k, v in blk.named_parameters():
+        if "sub_layers" in k:
+            continue
+        gv = v.grad if v.grad is not None else torch.zeros_like(v)
+        assert torch.allclose(po["att_blocks.0.att." + k].grad, gv, atol=1e-7, rtol=1e-4), k
+        d["g_" + k] = np_(gv)
+    np.savez_compressed(os.path.join(HERE, "block_drop_path.npz"), **d)
+    print(f"block_drop_path: seed {seed} margin {margin:.2e} kept {[len(l[3]) for l in lists]} dropped {[float((m == 0).float().mean()) for m in log]}")
+
+
 def gen_acts(ref):
     for act in ("relu", "silu", "sigmoid", "tanh"):
         gen_block(ref, "block_act_" + act, 1, 2e-2, C=32, act=act)
@@ -662,6 +722,9 @@ def main():
     if "--nobias-only" in sys.argv:
         gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
         return
+    if "--drop-path-only" in sys.argv:
+        gen_block_drop_path(ref)
+        return
     if "--lstm-dropout-only" in sys.argv:
         gen_lstm_dropout(ref)
         return
@@ -685,6 +748,7 @@ def main():
     gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
     gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
     gen_acts(ref)
+    gen_block_drop_path(ref)
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)

@@ -171,6 +171,59 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
 
 
+def test_sast_block_drop_path_vs_golden(golden_dir, dev):
+    """drop_path > 0 (SAST.py:42,188,193,232,248; the shipped YAML leaves it 0): timm's DropPath on the attention and on the MLP branch of
+    both MS-WSA layers -- one factor per KEPT ROW and branch (`SastMswsaArgs.drop1 / drop2`).  With the four factor vectors the reference
+    drew (fixture block_drop_path.npz, recovered through the oracle's bit-exact reproduction) injected: outputs, index lists and every
+    gradient; eval mode ignores DropPath; the module's own draw runs and differs from eval."""
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    g = _load(golden_dir, "block_drop_path")
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    B, H, W, C = x.shape
+    params = block_params(C, int(g["seed"]))
+    acfg = attn_cfg((4, 5), float(g["amp"]))
+    acfg.update(drop_path=float(g["p"]))
+    blk = SAST_block(C, acfg, first_block=True).to(dev)
+    load_params(blk, params, "att_blocks.0.att.")
+    assert not [k for k in blk.state_dict() if "drop" in k]                 # DropPath has no state: checkpoints are unaffected
+    rows = B * H * W
+
+    def padded(i):      # one factor per kept row; the tail of the upper-bound vector is never read
+        m = torch.from_numpy(g[f"drop{i}"])
+        return torch.cat([m, torch.full((rows - len(m),), float("nan"))]).to(dev)
+    blk.win_attn.drop_path_override = (padded(0), padded(1))
+    blk.grid_attn.drop_path_override = (padded(2), padded(3))
+    blk.train()
+    pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    xd = x.to(dev).requires_grad_(True)
+    out, cnt, lists = blk(xd, pe, r.to(dev), None)
+    assert int(cnt) == int(g["count"])
+    for li, sel in enumerate(lists):
+        got = sel.to_index_list()
+        for nm in ("index_window", "asy_index", "K"):
+            assert np.array_equal(got[LIST_NAMES.index(nm)].cpu().numpy(), g[f"l{li}_{nm}"]), (li, nm)
+    abs_close(out.detach().cpu(), torch.from_numpy(g["out"]), FWD_ATOL, "")
+    (out ** 2).mean().backward()
+    maxnorm_close(xd.grad, torch.from_numpy(g["dx"]), GRAD_RTOL, "dx")
+    kl = {}
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    oo, _c, _l = O.sast_block(x.clone(), O.position_embedding_sine(H, W, C), r, po, "att_blocks.0.att.",
+                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]),
+                                        drop_masks=[torch.from_numpy(g[f"drop{i}"]) for i in range(4)]), kink_log=kl)
+    (oo ** 2).mean().backward()
+    net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
+    blk.eval()
+    with torch.no_grad():
+        ev, _c, _l = blk(x.to(dev), pe, r.to(dev), None)
+    abs_close(ev.cpu(), torch.from_numpy(g["eval_out"]), FWD_ATOL, "eval")
+    blk.train()
+    blk.win_attn.drop_path_override = blk.grid_attn.drop_path_override = None
+    with torch.no_grad():
+        own, _c, _l = blk(x.to(dev), pe, r.to(dev), None)
+    assert bool(torch.isfinite(own).all()) and float((own - ev).abs().max()) > 1e-3
+
+
 def test_frozen_parameters_do_not_corrupt_neighbours(golden_dir, dev):
     """parameters with requires_grad=False get throw-away gradient buffers (functional._scratch_grad); those must outlive the launch --
     a buffer freed before it was handed out again as the NEXT parameter's fresh `.grad` and the kernel corrupted it through the stale

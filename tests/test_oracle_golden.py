@@ -70,6 +70,40 @@ def test_sast_block(golden_dir, name):
         assert torch.allclose(v.grad, torch.from_numpy(g[gk]), atol=1e-7, rtol=1e-3), k
 
 
+def test_sast_block_drop_path(golden_dir):
+    """drop_path > 0 (SAST.py:42,188,193,232,248): the reference block in training mode under a fixed RNG state.  The oracle reproduces
+    outputs, index lists and every gradient both with the four recorded factor vectors injected and by drawing them itself from the same RNG
+    state; eval mode ignores DropPath."""
+    g = _load(golden_dir, "block_drop_path")
+    x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
+    params = _block_params(x.shape[-1], int(g["seed"]))
+    assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
+    masks = [torch.from_numpy(g[f"drop{i}"]) for i in range(4)]
+    keep = 1.0 - float(g["p"])
+    assert all(set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1.0) / np.float32(keep))} for m in masks)
+    assert [len(m) for m in masks] == [len(g["l0_asy_index"])] * 2 + [len(g["l1_asy_index"])] * 2      # one factor per kept row and branch
+    pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])
+    for mode in ("inject", "draw"):
+        cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, drop_path=float(g["p"]), training=True,
+                        drop_masks=[m.clone() for m in masks] if mode == "inject" else None)
+        xo = x.clone().requires_grad_(True)
+        po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        torch.manual_seed(int(g["rng_seed"]))
+        out, cnt, lists = O.sast_block(xo, pe, r, po, "att_blocks.0.att.", cfg)
+        assert cnt == int(g["count"])
+        for li, l in enumerate(lists):
+            for nm, t in zip(LIST_NAMES, l):
+                assert np.array_equal(t.numpy(), g[f"l{li}_{nm}"]), (li, nm)
+        assert torch.allclose(out, torch.from_numpy(g["out"]), atol=ATOL, rtol=0), mode
+        (out ** 2).mean().backward()
+        assert torch.allclose(xo.grad, torch.from_numpy(g["dx"]), atol=1e-7, rtol=1e-4)
+        for k, v in po.items():
+            assert torch.allclose(v.grad, torch.from_numpy(g["g_" + k[len("att_blocks.0.att."):]]), atol=1e-7, rtol=1e-3), (mode, k)
+    ev, _c, _l = O.sast_block(x, pe, r, params, "att_blocks.0.att.", O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]),
+                                                                              training=False))
+    assert torch.allclose(ev, torch.from_numpy(g["eval_out"]), atol=ATOL, rtol=0)
+
+
 def test_two_blocks_reuse_index_lists(golden_dir):
     g = _load(golden_dir, "stage_two_blocks")
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
