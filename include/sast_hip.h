@@ -81,7 +81,7 @@ int sast_mask_token_bwd(const float* dy, const uint8_t* mask, float* dx, float* 
 typedef struct SastDownArgs {
   int32_t B, H, W, Cin, Cout, factor;
   const float* x;        /* [B*H*W, Cin] NHWC */
-  const float* w;        /* [Cout][k][k][Cin], k = 2*factor-1, replicate padding factor-1 */
+  const float* w;        /* [Cout][k][k][Cin], k = 2*factor-1, replicate padding factor-1 (see no_overlap) */
   const float* ln_w; const float* ln_b;
   const float* pe;       /* [Ho*Wo, Cout] or NULL */
   float* conv_out;       /* [B*Ho*Wo, Cout] saved for backward */
@@ -94,6 +94,8 @@ typedef struct SastDownArgs {
   int32_t x_dtype;       /* SAST_DT_F32 (0): x is fp32 NHWC.  SAST_DT_U8: x is the uint8 event tensor in NHWC bytes as written by
                             sast_input_prep_u8 (stem only: dx must be NULL) -- the conv loaders widen the bytes themselves, the fp32
                             copy of the input never exists (modules/detection.py:143-144 does `.float()` first) */
+  int32_t no_overlap;    /* 0: downsample_cfg.overlap True (every shipped config): k = 2*factor-1, replicate padding factor-1.
+                            1: overlap False (ops.py:74-76): k = factor, no padding; w is [Cout][factor][factor][Cin] */
 } SastDownArgs;
 int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream);
 int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream);
@@ -179,6 +181,8 @@ typedef struct SastMswsaArgs {
                             order = asy_index order) keep / keep_prob of the attention branch (drop1) and of the MLP branch (drop2); the caller
                             draws them.  Both or neither; NULL = no DropPath (p = 0 or eval).  Not with cb_tps > 0, not with fused_ws. */
   float* drop_ws;        /* bwd with drop1 / drop2: fp32[2 * R * C] scratch (the scaled branch gradients) */
+  const float* drop_mlp; /* `drop_mlp > 0` (ops.py:167: nn.Dropout between the GLU and the second linear; reference default 0): fp32[R, inner]
+                            keep mask / (1 - p) per kept row and hidden channel, drawn by the caller; NULL = none.  Not with fused_ws. */
   float* fused_ws;       /* optional fp32[sast_mswsa_fused_ws_floats()] (16-byte aligned): when non-NULL and that size is non-zero the
                             layer runs as ONE kernel per direction (csrc/k_mswsa_fused.hip: one wave per partition, activations in
                             registers from LN to the scatter).  With S == NULL (inference) nothing else is written; with the saved-activation

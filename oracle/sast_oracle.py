@@ -43,6 +43,7 @@ class AttnCfg:
     enable_cb: bool = False
     mlp_activation: str = "gelu"     # attention_cfg.mlp_activation (SAST.py:38,55 -> layers/create_act.py:62-79)
     drop_path: float = 0.0           # attention_cfg.drop_path (SAST.py:42,188,193): DropPath on the two residual branches, training mode only
+    drop_mlp: float = 0.0            # attention_cfg.drop_mlp (SAST.py:43,191 -> ops.py:167): nn.Dropout on the MLP hidden, training mode only
     training: bool = True
     drop_log: Optional[list] = None    # test plumbing: every DropPath factor vector drawn is appended (call order: layer 1 attention, MLP, layer 2 ...)
     drop_masks: Optional[list] = None  # test plumbing: factor vectors to USE instead of drawing, consumed in the same order
@@ -143,12 +144,13 @@ def grid_reverse(win: Tensor, hw: Tuple[int, int], img: Tuple[int, int]) -> Tens
 
 # --------------------------------------------------------------------------- a2
 def conv_downsample_cf2cl(x: Tensor, p: Params, pre: str, factor: int) -> Tensor:
-    """ops.py:54-95: conv k=2f-1, stride f, replicate pad f-1, no bias -> NHWC -> LayerNorm(1e-5)."""
+    """ops.py:54-95: conv k=2f-1, stride f, replicate pad f-1, no bias -> NHWC -> LayerNorm(1e-5).  downsample_cfg.overlap False
+    (:74-76) <=> the weight is f x f: no padding; norm_affine False (:69,87) <=> the dict holds no norm.weight / norm.bias."""
     w = p[pre + "conv.weight"]
-    pad = (2 * (factor - 1) + 1) // 2
-    y = F.conv2d(F.pad(x, (pad, pad, pad, pad), mode="replicate"), w, None, stride=factor)
+    pad = w.shape[-1] // 2 if w.shape[-1] != factor else 0
+    y = F.conv2d(F.pad(x, (pad, pad, pad, pad), mode="replicate") if pad else x, w, None, stride=factor)
     y = y.permute(0, 2, 3, 1).contiguous()
-    return F.layer_norm(y, (y.shape[-1],), p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5)
+    return F.layer_norm(y, (y.shape[-1],), p.get(pre + "norm.weight"), p.get(pre + "norm.bias"), 1e-5)
 
 
 # --------------------------------------------------------------------------- a6-a8
@@ -206,11 +208,21 @@ def drop_path(x: Tensor, cfg: "AttnCfg") -> Tensor:
     return x * rt
 
 
-def mlp_glu(x: Tensor, p: Params, pre: str, act: str = "gelu") -> Tensor:
-    """ops.py:111-175: Linear(C->2*inner) -> value * act(gate) (GELU_erf in every shipped config) -> Linear(inner->C)."""
+def mlp_glu(x: Tensor, p: Params, pre: str, act: str = "gelu", cfg: Optional["AttnCfg"] = None) -> Tensor:
+    """ops.py:111-175: Linear(C->2*inner) -> value * act(gate) (GELU_erf in every shipped config) -> Dropout(drop_mlp) -> Linear(inner->C).
+    The dropout is the reference's torch call (same RNG draw); the mask goes through the same test plumbing as DropPath's factors."""
     y = F.linear(x, p[pre + "net.0.proj.weight"], p.get(pre + "net.0.proj.bias"))       # (mlp_bias: False -> no bias keys)
     val, gate = torch.tensor_split(y, 2, dim=-1)
-    return F.linear(val * GLU_ACTS[act](gate), p[pre + "net.2.weight"], p.get(pre + "net.2.bias"))
+    h = val * GLU_ACTS[act](gate)
+    if cfg is not None and cfg.drop_mlp > 0.0 and cfg.training:
+        if cfg.drop_masks is not None:
+            mask = cfg.drop_masks.pop(0).view_as(h)
+        else:
+            mask = F.dropout(torch.ones_like(h), cfg.drop_mlp, True)      # keep / (1 - p): h * mask == F.dropout(h) bit for bit
+        if cfg.drop_log is not None:
+            cfg.drop_log.append(mask.clone())
+        h = h * mask
+    return F.linear(h, p[pre + "net.2.weight"], p.get(pre + "net.2.bias"))
 
 
 def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: AttnCfg) -> Tensor:
@@ -246,7 +258,7 @@ def ms_wsa(x: Tensor, idx: Sequence[Tensor], B: int, p: Params, pre: str, cfg: A
     x = XX[asy_index]
     x = shortcut + drop_path(x * p[pre + "ls1.gamma"], cfg)
     shortcut = x
-    x = mlp_glu(x, p, pre + "mlp.", cfg.mlp_activation)
+    x = mlp_glu(x, p, pre + "mlp.", cfg.mlp_activation, cfg)
     if cfg.enable_cb:  # SAST.py:240-246
         tX, tXX = torch.zeros_like(X), torch.zeros_like(XX)
         tXX[asy_index] = x

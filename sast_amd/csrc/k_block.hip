@@ -66,6 +66,7 @@ struct EpResidualLSScatterT {  // out[row_tok[m]] = res + [rs[m] *] gamma * (v +
 template <bool ANY>
 struct EpGluT {  // ops.py:136-137: value = first half, gate = second half
   float* ug; float* h; const float* bias; int inner; int act;
+  const float* drop;   // ANY only: keep mask / (1 - p) of the MLP's nn.Dropout (ops.py:167, `drop_mlp`) on the hidden [rows, inner], NULL = none
   struct Col { float bu, bg; };
   using Aux = EpNone;
   __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[inner + j]}; }
@@ -74,21 +75,23 @@ struct EpGluT {  // ops.py:136-137: value = first half, gate = second half
     const float u = v[0] + k.bu, g = v[1] + k.bg;
     ug[(size_t)m * 2 * inner + j] = u;
     ug[(size_t)m * 2 * inner + inner + j] = g;
-    if constexpr (ANY) h[(size_t)m * inner + j] = u * glu_act(g, act);
+    if constexpr (ANY) h[(size_t)m * inner + j] = (u * glu_act(g, act)) * (drop ? drop[(size_t)m * inner + j] : 1.f);
     else h[(size_t)m * inner + j] = u * gelu_erf(g);
   }
 };
 template <bool ANY>
 struct EpDGluT {  // v = dH -> d(value), d(gate)
   const float* ug; float* dug; int inner; int act;
+  const float* drop;   // ANY only: see EpGluT (the hidden's gradient passes through the same mask)
   using Col = EpNone;
   struct Aux { float u, g; };
   __device__ __forceinline__ Col col(int) const { return Col{}; }
   __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{ug[(size_t)m * 2 * inner + j], ug[(size_t)m * 2 * inner + inner + j]}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
     if constexpr (ANY) {
-      dug[(size_t)m * 2 * inner + j] = v[0] * glu_act(x.g, act);
-      dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * glu_act_grad(x.g, act);
+      const float dh = drop ? v[0] * drop[(size_t)m * inner + j] : v[0];
+      dug[(size_t)m * 2 * inner + j] = dh * glu_act(x.g, act);
+      dug[(size_t)m * 2 * inner + inner + j] = dh * x.u * glu_act_grad(x.g, act);
     } else {
       dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(x.g);
       dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * gelu_erf_grad(x.g);
@@ -305,7 +308,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   if (T > ATTN_MAX_T || a->mlp_act < 0 || a->mlp_act >= GLU_ACT_COUNT || (!a->drop1) != (!a->drop2)) return SAST_EINVAL;
   if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip: GeGLU, no DropPath)
-    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || a->mlp_act != 0 || a->drop1 || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
+    if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || a->mlp_act != 0 || a->drop1 || a->drop_mlp || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
     int rc = mswsa_fused_planes_launch(a, a->fused_ws, st);
     if (rc) return rc;
     return mswsa_fused_fwd_launch(a, a->fused_ws, st);
@@ -332,7 +335,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
       if (mode && C >= 256) return launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
       return launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     };
-    rc = a->mlp_act ? fc1(EpGluT<true>{a->UG, a->Hh, a->fc1_b, inner, a->mlp_act}) : fc1(EpGluT<false>{a->UG, a->Hh, a->fc1_b, inner, 0});
+    rc = (a->mlp_act || a->drop_mlp) ? fc1(EpGluT<true>{a->UG, a->Hh, a->fc1_b, inner, a->mlp_act, a->drop_mlp})
+                                     : fc1(EpGluT<false>{a->UG, a->Hh, a->fc1_b, inner, 0, nullptr});
     if (rc) return rc;
   }
   if (a->cb_tps <= 0)
@@ -393,7 +397,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     dz = a->drop_ws;
     dz_tok = nullptr;
   }
-  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && a->mlp_act == 0 && !a->drop1 && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
+  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && a->mlp_act == 0 && !a->drop1 && !a->drop_mlp && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
     // MLP backward as one kernel (k_mswsa_fused.hip): dY and dW1 / db1 / raw dW2 / colsum(dZ) from the saved Y, [u|g] recomputed
     rc = mswsa_fused_mlp_bwd_launch(a, a->fused_ws, dY, raw2, s2, R, st);
     if (rc) return rc;
@@ -412,7 +416,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     return a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, ep, R, inner, C, dR, st)
                   : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, ep, R, inner, C, dR, st);
   };
-  rc = a->mlp_act ? fc2_bwd(EpDGluT<true>{a->UG, dUG, inner, a->mlp_act}) : fc2_bwd(EpDGluT<false>{a->UG, dUG, inner, 0});
+  rc = (a->mlp_act || a->drop_mlp) ? fc2_bwd(EpDGluT<true>{a->UG, dUG, inner, a->mlp_act, a->drop_mlp})
+                                   : fc2_bwd(EpDGluT<false>{a->UG, dUG, inner, 0, nullptr});
   if (rc) return rc;
   // fc1: dW1 / db1, and dY = dZ + dUG W1
   rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,

@@ -431,8 +431,9 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) { SAST_E
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("down_fwd", a ? a->Cout : 0, a ? a->B * a->H * a->W : 0, st);
   if (!a || a->Cin % 4 || a->Cout % 4) return SAST_EINVAL;
-  const int k = 2 * a->factor - 1;
-  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
+  // ops.py:70-76: overlap (default) k = 2f-1 with replicate padding f-1; no_overlap: k = f, no padding (non-overlapping patches)
+  const int k = a->no_overlap ? a->factor : 2 * a->factor - 1;
+  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->no_overlap ? 0 : a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
   int rc;
   if (a->x_dtype == SAST_DT_U8)       // the stem on the stored uint8 event tensor (NHWC bytes, written by sast_input_prep_u8)
@@ -446,8 +447,8 @@ int sast_downsample_ln_fwd(const SastDownArgs* a, sast_stream_t stream) { SAST_E
 int sast_downsample_ln_bwd(const SastDownArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
   ProfScope ps_("down_bwd", a->Cout, a->B * a->H * a->W, st);
-  const int k = 2 * a->factor - 1;
-  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->factor - 1, 1, a->Cin);
+  const int k = a->no_overlap ? a->factor : 2 * a->factor - 1;
+  const ConvGeom g = geom_of(a->B, a->H, a->W, a->Cin, k, a->factor, a->no_overlap ? 0 : a->factor - 1, 1, a->Cin);
   const int M = a->B * g.Ho * g.Wo, K = k * k * a->Cin;
   float* dconv = a->ws;
   int rc = ln_bwd_launch(a->conv_out, a->dy, a->ln_w, a->mean, a->rstd, dconv, a->d_ln_w, a->d_ln_b, M, a->Cout, st);

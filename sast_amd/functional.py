@@ -264,6 +264,11 @@ class _DownsampleLN(torch.autograd.Function):
             raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
         B, H, W, Cin = x.shape
         Cout = w.shape[0]
+        k = w.shape[-1]
+        if k not in (factor, 2 * factor - 1) or w.shape[-2] != k:     # ops.py:70-76: overlap True -> 2f-1 (replicate pad f-1), False -> f (no pad)
+            raise RuntimeError(f"sast_amd: a factor-{factor} downsampling conv has a {2 * factor - 1}x{2 * factor - 1} (overlap) or "
+                               f"{factor}x{factor} (no overlap) kernel, not {tuple(w.shape[-2:])}")
+        no_overlap = int(k == factor)
         Ho, Wo = H // factor, W // factor
         M = B * Ho * Wo
         dev = x.device
@@ -274,24 +279,24 @@ class _DownsampleLN(torch.autograd.Function):
             raise RuntimeError("sast_amd: downsample_ln reads fp32 rows, or (the stem) the uint8 event tensor from input_prep(keep_bytes=True)")
         xdt = _DT[x.dtype]
         a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
-                  pe=_ptr(pe), conv_out=conv_out, mean=stats[0], rstd=stats[1], y=y, x_dtype=xdt)
+                  pe=_ptr(pe), conv_out=conv_out, mean=stats[0], rstd=stats[1], y=y, x_dtype=xdt, no_overlap=no_overlap)
         L.check(L.lib().sast_downsample_ln_fwd(C.byref(a), _stream()), "downsample_ln_fwd")
         ctx.save_for_backward(x, conv_out, stats)
         ctx.params = (w, ln_w, ln_b)
-        ctx.meta = (B, H, W, Cin, Cout, factor, xdt)
+        ctx.meta = (B, H, W, Cin, Cout, factor, xdt, no_overlap)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, conv_out, stats = ctx.saved_tensors
         w, ln_w, ln_b = ctx.params
-        B, H, W, Cin, Cout, factor, xdt = ctx.meta
+        B, H, W, Cin, Cout, factor, xdt, no_overlap = ctx.meta
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = torch.empty(conv_out.numel(), device=x.device)
         a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
                   conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=_g(w), d_ln_w=_g(ln_w), d_ln_b=_g(ln_b), ws=ws,
-                  x_dtype=xdt)
+                  x_dtype=xdt, no_overlap=no_overlap)
         L.check(L.lib().sast_downsample_ln_bwd(C.byref(a), _stream()), "downsample_ln_bwd")
         return dx, None, None, None, None, None
 
@@ -602,16 +607,25 @@ class _MSWSA(torch.autograd.Function):
         _fill(a, B=sel.B, H=sel.H, W=sel.W, C=Cc, ph=sel.ph, pw=sel.pw, mode=sel.mode, inner=inner, eps=eps, dim_head=dim_head, mlp_act=mlp_act, xin=xin, out=out)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
-        if drop is not None:       # DropPath: per kept row keep / keep_prob of the two residual branches (include/sast_hip.h: drop1 / drop2)
-            if cb_tps:
-                raise NotImplementedError("sast_amd: drop_path > 0 together with enable_CB is not implemented")
-            drop = tuple(d.contiguous() for d in drop)
-            if any(d.dtype != torch.float32 or d.numel() < R for d in drop):
-                raise RuntimeError("sast_amd: the DropPath factors must be fp32 with one entry per row upper bound")
-            _fill(a, drop1=drop[0], drop2=drop[1])
+        drop_mlp = None
+        if drop is not None:       # (d1, d2, mlp mask): DropPath row factors of the two residual branches, nn.Dropout mask of the MLP hidden
+            d1, d2, drop_mlp = (tuple(drop) + (None,))[:3]
+            drop = None
+            if d1 is not None:
+                if cb_tps:
+                    raise NotImplementedError("sast_amd: drop_path > 0 together with enable_CB is not implemented")
+                drop = (d1.contiguous(), d2.contiguous())
+                if any(d.dtype != torch.float32 or d.numel() < R for d in drop):
+                    raise RuntimeError("sast_amd: the DropPath factors must be fp32 with one entry per row upper bound")
+                _fill(a, drop1=drop[0], drop2=drop[1])
+            if drop_mlp is not None:
+                drop_mlp = drop_mlp.contiguous()
+                if drop_mlp.dtype != torch.float32 or drop_mlp.numel() < R * inner:
+                    raise RuntimeError("sast_amd: the MLP dropout mask must be fp32 [rows upper bound, inner]")
+                _fill(a, drop_mlp=drop_mlp)
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
-        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and drop is None and R >= _FUSED_MIN_ROWS) else 0
+        fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and drop is None and drop_mlp is None and R >= _FUSED_MIN_ROWS) else 0
         needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
         fws = None
         if fused_floats:
@@ -643,7 +657,7 @@ class _MSWSA(torch.autograd.Function):
         L.check(L.lib().sast_mswsa_fwd(C.byref(a), _stream()), "mswsa_fwd")
         ctx.save_for_backward(xin, stats, big, raw, fws)      # fws: the weight planes the fused kernels of this call pair stream (or None)
         ctx.sel, ctx.params, ctx.eps, ctx.inner, ctx.cb_tps, ctx.dim_head, ctx.mlp_act = sel, params, eps, inner, cb_tps, dim_head, mlp_act
-        ctx.drop = drop
+        ctx.drop, ctx.drop_mlp = drop, drop_mlp
         return out
 
     @staticmethod
@@ -677,6 +691,8 @@ class _MSWSA(torch.autograd.Function):
         if ctx.drop is not None:
             drop_ws = torch.empty(2 * R * Cc, device=xin.device)
             _fill(a, drop1=ctx.drop[0], drop2=ctx.drop[1], drop_ws=drop_ws)
+        if ctx.drop_mlp is not None:
+            _fill(a, drop_mlp=ctx.drop_mlp)
         if ctx.cb_tps:
             cb_m, cb_sum = torch.empty(R, Cc, device=xin.device), torch.empty(R // ctx.cb_tps, Cc, device=xin.device)
             _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
@@ -701,8 +717,9 @@ def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: i
     wave runs the whole layer for its <= 32 tokens, a latency the compacted GEMM chain does not have) -- SAST_block passes its AMP.
     mlp_activation: the gate activation of the GLU-MLP (attention_cfg.mlp_activation, layers/create_act.py:62-79): one of
     GLU_ACTIVATIONS; the one-kernel forward exists for "gelu".
-    drop_path: None, or (d1, d2) -- fp32 vectors with one entry per row (upper bound B*L; entry m belongs to the m-th KEPT row in
-    asy_index order): keep / keep_prob of timm's DropPath on the attention and on the MLP branch (SAST.py:188,193,232,248)."""
+    drop_path: None, or (d1, d2[, mlp_mask]) -- d1 / d2 (both or None): fp32 vectors with one entry per row (upper bound B*L; entry m
+    belongs to the m-th KEPT row in asy_index order): keep / keep_prob of timm's DropPath on the attention and on the MLP branch
+    (SAST.py:188,193,232,248); mlp_mask (or None): fp32 [rows, inner], keep / (1 - p) of the MLP's nn.Dropout (`drop_mlp`, ops.py:167)."""
     if mlp_activation not in GLU_ACTIVATIONS:
         raise NotImplementedError(f"sast_amd: mlp_activation {mlp_activation!r}: the GLU epilogues implement {sorted(GLU_ACTIVATIONS)}")
     return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), GLU_ACTIVATIONS[mlp_activation],

@@ -122,7 +122,8 @@ class MLP(_FusedOnly):
                  bias: bool = True, drop_prob: float = 0.):
         super().__init__()
         assert gated and channel_last, "sast_amd implements the gated channels-last MLP of MS_WSA only"
-        assert drop_prob == 0, "dropout inside the fused MLP is not supported (reference default drop_mlp: 0)"
+        if not 0.0 <= drop_prob < 1.0:
+            raise ValueError(f"drop_mlp must be in [0, 1), got {drop_prob}")
         inner = math.floor(int(dim * expansion_ratio) * 2 / 3 / 32) * 32
         self.inner_dim = inner
         self.net = nn.Sequential(GLU(dim, inner, True, act_layer, bias), nn.Dropout(p=drop_prob), nn.Linear(inner, dim, bias=bias))
@@ -143,6 +144,7 @@ def channels_last_conv_weight(cout, cin, k):
 
 class ConvDownsampling_Cf2Cl(DownsampleBase):
     """ops.py:54-95.  NCHW in -> NHWC out: conv(k=2f-1, stride f, replicate pad f-1, no bias) + LayerNorm(eps 1e-5).
+    downsample_cfg.overlap False: k = f without padding; norm_affine False: LayerNorm without weight / bias (neither is in a shipped YAML).
 
     `forward_nhwc(x_nhwc, pe)` is the fused entry used by the backbone: it also adds the block's
     position table (SAST.py:105) in the LayerNorm kernel.
@@ -154,16 +156,18 @@ class ConvDownsampling_Cf2Cl(DownsampleBase):
         assert downsample_factor in (2, 4, 8)
         norm_affine = cfg_get(downsample_cfg, 'norm_affine', True)
         overlap = cfg_get(downsample_cfg, 'overlap', True)
-        if not overlap or not norm_affine:
-            raise NotImplementedError("sast_amd: only overlap=True, norm_affine=True (every shipped config) is implemented")
         self.factor = downsample_factor
-        k = (downsample_factor - 1) * 2 + 1
+        k = (downsample_factor - 1) * 2 + 1 if overlap else downsample_factor      # ops.py:70-76 (no overlap: k = f, no padding)
         self.conv = nn.Module()
         self.conv.weight = channels_last_conv_weight(dim_out, dim_in, k)
-        self.norm = LayerNorm(num_channels=dim_out, eps=1e-5, affine=True)
+        self.norm = LayerNorm(num_channels=dim_out, eps=1e-5, affine=norm_affine)
+        if not norm_affine:    # the kernels always apply an affine: resident ones / zeros (not parameters, not in the state_dict)
+            self.register_buffer("_ln_ones", torch.ones(dim_out), persistent=False)
+            self.register_buffer("_ln_zeros", torch.zeros(dim_out), persistent=False)
 
     def forward_nhwc(self, x_nhwc: torch.Tensor, pe=None) -> torch.Tensor:
-        return SF.downsample_ln(x_nhwc, self.conv.weight, self.norm.weight, self.norm.bias, pe, self.factor)
+        ln_w, ln_b = (self.norm.weight, self.norm.bias) if self.norm.weight is not None else (self._ln_ones, self._ln_zeros)
+        return SF.downsample_ln(x_nhwc, self.conv.weight, ln_w, ln_b, pe, self.factor)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x_nhwc = SF.as_nhwc(x) if x.dtype == torch.float32 else SF.nchw_to_nhwc_float(x)

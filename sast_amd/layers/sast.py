@@ -123,7 +123,7 @@ class MS_WSA(nn.Module):
                        drop_prob=drop_mlp)
         self.ls2 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop2 = DropPath(drop_path) if drop_path > 0 else nn.Identity()
-        self.drop_path_override = None     # tests: fixed (d1, d2) row factors instead of a fresh draw
+        self.drop_path_override = None     # tests: fixed (d1, d2, mlp_mask) instead of a fresh draw (see _drop_path_factors)
         # aliased container, same state_dict duplicates as the reference (SAST.py:194)
         self.sub_layers = nn.ModuleList([self.ls1, self.drop1, self.norm2, self.mlp, self.ls2, self.drop2])
         self.eps = 1e-6
@@ -145,13 +145,21 @@ class MS_WSA(nn.Module):
                     ls2=getattr(self.ls2, "gamma", None))
 
     def _drop_path_factors(self, rows: int, device):
-        """DropPath in training mode (SAST.py:232,248 -> layers/drop.py): one Bernoulli(keep_prob) draw per KEPT ROW and branch, divided by
-        keep_prob.  The number of kept rows lives on the device, so the draw covers the row upper bound; entry m serves the m-th kept row."""
-        if not self.training or not isinstance(self.drop1, DropPath):
+        """training-mode randomness of the layer, in the reference's order (SAST.py:232-248): DropPath on the attention branch, nn.Dropout on
+        the MLP hidden (`drop_mlp`, ops.py:167), DropPath on the MLP branch.  DropPath (layers/drop.py): one Bernoulli(keep_prob) draw per
+        KEPT ROW, divided by keep_prob; the number of kept rows lives on the device, so the draws cover the row upper bound and entry m
+        serves the m-th kept row.  -> None, or (d1, d2, mlp_mask) with None for what is off."""
+        if not self.training:
             return None
         if self.drop_path_override is not None:
             return self.drop_path_override
-        return self.drop1.row_factors(rows, device), self.drop2.row_factors(rows, device)
+        dp, pm = isinstance(self.drop1, DropPath), self.mlp.net[1].p
+        if not dp and pm == 0.0:
+            return None
+        d1 = self.drop1.row_factors(rows, device) if dp else None
+        mask = torch.empty(rows, self.mlp.inner_dim, device=device).bernoulli_(1.0 - pm).div_(1.0 - pm) if pm > 0.0 else None
+        d2 = self.drop2.row_factors(rows, device) if dp else None
+        return d1, d2, mask
 
     def forward_image(self, x: torch.Tensor, sel: SF.Selection, enable_CB: bool = False, fused: bool = True) -> torch.Tensor:
         """device path: x (B,H,W,C) in IMAGE layout + device-side selection."""

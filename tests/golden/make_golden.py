@@ -144,13 +144,14 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
     print(f"{name}: seed {seed} margin {margin:.2e} kept {kept} of {B * H * W} count {cnt}")
 
 
-def gen_block_drop_path(ref):
+def gen_block_drop_path(ref, name="block_drop_path", pdrop=0.25, pmlp=0.0):
     """drop_path > 0 (SAST.py:42,188,193,232,248; shipped YAML: 0): DropPath on both residual branches of both MS-WSA layers, training mode,
-    fixed RNG state.  The oracle (same torch calls in the same order) reproduces the reference bit for bit and records the four factor
-    vectors it drew (= the reference's); the fixture holds them next to the reference's outputs and gradients."""
-    H, W, part, C, B, amp, pdrop = 16, 20, (4, 5), 32, 2, 2e-2, 0.25
+    fixed RNG state.  The oracle (same torch calls in the same order) reproduces the reference bit for bit and records the factor
+    vectors it drew (= the reference's); the fixture holds them next to the reference's outputs and gradients.
+    pmlp > 0: `drop_mlp` (SAST.py:43,191 -> ops.py:167: nn.Dropout on the MLP hidden) -- its masks join the record in call order."""
+    H, W, part, C, B, amp = 16, 20, (4, 5), 32, 2, 2e-2
     acfg = dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
-                mlp_ratio=4, drop_mlp=0, drop_path=pdrop, ls_init_value=0.5, enable_CB=False, AMP=amp, BOUNCE=1e-3)
+                mlp_ratio=4, drop_mlp=pmlp, drop_path=pdrop, ls_init_value=0.5, enable_CB=False, AMP=amp, BOUNCE=1e-3)
     pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     pe = O.position_embedding_sine(H, W, C)
     T, N = part[0] * part[1], H * W // (part[0] * part[1])
@@ -176,13 +177,13 @@ def gen_block_drop_path(ref):
     out, cnt, lists = blk(xx, pe_mod, r, None)
     (out ** 2).mean().backward()
     log = []
-    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, drop_path=pdrop, training=True, drop_log=log)
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, drop_path=pdrop, drop_mlp=pmlp, training=True, drop_log=log)
     xo = x.clone().requires_grad_(True)
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     torch.manual_seed(91)
     oo, oc, ol = O.sast_block(xo, pe, r, po, "att_blocks.0.att.", ocfg)
     assert oc == cnt and torch.equal(oo, out), float((oo - out).abs().max())
-    assert len(log) == 4 and all(0.1 < float((m == 0).float().mean()) < 0.4 for m in log)
+    assert len(log) == 2 * ((2 if pdrop else 0) + (1 if pmlp else 0)) and all(0.1 < float((m == 0).float().mean()) < 0.4 for m in log)
     (oo ** 2).mean().backward()
     assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
     blk.eval()
@@ -190,7 +191,7 @@ def gen_block_drop_path(ref):
         eout, _ec, _el = blk(x, pe_mod, r, None)
     d = dict(x=np_(x), r=np_(r), out=np_(out), eval_out=np_(eout), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)), p=np.float64(pdrop),
-             rng_seed=np.int64(91))
+             p_mlp=np.float64(pmlp), rng_seed=np.int64(91))
     for i, m in enumerate(log):
         d[f"drop{i}"] = np_(m)
     d.update(lists_to_np(lists, ""))
@@ -200,8 +201,34 @@ def gen_block_drop_path(ref):
         gv = v.grad if v.grad is not None else torch.zeros_like(v)
         assert torch.allclose(po["att_blocks.0.att." + k].grad, gv, atol=1e-7, rtol=1e-4), k
         d["g_" + k] = np_(gv)
-    np.savez_compressed(os.path.join(HERE, "block_drop_path.npz"), **d)
-    print(f"block_drop_path: seed {seed} margin {margin:.2e} kept {[len(l[3]) for l in lists]} dropped {[float((m == 0).float().mean()) for m in log]}")
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+    print(f"{name}: seed {seed} margin {margin:.2e} kept {[len(l[3]) for l in lists]} dropped {[float((m == 0).float().mean()) for m in log]}")
+
+
+def gen_downsample_variants(ref):
+    """ConvDownsampling_Cf2Cl with downsample_cfg.overlap False (k = f, no padding) and norm_affine False (ops.py:69-76,87; no shipped
+    YAML): the reference module's outputs and gradients for factor 4 (stem-like, 20 input channels) and factor 2."""
+    d = {}
+    g = torch.Generator().manual_seed(97)
+    for tag, cin, cout, f, hw in (("f4", 20, 32, 4, (16, 40)), ("f2", 32, 64, 2, (8, 20))):
+        m = ref.ops.ConvDownsampling_Cf2Cl(cin, cout, f, RI.to_cfg(dict(type="patch", overlap=False, norm_affine=False)))
+        w = (torch.rand(cout, cin, f, f, generator=g) * 2 - 1) / (cin * f * f) ** 0.5
+        m.load_state_dict({"conv.weight": w}, strict=True)
+        x = torch.randn(2, cin, *hw, generator=g)
+        wy = torch.randn(2, hw[0] // f, hw[1] // f, cout, generator=g)
+        xx = x.clone().requires_grad_(True)
+        y = m(xx)
+        (y * wy).sum().backward()
+        po = {"conv.weight": w.clone().requires_grad_(True)}
+        xo = x.clone().requires_grad_(True)
+        yo = O.conv_downsample_cf2cl(xo, po, "", f)
+        assert torch.equal(yo, y), tag
+        (yo * wy).sum().backward()
+        assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5) and torch.allclose(po["conv.weight"].grad, m.conv.weight.grad, atol=1e-6, rtol=1e-5)
+        d.update({tag + "_x": np_(x), tag + "_w": np_(w), tag + "_wy": np_(wy), tag + "_y": np_(y), tag + "_dx": np_(xx.grad),
+                  tag + "_dw": np_(m.conv.weight.grad)})
+    np.savez_compressed(os.path.join(HERE, "downsample_variants.npz"), **d)
+    print("downsample_variants ok")
 
 
 def gen_acts(ref):
@@ -722,8 +749,14 @@ def main():
     if "--nobias-only" in sys.argv:
         gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
         return
+    if "--downsample-only" in sys.argv:
+        gen_downsample_variants(ref)
+        return
     if "--drop-path-only" in sys.argv:
         gen_block_drop_path(ref)
+        return
+    if "--drop-mlp-only" in sys.argv:
+        gen_block_drop_path(ref, "block_drop_mlp", pdrop=0.0, pmlp=0.2)
         return
     if "--lstm-dropout-only" in sys.argv:
         gen_lstm_dropout(ref)
@@ -749,6 +782,8 @@ def main():
     gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
     gen_acts(ref)
     gen_block_drop_path(ref)
+    gen_block_drop_path(ref, "block_drop_mlp", pdrop=0.0, pmlp=0.2)
+    gen_downsample_variants(ref)
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)
     gen_pafpn(ref)

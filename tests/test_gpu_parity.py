@@ -171,29 +171,53 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
 
 
-def test_sast_block_drop_path_vs_golden(golden_dir, dev):
+def test_downsample_no_overlap_no_affine_vs_golden(golden_dir, dev):
+    """ConvDownsampling_Cf2Cl with downsample_cfg.overlap False (k = f, no padding: `SastDownArgs.no_overlap`) and norm_affine False (a
+    LayerNorm without parameters) -- ops.py:69-76,87, in no shipped YAML -- against the reference module's outputs and gradients"""
+    from sast_amd.layers.ops import ConvDownsampling_Cf2Cl
+    g = _load(golden_dir, "downsample_variants")
+    for tag, f in (("f4", 4), ("f2", 2)):
+        w = torch.from_numpy(g[tag + "_w"])
+        m = ConvDownsampling_Cf2Cl(w.shape[1], w.shape[0], f, dict(type="patch", overlap=False, norm_affine=False)).to(dev)
+        assert list(m.state_dict().keys()) == ["conv.weight"]                 # the reference's keys: no LayerNorm parameters
+        m.load_state_dict({"conv.weight": w}, strict=True)
+        x = torch.from_numpy(g[tag + "_x"]).to(dev).requires_grad_(True)
+        y = m(x)
+        abs_close(y.detach().cpu(), torch.from_numpy(g[tag + "_y"]), FWD_ATOL, tag)
+        (y * torch.from_numpy(g[tag + "_wy"]).to(dev)).sum().backward()
+        maxnorm_close(x.grad, torch.from_numpy(g[tag + "_dx"]), GRAD_RTOL, tag + " dx")
+        maxnorm_close(m.conv.weight.grad, torch.from_numpy(g[tag + "_dw"]), GRAD_RTOL, tag + " dw")
+
+
+@pytest.mark.parametrize("name", ["block_drop_path", "block_drop_mlp"])
+def test_sast_block_drop_path_vs_golden(golden_dir, dev, name):
     """drop_path > 0 (SAST.py:42,188,193,232,248; the shipped YAML leaves it 0): timm's DropPath on the attention and on the MLP branch of
     both MS-WSA layers -- one factor per KEPT ROW and branch (`SastMswsaArgs.drop1 / drop2`).  With the four factor vectors the reference
     drew (fixture block_drop_path.npz, recovered through the oracle's bit-exact reproduction) injected: outputs, index lists and every
-    gradient; eval mode ignores DropPath; the module's own draw runs and differs from eval."""
+    gradient; eval mode ignores DropPath; the module's own draw runs and differs from eval.  block_drop_mlp: the same for `drop_mlp > 0`
+    (SAST.py:43,191 -> ops.py:167: nn.Dropout on the MLP hidden; `SastMswsaArgs.drop_mlp`, a mask per kept row and hidden channel)."""
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
-    g = _load(golden_dir, "block_drop_path")
+    g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
     B, H, W, C = x.shape
     params = block_params(C, int(g["seed"]))
+    pmlp = float(g["p_mlp"])
     acfg = attn_cfg((4, 5), float(g["amp"]))
-    acfg.update(drop_path=float(g["p"]))
+    acfg.update(drop_path=float(g["p"]), drop_mlp=pmlp)
     blk = SAST_block(C, acfg, first_block=True).to(dev)
     load_params(blk, params, "att_blocks.0.att.")
     assert not [k for k in blk.state_dict() if "drop" in k]                 # DropPath has no state: checkpoints are unaffected
     rows = B * H * W
 
-    def padded(i):      # one factor per kept row; the tail of the upper-bound vector is never read
+    def padded(i):      # one factor (row of the mask) per kept row; the tail of the upper-bound tensor is never read
         m = torch.from_numpy(g[f"drop{i}"])
-        return torch.cat([m, torch.full((rows - len(m),), float("nan"))]).to(dev)
-    blk.win_attn.drop_path_override = (padded(0), padded(1))
-    blk.grid_attn.drop_path_override = (padded(2), padded(3))
+        return torch.cat([m, torch.full((rows - len(m),) + tuple(m.shape[1:]), float("nan"))]).to(dev)
+    if pmlp:
+        blk.win_attn.drop_path_override, blk.grid_attn.drop_path_override = (None, None, padded(0)), (None, None, padded(1))
+    else:
+        blk.win_attn.drop_path_override, blk.grid_attn.drop_path_override = (padded(0), padded(1), None), (padded(2), padded(3), None)
+    n_masks = 2 if pmlp else 4
     blk.train()
     pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     xd = x.to(dev).requires_grad_(True)
@@ -209,8 +233,8 @@ def test_sast_block_drop_path_vs_golden(golden_dir, dev):
     kl = {}
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     oo, _c, _l = O.sast_block(x.clone(), O.position_embedding_sine(H, W, C), r, po, "att_blocks.0.att.",
-                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]),
-                                        drop_masks=[torch.from_numpy(g[f"drop{i}"]) for i in range(4)]), kink_log=kl)
+                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]), drop_mlp=pmlp,
+                                        drop_masks=[torch.from_numpy(g[f"drop{i}"]) for i in range(n_masks)]), kink_log=kl)
     (oo ** 2).mean().backward()
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
     blk.eval()

@@ -70,21 +70,26 @@ def test_sast_block(golden_dir, name):
         assert torch.allclose(v.grad, torch.from_numpy(g[gk]), atol=1e-7, rtol=1e-3), k
 
 
-def test_sast_block_drop_path(golden_dir):
+@pytest.mark.parametrize("name", ["block_drop_path", "block_drop_mlp"])
+def test_sast_block_drop_path(golden_dir, name):
     """drop_path > 0 (SAST.py:42,188,193,232,248): the reference block in training mode under a fixed RNG state.  The oracle reproduces
     outputs, index lists and every gradient both with the four recorded factor vectors injected and by drawing them itself from the same RNG
     state; eval mode ignores DropPath."""
-    g = _load(golden_dir, "block_drop_path")
+    g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
     params = _block_params(x.shape[-1], int(g["seed"]))
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
-    masks = [torch.from_numpy(g[f"drop{i}"]) for i in range(4)]
-    keep = 1.0 - float(g["p"])
+    pmlp = float(g["p_mlp"])           # block_drop_mlp: `drop_mlp` (nn.Dropout on the MLP hidden, ops.py:167) instead of DropPath
+    masks = [torch.from_numpy(g[k]) for k in sorted((k for k in g.files if k.startswith("drop")), key=lambda k: int(k[4:]))]
+    keep = 1.0 - (pmlp if pmlp else float(g["p"]))
     assert all(set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1.0) / np.float32(keep))} for m in masks)
-    assert [len(m) for m in masks] == [len(g["l0_asy_index"])] * 2 + [len(g["l1_asy_index"])] * 2      # one factor per kept row and branch
+    if pmlp:
+        assert [tuple(m.shape) for m in masks] == [(len(g["l0_asy_index"]), 64), (len(g["l1_asy_index"]), 64)]      # kept rows x inner
+    else:
+        assert [len(m) for m in masks] == [len(g["l0_asy_index"])] * 2 + [len(g["l1_asy_index"])] * 2      # one factor per kept row and branch
     pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])
     for mode in ("inject", "draw"):
-        cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, drop_path=float(g["p"]), training=True,
+        cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, drop_path=float(g["p"]), drop_mlp=pmlp, training=True,
                         drop_masks=[m.clone() for m in masks] if mode == "inject" else None)
         xo = x.clone().requires_grad_(True)
         po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
@@ -100,8 +105,22 @@ def test_sast_block_drop_path(golden_dir):
         for k, v in po.items():
             assert torch.allclose(v.grad, torch.from_numpy(g["g_" + k[len("att_blocks.0.att."):]]), atol=1e-7, rtol=1e-3), (mode, k)
     ev, _c, _l = O.sast_block(x, pe, r, params, "att_blocks.0.att.", O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]),
-                                                                              training=False))
+                                                                              drop_mlp=pmlp, training=False))
     assert torch.allclose(ev, torch.from_numpy(g["eval_out"]), atol=ATOL, rtol=0)
+
+
+def test_downsample_no_overlap_no_affine(golden_dir):
+    """downsample_cfg.overlap False / norm_affine False (ops.py:69-76,87): the oracle against the reference module's numbers"""
+    g = _load(golden_dir, "downsample_variants")
+    for tag, f in (("f4", 4), ("f2", 2)):
+        x = torch.from_numpy(g[tag + "_x"]).requires_grad_(True)
+        p = {"conv.weight": torch.from_numpy(g[tag + "_w"]).requires_grad_(True)}
+        assert p["conv.weight"].shape[-1] == f
+        y = O.conv_downsample_cf2cl(x, p, "", f)
+        assert torch.allclose(y, torch.from_numpy(g[tag + "_y"]), atol=1e-6, rtol=0)
+        (y * torch.from_numpy(g[tag + "_wy"])).sum().backward()
+        assert torch.allclose(x.grad, torch.from_numpy(g[tag + "_dx"]), atol=1e-6, rtol=1e-4)
+        assert torch.allclose(p["conv.weight"].grad, torch.from_numpy(g[tag + "_dw"]), atol=1e-5, rtol=1e-4)
 
 
 def test_two_blocks_reuse_index_lists(golden_dir):
