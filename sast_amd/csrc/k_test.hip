@@ -63,13 +63,18 @@ extern "C" int sast_test_gemm_nt(const float* a, const float* w, const float* bi
   const EpStoreT ep(c, N, bias);
   // LARGE tiles with the reduction split over the GRID (atomic epilogue into a zeroed output): tile = 100 * kind + splits,
   // kind 6 = 128x128 (4 waves of 64x64), 7 = 64x128 (4 waves of 32x64), 8 = 128x64 (4 waves of 32x64)
-  if (tile >= 600 && tile < 900) {
+  // round 4: the SHIPPED small tiles (intra-workgroup k-groups) with an additional grid-level split: kind 9 = 32x64 with 4 k-groups,
+  // 10 = 32x32 with 8 k-groups, 11 = 64x64 with 2 k-groups (tools/gemm_gridsplit_small.py)
+  if (tile >= 600 && tile < 1200) {
     const int splits = tile % 100;
     const EpAtomicNT ea{c, N};
     switch (tile / 100) {
       case 6: return launch_gemm_split<TileBig>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
       case 7: return launch_gemm_split<TileMid>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
       case 8: return launch_gemm_split<TileN64>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
+      case 9: return launch_gemm_split<Tile<32, 64, 1, 2, 1, 16, 4>>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
+      case 10: return launch_gemm_split<Tile<32, 32, 1, 1, 1, 16, 8>>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
+      case 11: return launch_gemm_split<Tile<64, 64, 2, 2, 1, 16, 2>>(la, lb, ea, M, N, K, nullptr, splits, nullptr, st);
     }
   }
   switch (tile) {
