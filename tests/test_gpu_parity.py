@@ -1535,6 +1535,55 @@ def test_graph_replay_matches_eager(dev):
         maxnorm_close(gr[2].grad, eager[k][1], (1e-4, 1e-3, 3e-3)[k - 1], f"flat gradient after {k} updates, replay vs eager")
 
 
+def test_training_step_with_every_optional_config_branch_as_hipgraphs(dev):
+    """the config branches no shipped YAML uses, all at once, through the product's training step: mlp_activation silu, drop_path, drop_mlp,
+    cell_update_dropout and a depth-wise ConvLSTM in the backbone (downsampling without overlap / affine), depthwise PAFPN and head, the YOLOX
+    loss -- first eagerly, then captured as segmented hipGraphs (the random masks are drawn by torch's graph-safe generator INSIDE the
+    graphs: every replay sees fresh ones) and replayed.  No reference numbers here (each branch is pinned alone by its fixture): the
+    step must run, stay finite, train (the loss falls over 12 replays), and draw new masks per replay (two replays from the same
+    weights differ)."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN, YOLOXHead
+    from sast_amd.training import TrainStep
+    hw, part, E = (128, 160), (4, 5), 32
+    cfg = _rcfg(hw, part, E, 2e-3, 0.5)
+    cfg.stage.attention.update(mlp_activation="silu", drop_path=0.1, drop_mlp=0.1)
+    cfg.stage.lstm.update(dws_conv=True, drop_cell_update=0.1)
+    cfg.stage.downsample.update(overlap=False, norm_affine=False)
+    torch.manual_seed(3)
+    net = RNNDetector(cfg).to(dev)
+    chans = (2 * E, 4 * E, 8 * E)
+    fpn = YOLOPAFPN(depth=0.33, in_stages=(2, 3, 4), in_channels=chans, depthwise=True).to(dev)
+    head = YOLOXHead(num_classes=2, strides=(8, 16, 32), in_channels=chans, depthwise=True).to(dev)
+    for m in (net, fpn, head):
+        m.train()
+    ts = TrainStep(net, fpn, head, lr=2e-3, weight_decay=0.0, clip_value=1.0, eps=1e-3, segmented=True)
+    xs = [O.count_events(2, hw, seed=21, density=0.05).to(dev)]
+    labels = O.synthetic_labels(2, hw, 2, max_labels=4, seed=22)
+    labels[:, 0, :] = torch.tensor([1.0, 70.0, 60.0, 50.0, 40.0])
+    labels = labels.to(dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        l0 = float(ts.step(xs, None, labels))
+        l1 = float(ts.step(xs, None, labels))
+        assert l0 == l0 and l1 == l1 and bool(torch.isfinite(ts.flat.grad).all())
+        ts.capture(xs, None, labels)
+        losses = []
+        for _ in range(12):
+            ts.replay()
+            torch.cuda.synchronize()
+            losses.append(float(ts.loss))
+            assert bool(torch.isfinite(ts.flat.grad).all())
+        assert all(l == l for l in losses)
+        assert min(losses[-4:]) < losses[0], losses
+        # fresh masks per replay: freeze the weights (the learning rate is a device scalar the captured AdamW reads) and compare two replays
+        ts.opt.set_lr(0.0)
+        ts.replay(); torch.cuda.synchronize(); a = float(ts.loss)
+        ts.replay(); torch.cuda.synchronize(); b = float(ts.loss)
+        assert a != b, "two replays from the same weights gave the same loss: the dropout masks were baked into the graph"
+    torch.cuda.current_stream().wait_stream(s)
+
+
 # kept last: if this ever regresses the symptom is a GPU memory fault that aborts the process
 def test_conv_reads_stay_inside_the_input_buffer(dev):
     """the implicit-GEMM loaders prefetch k-tiles past the end of the reduction with clamped addresses; a clamp that is not
