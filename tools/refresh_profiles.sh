@@ -6,12 +6,14 @@ TAG=${SAST_PROFILE_TAG:-r02}
 O=gpurun_out/$TAG
 R=$PWD
 mkdir -p $O
-timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $R/$O/kt.log 2>&1)
 python tools/rocpd_stats.py /tmp/kt/kt_results.db --top 400 --out $O/kernel_trace_stats_bench_default.txt > /dev/null
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -o f -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/$O/pmc_fetch.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -o w -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/$O/pmc_write.log 2>&1)
 python tools/rocpd_pmc.py --fetch /tmp/pf/f_results.db --write /tmp/pw/w_results.db --out $O/pmc_hbm_traffic.json --top 5
+# the bench line of the set reads the counter summary of THIS binary (stamped with the csrc hash): install it first, then run the line
+cp $O/pmc_hbm_traffic.json profiles/pmc_hbm_traffic_latest.json
+timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_line.err
 python tools/family_table.py $O/kernel_trace_stats_bench_default.txt $O/pmc_hbm_traffic.json 66 8 > $O/kernel_families.md
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE -d /tmp/sq -o sq -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-graph > $R/$O/sq.log 2>&1)
 python tools/rocpd_sq.py /tmp/sq/sq_results.db --top 40 --out $O/sq_counters_eager_step.txt > /dev/null
