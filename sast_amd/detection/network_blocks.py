@@ -47,7 +47,8 @@ class BaseConv(nn.Module):
 
 
 class DWConv(nn.Module):
-    """Depthwise Conv + Conv (network_blocks.py:57-76): BaseConv(in, in, ksize, stride, groups=in) then BaseConv(in, out, 1)."""
+    """network_blocks.py:57-76: a depth-wise k x k unit (groups = channels; carries the stride) followed by a point-wise 1x1 unit, each
+    with its own BatchNorm + SiLU.  Parameter names (`dconv.*`, `pconv.*`) are the reference's, so its checkpoints load."""
 
     def __init__(self, in_channels, out_channels, ksize, stride=1, act="silu"):
         super().__init__()

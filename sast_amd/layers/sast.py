@@ -83,7 +83,7 @@ class DropPath(nn.Module):
         return f.div_(keep) if (keep > 0.0 and self.scale_by_keep) else f
 
     def extra_repr(self):
-        return f'drop_prob={round(self.drop_prob, 3):0.3f}'
+        return f"p={self.drop_prob:g}, scale_by_keep={self.scale_by_keep}"
 
 
 def _glu_activation_name(act) -> str:
