@@ -462,7 +462,9 @@ def main():
                        "loss_first_step": loss_first, "loss": float(tr.loss),
                        "grads_finite": bool(torch.isfinite(tr.flat.grad).all()), "grad_absmax": float(tr.flat.grad.abs().max())},
         }
-        if not args.no_roofline:
+        # (the roofline leg re-runs the step on rank 0 ALONE: with SyncBatchNorm over several ranks its statistics all-reduces would wait
+        # for ranks that are not there -- skipped, `roofline` is then absent from the line)
+        if not args.no_roofline and not (tr.sync_bn and world > 1):
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr, ms_per_step=res["ms_per_step"] / max(args.seq_len, 1), hw=HW, batch=BATCH)
         if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy" and args.precision == "f32":
