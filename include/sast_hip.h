@@ -179,7 +179,7 @@ typedef struct SastMswsaArgs {
                             SAME call pair (saves the backward a clearing launch); NULL = backward clears its own scratch */
   const float *drop1, *drop2;  /* DropPath (`drop_path > 0`, SAST.py:188,193,232,248; reference default 0): fp32[R] each, per KEPT ROW (compact
                             order = asy_index order) keep / keep_prob of the attention branch (drop1) and of the MLP branch (drop2); the caller
-                            draws them.  Both or neither; NULL = no DropPath (p = 0 or eval).  Not with cb_tps > 0, not with fused_ws. */
+                            draws them.  Both or neither; NULL = no DropPath (p = 0 or eval).  Not with fused_ws. */
   float* drop_ws;        /* bwd with drop1 / drop2: fp32[2 * R * C] scratch (the scaled branch gradients) */
   const float* drop_mlp; /* `drop_mlp > 0` (ops.py:167: nn.Dropout between the GLU and the second linear; reference default 0): fp32[R, inner]
                             keep mask / (1 - p) per kept row and hidden channel, drawn by the caller; NULL = none.  Not with fused_ws. */

@@ -344,14 +344,13 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
                                 EpResidualLSScatterT<true>{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C, a->drop2}, R, C, inner, dR, st)
                     : gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0},
                                 EpResidualLSScatterT<false>{a->out, a->Y, a->fc2_b, a->ls2, a->sel.row_tok, C, nullptr}, R, C, inner, dR, st);
-  if (a->drop2) return SAST_EINVAL;     // DropPath together with Context Broadcasting is not built
   // Context Broadcasting (SAST.py:240-246): the MLP output is mixed with its per-sample mean over ALL L tokens before LayerScale
   if (!a->cb_m || !a->cb_sum || R % a->cb_tps) return SAST_EINVAL;
   rc = gemm_auto(LdRows{a->Hh, inner, nullptr}, LdWeightNT{a->fc2_w, inner, 0}, EpStore{a->cb_m, C, a->fc2_b}, R, C, inner, dR, st);
   if (rc) return rc;
   rc = cb_sample_sum_launch(a->cb_m, C, false, a->sel.row_tok, dR, R, a->cb_tps, R / a->cb_tps, C, a->cb_sum, st);
   if (rc) return rc;
-  return cb_apply_fwd_launch(a->cb_m, a->Y, a->ls2, a->cb_sum, a->sel.row_tok, dR, R, a->cb_tps, C, a->out, st);
+  return cb_apply_fwd_launch(a->cb_m, a->Y, a->ls2, a->cb_sum, a->sel.row_tok, dR, R, a->cb_tps, C, a->out, st, a->drop2);   // DropPath acts behind the broadcast (SAST.py:248)
 }
 
 int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
@@ -381,17 +380,18 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const int* dz_tok = row_tok;
   if (a->cb_tps > 0) {
     if (!a->cb_m || !a->cb_sum || R % a->cb_tps) return SAST_EINVAL;
-    rc = cb_sample_sum_launch(a->dout, C, true, row_tok, dR, R, a->cb_tps, R / a->cb_tps, C, a->cb_sum, st);
+    // (with DropPath the gradient that enters the broadcast is drop2[r] * dZ[r]: both kernels take the row factors)
+    rc = cb_sample_sum_launch(a->dout, C, true, row_tok, dR, R, a->cb_tps, R / a->cb_tps, C, a->cb_sum, st, a->drop2);
     if (rc) return rc;
-    rc = cb_apply_bwd_launch(a->dout, a->cb_sum, row_tok, dR, R, a->cb_tps, C, a->cb_m, st);
+    rc = cb_apply_bwd_launch(a->dout, a->cb_sum, row_tok, dR, R, a->cb_tps, C, a->cb_m, st, a->drop2);
     if (rc) return rc;
     dz = a->cb_m;
     dz_tok = nullptr;
   }
   // DropPath (drop1 / drop2: per kept row keep / keep_prob): what enters a residual BRANCH is the row factor times the gradient of the
   // sum -- a scaled compact copy for the branch GEMMs, the unscaled gradient for the identity path
-  if ((!a->drop1) != (!a->drop2) || (a->drop1 && (!a->drop_ws || a->cb_tps > 0))) return SAST_EINVAL;
-  if (a->drop2) {
+  if ((!a->drop1) != (!a->drop2) || (a->drop1 && !a->drop_ws)) return SAST_EINVAL;
+  if (a->drop2 && a->cb_tps <= 0) {
     rc = row_scale_launch(a->dout, row_tok, a->drop2, a->drop_ws, dR, R, C, st);
     if (rc) return rc;
     dz = a->drop_ws;

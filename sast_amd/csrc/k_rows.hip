@@ -986,7 +986,7 @@ int zero_samples_launch(float* x, int B, size_t sample_floats, const SastSampleM
 // strip of rows touches at most a few samples; the sample of row r is row_tok[r] / tps (tps = tokens per sample).
 __global__ __launch_bounds__(256) void cb_sample_sum_kernel(const float* __restrict__ src, int ld, const int* __restrict__ gather,
                                                             const int* __restrict__ row_tok, const int* __restrict__ nrows_dev,
-                                                            int tps, int C, int strip, float* __restrict__ out) {
+                                                            int tps, int C, int strip, float* __restrict__ out, const float* __restrict__ rs) {
   __shared__ float4 red[256];
   const int nrows = *nrows_dev;
   const int r0 = blockIdx.x * strip;
@@ -1002,7 +1002,8 @@ __global__ __launch_bounds__(256) void cb_sample_sum_kernel(const float* __restr
       const int t = row_tok[r];
       if (t / tps == b) {
         const float4 v = ld4(src + (size_t)(gather ? t : r) * ld + c4 * 4);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        const float d = rs ? rs[r] : 1.f;       // DropPath row factor (backward: the gradient entering the broadcast is rs[r] * dout)
+        acc.x += v.x * d; acc.y += v.y * d; acc.z += v.z * d; acc.w += v.w * d;
       }
     }
   red[threadIdx.x] = acc;
@@ -1016,12 +1017,14 @@ __global__ __launch_bounds__(256) void cb_sample_sum_kernel(const float* __restr
     atomicAdd(o, acc.x); atomicAdd(o + 1, acc.y); atomicAdd(o + 2, acc.z); atomicAdd(o + 3, acc.w);
   }
 }
-// forward: out[row_tok[r]] = y[r] + gamma * (0.5 m[r] + (0.5 / tps) * sum[sample]);  backward: dz[r] = 0.5 dout[row_tok[r]] + (0.5 / tps) * G[sample]
+// forward: out[row_tok[r]] = y[r] + rs[r] * gamma * (0.5 m[r] + (0.5 / tps) * sum[sample]);
+// backward: dz[r] = 0.5 rs[r] dout[row_tok[r]] + (0.5 / tps) * G[sample], G = sum over the sample of rs[r'] dout[row_tok[r']]
+// rs: DropPath row factors of the MLP branch (SAST.py:248), NULL = 1
 template <bool FWD>
 __global__ __launch_bounds__(256) void cb_apply_kernel(const float* __restrict__ a, const float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ sum,
                                                        const int* __restrict__ row_tok, const int* __restrict__ nrows_dev, int tps,
-                                                       int C, float* __restrict__ out) {
+                                                       int C, float* __restrict__ out, const float* __restrict__ rs) {
   const int C4 = C >> 2;
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   const int r = (int)(e / C4), c = (int)(e % C4) * 4;
@@ -1032,40 +1035,46 @@ __global__ __launch_bounds__(256) void cb_apply_kernel(const float* __restrict__
   if (FWD) {
     const float4 m = ld4(a + (size_t)r * C + c), yv = ld4(y + (size_t)r * C + c);
     const float4 g = gamma ? ld4(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    if (rs) {
+      const float d = rs[r];
+      st4(out + (size_t)t * C + c, make_float4(yv.x + (g.x * (0.5f * m.x + hs * sv.x)) * d, yv.y + (g.y * (0.5f * m.y + hs * sv.y)) * d,
+                                               yv.z + (g.z * (0.5f * m.z + hs * sv.z)) * d, yv.w + (g.w * (0.5f * m.w + hs * sv.w)) * d));
+    } else
     st4(out + (size_t)t * C + c, make_float4(yv.x + g.x * (0.5f * m.x + hs * sv.x), yv.y + g.y * (0.5f * m.y + hs * sv.y),
                                              yv.z + g.z * (0.5f * m.z + hs * sv.z), yv.w + g.w * (0.5f * m.w + hs * sv.w)));
   } else {
-    const float4 d = ld4(a + (size_t)t * C + c);
+    float4 d = ld4(a + (size_t)t * C + c);
+    if (rs) { const float f = rs[r]; d.x *= f; d.y *= f; d.z *= f; d.w *= f; }
     st4(out + (size_t)r * C + c, make_float4(0.5f * d.x + hs * sv.x, 0.5f * d.y + hs * sv.y, 0.5f * d.z + hs * sv.z, 0.5f * d.w + hs * sv.w));
   }
 }
 
 int cb_sample_sum_launch(const float* src, int ld, bool gather, const int* row_tok, const int* nrows_dev, int rows_max, int tps,
-                         int n_samples, int C, float* out, hipStream_t st) {
+                         int n_samples, int C, float* out, hipStream_t st, const float* rs) {
   if (C % 4 || C > 1024 || tps <= 0) return SAST_EINVAL;
   int rc = zero_fill(out, sizeof(float) * (size_t)n_samples * C, st);
   if (rc || rows_max <= 0) return rc;
   const int strip = 256;
   SAST_LAUNCH(cb_sample_sum_kernel, dim3((rows_max + strip - 1) / strip, n_samples), dim3(256), 0, st, src, ld,
-                     gather ? row_tok : nullptr, row_tok, nrows_dev, tps, C, strip, out);
+                     gather ? row_tok : nullptr, row_tok, nrows_dev, tps, C, strip, out, rs);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int cb_apply_fwd_launch(const float* m, const float* y, const float* gamma, const float* sum, const int* row_tok,
-                        const int* nrows_dev, int rows_max, int tps, int C, float* out, hipStream_t st) {
+                        const int* nrows_dev, int rows_max, int tps, int C, float* out, hipStream_t st, const float* rs) {
   if (rows_max <= 0) return SAST_OK;
   const size_t n = (size_t)rows_max * (C / 4);
   SAST_LAUNCH(cb_apply_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m, y, gamma, sum, row_tok, nrows_dev,
-                     tps, C, out);
+                     tps, C, out, rs);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int cb_apply_bwd_launch(const float* dout, const float* gsum, const int* row_tok, const int* nrows_dev, int rows_max, int tps, int C,
-                        float* dz, hipStream_t st) {
+                        float* dz, hipStream_t st, const float* rs) {
   if (rows_max <= 0) return SAST_OK;
   const size_t n = (size_t)rows_max * (C / 4);
   SAST_LAUNCH(cb_apply_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dout, nullptr, nullptr, gsum, row_tok,
-                     nrows_dev, tps, C, dz);
+                     nrows_dev, tps, C, dz, rs);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

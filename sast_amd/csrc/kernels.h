@@ -45,11 +45,11 @@ int ls_linear_finish2_launch(const float* w0, const float* b0, const float* g0, 
                              float* dw1, float* db1, float* dg1, int K1, int C, hipStream_t st);
 // Context Broadcasting (SAST.py:240-246): per-sample column sums of the kept rows, and the two pointwise halves
 int cb_sample_sum_launch(const float* src, int ld, bool gather, const int* row_tok, const int* nrows_dev, int rows_max, int tps,
-                         int n_samples, int C, float* out, hipStream_t st);
+                         int n_samples, int C, float* out, hipStream_t st, const float* rs = nullptr);
 int cb_apply_fwd_launch(const float* m, const float* y, const float* gamma, const float* sum, const int* row_tok,
-                        const int* nrows_dev, int rows_max, int tps, int C, float* out, hipStream_t st);
+                        const int* nrows_dev, int rows_max, int tps, int C, float* out, hipStream_t st, const float* rs = nullptr);
 int cb_apply_bwd_launch(const float* dout, const float* gsum, const int* row_tok, const int* nrows_dev, int rows_max, int tps, int C,
-                        float* dz, hipStream_t st);
+                        float* dz, hipStream_t st, const float* rs = nullptr);
 
 int sample_gather_launch(const SastSampleGather& a, bool backward, hipStream_t st);
 int zero_samples_launch(float* x, int B, size_t sample_floats, const SastSampleMask& m, hipStream_t st);

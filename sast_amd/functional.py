@@ -612,8 +612,6 @@ class _MSWSA(torch.autograd.Function):
             d1, d2, drop_mlp = (tuple(drop) + (None,))[:3]
             drop = None
             if d1 is not None:
-                if cb_tps:
-                    raise NotImplementedError("sast_amd: drop_path > 0 together with enable_CB is not implemented")
                 drop = (d1.contiguous(), d2.contiguous())
                 if any(d.dtype != torch.float32 or d.numel() < R for d in drop):
                     raise RuntimeError("sast_amd: the DropPath factors must be fp32 with one entry per row upper bound")

@@ -144,14 +144,14 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
     print(f"{name}: seed {seed} margin {margin:.2e} kept {kept} of {B * H * W} count {cnt}")
 
 
-def gen_block_drop_path(ref, name="block_drop_path", pdrop=0.25, pmlp=0.0):
+def gen_block_drop_path(ref, name="block_drop_path", pdrop=0.25, pmlp=0.0, enable_cb=False):
     """drop_path > 0 (SAST.py:42,188,193,232,248; shipped YAML: 0): DropPath on both residual branches of both MS-WSA layers, training mode,
     fixed RNG state.  The oracle (same torch calls in the same order) reproduces the reference bit for bit and records the factor
     vectors it drew (= the reference's); the fixture holds them next to the reference's outputs and gradients.
     pmlp > 0: `drop_mlp` (SAST.py:43,191 -> ops.py:167: nn.Dropout on the MLP hidden) -- its masks join the record in call order."""
     H, W, part, C, B, amp = 16, 20, (4, 5), 32, 2, 2e-2
     acfg = dict(partition_size=part, dim_head=32, attention_bias=True, mlp_activation="gelu", mlp_bias=True,
-                mlp_ratio=4, drop_mlp=pmlp, drop_path=pdrop, ls_init_value=0.5, enable_CB=False, AMP=amp, BOUNCE=1e-3)
+                mlp_ratio=4, drop_mlp=pmlp, drop_path=pdrop, ls_init_value=0.5, enable_CB=enable_cb, AMP=amp, BOUNCE=1e-3)
     pe_mod = ref.sast_rnn.PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     pe = O.position_embedding_sine(H, W, C)
     T, N = part[0] * part[1], H * W // (part[0] * part[1])
@@ -177,7 +177,7 @@ def gen_block_drop_path(ref, name="block_drop_path", pdrop=0.25, pmlp=0.0):
     out, cnt, lists = blk(xx, pe_mod, r, None)
     (out ** 2).mean().backward()
     log = []
-    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, drop_path=pdrop, drop_mlp=pmlp, training=True, drop_log=log)
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, drop_path=pdrop, drop_mlp=pmlp, training=True, drop_log=log, enable_cb=enable_cb)
     xo = x.clone().requires_grad_(True)
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     torch.manual_seed(91)
@@ -191,7 +191,7 @@ def gen_block_drop_path(ref, name="block_drop_path", pdrop=0.25, pmlp=0.0):
         eout, _ec, _el = blk(x, pe_mod, r, None)
     d = dict(x=np_(x), r=np_(r), out=np_(out), eval_out=np_(eout), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)), p=np.float64(pdrop),
-             p_mlp=np.float64(pmlp), rng_seed=np.int64(91))
+             p_mlp=np.float64(pmlp), rng_seed=np.int64(91), enable_cb=np.int64(enable_cb))
     for i, m in enumerate(log):
         d[f"drop{i}"] = np_(m)
     d.update(lists_to_np(lists, ""))
@@ -758,6 +758,9 @@ def main():
     if "--drop-mlp-only" in sys.argv:
         gen_block_drop_path(ref, "block_drop_mlp", pdrop=0.0, pmlp=0.2)
         return
+    if "--drop-cb-only" in sys.argv:
+        gen_block_drop_path(ref, "block_drop_path_cb", pdrop=0.25, pmlp=0.2, enable_cb=True)
+        return
     if "--lstm-dropout-only" in sys.argv:
         gen_lstm_dropout(ref)
         return
@@ -783,6 +786,7 @@ def main():
     gen_acts(ref)
     gen_block_drop_path(ref)
     gen_block_drop_path(ref, "block_drop_mlp", pdrop=0.0, pmlp=0.2)
+    gen_block_drop_path(ref, "block_drop_path_cb", pdrop=0.25, pmlp=0.2, enable_cb=True)
     gen_downsample_variants(ref)
     gen_two_blocks(ref)
     gen_backbone_tiny(ref)

@@ -189,22 +189,24 @@ def test_downsample_no_overlap_no_affine_vs_golden(golden_dir, dev):
         maxnorm_close(m.conv.weight.grad, torch.from_numpy(g[tag + "_dw"]), GRAD_RTOL, tag + " dw")
 
 
-@pytest.mark.parametrize("name", ["block_drop_path", "block_drop_mlp"])
+@pytest.mark.parametrize("name", ["block_drop_path", "block_drop_mlp", "block_drop_path_cb"])
 def test_sast_block_drop_path_vs_golden(golden_dir, dev, name):
     """drop_path > 0 (SAST.py:42,188,193,232,248; the shipped YAML leaves it 0): timm's DropPath on the attention and on the MLP branch of
     both MS-WSA layers -- one factor per KEPT ROW and branch (`SastMswsaArgs.drop1 / drop2`).  With the four factor vectors the reference
     drew (fixture block_drop_path.npz, recovered through the oracle's bit-exact reproduction) injected: outputs, index lists and every
     gradient; eval mode ignores DropPath; the module's own draw runs and differs from eval.  block_drop_mlp: the same for `drop_mlp > 0`
-    (SAST.py:43,191 -> ops.py:167: nn.Dropout on the MLP hidden; `SastMswsaArgs.drop_mlp`, a mask per kept row and hidden channel)."""
+    (SAST.py:43,191 -> ops.py:167: nn.Dropout on the MLP hidden; `SastMswsaArgs.drop_mlp`, a mask per kept row and hidden channel);
+    block_drop_path_cb: both together with enable_CB (DropPath then acts behind the broadcast: the CB kernels take the row factors)."""
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
     B, H, W, C = x.shape
     params = block_params(C, int(g["seed"]))
-    pmlp = float(g["p_mlp"])
-    acfg = attn_cfg((4, 5), float(g["amp"]))
-    acfg.update(drop_path=float(g["p"]), drop_mlp=pmlp)
+    pmlp, pdp = float(g["p_mlp"]), float(g["p"])
+    cb = bool(int(g["enable_cb"])) if "enable_cb" in g else False
+    acfg = attn_cfg((4, 5), float(g["amp"]), cb=cb)
+    acfg.update(drop_path=pdp, drop_mlp=pmlp)
     blk = SAST_block(C, acfg, first_block=True).to(dev)
     load_params(blk, params, "att_blocks.0.att.")
     assert not [k for k in blk.state_dict() if "drop" in k]                 # DropPath has no state: checkpoints are unaffected
@@ -213,11 +215,14 @@ def test_sast_block_drop_path_vs_golden(golden_dir, dev, name):
     def padded(i):      # one factor (row of the mask) per kept row; the tail of the upper-bound tensor is never read
         m = torch.from_numpy(g[f"drop{i}"])
         return torch.cat([m, torch.full((rows - len(m),) + tuple(m.shape[1:]), float("nan"))]).to(dev)
-    if pmlp:
-        blk.win_attn.drop_path_override, blk.grid_attn.drop_path_override = (None, None, padded(0)), (None, None, padded(1))
-    else:
-        blk.win_attn.drop_path_override, blk.grid_attn.drop_path_override = (padded(0), padded(1), None), (padded(2), padded(3), None)
-    n_masks = 2 if pmlp else 4
+    per_layer = (2 if pdp else 0) + (1 if pmlp else 0)      # recorded in call order per layer: [DropPath 1][MLP mask][DropPath 2]
+    n_masks = 2 * per_layer
+    for li, layer in enumerate((blk.win_attn, blk.grid_attn)):
+        i = li * per_layer
+        d1 = padded(i) if pdp else None
+        mm = padded(i + (1 if pdp else 0)) if pmlp else None
+        d2 = padded(i + per_layer - 1) if pdp else None
+        layer.drop_path_override = (d1, d2, mm)
     blk.train()
     pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
     xd = x.to(dev).requires_grad_(True)
@@ -233,7 +238,7 @@ def test_sast_block_drop_path_vs_golden(golden_dir, dev, name):
     kl = {}
     po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     oo, _c, _l = O.sast_block(x.clone(), O.position_embedding_sine(H, W, C), r, po, "att_blocks.0.att.",
-                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]), drop_mlp=pmlp,
+                              O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=pdp, drop_mlp=pmlp, enable_cb=cb,
                                         drop_masks=[torch.from_numpy(g[f"drop{i}"]) for i in range(n_masks)]), kink_log=kl)
     (oo ** 2).mean().backward()
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")

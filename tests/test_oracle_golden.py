@@ -70,7 +70,7 @@ def test_sast_block(golden_dir, name):
         assert torch.allclose(v.grad, torch.from_numpy(g[gk]), atol=1e-7, rtol=1e-3), k
 
 
-@pytest.mark.parametrize("name", ["block_drop_path", "block_drop_mlp"])
+@pytest.mark.parametrize("name", ["block_drop_path", "block_drop_mlp", "block_drop_path_cb"])
 def test_sast_block_drop_path(golden_dir, name):
     """drop_path > 0 (SAST.py:42,188,193,232,248): the reference block in training mode under a fixed RNG state.  The oracle reproduces
     outputs, index lists and every gradient both with the four recorded factor vectors injected and by drawing them itself from the same RNG
@@ -81,15 +81,18 @@ def test_sast_block_drop_path(golden_dir, name):
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
     pmlp = float(g["p_mlp"])           # block_drop_mlp: `drop_mlp` (nn.Dropout on the MLP hidden, ops.py:167) instead of DropPath
     masks = [torch.from_numpy(g[k]) for k in sorted((k for k in g.files if k.startswith("drop")), key=lambda k: int(k[4:]))]
-    keep = 1.0 - (pmlp if pmlp else float(g["p"]))
-    assert all(set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1.0) / np.float32(keep))} for m in masks)
-    if pmlp:
-        assert [tuple(m.shape) for m in masks] == [(len(g["l0_asy_index"]), 64), (len(g["l1_asy_index"]), 64)]      # kept rows x inner
-    else:
-        assert [len(m) for m in masks] == [len(g["l0_asy_index"])] * 2 + [len(g["l1_asy_index"])] * 2      # one factor per kept row and branch
+    pdp, cb = float(g["p"]), bool(int(g["enable_cb"])) if "enable_cb" in g else False    # block_drop_path_cb: both dropouts + Context Broadcasting
+    want = []      # call order per layer (SAST.py:232-248): DropPath factors (kept rows), MLP mask (kept rows x inner), DropPath factors
+    for li in (0, 1):
+        k = len(g[f"l{li}_asy_index"])
+        want += ([(k,)] if pdp else []) + ([(k, 64)] if pmlp else []) + ([(k,)] if pdp else [])
+    assert [tuple(m.shape) for m in masks] == want
+    for m in masks:
+        keep = 1.0 - (pmlp if m.dim() == 2 else pdp)
+        assert set(torch.unique(m).tolist()) <= {0.0, float(np.float32(1.0) / np.float32(keep))}
     pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])
     for mode in ("inject", "draw"):
-        cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, drop_path=float(g["p"]), drop_mlp=pmlp, training=True,
+        cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, drop_path=pdp, drop_mlp=pmlp, training=True, enable_cb=cb,
                         drop_masks=[m.clone() for m in masks] if mode == "inject" else None)
         xo = x.clone().requires_grad_(True)
         po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
@@ -104,8 +107,8 @@ def test_sast_block_drop_path(golden_dir, name):
         assert torch.allclose(xo.grad, torch.from_numpy(g["dx"]), atol=1e-7, rtol=1e-4)
         for k, v in po.items():
             assert torch.allclose(v.grad, torch.from_numpy(g["g_" + k[len("att_blocks.0.att."):]]), atol=1e-7, rtol=1e-3), (mode, k)
-    ev, _c, _l = O.sast_block(x, pe, r, params, "att_blocks.0.att.", O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=float(g["p"]),
-                                                                              drop_mlp=pmlp, training=False))
+    ev, _c, _l = O.sast_block(x, pe, r, params, "att_blocks.0.att.", O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), drop_path=pdp,
+                                                                              drop_mlp=pmlp, training=False, enable_cb=cb))
     assert torch.allclose(ev, torch.from_numpy(g["eval_out"]), atol=ATOL, rtol=0)
 
 
