@@ -266,9 +266,9 @@ typedef struct SastConvBnArgs {
        fwd 2  BatchNorm + SiLU from bn_ws as it now is, over m_total rows (running statistics updated with the global mean and the
               unbiased global variance, like torch); the conv is not run again.
        bwd 1  this process's (sum dz, sum dz*xhat) into the fp32 block bn_ws[4*COPIES*Cout, 6*COPIES*Cout) (not run when
-              bn_red_done: the consumer's dX epilogue has them already), return.  The host adds the block, summed over its COPIES,
-              to d_bn_b / d_bn_w -- the affine gradients stay LOCAL sums as in torch.nn.SyncBatchNorm (DDP averages them with every
-              other gradient) -- and then all-reduces (SUM) the block;
+              bn_red_done: the consumer's dX epilogue has them already); the block, summed over its COPIES, is added to d_bn_b /
+              d_bn_w (when both are non-NULL) -- the affine gradients stay LOCAL sums as in torch.nn.SyncBatchNorm (DDP averages them
+              with every other gradient); return.  The host then all-reduces (SUM) the block;
        bwd 2  the rest (BatchNorm-backward apply with 1 / m_total, dW, dX, producer folding); d_bn_w / d_bn_b NULL. */
   int32_t sync_phase, m_total;
   int32_t groups;        /* 0 / 1: dense conv.  == Cin == Cout: depth-wise conv -- the `dconv` of YOLOX's DWConv (network_blocks.py:57-76:

@@ -225,6 +225,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
     st4(dconv + m * jb.lddconv + c, make_float4(out[0], out[1], out[2], out[3]));
   }
 }
+// SyncBatchNorm, backward phase 1: the affine gradients are this process's LOCAL sums (torch.nn.SyncBatchNorm: DDP averages them with
+// every other gradient) -- published from the reduction scratch before the host all-reduces it
+__global__ __launch_bounds__(256) void bn_publish_affine_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < BN_STAT_COPIES; ++k) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
+  dbeta[c] += s1;
+  dgamma[c] += s2;
+}
 // ---------------------------------------------------------------- upsample / concat
 __global__ __launch_bounds__(256) void upsample_cat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                float* __restrict__ out, int H, int W, int C1, int C2, size_t n4) {
@@ -560,7 +571,11 @@ int sast_conv_bn_silu_bwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
   }
   const BnBwdJob jb{a->conv_out, a->stats, a->bn_w, a->bn_b, a->dy, a->lddy, sums, dconv, a->d_bn_w, a->d_bn_b, a->dy2, C};
   if (!a->bn_red_done && phase != 2) bn_bwd_reduce_launch(jb, jb, 1, M, C, st);   // skipped when the conv consuming y folded it into its dX epilogue
-  if (phase == 1) { SAST_CHECK_LAUNCH(); return SAST_OK; }
+  if (phase == 1) {
+    if (a->d_bn_w && a->d_bn_b) SAST_LAUNCH(bn_publish_affine_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sums, a->d_bn_w, a->d_bn_b, C);
+    SAST_CHECK_LAUNCH();
+    return SAST_OK;
+  }
   bn_bwd_apply_launch(jb, jb, 1, M, C, a->training, st, phase == 2 ? a->m_total : 0);
   SAST_CHECK_LAUNCH();
   // producers of x / x2 whose only consumer is this conv: their reductions ride on this conv's dX epilogue

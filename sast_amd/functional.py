@@ -1009,13 +1009,8 @@ class _ConvBnSilu(torch.autograd.Function):
             sync, m_total = ctx.sync
             a.sync_phase = 1
             L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
-            red = _bn_ws_blocks(bn_ws, Cout)[1]
-            loc = red.view(-1, 2, Cout).sum(0)              # this process's (sum dz, sum dz * xhat): the affine gradients stay local
-            for prm, v in ((bn_b, loc[0]), (bn_w, loc[1])):
-                g = _gbuf(prm)
-                if g is not None:
-                    g.add_(v)
-            sync.all_reduce(red)
+            # (phase 1 also added this process's (sum dz, sum dz * xhat) to d_bn_b / d_bn_w: the affine gradients stay local)
+            sync.all_reduce(_bn_ws_blocks(bn_ws, Cout)[1])
             a.sync_phase, a.m_total, a.d_bn_w, a.d_bn_b = 2, m_total, None, None
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
         for h in (p1, p2):
