@@ -38,23 +38,25 @@ __device__ __forceinline__ int plane_off(int row, int chunk) { return row * 64 +
 // Two steps so that the loads of ALL staged matrices are in flight together (branch-free: clamped row + select at commit time; a
 // predicated load would make hipcc drain vmcnt after every single one).  64*NTMAX threads cover the 32*NTMAX x 8 float4 slots in
 // 4 rounds.
-struct Staged { float4 v[4]; };
-template <int NTMAX>
-__device__ __forceinline__ Staged stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K, int dh) {
-  Staged st;
+// NW: waves of the workgroup that stage together (NTMAX, or 2 NTMAX in the split-role backward): 256 NTMAX slots in 4 NTMAX / NW rounds
+template <int ROUNDS> struct StagedT { float4 v[ROUNDS]; };
+using Staged = StagedT<4>;
+template <int NTMAX, int NW = NTMAX>
+__device__ __forceinline__ StagedT<4 * NTMAX / NW> stage_issue(const float* __restrict__ src, int ld, int coff, int r0, int K, int dh) {
+  StagedT<4 * NTMAX / NW> st;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int s = threadIdx.x + it * 64 * NTMAX, row = s >> 3, dq = (s & 7) * 4;
+  for (int it = 0; it < 4 * NTMAX / NW; ++it) {
+    const int s = threadIdx.x + it * 64 * NW, row = s >> 3, dq = (s & 7) * 4;
     st.v[it] = ld4(src + (size_t)(r0 + min(row, K - 1)) * ld + coff + min(dq, dh - 4));
   }
   return st;
 }
-template <int NTMAX>
-__device__ __forceinline__ void stage_commit(char* mat, const Staged& st, int K, int KT, float mul, int dh) {
+template <int NTMAX, int NW = NTMAX>
+__device__ __forceinline__ void stage_commit(char* mat, const StagedT<4 * NTMAX / NW>& st, int K, int KT, float mul, int dh) {
   constexpr int PLANE = 32 * NTMAX * 64;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int s = threadIdx.x + it * 64 * NTMAX, row = s >> 3, q = s & 7;
+  for (int it = 0; it < 4 * NTMAX / NW; ++it) {
+    const int s = threadIdx.x + it * 64 * NW, row = s >> 3, q = s & 7;
     if (s < KT * 8) {
       const float m = (row < K && 4 * q < dh) ? mul : 0.f;   // rows >= K and channels dh..31 of the image are zero
       const float4 v = make_float4(st.v[it].x * m, st.v[it].y * m, st.v[it].z * m, st.v[it].w * m);
@@ -309,8 +311,145 @@ __device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict_
   }
 }
 
-template <int NTMAX>
-__global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+// ------------------------------------------------------------------ backward, split roles (round 4)
+// The two passes of attn_bwd_body are independent up to D_i: 2 NTMAX waves per (group, head) run them SIDE BY SIDE on the same LDS
+// images -- waves [0, NTMAX) pass B (scores transposed: softmax, D_i, dS^T, dQ), waves [NTMAX, 2 NTMAX) pass A (P, dV, then dS, dK).
+// Pass A needs D_i only for dS: it evaluates S, dP, P and dV first and meets pass B at the ONE barrier behind the D_i store.  The
+// dependent chain of a workgroup is roughly halved, its LDS is unchanged (twice the waves per byte), the staging is shared by twice
+// the threads.  Same arithmetic in the same order per output element as attn_bwd_body: results are identical.
+template <int NTMAX, int NT>
+__device__ __forceinline__ void attn_bwd_body_split(char* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                    const float* __restrict__ lse, float* __restrict__ dqkv, const int* __restrict__ row_seg,
+                                                    int r0, int K, int C, int heads, int h, float scale, int dh) {
+  constexpr int KT = NT * 32, MAT = 3 * 32 * NTMAX * 64, NW = 2 * NTMAX;
+  char* Qm = sm;                  // pre-scaled q
+  char* Km = Qm + MAT;
+  char* Vm = Km + MAT;
+  char* Gm = Vm + MAT;            // dO
+  float* lse_s = reinterpret_cast<float*>(Gm + MAT);     // [32 NTMAX] log-sum-exp of the queries
+  float* D_s = lse_s + 32 * NTMAX;                       // [32 NTMAX] D_i = sum_j P_ij dP_ij
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int role = wv / NTMAX, w = wv - role * NTMAX;    // role 0: pass B, role 1: pass A
+  const int C3 = 3 * C, coff = h * 3 * dh;
+  {
+    const auto sq = stage_issue<NTMAX, NW>(qkv, C3, coff, r0, K, dh), sk = stage_issue<NTMAX, NW>(qkv, C3, coff + dh, r0, K, dh);
+    const auto sv = stage_issue<NTMAX, NW>(qkv, C3, coff + 2 * dh, r0, K, dh), sg = stage_issue<NTMAX, NW>(dout, C, h * dh, r0, K, dh);
+    const int il = threadIdx.x;
+    const float lv = lse[(size_t)(r0 + min(il, K - 1)) * heads + h];      // 128 NTMAX threads >= KT: clamped, branch-free
+    stage_commit<NTMAX, NW>(Qm, sq, K, KT, scale, dh);
+    stage_commit<NTMAX, NW>(Km, sk, K, KT, 1.f, dh);
+    stage_commit<NTMAX, NW>(Vm, sv, K, KT, 1.f, dh);
+    stage_commit<NTMAX, NW>(Gm, sg, K, KT, 1.f, dh);
+    if (il < 32 * NTMAX) lse_s[il] = lv;
+  }
+  __syncthreads();
+  const bool active = w < NT;
+  const int seg = row_seg ? row_seg[r0 + min(w * 32 + l31, K - 1)] : (K << 16), glo = seg & 0xffff, ghi = seg >> 16;
+  f32x16 s[NT], dp[NT];
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { s[t][e] = 0.f; dp[t][e] = 0.f; }
+  }
+  if (role == 0) {
+    // ---- pass B: S^T[j][i] = K_t Q_w^T, dP^T[j][i] = V_t dO_w^T  (column = query i = 32 w + l31)
+    const int i = w * 32 + l31;
+    const bool qv = i < K;
+    float D = 0.f;
+    if (active) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const Split3 qb = rd_read<NTMAX>(Qm, w * 32 + l31, 2 * u + hf), gb = rd_read<NTMAX>(Gm, w * 32 + l31, 2 * u + hf);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          s[t] = mfma6(rd_read<NTMAX>(Km, t * 32 + l31, 2 * u + hf), qb, s[t]);
+          dp[t] = mfma6(rd_read<NTMAX>(Vm, t * 32 + l31, 2 * u + hf), gb, dp[t]);
+        }
+      }
+      const float li = lse_s[i];
+      float dloc = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int jj = t * 32 + crow(e, lane);
+          const float pt = (qv && jj >= glo && jj < ghi) ? __expf(s[t][e] - li) : 0.f;
+          s[t][e] = pt;
+          dloc += pt * dp[t][e];
+        }
+      D = pair_sum(dloc);
+      if (hf == 0) D_s[i] = D;
+    }
+    __syncthreads();   // D_s complete: pass A continues with dS
+    if (!active) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) dp[t][e] = s[t][e] * (dp[t][e] - D);     // dS^T
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc = mfma6(tk_read<NTMAX>(Km, t * 32 + 16 * u, lane), c_tile_operand(dp[t], u), acc);
+    if (qv) store_rows_per_lane(dqkv + (size_t)(r0 + i) * C3 + coff, acc, scale, lane, dh);
+    return;
+  }
+  // ---- pass A: S[i][j] = Q_t K_w^T, dP[i][j] = dO_t V_w^T  (column = key j = 32 w + l31, rows = queries of tile t)
+  const int j = w * 32 + l31;
+  const bool kv = j < K;
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const Split3 kb = rd_read<NTMAX>(Km, w * 32 + l31, 2 * u + hf), vb = rd_read<NTMAX>(Vm, w * 32 + l31, 2 * u + hf);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        s[t] = mfma6(rd_read<NTMAX>(Qm, t * 32 + l31, 2 * u + hf), kb, s[t]);
+        dp[t] = mfma6(rd_read<NTMAX>(Gm, t * 32 + l31, 2 * u + hf), vb, dp[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = t * 32 + crow(e, lane);
+        s[t][e] = (kv && i >= glo && i < ghi) ? __expf(s[t][e] - lse_s[min(i, 32 * NTMAX - 1)]) : 0.f;     // P
+      }
+    // dV^T[d][j] = sum_i dO^T[d][i] P[i][j]: needs no D_i -- before the barrier
+    f32x16 av;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) av[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) av = mfma6(tk_read<NTMAX>(Gm, t * 32 + 16 * u, lane), c_tile_operand(s[t], u), av);
+    if (kv) store_rows_per_lane(dqkv + (size_t)(r0 + j) * C3 + coff + 2 * dh, av, 1.f, lane, dh);
+  }
+  __syncthreads();   // D_s complete
+  if (!active) return;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = t * 32 + crow(e, lane);
+      dp[t][e] = s[t][e] * (dp[t][e] - D_s[i]);            // dS
+    }
+  // dK^T[d][j] = sum_i (scale q)^T[d][i] dS[i][j]
+  f32x16 ak;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ak[e] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) ak = mfma6(tk_read<NTMAX>(Qm, t * 32 + 16 * u, lane), c_tile_operand(dp[t], u), ak);
+  if (kv) store_rows_per_lane(dqkv + (size_t)(r0 + j) * C3 + coff + dh, ak, 1.f, lane, dh);
+}
+
+// (split form, NTMAX 2 / 3: 3 / 2 workgroups per CU are what its LDS allows -- ask for the registers to allow them too: 12 waves per CU)
+template <int NTMAX, bool SPLIT = false>
+__global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ? 3 : 2) : 1) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                    const int* __restrict__ row_off, const int* __restrict__ pack_rows,
                                                                    const int* __restrict__ row_seg, int C, int heads, float scale, int dh, int W,
@@ -318,7 +457,7 @@ __global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* 
   __shared__ __attribute__((aligned(16))) char sm[4 * 3 * 32 * NTMAX * 64 + 2 * 32 * NTMAX * 4];
   if (blockIdx.x >= W) {   // side workgroups: the LayerScale'd fc2 / proj gradient finish of the same MS-WSA layer (independent work
     if (blockIdx.y == 0) {  // that used to be a launch of its own), one wave per output channel
-      const int row = (blockIdx.x - W) * NTMAX + (threadIdx.x >> 6);
+      const int row = (blockIdx.x - W) * (NTMAX * (SPLIT ? 2 : 1)) + (threadIdx.x >> 6);
       if (row < fC) ls_finish_row(f0, row, threadIdx.x & 63);
       else if (row < 2 * fC) ls_finish_row(f1, row - fC, threadIdx.x & 63);
     }
@@ -328,6 +467,15 @@ __global__ __launch_bounds__(64 * NTMAX) void attn_bwd_mfma_kernel(const float* 
   const int K = pack_rows[g];
   if (K == 0) return;
   const int r0 = row_off[g];
+  if constexpr (SPLIT) {
+    switch ((K + 31) >> 5) {
+      case 1: attn_bwd_body_split<NTMAX, 1>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
+      case 2: attn_bwd_body_split<NTMAX, 2>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
+      case 3: if constexpr (NTMAX >= 3) attn_bwd_body_split<NTMAX, 3>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
+      case 4: if constexpr (NTMAX >= 4) attn_bwd_body_split<NTMAX, 4>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
+    }
+    return;
+  }
   switch ((K + 31) >> 5) {
     case 1: attn_bwd_body<NTMAX, 1>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
     case 2: attn_bwd_body<NTMAX, 2>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
@@ -396,6 +544,18 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
   const LsFinish& a0 = f0 ? *f0 : z;
   const LsFinish& a1 = f1 ? *f1 : z;
   if (!f0 || !f1) fC = 0;
+  // SAST_ATTN_BWD_SPLIT (default 1): the two passes of the backward on 2 NTMAX waves side by side (attn_bwd_body_split; measured -0.7 ...
+  // -1.5 % of the step on every configuration of the B = 8 sweep, B = 4 and B = 1, profiles/r04_z_ab_attn_bwd_split.txt); 0: one pass
+  // after the other on NTMAX waves
+  static int split = -1;
+  if (split < 0) { const char* e = getenv("SAST_ATTN_BWD_SPLIT"); split = e ? atoi(e) : 1; }
+  if (split && T <= 96) {      // (T > 96: eight waves of 256 registers spill -- those partitions keep the sequential form)
+    const int wpb2 = T <= 64 ? 4 : 6, side2 = (2 * fC + wpb2 - 1) / wpb2;
+    if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<2, true>), dim3(W + side2, heads), dim3(256), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
+    else SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<3,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<3, true>), dim3(W + side2, heads), dim3(384), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
+    SAST_CHECK_LAUNCH();
+    return SAST_OK;
+  }
   const int wpb = T <= 64 ? 2 : (T <= 96 ? 3 : 4), side = (2 * fC + wpb - 1) / wpb;
   // bytes: QKV (3C) + dO (C) read, dQKV (3C) written per kept row
   if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2>", 10.0, 7.0, (attn_bwd_mfma_kernel<2>), dim3(W + side, heads), dim3(128), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
