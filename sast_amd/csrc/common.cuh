@@ -84,7 +84,8 @@ __device__ __forceinline__ float wave_max(float v) { return group_reduce<64>(v, 
 template <int G>
 __device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, OpSum{}); }
 
-// sigmoid on the hardware exp2 path (v_exp_f32 is 1 ulp; the x*log2e pre-multiply adds ~|x|*6e-8 relative)
+// THE sigmoid of the library (SiLU, LSTM gates, STP weights, the silu / sigmoid GLU gates): on the hardware exp2 path
+// (v_exp_f32 is 1 ulp; the x*log2e pre-multiply adds ~|x|*6e-8 relative) -- measured inside the fp32 parity bars everywhere it is used
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) instead of libm's branchy erff:
@@ -111,12 +112,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 //   0 gelu (erf form: GeGLU, every shipped config)  1 relu (ReGLU)  2 silu / swish (SwiGLU)  3 sigmoid (GLU)  4 tanh
 // the code is wave-uniform (one layer per launch): the switch is a scalar branch
 constexpr int GLU_ACT_COUNT = 5;
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float glu_act(float g, int act) {
   switch (act) {
     case 1: return fmaxf(g, 0.0f);
-    case 2: return g * sigmoid_f(g);
-    case 3: return sigmoid_f(g);
+    case 2: return g * sigmoid_exact(g);
+    case 3: return sigmoid_exact(g);
     case 4: return tanhf(g);
     default: return gelu_erf(g);
   }
@@ -124,8 +124,8 @@ __device__ __forceinline__ float glu_act(float g, int act) {
 __device__ __forceinline__ float glu_act_grad(float g, int act) {
   switch (act) {
     case 1: return g > 0.0f ? 1.0f : 0.0f;                  // torch: relu'(0) = 0
-    case 2: { const float s = sigmoid_f(g); return s * (1.0f + g * (1.0f - s)); }
-    case 3: { const float s = sigmoid_f(g); return s * (1.0f - s); }
+    case 2: { const float s = sigmoid_exact(g); return s * (1.0f + g * (1.0f - s)); }
+    case 3: { const float s = sigmoid_exact(g); return s * (1.0f - s); }
     case 4: { const float t = tanhf(g); return 1.0f - t * t; }
     default: return gelu_erf_grad(g);
   }

@@ -23,6 +23,15 @@ class BaseConv(nn.Module):
         self.bn = nn.BatchNorm2d(out_channels)
         self.sync_bn = None       # a functional.SyncBatchNormGroup after convert_sync_batchnorm: batch statistics over all ranks
 
+    def sync_group(self):
+        """the SyncBatchNormGroup of this unit, or None.  `torch.nn.SyncBatchNorm.convert_sync_batchnorm` (what the reference's
+        `Trainer(sync_batchnorm=True)` runs under DDP, train.py:167) replaces `self.bn` by a torch.nn.SyncBatchNorm holding the same
+        parameters and buffers; the fused op never calls that module, so its class is the request: statistics over the ranks of its
+        `process_group` -- never silently rank-local."""
+        if self.sync_bn is None and isinstance(self.bn, nn.SyncBatchNorm):
+            self.sync_bn = SF.sync_group_for(self.bn.process_group)
+        return self.sync_bn
+
     def forward_nhwc(self, x, arena=None, sole=False, two_outputs=False):
         """arena: optional `BnArena` handing out zero-filled reduction scratch (one memset per FPN forward) and
         batching the num_batches_tracked increments.  sole: the caller guarantees this conv is the only consumer of x
@@ -31,8 +40,13 @@ class BaseConv(nn.Module):
         conv's BatchNorm-backward kernels, not by an autograd launch)."""
         bn = self.bn
         ws = arena.take(SF.bn_ws_floats(bn.num_features)) if arena is not None else None
+        sync = self.sync_group()
+        if sync is not None and arena is None and self.training and sync.active():
+            # a unit called on its own (no PAFPN / head pass around it that exchanged the sample counts): its own exchange
+            x0 = x[0] if isinstance(x, (tuple, list)) else x
+            sync.exchange_batch(x0.shape[0], x0.device)
         y = SF.conv_bn_silu(x, self.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.ksize, self.stride,
-                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole, two_outputs=two_outputs, sync=self.sync_bn)
+                            self.training, bn.momentum, bn.eps, ws, sole_consumer=sole, two_outputs=two_outputs, sync=sync)
         if self.training and bn.num_batches_tracked is not None:
             if arena is not None:
                 arena.counters.append(bn.num_batches_tracked)
@@ -66,7 +80,37 @@ class DWConv(nn.Module):
 
 def sync_active(conv: "BaseConv") -> bool:
     """training-mode statistics of this unit span several ranks: the stacked two-conv launches (one process's rows) are not used"""
-    return conv.sync_bn is not None and conv.sync_bn.active()
+    grp = conv.sync_group()
+    return grp is not None and grp.active()
+
+
+def bn_scratch_floats(module: nn.Module) -> int:
+    """BatchNorm reduction scratch of every conv + BatchNorm unit below `module` (BatchNorm2d, or the torch.nn.SyncBatchNorm that
+    torch's conversion put in its place)"""
+    return sum(SF.bn_ws_floats(m.num_features) for m in module.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm))
+
+
+def pass_sync_group(module: nn.Module):
+    """the SyncBatchNormGroup a PAFPN / head pass exchanges its sample counts on, or None: the one `convert_sync_batchnorm` installed
+    (`module._sync_group`), else the one behind torch.nn.SyncBatchNorm modules left by torch's own conversion -- looked up when the
+    module's first unit turns out to be converted (the conversion replaces every BatchNorm below a module, so one unit tells) and
+    then installed on every unit below `module`."""
+    grp = module._sync_group
+    if grp is None:
+        first = next((m for m in module.modules() if isinstance(m, BaseConv)), None)
+        if first is not None and isinstance(first.bn, nn.SyncBatchNorm):
+            groups = {id(m.bn.process_group): m.bn.process_group for m in module.modules()
+                      if isinstance(m, BaseConv) and isinstance(m.bn, nn.SyncBatchNorm)}
+            if len(groups) != 1:
+                raise RuntimeError("sast_amd: the SyncBatchNorm modules of one PAFPN / head span several process groups")
+            grp = SF.sync_group_for(next(iter(groups.values())))
+            for m in module.modules():
+                if isinstance(m, BaseConv):
+                    if not isinstance(m.bn, nn.SyncBatchNorm):
+                        raise RuntimeError("sast_amd: only some BatchNorm modules of this PAFPN / head were converted to SyncBatchNorm")
+                    m.sync_bn = grp
+            module._sync_group = grp
+    return grp
 
 
 def convert_sync_batchnorm(module: nn.Module, process_group=None, force: bool = False):

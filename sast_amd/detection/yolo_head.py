@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import functional as SF
-from .network_blocks import BaseConv, BnArena, DWConv
+from .network_blocks import BaseConv, BnArena, DWConv, bn_scratch_floats, pass_sync_group
 
 
 class _PredConv(nn.Module):
@@ -65,11 +65,12 @@ class YOLOXHead(nn.Module):
         -> (predictions (B, A, 5+nc), losses dict like yolo_head.py:224-231)"""
         per_level, levels = [], []
         if not hasattr(self, "_bn_floats"):
-            self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+            self._bn_floats = bn_scratch_floats(self)
         ar = BnArena(self._bn_floats, feats[0].device)     # one memset / one counter update for the 15 BatchNorms
-        sync = self.training and self._sync_group is not None and self._sync_group.active()
-        if sync and not self._sync_group.reuse_batch(feats[0].shape[0]):
-            self._sync_group.exchange_batch(feats[0].shape[0], feats[0].device)
+        grp = pass_sync_group(self) if self.training else None
+        sync = grp is not None and grp.active()
+        if sync and not grp.same_pass(feats[0]):
+            grp.exchange_batch(feats[0].shape[0], feats[0].device)
         for k, (x, stride) in enumerate(zip(feats, self.strides)):
             x = self.stems[k].forward_nhwc(x, ar)
             if SF.CONV_PAIR and not sync and not self.depthwise:

@@ -6,7 +6,7 @@ from typing import Dict, Optional, Tuple
 import torch.nn as nn
 
 from .. import functional as SF
-from .network_blocks import BaseConv, BnArena, CSPLayer, DWConv
+from .network_blocks import BaseConv, BnArena, CSPLayer, DWConv, bn_scratch_floats, pass_sync_group
 
 
 class YOLOPAFPN(nn.Module):
@@ -38,10 +38,12 @@ class YOLOPAFPN(nn.Module):
     def forward_nhwc(self, feats: Dict[int, object]):
         x2, x1, x0 = (feats[f] for f in self.in_features)
         if not hasattr(self, "_bn_floats"):
-            self._bn_floats = sum(SF.bn_ws_floats(m.num_features) for m in self.modules() if isinstance(m, nn.BatchNorm2d))
+            self._bn_floats = bn_scratch_floats(self)
         ar = BnArena(self._bn_floats, x0.device)                            # one memset for all 32 BatchNorm reductions
-        if self.training and self._sync_group is not None and self._sync_group.active():
-            self._sync_group.exchange_batch(x0.shape[0], x0.device)           # SyncBatchNorm: the sample counts of all ranks, once per pass
+        grp = pass_sync_group(self) if self.training else None
+        token = None
+        if grp is not None and grp.active():
+            token = grp.exchange_batch(x0.shape[0], x0.device)                # SyncBatchNorm: the sample counts of all ranks, once per pass
         # outputs with two consumers come as (y, alias) pairs: autograd then delivers the two gradients separately and the producing
         # conv's BatchNorm-backward kernels add them while reading (no accumulation launch)
         fpn_out0, fpn_out0b = self.lateral_conv0.forward_nhwc(x0, ar, two_outputs=True)
@@ -53,6 +55,8 @@ class YOLOPAFPN(nn.Module):
         p_out0 = (self.bu_conv1.forward_nhwc(pan_out1b, ar), fpn_out0b)   # th.cat (yolo_pafpn.py:134)
         pan_out0 = self.C3_n4.forward_nhwc(p_out0, ar, sole_input=(True, False))
         ar.finish()
+        if token is not None:          # a head handed these very tensors takes the exchange over (SyncBatchNormGroup.same_pass)
+            pan_out2._sast_sync_pass = pan_out1._sast_sync_pass = pan_out0._sast_sync_pass = token
         return pan_out2, pan_out1, pan_out0
 
     def forward(self, input):

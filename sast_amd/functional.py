@@ -1,10 +1,17 @@
 """torch.autograd bindings of the C-ABI ops (include/sast_hip.h).
 
-Layout: activations are fp32 NHWC ("image layout" rows [B*H*W, C]).  Parameter gradients are
-ACCUMULATED IN PLACE into `param.grad` by the backward kernels (atomicAdd, "+=" semantics, the
-buffer is created zero-filled when missing) and the autograd edge of a parameter returns None --
-the same contract as Megatron's fused gradient accumulation.  `loss.backward()` therefore fills
-`.grad` exactly like the reference; `torch.autograd.grad(..., params)` is not supported.
+Layout: activations are fp32 NHWC ("image layout" rows [B*H*W, C]).  Parameter gradients, two modes (`_ParamGrads`):
+  * default, IN PLACE: the backward kernels accumulate into `param.grad` (atomicAdd, "+=" semantics, the buffer is created
+    zero-filled when missing) and the autograd edge of a parameter returns None -- the same contract as Megatron's fused gradient
+    accumulation.  `loss.backward()` fills `.grad` exactly like the reference; the AccumulateGrad node of a parameter still runs
+    (with an undefined gradient) AFTER every kernel that writes its `.grad` has been enqueued, so its post hooks -- what
+    torch.nn.parallel.DistributedDataParallel reduces from -- see the finished buffer.  `torch.autograd.grad(..., params)` is
+    not supported in this mode.
+  * AUTOGRAD-VISIBLE (`set_autograd_visible_grads(True)` / SAST_AUTOGRAD_GRADS=1): every backward call accumulates into a fresh
+    zero-filled buffer (one allocation + one fill per call for all its parameters) and RETURNS it on the parameter's autograd
+    edge, so AccumulateGrad, tensor hooks, `torch.autograd.grad` and anything else that expects ordinary autograd gradients work;
+    with `zero_grad(set_to_none=True)` AccumulateGrad adopts the buffer without a copy.  `dist.FlatParams` (TrainStep) needs the
+    in-place mode.
 
 There is no CPU implementation: every op raises if its tensors are not on a HIP device.
 """
@@ -42,6 +49,16 @@ def _fill(struct, **kw):
     return struct
 
 
+AUTOGRAD_GRADS = os.environ.get("SAST_AUTOGRAD_GRADS", "0") == "1"
+
+
+def set_autograd_visible_grads(on: bool = True) -> bool:
+    """switch between the two parameter-gradient modes of the header (process-wide); returns the previous setting"""
+    global AUTOGRAD_GRADS
+    prev, AUTOGRAD_GRADS = AUTOGRAD_GRADS, bool(on)
+    return prev
+
+
 def _gbuf(p: Optional[torch.Tensor]):
     """gradient accumulation buffer of a parameter (created zero-filled with the parameter's strides)."""
     if p is None or not p.requires_grad:
@@ -56,6 +73,8 @@ def _gbuf(p: Optional[torch.Tensor]):
 
 _SCRATCH_KEEP = collections.deque()
 _SCRATCH_KEEP_BYTES = 64 << 20     # a few launches' worth: same-stream reuse by the caching allocator is safe once the launch is enqueued
+_SCRATCH_KEEP_MAX = 512            # ... and a bound on the entries: the usual customers are 256 B ... 1 KB vectors
+_scratch_bytes = 0
 
 
 def _scratch_grad(p: torch.Tensor):
@@ -64,20 +83,72 @@ def _scratch_grad(p: torch.Tensor):
     the launch is handed out again by the caching allocator -- to the next parameter's freshly created `.grad`, which the kernel would
     then corrupt through the stale pointer (found with the attention_bias=False fixture).  Call sites hold their scratch buffers in a
     local until the launch is enqueued (that alone is sufficient: the caching allocator only re-uses the memory on the same stream,
-    behind the launch); as a second line of defence the most recent ones are also kept alive here, bounded by BYTES so that a model
-    with large frozen weights (fine-tuning on a frozen backbone) does not pin hundreds of MB for the life of the process."""
+    behind the launch); as a second line of defence the most recent ones are also kept alive here, bounded by BYTES (a model with
+    large frozen weights must not pin hundreds of MB for the life of the process) and by COUNT (thousands of tiny vectors would make
+    every call walk a long queue and pin as many allocator blocks)."""
+    global _scratch_bytes
     t = torch.zeros_like(p)
     _SCRATCH_KEEP.append(t)
-    total = sum(x.numel() * x.element_size() for x in _SCRATCH_KEEP)
-    while len(_SCRATCH_KEEP) > 1 and total > _SCRATCH_KEEP_BYTES:
+    _scratch_bytes += t.numel() * t.element_size()
+    while len(_SCRATCH_KEEP) > 1 and (_scratch_bytes > _SCRATCH_KEEP_BYTES or len(_SCRATCH_KEEP) > _SCRATCH_KEEP_MAX):
         old = _SCRATCH_KEEP.popleft()
-        total -= old.numel() * old.element_size()
+        _scratch_bytes -= old.numel() * old.element_size()
     return t
 
 
 def _g(p):
     g = _gbuf(p)
     return g if g is not None else (_scratch_grad(p) if p is not None else None)
+
+
+def _like_view(flat: torch.Tensor, p: torch.Tensor):
+    """`flat` (1-D, p.numel() elements) seen with p's shape AND strides (dense contiguous or channels-last 4-D), else None"""
+    if p.is_contiguous():
+        return flat.view(p.shape)
+    if p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous():
+        co, ci, kh, kw = p.shape
+        return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+    return None
+
+
+class _ParamGrads:
+    """the parameter gradients of ONE Function.backward call: `pg[i]` is the buffer the kernels accumulate parameter i's gradient into
+    (None for a None parameter), `pg.out()` what the call returns on the parameters' autograd edges.
+    In-place mode: `p.grad` (created zero-filled) / None.  Autograd-visible mode: views of ONE fresh zero-filled allocation / the same
+    views (AccumulateGrad adopts or adds them).  Frozen parameters and non-parameter stand-ins (resident zero biases) get a throw-away
+    buffer and return None in both modes.  The object holds every buffer until the caller drops it behind the launch."""
+
+    def __init__(self, *params):
+        self.bufs, self.ret = [], []
+        if not AUTOGRAD_GRADS:
+            for p in params:
+                self.bufs.append(_g(p))
+                self.ret.append(None)
+            return
+        live = [p for p in params if p is not None and p.requires_grad]
+        n = sum((p.numel() + 3) // 4 * 4 for p in live)
+        flat = torch.zeros(n, device=live[0].device, dtype=torch.float32) if live else None
+        off = 0
+        for p in params:
+            if p is None:
+                self.bufs.append(None)
+                self.ret.append(None)
+            elif not p.requires_grad:
+                self.bufs.append(_scratch_grad(p))
+                self.ret.append(None)
+            else:
+                v = _like_view(flat[off:off + p.numel()], p) if p.dtype == torch.float32 else None
+                if v is None:
+                    v = torch.zeros_like(p)
+                off += (p.numel() + 3) // 4 * 4
+                self.bufs.append(v)
+                self.ret.append(v)
+
+    def __getitem__(self, i):
+        return self.bufs[i]
+
+    def out(self):
+        return tuple(self.ret)
 
 
 def _consume(ctx, what: str):
@@ -294,11 +365,12 @@ class _DownsampleLN(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         ws = torch.empty(conv_out.numel(), device=x.device)
+        pg = _ParamGrads(w, ln_w, ln_b)
         a = _fill(L.SastDownArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, factor=factor, x=x, w=w, ln_w=ln_w, ln_b=ln_b,
-                  conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=_g(w), d_ln_w=_g(ln_w), d_ln_b=_g(ln_b), ws=ws,
+                  conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=pg[0], d_ln_w=pg[1], d_ln_b=pg[2], ws=ws,
                   x_dtype=xdt, no_overlap=no_overlap)
         L.check(L.lib().sast_downsample_ln_bwd(C.byref(a), _stream()), "downsample_ln_bwd")
-        return dx, None, None, None, None, None
+        return (dx,) + pg.out() + (None, None)
 
 
 def downsample_ln(x_nhwc, w, ln_w, ln_b, pe, factor):
@@ -325,9 +397,10 @@ class _MaskToken(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
         Cc = dy.shape[-1]
-        L.check(L.lib().sast_mask_token_bwd(dy.data_ptr(), m.data_ptr(), dx.data_ptr(), _g(ctx.token).data_ptr(), dy.numel() // Cc, Cc, _stream()),
+        pg = _ParamGrads(ctx.token)
+        L.check(L.lib().sast_mask_token_bwd(dy.data_ptr(), m.data_ptr(), dx.data_ptr(), pg[0].data_ptr(), dy.numel() // Cc, Cc, _stream()),
                 "mask_token_bwd")
-        return dx, None, None, None
+        return dx, None, pg.out()[0], None
 
 
 def mask_token(x_nhwc, token_mask, token, pos_emb_table=None):
@@ -372,10 +445,11 @@ class _ScoreSTP(torch.autograd.Function):
         dxw = dxw.contiguous()
         dxp = torch.empty_like(xp)
         ws = torch.empty(B * Lt * Cc + B * Cc, device=xp.device)
+        pg = _ParamGrads(ws_w, ws_b, wc)
         a = _fill(L.SastScoreArgs(), B=B, L=Lt, C=Cc, r_stride=r.stride(0), amp=amp, xp=xp, r=r, ws_w=ws_w, ws_b=ws_b, wc=wc,
-                  scale=scale, s=s, dxw=dxw, dxp=dxp, d_ws_w=_g(ws_w), d_ws_b=_g(ws_b), d_wc=_g(wc), ws=ws, dscale_ws=dscale)
+                  scale=scale, s=s, dxw=dxw, dxp=dxp, d_ws_w=pg[0], d_ws_b=pg[1], d_wc=pg[2], ws=ws, dscale_ws=dscale)
         L.check(L.lib().sast_score_stp_bwd(C.byref(a), _stream()), "score_stp_bwd")
-        return dxp, None, None, None, None, None
+        return (dxp, None) + pg.out() + (None,)
 
 
 def score_stp(xp, r, ws_w, ws_b, wc, amp) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -591,7 +665,7 @@ _FUSED_MIN_ROWS = int(os.environ.get("SAST_MSWSA_FUSED_MIN_ROWS", "49152"))
 
 class _MSWSA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, mlp_act, drop, *params):
+    def forward(ctx, xin, sel: Selection, eps, cb_tps, dim_head, fused, mlp_act, drop, grad_on, *params):
         _need_gpu(xin)
         xin = xin.contiguous()
         p = dict(zip(_MSWSA_PARAMS, params))
@@ -624,7 +698,9 @@ class _MSWSA(torch.autograd.Function):
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
         fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and drop is None and drop_mlp is None and R >= _FUSED_MIN_ROWS) else 0
-        needs_bwd = any(ctx.needs_input_grad)      # (grad mode is off inside Function.forward: ask the context)
+        # a backward can follow: grad mode was on at the call (it is always off inside Function.forward, and `needs_input_grad` says
+        # True for trainable parameters under torch.no_grad() too -- `mswsa` samples the mode) and some input wants a gradient
+        needs_bwd = bool(grad_on) and any(ctx.needs_input_grad)
         fws = None
         if fused_floats:
             fws = torch.empty(fused_floats, device=dev)
@@ -696,10 +772,10 @@ class _MSWSA(torch.autograd.Function):
             _fill(a, cb_tps=ctx.cb_tps, cb_m=cb_m, cb_sum=cb_sum)
         sel.fill_struct(a.sel)
         _fill(a, **{k: _ptr(v) for k, v in p.items()})
-        grads = {k: _g(v) for k, v in p.items()}          # held until the launch is enqueued (scratch buffers among them)
-        _fill(a, **{"d_" + k: _ptr(v) for k, v in grads.items()})
+        pg = _ParamGrads(*params)                          # held until the launch is enqueued (scratch buffers among them)
+        _fill(a, **{"d_" + k: _ptr(pg[i]) for i, k in enumerate(_MSWSA_PARAMS)})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
-        return (dxin, None, None, None, None, None, None, None) + (None,) * len(params)
+        return (dxin, None, None, None, None, None, None, None, None) + pg.out()
 
 
 GLU_ACTIVATIONS = {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4}     # include/sast_hip.h: SastMswsaArgs.mlp_act
@@ -721,7 +797,7 @@ def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: i
     if mlp_activation not in GLU_ACTIVATIONS:
         raise NotImplementedError(f"sast_amd: mlp_activation {mlp_activation!r}: the GLU epilogues implement {sorted(GLU_ACTIVATIONS)}")
     return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), GLU_ACTIVATIONS[mlp_activation],
-                        drop_path, *[params[k] for k in _MSWSA_PARAMS])
+                        drop_path, torch.is_grad_enabled(), *[params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12
@@ -769,10 +845,11 @@ class _LSTM(torch.autograd.Function):
         dh0 = torch.empty_like(x) if need_h else None
         dc0 = torch.empty_like(x) if need_c else None
         ws = torch.empty(B * Lt * 4 * Cc, device=x.device)
+        pg = _ParamGrads(w, b)
         a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, c1=c1, gates=gates, dh1=dh1,
-                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=_g(w), db=_g(b), ws=ws, dh1b=_ptr(dh1b), drop=_ptr(drop))
+                  dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=pg[0], db=pg[1], ws=ws, dh1b=_ptr(dh1b), drop=_ptr(drop))
         L.check(L.lib().sast_lstm_bwd(C.byref(a), _stream()), "lstm_bwd")
-        return dx, dh0, dc0, None, None, None
+        return (dx, dh0, dc0) + pg.out() + (None,)
 
 
 def conv_lstm(x_nhwc, h0, c0, w, b, two_h=False, drop_mask=None):
@@ -810,11 +887,12 @@ class _DwConv(torch.autograd.Function):
         k = w.shape[-1]
         dy = dy.contiguous()
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        gw = _g(w)
-        gb = _g(b) if b is not None else torch.zeros(w.shape[0], device=x.device)
+        pg = _ParamGrads(w, b)
+        gw = pg[0]
+        gb = pg[1] if b is not None else torch.zeros(w.shape[0], device=x.device)
         L.check(L.lib().sast_dwconv_bwd(x.data_ptr(), w.data_ptr() + 4 * c0 * k * k, dy.data_ptr(), _ptr(dx), gw.data_ptr() + 4 * c0 * k * k,
                                         gb.data_ptr() + 4 * c0, B, H, W, Cc, k, _stream()), "dwconv_bwd")
-        return dx, None, None, None
+        return (dx,) + pg.out() + (None,)
 
 
 def dwconv(x_nhwc: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], c0: int = 0) -> torch.Tensor:
@@ -842,17 +920,26 @@ class BnHandle:
 class SyncBatchNormGroup:
     """SyncBatchNorm for the conv + BatchNorm + SiLU units: the reference trains with `sync_batchnorm=True` whenever it runs DDP
     (train.py:167 -> torch.nn.SyncBatchNorm: batch statistics over the rows of ALL ranks, affine gradients local).  One object is shared
-    by the BaseConvs of a model (`sast_amd.detection.convert_sync_batchnorm`); the C entry points are called in two phases around the
-    all-reduces issued here (include/sast_hip.h: SastConvBnArgs.sync_phase).  On the RCCL backend ("nccl") the statistics all-reduces
-    are captured INTO the step's hipGraph like any kernel node (`capturable()`, training.TrainStep.capture); a host-side backend (gloo:
-    plumbing tests) cannot be captured and runs its PAFPN / head eagerly.  `force=True` keeps the two-phase path on with ONE rank (the
-    all-reduce is then the identity): the captured path can be exercised on a single GPU."""
+    by the BaseConvs of a model (`sast_amd.detection.convert_sync_batchnorm`, or found from the `torch.nn.SyncBatchNorm` modules that
+    `torch.nn.SyncBatchNorm.convert_sync_batchnorm` / Lightning's `Trainer(sync_batchnorm=True)` left behind: `sync_group_for`); the C
+    entry points are called in two phases around the all-reduces issued here (include/sast_hip.h: SastConvBnArgs.sync_phase).  On the
+    RCCL backend ("nccl") the statistics all-reduces are captured INTO the step's hipGraph like any kernel node (`capturable()`,
+    training.TrainStep.capture); a host-side backend (gloo: plumbing tests) cannot be captured and runs its PAFPN / head eagerly.
+    `force=True` keeps the two-phase path on with ONE rank (the all-reduce is then the identity): the captured path can be exercised on
+    a single GPU.
+
+    Communicator: on RCCL the statistics all-reduces run on a PRIVATE communicator over the same ranks (`dist.new_group`, created at the
+    first collective, which every rank reaches at the same point of the same model code).  The gradient buckets of the segmented step
+    are all-reduced eagerly on a side stream WHILE the captured statistics all-reduces of the next segment replay on the main stream;
+    two collectives in flight on ONE communicator from two streams have no defined order across ranks (hang or mixed-up sums), on two
+    communicators they are independent."""
 
     def __init__(self, process_group=None, force: bool = False):
         import torch.distributed as dist
         self.dist, self.group = dist, process_group
         self._world = None          # resolved on first use: convert_sync_batchnorm may run before init_process_group
         self._ratio = None
+        self._comm = None           # the communicator the statistics travel on (see the class docstring); False = use self.group
         self.force = bool(force)
         self.n_collectives = 0
 
@@ -874,34 +961,49 @@ class SyncBatchNormGroup:
             return True
         return self.dist.get_backend(self.group) == "nccl"
 
+    def communicator(self):
+        """the process group the statistics all-reduces are issued on (created once, at the first eager collective)"""
+        if self._comm is None:
+            d = self.dist
+            if d.get_backend(self.group) == "nccl":
+                if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("sast_amd: SyncBatchNormGroup needs one eager pass before a hipGraph capture (it creates the "
+                                       "private RCCL communicator of the statistics all-reduces)")
+                ranks = d.get_process_group_ranks(self.group if self.group is not None else d.group.WORLD)
+                self._comm = d.new_group(ranks=ranks, backend="nccl", use_local_synchronization=True)
+            else:
+                self._comm = False
+        return self.group if self._comm is False else self._comm
+
     def exchange_batch(self, n_local: int, device):
         """once per pass over a model: every BatchNorm of the pass sees rows = samples * H_out * W_out, so the rows of all ranks follow
         from the SAMPLE counts (they differ between ranks when a step keeps only the labelled samples, modules/detection.py:161-171).
         Inside a stream capture the counts are those of the eager pass that preceded it: a replayed graph has static shapes on every
-        rank, and reading the sum back is a host synchronisation a capture does not allow."""
+        rank, and reading the sum back is a host synchronisation a capture does not allow.
+        -> the pass token (group, local samples): the PAFPN tags its outputs with it, and a head that is handed those very tensors takes
+        the exchange over (`same_pass`) instead of repeating it."""
         if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
             if self._ratio is None or self._ratio[1] != int(n_local):
                 raise RuntimeError("sast_amd: SyncBatchNormGroup inside a hipGraph capture needs one eager pass with the same per-rank "
                                    "batch first (it fixes the sample counts of all ranks)")
-            self._fresh = True
-            return
+            return (self, int(n_local))
         if self.world > 1:
             t = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
-            self.dist.all_reduce(t, group=self.group)
+            self.dist.all_reduce(t, group=self.communicator())
             self.n_collectives += 1
             total = int(round(float(t.item())))
         else:
             total = int(n_local)
         self._ratio = (total, int(n_local))
-        self._fresh = True
+        return (self, int(n_local))
 
-    def reuse_batch(self, n_local: int) -> bool:
-        """the YOLOX head runs right behind the PAFPN on the same samples: it takes over the PAFPN's sample-count exchange of this pass
-        (one host sync less per step).  True = taken over; every rank takes the same branch (same model code, same call order)."""
-        if getattr(self, "_fresh", False) and self._ratio is not None and self._ratio[1] == int(n_local):
-            self._fresh = False
-            return True
-        return False
+    def same_pass(self, x) -> bool:
+        """the YOLOX head runs right behind the PAFPN: when its input IS a tensor the PAFPN tagged in this pass (`_sast_sync_pass`), the
+        sample counts of all ranks are the ones already exchanged -- one host sync less per step.  The decision depends on the model code
+        only (is the head fed the PAFPN's outputs directly?), never on a rank's data, so every rank takes the same branch; a head fed
+        anything else (re-batched, filtered, or through a layout wrapper that made new tensor objects) does its own exchange."""
+        tok = getattr(x, "_sast_sync_pass", None)
+        return tok is not None and tok[0] is self and self._ratio is not None and tok[1] == self._ratio[1] == int(x.shape[0])
 
     def rows_total(self, m_local: int, batch_local: int) -> int:
         if self._ratio is None or self._ratio[1] != batch_local:
@@ -910,8 +1012,21 @@ class SyncBatchNormGroup:
 
     def all_reduce(self, t):
         if self.dist.is_initialized():
-            self.dist.all_reduce(t, group=self.group)
+            self.dist.all_reduce(t, group=self.communicator())
         self.n_collectives += 1
+
+
+_SYNC_GROUPS = {}
+
+
+def sync_group_for(process_group=None) -> SyncBatchNormGroup:
+    """the SyncBatchNormGroup standing for `torch.nn.SyncBatchNorm(process_group=...)` modules: one per process group, shared by
+    every unit whose BatchNorm was converted by torch (`torch.nn.SyncBatchNorm.convert_sync_batchnorm`, train.py:167)"""
+    key = id(process_group) if process_group is not None else None
+    g = _SYNC_GROUPS.get(key)
+    if g is None:
+        g = _SYNC_GROUPS[key] = SyncBatchNormGroup(process_group)
+    return g
 
 
 def _bn_ws_blocks(bn_ws, Cout):
@@ -1000,10 +1115,11 @@ class _ConvBnSilu(torch.autograd.Function):
                 pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
                            pre + "bn_ws": h.bn_ws})
         own = ctx.handle
+        pg = _ParamGrads(w, bn_w, bn_b)
         a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
                   ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
-                  eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=_g(w),
-                  d_bn_w=_g(bn_w), d_bn_b=_g(bn_b), bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2),
+                  eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=pg[0],
+                  d_bn_w=pg[1], d_bn_b=pg[2], bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2),
                   groups=ctx.groups, **pk)
         if ctx.sync is not None:
             sync, m_total = ctx.sync
@@ -1016,7 +1132,7 @@ class _ConvBnSilu(torch.autograd.Function):
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 15
+        return (dx, dx2) + pg.out() + (None,) * 12
 
 
 def _conv_groups(w, cin: int, x2=None) -> int:
@@ -1102,16 +1218,18 @@ class _ConvBnSilu2(torch.autograd.Function):
                 pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
                            pre + "bn_ws": h.bn_ws})
         h0, h1 = ctx.handles
+        pg = _ParamGrads(w0, bnw0, bnb0, w1, bnw1, bnb1)
         a = _fill(L.SastConvBn2Args(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ldx=Cin1, Cin1=Cin1, ldx2=Cin - Cin1, bn_ws_zeroed=1, training=1, ksize=ksize,
                   bn_red_done0=int(h0.red_done), bn_red_done1=int(h1.red_done), momentum0=mom0, momentum1=mom1, eps0=eps0, eps1=eps1,
                   x=x, x2=_ptr(x2), w0=w0, w1=w1, bn_w0=bnw0, bn_w1=bnw1, bn_b0=bnb0, bn_b1=bnb1, conv_out0=co0, conv_out1=co1,
-                  stats0=st0, stats1=st1, bn_ws0=ws0, bn_ws1=ws1, dy0=dy0, dy1=dy1, dw0=_g(w0), dw1=_g(w1), d_bn_w0=_g(bnw0),
-                  d_bn_w1=_g(bnw1), d_bn_b0=_g(bnb0), d_bn_b1=_g(bnb1), ws0=dws, dx=_ptr(dx), dx2=_ptr(dx2), **pk)
+                  stats0=st0, stats1=st1, bn_ws0=ws0, bn_ws1=ws1, dy0=dy0, dy1=dy1, dw0=pg[0], dw1=pg[3], d_bn_w0=pg[1],
+                  d_bn_w1=pg[4], d_bn_b0=pg[2], d_bn_b1=pg[5], ws0=dws, dx=_ptr(dx), dx2=_ptr(dx2), **pk)
         L.check(L.lib().sast_conv_bn_silu2_bwd(C.byref(a), _stream()), "conv_bn_silu2_bwd")
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True
-        return (dx, dx2) + (None,) * 19
+        g = pg.out()        # forward(ctx, x, x2, w0, bnw0, bnb0, rm0, rv0, w1, bnw1, bnb1, rm1, rv1, ... 9 more)
+        return (dx, dx2) + g[0:3] + (None, None) + g[3:6] + (None,) * 11
 
 
 @torch.no_grad()
@@ -1420,13 +1538,13 @@ class _HeadPredLoss(torch.autograd.Function):
             rf, cf = feats[2 * k], feats[2 * k + 1]
             w_reg, b_reg, w_obj, b_obj, w_cls, b_cls = ctx.params[k]
             drf, dcf = torch.empty_like(rf), torch.empty_like(cf)
-            gp = [_g(t) for t in (w_reg, b_reg, w_obj, b_obj, w_cls, b_cls)]      # held until the launch is enqueued
+            gp = _ParamGrads(w_reg, b_reg, w_obj, b_obj, w_cls, b_cls)      # held until the launch is enqueued
             L.check(L.lib().sast_head_pred_bwd(draw.data_ptr(), rf.data_ptr(), cf.data_ptr(), w_reg.data_ptr(), w_obj.data_ptr(), w_cls.data_ptr(),
                                                drf.data_ptr(), dcf.data_ptr(), gp[0].data_ptr(), gp[1].data_ptr(), gp[2].data_ptr(),
                                                gp[3].data_ptr(), gp[4].data_ptr(), gp[5].data_ptr(), B, int(h), int(w), hid,
                                                num_classes, off, A, _stream()), "head_pred_bwd")
             off += int(h) * int(w)
-            grads += [drf, dcf, None, None, None, None, None, None]
+            grads += [drf, dcf] + list(gp.out())
         return tuple(grads)
 
 

@@ -28,6 +28,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as SF
+from .detection.network_blocks import pass_sync_group
 from .dist import FlatParams, FusedAdamW, OneCycleLR
 
 
@@ -217,7 +218,7 @@ class TrainStep:
         world > 1: one graph for forward + backward, all-reduce + update behind it."""
         self.flat.check_views()
         for m in (self.fpn, self.head):
-            grp = getattr(m, "_sync_group", None)
+            grp = pass_sync_group(m) if m is not None else None
             if grp is not None and grp.active() and not grp.capturable():
                 raise RuntimeError("sast_amd.TrainStep.capture: the model was converted with convert_sync_batchnorm and the process group's "
                                    f"backend ({dist.get_backend(grp.group)}) runs its collectives on the host; the statistics all-reduces "

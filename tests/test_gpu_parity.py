@@ -1939,6 +1939,174 @@ def test_sync_batchnorm_two_ranks_match_whole_batch(dev, tmp_path, split):
     print(r.stdout[-300:])
 
 
+_DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from oracle import sast_oracle as O                      # the checker: backbone + PAFPN on the CONCATENATED batch of both ranks
+from sast_amd import functional as SF
+from sast_amd.detection import RNNDetector, YOLOPAFPN, BaseConv
+from test_gpu_parity import load_params, _rcfg
+from parity_helpers import net_grads_close, GRAD_RTOL
+dist.init_process_group("gloo")                          # two ranks sharing the one GPU of the box: the wrapper's collectives are what is tested
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+SF.set_autograd_visible_grads(sys.argv[2] == "visible")
+SF._FUSED_MIN_ROWS = 0
+hw, part, E, chans, per = (128, 160), (4, 5), 32, (64, 128, 256), 2
+ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+params = O.init_backbone_params(ocfg, seed=3, ls_init=0.5)
+fparams = O.init_pafpn_params(chans, seed=4)
+class Model(torch.nn.Module):                            # what Module.training_step drives (modules/detection.py:141-177), one timestep
+    def __init__(self):
+        super().__init__()
+        self.net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5))
+        self.fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans)
+    def forward(self, x):
+        out, _states, _P = self.net(x)
+        return self.fpn(out)
+model = Model().to(dev)
+load_params(model.net, params)
+load_params(model.fpn, fparams)
+model.train()
+# the reference's own caller, in its order: Trainer(sync_batchnorm=True) converts (train.py:166-167), then the strategy wraps
+# (train.py:96-98: DDPStrategy(find_unused_parameters=False, gradient_as_bucket_view=True))
+model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+assert all(isinstance(m.bn, torch.nn.SyncBatchNorm) for m in model.modules() if isinstance(m, BaseConv))
+ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=False, gradient_as_bucket_view=True)
+worst = 0.0
+for it, set_to_none in enumerate((True, True, False)):   # Lightning's optimizer.zero_grad() default, then grads zeroed in place (bucket views)
+    ddp.zero_grad(set_to_none=set_to_none)
+    full = O.count_events(world * per, hw, seed=10 + it, density=0.05)
+    x = full[rank * per:(rank + 1) * per].to(dev)
+    outs = ddp(x)
+    sum((o ** 2).mean() for o in outs).backward()
+    torch.cuda.synchronize()
+    grp = model.fpn._sync_group
+    assert grp is not None and grp.active() and grp.world == world, "the torch.nn.SyncBatchNorm modules were not honoured"
+    # the oracle on the whole batch; the objective the ranks minimise together is the MEAN of their local losses (DDP averages)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    fo = {k: (v.clone().requires_grad_(True) if "running" not in k else v.clone()) for k, v in fparams.items()}
+    kinks = {}
+    o_ref, _s, _P = O.backbone(full, None, po, ocfg, kink_log=kinks)
+    f_ref = O.pafpn(o_ref, fo, training=True)
+    loss = 0
+    for r in range(world):
+        loss = loss + sum((o[r * per:(r + 1) * per] ** 2).mean() for o in f_ref) / world
+    loss.backward()
+    for o, r in zip(outs, f_ref):
+        err = float((o.detach().cpu() - r[rank * per:(rank + 1) * per].detach()).abs().max())
+        assert err <= 1e-4, f"rank {rank} it {it} forward: {err:.3e}"
+    named = [("net." + k, v) for k, v in model.net.named_parameters()] + [("fpn." + k, v) for k, v in model.fpn.named_parameters()]
+    assert all(v.grad is not None for _k, v in named)
+    ref = lambda k: (po if k.startswith("net.") else fo)[k[4:]].grad
+    net_grads_close(named, ref, {"net." + k: v for k, v in kinks.items()}, GRAD_RTOL)
+    for k, v in named:
+        if "to_scores" not in k:
+            worst = max(worst, float((v.grad.cpu() - ref(k)).abs().max()) / (float(ref(k).abs().max()) + 1e-30))
+n = grp.n_collectives
+dist.barrier()
+dist.destroy_process_group()
+print(f"ok rank {rank} mode {sys.argv[2]} worst grad err {worst:.2e} sync collectives {n}")
+"""
+
+
+@pytest.mark.parametrize("mode", ["inplace", "visible"])
+def test_reference_ddp_caller_with_sync_batchnorm(dev, tmp_path, mode):
+    """the reference's multi-GPU caller on these modules, unchanged (train.py:96-98,166-167): `torch.nn.SyncBatchNorm.convert_sync_batchnorm`
+    (what Trainer(sync_batchnorm=True) runs), then `torch.nn.parallel.DistributedDataParallel(find_unused_parameters=False,
+    gradient_as_bucket_view=True)` around backbone + PAFPN; two ranks (gloo, sharing the GPU) with two samples each, three iterations
+    (zero_grad with set_to_none True, True, False -- the last one zeroes the DDP bucket views in place).  After every backward each rank's
+    `.grad` must be the gradient of the MEAN of the ranks' losses with BatchNorm statistics over ALL four samples = the oracle on the
+    concatenated batch: outputs <= 1e-4, every parameter gradient <= 3e-4 (scoring layer kink-aware).
+    "inplace": the default gradient contract (kernels accumulate into `.grad`, DDP's AccumulateGrad hooks fire behind them);
+    "visible": `set_autograd_visible_grads(True)` (gradients returned on the autograd edges)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29751" if mode == "inplace" else "29752", str(script), root, mode],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok rank") == 2, r.stdout[-2000:]
+    print(r.stdout[-400:])
+
+
+def test_autograd_visible_parameter_gradients_match_in_place(dev):
+    """`set_autograd_visible_grads(True)`: every backward returns its parameter gradients on the autograd edges instead of accumulating
+    into `.grad` -- `torch.autograd.grad(loss, params)` works and equals what the in-place contract leaves in `.grad` (same kernels, same
+    accumulation order up to atomics), through backbone + PAFPN + YOLOX head (every Function with parameters)."""
+    from sast_amd import functional as SF
+    from sast_amd.detection import RNNDetector, YOLOPAFPN, YOLOXHead
+    hw, part, E, chans = (128, 160), (4, 5), 32, (64, 128, 256)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev).train()
+    head = YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=chans).to(dev).train()
+    load_params(net, O.init_backbone_params(ocfg, seed=3, ls_init=0.5))
+    load_params(fpn, O.init_pafpn_params(chans, seed=4))
+    load_params(head, O.init_head_params(chans, num_classes=3, seed=9))
+    x = O.count_events(2, hw, seed=1, density=0.05).to(dev)
+    labels = O.synthetic_labels(2, hw, 3, max_labels=6, seed=11)
+    labels[:, 0, :] = torch.tensor([1.0, 100.0, 90.0, 60.0, 50.0])
+    labels = labels.to(dev)
+    params = [p for m in (net, fpn, head) for p in m.parameters()]
+
+    def loss_of():
+        out, _st, _P = net(x)
+        _pred, losses = head(fpn(out), labels)
+        return losses["loss"]
+
+    prev = SF.set_autograd_visible_grads(False)
+    try:
+        loss_of().backward()
+        ref = [p.grad.clone() for p in params]
+        for p in params:
+            p.grad = None
+        SF.set_autograd_visible_grads(True)
+        got = torch.autograd.grad(loss_of(), params)
+        assert all(p.grad is None for p in params)          # nothing was written behind autograd's back
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert g.stride() == params[i].stride()
+            maxnorm_close(g, r, 2e-5, f"param {i}")
+        loss_of().backward()                                # and the ordinary way: AccumulateGrad adopts the returned buffers
+        for i, (p, r) in enumerate(zip(params, ref)):
+            maxnorm_close(p.grad, r, 2e-5, f"param {i} (.grad)")
+    finally:
+        SF.set_autograd_visible_grads(prev)
+
+
+def test_fused_forward_under_no_grad_takes_the_inference_form(dev):
+    """torch.no_grad() around a TRAINABLE model (validation of a model in training, bench.py --fwd-only): `needs_input_grad` still says
+    True for the parameters, the grad mode decides -- the one-kernel MS-WSA forward must then write nothing but its output (no saved
+    activations are allocated) and return the same values as under grad mode."""
+    from sast_amd import functional as SF
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    torch.manual_seed(0)
+    B, H, W, C = 2, 48, 80, 64
+    blk = SAST_block(C, attn_cfg((6, 10), 2e-4), first_block=True).to(dev)
+    pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    x = torch.randn(B, H, W, C, device=dev)
+    r = torch.rand(B, 20, device=dev) * 0.05
+    assert SF._FUSED_MIN_ROWS == 0 and blk.fused_forward
+    y_train, _p, _l = blk(x, pe, r, None)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        y_eval, _p, _l = blk(x, pe, r, None)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    maxnorm_close(y_eval, y_train.detach(), 1e-6, "inference form vs training form")
+    rows = B * H * W
+    saved = 4 * rows * (6 * C + 3 * blk.win_attn.mlp.inner_dim)     # what one training-form layer saves for its backward
+    assert peak < saved, (peak, saved)                      # (the inference form allocates xw, two outputs, scores: ~5 * rows * C floats)
+
+
 @pytest.mark.parametrize("hw,raw,B", [((128, 160), (120, 152), 2), ((384, 640), (360, 640), 2)])
 def test_stem_reads_uint8_event_tensor(dev, hw, raw, B):
     """the dataset stores uint8 counts (data/genx_utils/sequence_base.py:88-98); the reference pads and `.float()`s them

@@ -340,10 +340,75 @@ def test_sync_batchnorm_group_forced_and_capturable():
     assert f.active() and f.world == 1 and f.capturable()
     f.exchange_batch(3, torch.device("cpu"))
     assert f.n_collectives == 0 and f.rows_total(3 * 8 * 10, 3) == 3 * 8 * 10
-    assert f.reuse_batch(3) and not f.reuse_batch(3)       # the head takes over the PAFPN's exchange once per pass
+    tok = f.exchange_batch(3, torch.device("cpu"))
+    x, y = torch.zeros(3, 2), torch.zeros(3, 2)
+    x._sast_sync_pass = tok                                # the PAFPN tags its outputs with the pass token ...
+    assert f.same_pass(x) and not f.same_pass(y)           # ... and only a head handed THOSE tensors takes the exchange over
+    assert not SyncBatchNormGroup(force=True).same_pass(x)  # (another group's token does not count)
     t = torch.ones(4, dtype=torch.float64)
     f.all_reduce(t)                                        # no process group: the identity, but counted
     assert f.n_collectives == 1 and torch.equal(t, torch.ones(4, dtype=torch.float64))
+
+
+def test_torch_sync_batchnorm_conversion_is_honoured_not_silently_local():
+    """the reference's own caller: Lightning's Trainer(sync_batchnorm=True) runs torch.nn.SyncBatchNorm.convert_sync_batchnorm on the model
+    before DDP wraps it (train.py:166-167).  That swaps BaseConv.bn for a torch.nn.SyncBatchNorm the fused op never calls; the units
+    must then take their statistics over the ranks of that module's process group (one shared SyncBatchNormGroup per process group), the
+    reduction scratch must still be sized (SyncBatchNorm is not a BatchNorm2d), and the state_dict keys must not move."""
+    from sast_amd.detection import YOLOPAFPN, YOLOXHead, BaseConv
+    from sast_amd.detection.network_blocks import pass_sync_group, sync_active, bn_scratch_floats
+    from sast_amd.functional import SyncBatchNormGroup
+    fpn = YOLOPAFPN(depth=0.33, in_stages=(2, 3, 4), in_channels=(16, 32, 64))
+    head = YOLOXHead(num_classes=2, strides=(8, 16, 32), in_channels=(16, 32, 64))
+    both = torch.nn.ModuleList([fpn, head])
+    keys = list(both.state_dict().keys())
+    floats = bn_scratch_floats(fpn)
+    assert pass_sync_group(fpn) is None and floats > 0
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(both)
+    assert conv is both and list(both.state_dict().keys()) == keys
+    units = [m for m in both.modules() if isinstance(m, BaseConv)]
+    assert all(isinstance(m.bn, torch.nn.SyncBatchNorm) and m.sync_bn is None for m in units)
+    assert bn_scratch_floats(fpn) == floats
+    g = pass_sync_group(fpn)
+    assert isinstance(g, SyncBatchNormGroup) and pass_sync_group(head) is g and fpn._sync_group is g
+    assert all(m.sync_bn is g for m in units)
+    assert not g.active() and not any(sync_active(m) for m in units)     # one process, no process group: inert like torch's module
+    lone = BaseConv(8, 8, 1, 1)
+    lone.bn = torch.nn.SyncBatchNorm(8)
+    assert lone.sync_group() is g                                        # a unit on its own resolves to the same default-group object
+    half = YOLOPAFPN(depth=0.33, in_stages=(2, 3, 4), in_channels=(16, 32, 64))
+    half.lateral_conv0.bn = torch.nn.SyncBatchNorm(32)
+    with pytest.raises(RuntimeError, match="only some"):
+        pass_sync_group(half)
+
+
+def test_param_grads_modes_on_cpu_tensors():
+    """functional._ParamGrads: the in-place contract hands out `p.grad` (created zero-filled, parameter's strides) and returns None on
+    the autograd edge; the autograd-visible mode hands out views of one fresh zero block and returns them; frozen parameters and
+    non-parameter stand-ins accumulate into throw-away buffers in both modes."""
+    from sast_amd import functional as SF
+    w = torch.nn.Parameter(torch.randn(8, 3, 3, 4).permute(0, 3, 1, 2))     # channels-last conv weight
+    b = torch.nn.Parameter(torch.randn(5))
+    frozen = torch.nn.Parameter(torch.randn(6), requires_grad=False)
+    prev = SF.set_autograd_visible_grads(False)
+    try:
+        pg = SF._ParamGrads(w, None, b, frozen)
+        assert pg[0] is w.grad and pg[2] is b.grad and pg[1] is None and pg[3] is not None and frozen.grad is None
+        assert pg[0].stride() == w.stride() and pg.out() == (None, None, None, None)
+        SF.set_autograd_visible_grads(True)
+        w.grad = b.grad = None
+        pg = SF._ParamGrads(w, None, b, frozen)
+        out = pg.out()
+        assert w.grad is None and b.grad is None and out[0] is pg[0] and out[2] is pg[2] and out[1] is None and out[3] is None
+        assert pg[0].shape == w.shape and pg[0].stride() == w.stride() and float(pg[0].abs().sum()) == 0.0
+        assert pg[0].data_ptr() % 16 == 0 and pg[2].data_ptr() % 16 == 0
+        n0 = len(SF._SCRATCH_KEEP)
+        for _ in range(2 * SF._SCRATCH_KEEP_MAX):
+            SF._scratch_grad(frozen)
+        assert len(SF._SCRATCH_KEEP) <= SF._SCRATCH_KEEP_MAX and SF._scratch_bytes == sum(t.numel() * 4 for t in SF._SCRATCH_KEEP)
+        assert n0 <= SF._SCRATCH_KEEP_MAX
+    finally:
+        SF.set_autograd_visible_grads(prev)
 
 
 def test_glu_activation_names():
