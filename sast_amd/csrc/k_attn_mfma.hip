@@ -105,7 +105,7 @@ __device__ __forceinline__ void store_rows_per_lane(float* __restrict__ dst, con
 // ------------------------------------------------------------------ forward
 template <int NTMAX, int NT>
 __device__ __forceinline__ void attn_fwd_body(char* sm, const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
-                                              const int* __restrict__ row_seg, int r0, int K, int C, int heads, int h, float scale, int dh) {
+                                              int r0, int K, int C, int heads, int h, float scale, int dh) {
   constexpr int KT = NT * 32, MAT = 3 * 32 * NTMAX * 64;
   char* Qm = sm;                  // pre-scaled q
   char* Km = sm + MAT;
@@ -121,8 +121,6 @@ __device__ __forceinline__ void attn_fwd_body(char* sm, const float* __restrict_
   }
   __syncthreads();
   if (w >= NT) return;
-  // the rows [0, K) are a PACK of whole groups (SastSel.pack_rows / row_seg): a query attends the keys [klo, khi) of its own group
-  const int seg = row_seg ? row_seg[r0 + min(w * 32 + l31, K - 1)] : (K << 16), klo = seg & 0xffff, khi = seg >> 16;
   // S^T tiles: rows = keys of tile t, column = this lane's query i = 32 w + l31
   f32x16 s[NT];
 #pragma unroll
@@ -142,8 +140,7 @@ __device__ __forceinline__ void attn_fwd_body(char* sm, const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int j = t * 32 + crow(e, lane);
-      const bool kv = j >= klo && j < khi;
-      s[t][e] = kv ? s[t][e] : -INFINITY;
+      s[t][e] = j < K ? s[t][e] : -INFINITY;
       mloc = fmaxf(mloc, s[t][e]);
     }
   const float m = pair_max(mloc);
@@ -153,7 +150,7 @@ __device__ __forceinline__ void attn_fwd_body(char* sm, const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int j = t * 32 + crow(e, lane);
-      const float pt = (j >= klo && j < khi) ? __expf(s[t][e] - m) : 0.f;
+      const float pt = j < K ? __expf(s[t][e] - m) : 0.f;
       s[t][e] = pt;
       ploc += pt;
     }
@@ -174,20 +171,17 @@ __device__ __forceinline__ void attn_fwd_body(char* sm, const float* __restrict_
 template <int NTMAX>
 __global__ __launch_bounds__(64 * NTMAX) void attn_fwd_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                    float* __restrict__ lse, const int* __restrict__ row_off,
-                                                                   const int* __restrict__ pack_rows, const int* __restrict__ row_seg, int C,
-                                                                   int heads, float scale, int dh) {
+                                                                   const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
   __shared__ __attribute__((aligned(16))) char sm[3 * 3 * 32 * NTMAX * 64];
   const int g = blockIdx.x, h = blockIdx.y;
-  // pack_rows: rows of the pack this group leads (0: another group's workgroup serves it, or nothing is kept); with row_seg == NULL it
-  // is the group's own kept-token count K and every group is served alone
-  const int K = pack_rows[g];
+  const int K = Kw[g];       // kept tokens of this group (0: nothing to do)
   if (K == 0) return;
   const int r0 = row_off[g];
   switch ((K + 31) >> 5) {   // block-uniform
-    case 1: attn_fwd_body<NTMAX, 1>(sm, qkv, o, lse, row_seg, r0, K, C, heads, h, scale, dh); break;
-    case 2: attn_fwd_body<NTMAX, 2>(sm, qkv, o, lse, row_seg, r0, K, C, heads, h, scale, dh); break;
-    case 3: if constexpr (NTMAX >= 3) attn_fwd_body<NTMAX, 3>(sm, qkv, o, lse, row_seg, r0, K, C, heads, h, scale, dh); break;
-    case 4: if constexpr (NTMAX >= 4) attn_fwd_body<NTMAX, 4>(sm, qkv, o, lse, row_seg, r0, K, C, heads, h, scale, dh); break;
+    case 1: attn_fwd_body<NTMAX, 1>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+    case 2: attn_fwd_body<NTMAX, 2>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+    case 3: if constexpr (NTMAX >= 3) attn_fwd_body<NTMAX, 3>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
+    case 4: if constexpr (NTMAX >= 4) attn_fwd_body<NTMAX, 4>(sm, qkv, o, lse, r0, K, C, heads, h, scale, dh); break;
   }
 }
 
@@ -196,7 +190,7 @@ __global__ __launch_bounds__(64 * NTMAX) void attn_fwd_mfma_kernel(const float* 
 // Pass A (wave w owns KEY tile w, queries over all tiles; scores in the plain orientation): P, dS -> dV, dK.
 template <int NTMAX, int NT>
 __device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
-                                              const float* __restrict__ lse, float* __restrict__ dqkv, const int* __restrict__ row_seg,
+                                              const float* __restrict__ lse, float* __restrict__ dqkv,
                                               int r0, int K, int C, int heads, int h, float scale, int dh) {
   constexpr int KT = NT * 32, MAT = 3 * 32 * NTMAX * 64;
   char* Qm = sm;                  // pre-scaled q
@@ -220,8 +214,6 @@ __device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict_
   }
   __syncthreads();
   const bool active = w < NT;
-  // pack of whole groups: token 32 w + l31 (a query in pass B, a key in pass A) interacts with the rows [glo, ghi) of its own group
-  const int seg = row_seg ? row_seg[r0 + min(w * 32 + l31, K - 1)] : (K << 16), glo = seg & 0xffff, ghi = seg >> 16;
   f32x16 s[NT], dp[NT];
   if (active) {
     // ---- pass B: S^T[j][i] = K_t Q_w^T, dP^T[j][i] = V_t dO_w^T  (column = query i = 32 w + l31)
@@ -247,7 +239,7 @@ __device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict_
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int jj = t * 32 + crow(e, lane);
-        const float pt = (qv && jj >= glo && jj < ghi) ? __expf(s[t][e] - li) : 0.f;
+        const float pt = (qv && jj < K) ? __expf(s[t][e] - li) : 0.f;
         s[t][e] = pt;
         dloc += pt * dp[t][e];
       }
@@ -290,7 +282,7 @@ __device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int i = t * 32 + crow(e, lane);
-      const float pt = (kv && i >= glo && i < ghi) ? __expf(s[t][e] - lse_s[min(i, 32 * NTMAX - 1)]) : 0.f;
+      const float pt = (kv && i < K) ? __expf(s[t][e] - lse_s[min(i, 32 * NTMAX - 1)]) : 0.f;
       s[t][e] = pt;                                   // P
       dp[t][e] = pt * (dp[t][e] - D_s[i]);            // dS
     }
@@ -319,7 +311,7 @@ __device__ __forceinline__ void attn_bwd_body(char* sm, const float* __restrict_
 // the threads.  Same arithmetic in the same order per output element as attn_bwd_body: results are identical.
 template <int NTMAX, int NT>
 __device__ __forceinline__ void attn_bwd_body_split(char* sm, const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                    const float* __restrict__ lse, float* __restrict__ dqkv, const int* __restrict__ row_seg,
+                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
                                                     int r0, int K, int C, int heads, int h, float scale, int dh) {
   constexpr int KT = NT * 32, MAT = 3 * 32 * NTMAX * 64, NW = 2 * NTMAX;
   char* Qm = sm;                  // pre-scaled q
@@ -344,7 +336,6 @@ __device__ __forceinline__ void attn_bwd_body_split(char* sm, const float* __res
   }
   __syncthreads();
   const bool active = w < NT;
-  const int seg = row_seg ? row_seg[r0 + min(w * 32 + l31, K - 1)] : (K << 16), glo = seg & 0xffff, ghi = seg >> 16;
   f32x16 s[NT], dp[NT];
   if (active) {
 #pragma unroll
@@ -374,7 +365,7 @@ __device__ __forceinline__ void attn_bwd_body_split(char* sm, const float* __res
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int jj = t * 32 + crow(e, lane);
-          const float pt = (qv && jj >= glo && jj < ghi) ? __expf(s[t][e] - li) : 0.f;
+          const float pt = (qv && jj < K) ? __expf(s[t][e] - li) : 0.f;
           s[t][e] = pt;
           dloc += pt * dp[t][e];
         }
@@ -415,7 +406,7 @@ __device__ __forceinline__ void attn_bwd_body_split(char* sm, const float* __res
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = t * 32 + crow(e, lane);
-        s[t][e] = (kv && i >= glo && i < ghi) ? __expf(s[t][e] - lse_s[min(i, 32 * NTMAX - 1)]) : 0.f;     // P
+        s[t][e] = (kv && i < K) ? __expf(s[t][e] - lse_s[min(i, 32 * NTMAX - 1)]) : 0.f;     // P
       }
     // dV^T[d][j] = sum_i dO^T[d][i] P[i][j]: needs no D_i -- before the barrier
     f32x16 av;
@@ -451,8 +442,8 @@ __device__ __forceinline__ void attn_bwd_body_split(char* sm, const float* __res
 template <int NTMAX, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ? 3 : 2) : 1) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
-                                                                   const int* __restrict__ row_off, const int* __restrict__ pack_rows,
-                                                                   const int* __restrict__ row_seg, int C, int heads, float scale, int dh, int W,
+                                                                   const int* __restrict__ row_off, const int* __restrict__ Kw,
+                                                                   int C, int heads, float scale, int dh, int W,
                                                                    LsFinish f0, LsFinish f1, int fC) {
   __shared__ __attribute__((aligned(16))) char sm[4 * 3 * 32 * NTMAX * 64 + 2 * 32 * NTMAX * 4];
   if (blockIdx.x >= W) {   // side workgroups: the LayerScale'd fc2 / proj gradient finish of the same MS-WSA layer (independent work
@@ -464,23 +455,23 @@ __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ?
     return;
   }
   const int g = blockIdx.x, h = blockIdx.y;
-  const int K = pack_rows[g];
+  const int K = Kw[g];
   if (K == 0) return;
   const int r0 = row_off[g];
   if constexpr (SPLIT) {
     switch ((K + 31) >> 5) {
-      case 1: attn_bwd_body_split<NTMAX, 1>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
-      case 2: attn_bwd_body_split<NTMAX, 2>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
-      case 3: if constexpr (NTMAX >= 3) attn_bwd_body_split<NTMAX, 3>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
-      case 4: if constexpr (NTMAX >= 4) attn_bwd_body_split<NTMAX, 4>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
+      case 1: attn_bwd_body_split<NTMAX, 1>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+      case 2: attn_bwd_body_split<NTMAX, 2>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+      case 3: if constexpr (NTMAX >= 3) attn_bwd_body_split<NTMAX, 3>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+      case 4: if constexpr (NTMAX >= 4) attn_bwd_body_split<NTMAX, 4>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
     }
     return;
   }
   switch ((K + 31) >> 5) {
-    case 1: attn_bwd_body<NTMAX, 1>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
-    case 2: attn_bwd_body<NTMAX, 2>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
-    case 3: if constexpr (NTMAX >= 3) attn_bwd_body<NTMAX, 3>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
-    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4>(sm, qkv, dout, lse, dqkv, row_seg, r0, K, C, heads, h, scale, dh); break;
+    case 1: attn_bwd_body<NTMAX, 1>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 2: attn_bwd_body<NTMAX, 2>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 3: if constexpr (NTMAX >= 3) attn_bwd_body<NTMAX, 3>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
+    case 4: if constexpr (NTMAX >= 4) attn_bwd_body<NTMAX, 4>(sm, qkv, dout, lse, dqkv, r0, K, C, heads, h, scale, dh); break;
   }
 }
 
@@ -501,45 +492,35 @@ __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ?
 
 // T: tokens per partition (upper bound of K_m)
 // rows of a pack (SastSel.pack_rows / row_seg): ONE 32-token tile by default.  The packs serve the fused MS-WSA layer kernel
-// (k_mswsa_fused.hip), where a wave runs the whole layer for its tile, and -- optionally, SAST_ATTN_KERNEL_PACKS=1 -- the stand-alone
-// attention kernels below.  Measured on the B = 8 sparsity sweep (profiles/r04_j_ab_packs_and_fused_forward.txt): with a 64-row
-// budget the attention kernels are SLOWER than unpacked (+0.08 / +0.19 / +0.13 ms per step at 33 / 15 / 3 % kept tokens: two 30-row
-// groups in one pack evaluate the two masked off-diagonal score tiles as well -- 2x the MFMA work in longer workgroups -- and the
-// number of attention workgroups was never the limiter); with a one-tile budget they are neutral (+-0.02 ms), as is the fused kernel.
-// SAST_ATTN_PACKS=<rows> overrides the budget (0: every group is its own pack).
+// (k_mswsa_fused.hip), where a wave runs the whole layer for its tile.  The stand-alone attention kernels below run one workgroup per
+// GROUP: packs were measured there (profiles/r04_j_ab_fused_forward_and_pack_budgets.txt: neutral with a one-tile budget, slower with
+// 64 rows -- the masked off-diagonal score tiles double the MFMA work, and the number of workgroups was never the limiter) and are
+// kept as tools/experiments/r05_removed_experiments.patch.  SAST_ATTN_PACKS=<rows> overrides the budget (0: every group is its own pack).
 int attn_pack_limit(int T) {
   static int lim = -1;
   if (lim < 0) { const char* e = getenv("SAST_ATTN_PACKS"); lim = e ? atoi(e) : 32; }
   const int cap = T <= 64 ? 64 : (T <= 96 ? 96 : 128);      // what the kernels instantiated for T can hold
   return lim < cap ? lim : cap;
 }
-static bool attn_kernels_use_packs() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SAST_ATTN_KERNEL_PACKS"); on = e ? atoi(e) : 0; }
-  return on != 0;
-}
 
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, const int* pack_rows,
-                         const int* row_seg, int W, int T, int C, int dh, hipStream_t st) {
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh, hipStream_t st) {
   if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (!attn_kernels_use_packs() || !pack_rows || !row_seg) { pack_rows = Kw; row_seg = nullptr; }     // one workgroup per group
   // the LDS images are sized by the number of 32-token tiles a partition can need (36.9 KB for T <= 64: four workgroups per CU).
   // bytes: QKV (3C) read + O (C) written per kept row
-  if (T <= 64) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<2>", 4.0, 4.0, (attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), qkv, o, lse, row_off, pack_rows, row_seg, C, heads, scale, dh);
-  else if (T <= 96) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<3>", 4.0, 4.0, (attn_fwd_mfma_kernel<3>), dim3(W, heads), dim3(192), qkv, o, lse, row_off, pack_rows, row_seg, C, heads, scale, dh);
-  else SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<4>", 4.0, 4.0, (attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), qkv, o, lse, row_off, pack_rows, row_seg, C, heads, scale, dh);
+  if (T <= 64) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<2>", 4.0, 4.0, (attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else if (T <= 96) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<3>", 4.0, 4.0, (attn_fwd_mfma_kernel<3>), dim3(W, heads), dim3(192), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  else SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<4>", 4.0, 4.0, (attn_fwd_mfma_kernel<4>), dim3(W, heads), dim3(256), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw,
-                         const int* pack_rows, const int* row_seg, int W, int T, int C, int dh, hipStream_t st, const LsFinish* f0,
+                         int W, int T, int C, int dh, hipStream_t st, const LsFinish* f0,
                          const LsFinish* f1, int fC) {
   if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (!attn_kernels_use_packs() || !pack_rows || !row_seg) { pack_rows = Kw; row_seg = nullptr; }     // one workgroup per group
   const LsFinish z{};
   const LsFinish& a0 = f0 ? *f0 : z;
   const LsFinish& a1 = f1 ? *f1 : z;
@@ -551,16 +532,16 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
   if (split < 0) { const char* e = getenv("SAST_ATTN_BWD_SPLIT"); split = e ? atoi(e) : 1; }
   if (split && T <= 96) {      // (T > 96: eight waves of 256 registers spill -- those partitions keep the sequential form)
     const int wpb2 = T <= 64 ? 4 : 6, side2 = (2 * fC + wpb2 - 1) / wpb2;
-    if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<2, true>), dim3(W + side2, heads), dim3(256), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
-    else SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<3,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<3, true>), dim3(W + side2, heads), dim3(384), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
+    if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<2, true>), dim3(W + side2, heads), dim3(256), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+    else SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<3,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<3, true>), dim3(W + side2, heads), dim3(384), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
     SAST_CHECK_LAUNCH();
     return SAST_OK;
   }
   const int wpb = T <= 64 ? 2 : (T <= 96 ? 3 : 4), side = (2 * fC + wpb - 1) / wpb;
   // bytes: QKV (3C) + dO (C) read, dQKV (3C) written per kept row
-  if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2>", 10.0, 7.0, (attn_bwd_mfma_kernel<2>), dim3(W + side, heads), dim3(128), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
-  else if (T <= 96) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<3>", 10.0, 7.0, (attn_bwd_mfma_kernel<3>), dim3(W + side, heads), dim3(192), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
-  else SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<4>", 10.0, 7.0, (attn_bwd_mfma_kernel<4>), dim3(W + side, heads), dim3(256), qkv, dout, lse, dqkv, row_off, pack_rows, row_seg, C, heads, scale, dh, W, a0, a1, fC);
+  if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2>", 10.0, 7.0, (attn_bwd_mfma_kernel<2>), dim3(W + side, heads), dim3(128), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else if (T <= 96) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<3>", 10.0, 7.0, (attn_bwd_mfma_kernel<3>), dim3(W + side, heads), dim3(192), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
+  else SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<4>", 10.0, 7.0, (attn_bwd_mfma_kernel<4>), dim3(W + side, heads), dim3(256), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

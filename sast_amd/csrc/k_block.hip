@@ -319,7 +319,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   if (rc) return rc;
   rc = gemm_auto(LdRows{a->S, C, nullptr}, LdWeightNT{a->qkv_w, C, 0}, EpStore{a->QKV, 3 * C, a->qkv_b}, R, 3 * C, C, dR, st);
   if (rc) return rc;
-  rc = attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, a->sel.pack_rows, a->sel.row_seg, NW, T, C, dh, st);
+  rc = attn_fwd_mfma_launch(a->QKV, a->O, a->lse, a->sel.row_off, a->sel.K, NW, T, C, dh, st);
   if (rc) return rc;
   rc = a->drop1 ? gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLST<true>{a->Y, a->S, a->proj_b, a->ls1, C, a->drop1}, R, C, C, dR, st)
                 : gemm_auto(LdRows{a->O, C, nullptr}, LdWeightNT{a->proj_w, C, 0}, EpResidualLST<false>{a->Y, a->S, a->proj_b, a->ls1, C, nullptr}, R, C, C, dR, st);
@@ -397,11 +397,6 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     dz = a->drop_ws;
     dz_tok = nullptr;
   }
-  if (a->fused_ws && mswsa_fused_mlp_bwd_enabled() && a->cb_tps <= 0 && a->mlp_act == 0 && !a->drop1 && !a->drop_mlp && mswsa_fused_supported(C, inner, T, dh, a->cb_tps)) {
-    // MLP backward as one kernel (k_mswsa_fused.hip): dY and dW1 / db1 / raw dW2 / colsum(dZ) from the saved Y, [u|g] recomputed
-    rc = mswsa_fused_mlp_bwd_launch(a, a->fused_ws, dY, raw2, s2, R, st);
-    if (rc) return rc;
-  } else {
   // Every (weight gradient, activation gradient) pair below consumes the same dY and goes out as ONE launch (gemm_pair).
   // fc2: raw dW2 / db2 (LayerScale applied in the finish kernel) need dZ (= dout rows) and H;  dH = (gamma2 * dZ) W2 fused
   // with the GLU backward: dUG from the saved pre-activations
@@ -423,7 +418,6 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
                  LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);
   if (rc) return rc;
-  }
   // proj: raw dWp / dbp, and dO = (gamma1 * dY) Wp   (DropPath: the branch sees drop1 (.) dY, the identity path below the plain dY)
   const float* dYb = dY;
   if (a->drop1) {
@@ -446,7 +440,7 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   {
     const LsFinish f2{a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner};
     const LsFinish f1{a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C};
-    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, a->sel.pack_rows, a->sel.row_seg, NW, T, C, dh, st, &f2, &f1, C);
+    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C);
   }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv

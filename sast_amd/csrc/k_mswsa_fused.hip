@@ -40,18 +40,12 @@ constexpr int TILE_U4 = 3 * 64;
 #define SAST_FUSED_RING 2
 #endif
 constexpr int RING = SAST_FUSED_RING;   // forward: tiles in flight per wave (power of two); 3 KB of LDS per tile and wave
-constexpr int RINGB = 4;                // MLP backward: one wave per SIMD, nobody else hides the L2 latency (a ring of 2 ran 4x slower)
 constexpr int STREAM_PAD = 8;           // tiles of padding behind every stream (>= any ring depth: the prefetcher reads past the end)
 
 // The kernels consume the tiles of all matrices of the layer in ONE fixed order ("stream"): tile n of a stream sits at byte 3072 n.
 // A wave prefetches the stream through a private LDS ring with LDS-DMA loads (global_load_lds_dwordx4: no staging registers), RING
 // tiles ahead of its MFMAs -- one wave per SIMD has nobody else to hide the L2 latency behind.
 struct TileRef { int mat, nt, ks, tr; };   // mat: 0 qkv [3C][C], 1 proj [C][C], 2 fc1 [2 inner][C], 3 fc2 [C][inner]; tr: tile of the TRANSPOSED matrix
-// SAST_FUSED_PIPELINED_MLP=1 (experiment): the MLP loop of the forward is software-pipelined -- the fc1 MFMAs of chunk k + 1 are issued
-// between slices of the GELU / split VALU work of chunk k -- and the tile stream carries fc1(k + 1) in front of fc2(k)
-#ifndef SAST_FUSED_PIPELINED_MLP
-#define SAST_FUSED_PIPELINED_MLP 0
-#endif
 // forward order: per head { per ks: q, k, v tile; per (u, ct): proj tile }, then per hidden chunk { per ks: u, g tile; per (u, ct): fc2 tile }
 __host__ __device__ inline int fwd_stream_tiles(int C, int inner) { return (C / 32) * (3 * (C / 16) + 2 * (C / 32)) + (inner / 32) * (2 * (C / 16) + 2 * (C / 32)); }
 __host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
@@ -63,46 +57,19 @@ __host__ __device__ inline TileRef fwd_stream_tile(int n, int C, int inner) {
     return TileRef{1, jj % CT, 2 * h + jj / CT, 0};       // (half u, channel tile ct): the two ct tiles of a half are consumed together
   }
   n -= H * per_head;
-#if SAST_FUSED_PIPELINED_MLP
-  // fc1(0) | { fc1(k + 1), fc2(k) } for k < IT - 1 | fc2(IT - 1)
-  if (n < 2 * KS) return TileRef{2, (n & 1) * IT, n / 2, 0};
-  n -= 2 * KS;
-  {
-    const int kc = n / per_chunk, j = n - kc * per_chunk;
-    if (kc < IT - 1) {
-      if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc + 1, j / 2, 0};
-      const int jj = j - 2 * KS;
-      return TileRef{3, jj % CT, 2 * kc + jj / CT, 0};
-    }
-    return TileRef{3, j % CT, 2 * (IT - 1) + j / CT, 0};
-  }
-#else
   const int kc = n / per_chunk, j = n - kc * per_chunk;
   if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc, j / 2, 0};
   const int jj = j - 2 * KS;
   return TileRef{3, jj % CT, 2 * kc + jj / CT, 0};
-#endif
-}
-// MLP-backward order, per hidden chunk kc: { per ks: W1 u, g tile (recompute of [u|g]) } { per ks: W2^T tile (dH = (ls2 dZ) W2: index = hidden
-// channel of the chunk, reduce = c) } { per ct, per part (u, g), per half: W1^T tile (dY += dUG W1: index = c, reduce = hidden row) }
-__host__ __device__ inline int mlpb_stream_tiles(int C, int inner) { return (inner / 32) * (2 * (C / 16) + (C / 16) + 4 * (C / 32)); }
-__host__ __device__ inline TileRef mlpb_stream_tile(int n, int C, int inner) {
-  const int KS = C / 16, CT = C / 32, IT = inner / 32, per_chunk = 3 * KS + 4 * CT;
-  const int kc = n / per_chunk, j = n - kc * per_chunk;
-  if (j < 2 * KS) return TileRef{2, (j & 1) * IT + kc, j / 2, 0};
-  if (j < 3 * KS) return TileRef{3, kc, j - 2 * KS, 1};                     // (W2^T)[k][c]: tile row block = the chunk, k-step over c
-  const int jj = j - 3 * KS, ct = jj / 4, part = (jj >> 1) & 1, u = jj & 1;
-  return TileRef{2, ct, (part * inner + kc * 32) / 16 + u, 1};             // (W1^T)[c][j]: tile row block = ct, k-step over the hidden rows
 }
 
-struct PlaneArgs { const float* w[4]; int ld[4]; int C, inner, ntiles_fwd, ntiles; };   // tiles [0, ntiles_fwd): forward stream (+ RING of padding), then the MLP-backward stream
-// dir 0: forward stream (operand = the weight as stored: index = output channel, reduce = input channel)
+struct PlaneArgs { const float* w[4]; int ld[4]; int C, inner, ntiles; };
+// the forward stream (operand = the weight as stored: index = output channel, reduce = input channel)
 __global__ __launch_bounds__(256) void weight_planes_kernel(PlaneArgs a, u4* __restrict__ dst) {
   const int item = blockIdx.x * 256 + threadIdx.x;
   if (item >= a.ntiles * 64) return;
   const int tile = item >> 6, lane = item & 63;
-  const bool fwd = tile < a.ntiles_fwd;
-  const TileRef t = fwd ? fwd_stream_tile(tile, a.C, a.inner) : mlpb_stream_tile(tile - a.ntiles_fwd, a.C, a.inner);
+  const TileRef t = fwd_stream_tile(tile, a.C, a.inner);
   const int n = t.nt * 32 + (lane & 31), k0 = t.ks * 16 + 8 * (lane >> 5);
   float v[8];
   if (!t.tr) {
@@ -114,7 +81,7 @@ __global__ __launch_bounds__(256) void weight_planes_kernel(PlaneArgs a, u4* __r
     for (int i = 0; i < 8; ++i) v[i] = a.w[t.mat][(size_t)(k0 + i) * a.ld[t.mat] + n];      // V[n][k] = W[k][n]
   }
   const Split3 s = split3(v);
-  u4* d = dst + (size_t)(tile + (fwd ? 0 : STREAM_PAD)) * TILE_U4 + lane;     // the forward stream is followed by STREAM_PAD tiles of padding
+  u4* d = dst + (size_t)tile * TILE_U4 + lane;                                // (the stream is followed by STREAM_PAD tiles of padding)
   d[0] = __builtin_bit_cast(u4, s.h);
   d[64] = __builtin_bit_cast(u4, s.m);
   d[128] = __builtin_bit_cast(u4, s.l);
@@ -252,10 +219,8 @@ constexpr int FTL_SLOTS = 24, FTL_WAVES = 4096;   // (the timeline tool reads th
 __device__ unsigned long long fused_tl[FTL_WAVES * FTL_SLOTS];
 #define FTL(k) do { const int wv_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) { fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); \
     if ((k) == 0) fused_tl[wv_ * FTL_SLOTS + 21] = wall_clock64(); if ((k) == 20) fused_tl[wv_ * FTL_SLOTS + 22] = wall_clock64(); } } while (0)
-#define FTLB(k) do { const int wv_ = blockIdx.x * 4 + (threadIdx.x >> 6); if ((threadIdx.x & 63) == 0 && wv_ < FTL_WAVES) fused_tl[wv_ * FTL_SLOTS + (k)] = clock64(); } while (0)
 #else
 #define FTL(k)
-#define FTLB(k)
 #endif
 struct FwdArgs {
   const float* xin; float* out;
@@ -473,65 +438,6 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
   Tile z[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) z[ct] = tzero();
-#if SAST_FUSED_PIPELINED_MLP
-  static_assert(KS == 4, "the pipelined MLP loop slices the 16 registers of a tile over the 4 k-steps of fc1");
-  const auto fc1_bias = [&](int kc, Tile& u_, Tile& g_) {
-    float bu[16], bg[16];
-    rowvec(vec + V::FC1B + kc * 32, 0, hf, bu);
-    rowvec(vec + V::FC1B + INNER + kc * 32, 0, hf, bg);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { u_[e] = bu[e]; g_[e] = bg[e]; }
-  };
-  Tile uu, gg;
-  fc1_bias(0, uu, gg);
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const Split3 wu = ws.take(), wg = ws.take();
-    mfma6x2(wu, yop[ks], uu, wg, yop[ks], gg);
-  }
-#pragma unroll 1
-  for (int kc = 0; kc < IT; ++kc) {
-    Tile un, gn;
-    Split3 hop[2];
-    // slice q of the GELU / save / split work of chunk kc: registers 4 q .. 4 q + 3
-    const auto slice = [&](int q) {
-      if (save && a.UG) {
-        float* ug = a.UG + crow_g * (2 * INNER) + kc * 32;
-        st4(ug + 8 * q + 4 * hf, make_float4(uu[4 * q], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]));
-        st4(ug + INNER + 8 * q + 4 * hf, make_float4(gg[4 * q], gg[4 * q + 1], gg[4 * q + 2], gg[4 * q + 3]));
-      }
-#pragma unroll
-      for (int e = 4 * q; e < 4 * q + 4; ++e) uu[e] *= gelu_erf(gg[e]);
-      if (save && a.Hh) st4(a.Hh + crow_g * INNER + kc * 32 + 8 * q + 4 * hf, make_float4(uu[4 * q], uu[4 * q + 1], uu[4 * q + 2], uu[4 * q + 3]));
-      if (q == 1) hop[0] = c_tile_operand(uu, 0);
-      if (q == 3) hop[1] = c_tile_operand(uu, 1);
-    };
-    if (kc + 1 < IT) {
-      fc1_bias(kc + 1, un, gn);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const Split3 wu = ws.take(), wg = ws.take();
-        mfma6x2(wu, yop[ks], un, wg, yop[ks], gn);       // chunk kc + 1 on the matrix pipe ...
-        slice(ks);                                         // ... under a quarter of chunk kc's VALU work
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {                     // one MFMA, then ~a twelfth of the slice's VALU instructions
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) slice(ks);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {                          // stream order (u, ct)
-      const Split3 w0 = ws.take(), w1 = ws.take();
-      mfma6x2(w0, hop[u], z[0], w1, hop[u], z[1]);
-    }
-    uu = un; gg = gn;
-    FTL(13 + kc);
-  }
-#else
 #pragma unroll 1
   for (int kc = 0; kc < IT; ++kc) {
     Tile uu, gg;
@@ -574,7 +480,6 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     }
     FTL(13 + kc);
   }
-#endif
   FTL(19);
   // ---- out = Y + ls2 * (Z + b2), scattered to the image rows of the kept tokens   (SAST.py:248-253)
 #pragma unroll
@@ -648,233 +553,6 @@ __global__ __launch_bounds__(64 * NTW, 2) void mswsa_fused_fwd_kernel(FwdArgs a)
 }
 
 
-// ------------------------------------------------------------------------------------------------ MLP backward (fc2 . GLU . fc1)
-// out = Y + ls2 (W2 (u gelu(g)) + b2), [u|g] = W1 Y + b1 (ops.py:136-137, SAST.py:248).  Given dZ = d(out) on the kept rows and the
-// saved Y, ONE kernel produces dY = dZ + dUG W1 and the parameter gradients, recomputing [u|g] chunk by chunk -- the forward keeps
-// neither the pre-activations (5 A bytes) nor the hidden layer (2.5 A), and the two (dW || dX) launches of the chain, which move 28 A
-// bytes at the HBM rate, are gone.  A wave owns 32 compact rows (lane = row, everything transposed in the MFMA C layout like the
-// forward); a workgroup of four waves shares the accumulators of the weight gradients in LDS:
-//   * dX path, per hidden chunk: [u|g] = W1 Y (recompute), dH = W2^T (ls2 dZ), dU = dH gelu(g), dG = dH u gelu'(g), dY += W1^T [dU; dG]
-//     -- the same register chain as the forward, weights from the MLP-backward tile stream (transposed tiles for the two ^T products);
-//   * dW path: a weight gradient reduces over the ROWS, which sit in the lanes of every tile: the tiles of dZ, Y (once) and h, dU, dG
-//     (per chunk) go through a wave-private LDS scratch ([channel][32 rows], written by row, read by channel: 16 ds_write_b32 + 4
-//     ds_read_b128 per tile) and come back as operands with the rows as reduce index; their row sums are the bias gradients;
-//   * the six partial dW tiles of a chunk are summed over the four waves by an owner wave each (the others park theirs in LDS with plain
-//     stores) and leave as one float atomic per element and workgroup.  Atomic adds run at ~1.2 TB/s chip-wide whatever their addresses
-//     (profiles/r04_a): one flush per 128 rows keeps them at 58 MB per launch.
-constexpr int TR_LD = 36;                          // scratch row: 32 rows of the tile + 4 floats (16-byte aligned, conflict-free b128 reads)
-constexpr int TR_FLOATS = 32 * TR_LD;
-
-struct MlpBwdArgs {
-  const float* Y; const float* dout; float* dY;
-  const int* row_tok; const int* count;             // compact row -> image row; device-side number of kept rows
-  const char* wstream;                              // MLP-backward tile stream
-  const float *fc1_b, *ls2;
-  float *d_fc1_w, *d_fc1_b, *raw2, *s2;             // dW1 / db1 accumulate in place; raw2 / s2: gamma-free dW2 and column sums of dZ (LsFinish)
-  int rows_max;
-};
-
-__device__ __forceinline__ void lds_add(float* p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-// tile X^T[channel][row] -> the two operands (rows 0-15, 16-31 as reduce index; index = channel 32 ct' + lane % 32) and the channel's
-// sum over the 32 rows
-__device__ __forceinline__ void tr_operands(float* __restrict__ tr, const Tile& x, int lane, Split3 (&op)[2], float& rowsum) {
-  const int l31 = lane & 31, hf = lane >> 5;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) tr[crow(e, lane) * TR_LD + l31] = x[e];
-  // the LDS executes a wave's operations in order: the reads below see the writes above, and the next tile's writes come after these
-  // reads, without any wait.  Only the COMPILER must keep the order -- a memory fence builtin would also drain vmcnt, i.e. the whole
-  // LDS-DMA weight ring (measured: the kernel ran 4x slower with wavefront-scope fences here)
-  asm volatile("" ::: "memory");
-  float sum = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < 2; ++kt) {
-    const float4 a = ld4(tr + l31 * TR_LD + 16 * kt + 8 * hf), b = ld4(tr + l31 * TR_LD + 16 * kt + 8 * hf + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    op[kt] = split3(v);
-  }
-  rowsum = pair_sum(sum);
-  asm volatile("" ::: "memory");
-}
-// acc tile (rows = crow, column = lane % 32) += into a row-major LDS block with row stride ld
-__device__ __forceinline__ void lds_add_tile(float* __restrict__ blk, int ld, const Tile& t, int lane) {
-  const int l31 = lane & 31;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) lds_add(blk + crow(e, lane) * ld + l31, t[e]);
-}
-
-template <int C, int INNER>
-__global__ __launch_bounds__(256) void mswsa_fused_mlp_bwd_kernel(MlpBwdArgs a) {
-  constexpr int CT = C / 32, KS = C / 16, IT = INNER / 32;
-  __shared__ __attribute__((aligned(16))) char ring_s[4 * RINGB * TILE_BYTES];
-  __shared__ __attribute__((aligned(16))) float trs[4 * TR_FLOATS];
-  // the six dW tiles of a chunk (0, 1: dW2 ct 0 / 1; 2, 3: dW1 u-rows ct 0 / 1; 4, 5: dW1 g-rows) are summed over the four waves by an
-  // OWNER wave (tile i: wave i & 3): the other three park their partial tiles here (lane-linear float4 stores), the owner adds them to its
-  // own and issues the global atomics.  (LDS float atomics into shared accumulators cost ~760 cycles per wave instruction: r04_m.)
-  __shared__ __attribute__((aligned(16))) float stage[6 * 3 * 64 * 16];
-  __shared__ float db1[2 * INNER], s2s[C], vb1[2 * INNER], vg2[C];
-  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hf = lane >> 5;
-  const int count = min(*a.count, a.rows_max);
-  const int wg_row0 = blockIdx.x * 128;
-  if (wg_row0 >= count) return;                                               // workgroup-uniform
-  for (int i = threadIdx.x; i < 2 * INNER; i += 256) { db1[i] = 0.f; vb1[i] = a.fc1_b[i]; }
-  if (threadIdx.x < C) { s2s[threadIdx.x] = 0.f; vg2[threadIdx.x] = a.ls2 ? a.ls2[threadIdx.x] : 1.f; }
-  __syncthreads();
-  FTLB(0);
-  const int row0 = wg_row0 + w * 32;
-  const bool wave_on = row0 < count;                                          // waves past the last kept row only keep the barriers
-  float* tr = trs + w * TR_FLOATS;
-  Tile y[CT], dz[CT], dy[CT];
-  Split3 yop[KS], dzop[KS], yT[CT][2], dzT[CT][2];
-  WStreamT<RINGB> ws;
-  const int r = row0 + l31;
-  const bool valid = r < count;
-  if (wave_on) {
-    const size_t rc = (size_t)min(r, count - 1);
-    load_token<CT>(a.Y + rc * C, hf, y);
-    load_token<CT>(a.dout + (size_t)a.row_tok[rc] * C, hf, dz);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) dz[ct][e] = valid ? dz[ct][e] : 0.f;      // rows past the count contribute nothing anywhere below
-    ws.src = a.wstream + lane * 16;
-    char* ring = ring_s + w * (RINGB * TILE_BYTES);
-    ws.ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
-    ws.ring = ring + lane * 16;
-    ws.start();
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) yop[ks] = c_tile_operand(y[ks >> 1], ks & 1);
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      float g2[16];
-      rowvec(vg2, ct, hf, g2);
-      Tile t;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) t[e] = g2[e] * dz[ct][e];
-      dzop[2 * ct] = c_tile_operand(t, 0);
-      dzop[2 * ct + 1] = c_tile_operand(t, 1);
-      float sy, sz;
-      tr_operands(tr, y[ct], lane, yT[ct], sy);
-      tr_operands(tr, dz[ct], lane, dzT[ct], sz);                             // raw dZ: LayerScale is applied by the finish (LsFinish)
-      if (hf == 0) lds_add(s2s + ct * 32 + l31, sz);
-      dy[ct] = dz[ct];                                                        // dY = dZ + ...
-    }
-  }
-  FTLB(1);
-  Tile own0, own1;                           // this wave's own partial of the dW tiles it owns (w, w + 4)
-#pragma unroll 1
-  for (int kc = 0; kc < IT; ++kc) {
-    if (wave_on) {
-      Tile uu, gg, dh = tzero();
-      {
-        float bu[16], bg[16];
-        rowvec(vb1 + kc * 32, 0, hf, bu);
-        rowvec(vb1 + INNER + kc * 32, 0, hf, bg);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { uu[e] = bu[e]; gg[e] = bg[e]; }
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const Split3 wu = ws.take(), wg = ws.take();
-        uu = mfma6(wu, yop[ks], uu);
-        gg = mfma6(wg, yop[ks], gg);
-      }
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) dh = mfma6(ws.take(), dzop[ks], dh);   // dH^T[k][t] = sum_c W2[c][k] ls2[c] dZ[t][c]
-      FTLB(2 + 4 * kc);
-      Tile hh, du, dg;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float gl = gelu_erf(gg[e]);
-        hh[e] = uu[e] * gl;
-        du[e] = dh[e] * gl;
-        dg[e] = dh[e] * uu[e] * gelu_erf_grad(gg[e]);
-      }
-      {
-        const Split3 du0 = c_tile_operand(du, 0), du1 = c_tile_operand(du, 1), dg0 = c_tile_operand(dg, 0), dg1 = c_tile_operand(dg, 1);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          dy[ct] = mfma6(ws.take(), du0, dy[ct]);
-          dy[ct] = mfma6(ws.take(), du1, dy[ct]);
-          dy[ct] = mfma6(ws.take(), dg0, dy[ct]);
-          dy[ct] = mfma6(ws.take(), dg1, dy[ct]);
-        }
-      }
-      FTLB(3 + 4 * kc);
-      Split3 hT[2], duT[2], dgT[2];
-      float sh, su, sg;
-      tr_operands(tr, hh, lane, hT, sh);
-      tr_operands(tr, du, lane, duT, su);
-      tr_operands(tr, dg, lane, dgT, sg);
-      if (hf == 0) { lds_add(db1 + kc * 32 + l31, su); lds_add(db1 + INNER + kc * 32 + l31, sg); }
-      Tile pt[6];
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        pt[ct] = tzero();                                                     // raw dW2[c][k] = sum_t dZ[t][c] h[t][k]
-        pt[2 + ct] = tzero(); pt[4 + ct] = tzero();                           // dW1[j][c] = sum_t dUG[t][j] Y[t][c]
-        mfma6x3(dzT[ct][0], hT[0], pt[ct], duT[0], yT[ct][0], pt[2 + ct], dgT[0], yT[ct][0], pt[4 + ct]);
-        mfma6x3(dzT[ct][1], hT[1], pt[ct], duT[1], yT[ct][1], pt[2 + ct], dgT[1], yT[ct][1], pt[4 + ct]);
-      }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        if ((i & 3) == w) { if (i < 4) own0 = pt[i]; else own1 = pt[i]; }
-        else {
-          float* sp = stage + ((i * 3 + ((w - (i & 3) - 1) & 3)) * 64 + lane) * 16;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) st4(sp + 4 * q, make_float4(pt[i][4 * q], pt[i][4 * q + 1], pt[i][4 * q + 2], pt[i][4 * q + 3]));
-        }
-      }
-    } else {                               // a wave past the last kept row: its partial tiles are zero
-      own0 = tzero(); own1 = tzero();
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-        if ((i & 3) != w) {
-          float* sp = stage + ((i * 3 + ((w - (i & 3) - 1) & 3)) * 64 + lane) * 16;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) st4(sp + 4 * q, zero4());
-        }
-    }
-    FTLB(4 + 4 * kc);
-    __syncthreads();                       // every wave's partial tiles of this chunk are parked
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int i = w + 4 * half;          // the tiles this wave owns: w, and w + 4 for waves 0 and 1
-      if (i < 6) {
-        Tile t = half ? own1 : own0;
-#pragma unroll
-        for (int sl = 0; sl < 3; ++sl) {
-          const float* sp = stage + ((i * 3 + sl) * 64 + lane) * 16;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = ld4(sp + 4 * q);
-            t[4 * q] += v.x; t[4 * q + 1] += v.y; t[4 * q + 2] += v.z; t[4 * q + 3] += v.w;
-          }
-        }
-        const int ct = i & 1;
-        float* dst = i < 2 ? a.raw2 + (size_t)(ct * 32) * INNER + kc * 32                       // [c][k]
-                           : a.d_fc1_w + (size_t)((i >= 4 ? INNER : 0) + kc * 32) * C + ct * 32;   // [j][c]
-        const int ld = i < 2 ? INNER : C;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) atomicAdd(dst + (size_t)crow(e, lane) * ld + l31, t[e]);
-      }
-    }
-    __syncthreads();                       // ... and read before the next chunk overwrites them
-    FTLB(5 + 4 * kc);
-  }
-  if (wave_on) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the ring's padding tiles must land before the LDS goes
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) (void)0;
-    if (valid) store_token<CT>(a.dY + (size_t)r * C, hf, dy);
-  }
-  __syncthreads();
-  FTLB(22);
-  for (int i = threadIdx.x; i < 2 * INNER; i += 256) atomicAdd(a.d_fc1_b + i, db1[i]);
-  if (threadIdx.x < C) atomicAdd(a.s2 + threadIdx.x, s2s[threadIdx.x]);
-  FTLB(23);
-}
-
 }  // namespace fused
 #ifdef SAST_FUSED_TL
 extern "C" int sast_fused_tl_read(unsigned long long* host_out, int nwaves) {
@@ -888,19 +566,17 @@ extern "C" int sast_fused_tl_read(unsigned long long* host_out, int nwaves) {
 bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps) {
   return C == 64 && inner == 160 && T <= 128 && dim_head == 32 && cb_tps == 0;
 }
-// fp32 words of the weight planes: the forward stream and the MLP-backward stream, each followed by STREAM_PAD tiles of padding
+// fp32 words of the weight planes: the forward stream followed by STREAM_PAD tiles of padding
 size_t mswsa_fused_plane_floats(int C, int inner) {
-  return (size_t)(fused::fwd_stream_tiles(C, inner) + fused::mlpb_stream_tiles(C, inner) + 2 * fused::STREAM_PAD) * fused::TILE_BYTES / 4;
+  return (size_t)(fused::fwd_stream_tiles(C, inner) + fused::STREAM_PAD) * fused::TILE_BYTES / 4;
 }
 
-bool mswsa_fused_mlp_bwd_enabled();
 int mswsa_fused_planes_launch(const SastMswsaArgs* a, float* planes, hipStream_t st) {
   using namespace fused;
   const int C = a->C, inner = a->inner;
   PlaneArgs pa{};
   pa.w[0] = a->qkv_w; pa.ld[0] = C; pa.w[1] = a->proj_w; pa.ld[1] = C; pa.w[2] = a->fc1_w; pa.ld[2] = C; pa.w[3] = a->fc2_w; pa.ld[3] = inner;
-  pa.C = C; pa.inner = inner; pa.ntiles_fwd = fwd_stream_tiles(C, inner);
-  pa.ntiles = pa.ntiles_fwd + (mswsa_fused_mlp_bwd_enabled() ? mlpb_stream_tiles(C, inner) : 0);      // the backward stream only when its kernel will run
+  pa.C = C; pa.inner = inner; pa.ntiles = fwd_stream_tiles(C, inner);
   SAST_LAUNCH(weight_planes_kernel, dim3((pa.ntiles * 64 + 255) / 256), dim3(256), 0, st, pa, reinterpret_cast<u4*>(planes));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -920,8 +596,7 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
   f.ln1_w = a->ln1_w; f.ln1_b = a->ln1_b; f.ln2_w = a->ln2_w; f.ln2_b = a->ln2_b; f.qkv_b = a->qkv_b; f.proj_b = a->proj_b; f.ls1 = a->ls1;
   f.fc1_b = a->fc1_b; f.fc2_b = a->fc2_b; f.ls2 = a->ls2;
   f.S = a->S; f.QKV = a->QKV; f.O = a->O; f.lse = a->lse; f.Y = a->Y;
-  const bool keep_hidden = !mswsa_fused_mlp_bwd_enabled();      // the fused MLP backward recomputes [u|g] and h from Y
-  f.UG = keep_hidden ? a->UG : nullptr; f.Hh = keep_hidden ? a->Hh : nullptr;
+  f.UG = a->UG; f.Hh = a->Hh;
   f.mean1 = a->mean1; f.rstd1 = a->rstd1; f.mean2 = a->mean2; f.rstd2 = a->rstd2;
   if (f.S && (!f.QKV || !f.O || !f.lse || !f.Y || !f.mean1 || !f.rstd1 || !f.mean2 || !f.rstd2)) return SAST_EINVAL;
   f.zero_ptr = a->raw_ws; f.zero_n4 = a->raw_ws ? (int)(sast_mswsa_raw_ws_floats(C, inner) / 4) : 0;
@@ -943,46 +618,6 @@ int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStrea
     SAST_FUSED_FWD_LAUNCH(SAST_EXT_LAUNCH, e0, e1, 0, f);
   } else {
     SAST_FUSED_FWD_LAUNCH(SAST_LAUNCH, f);
-  }
-  SAST_CHECK_LAUNCH();
-  return SAST_OK;
-}
-
-// OFF by default (SAST_MSWSA_FUSED_MLP_BWD=1 enables): correct (tests/test_gpu_parity.py: test_fused_mlp_backward_opt_in) but measured
-// SLOWER than the two (dW || dX) launch pairs it replaces -- 1Mpx B = 4 step 4.955 -> 5.064 ms (profiles/r04_o), i.e. ~180 us per launch
-// against the pairs' 93 us + the 15 us the forward saves by not writing [u|g] and h:
-//   * a wave needs 174 kcycles (89 us at 1.95 GHz) for its 32 rows and the 1920 waves of a 1Mpx B = 4 layer are two rounds of the chip;
-//     per hidden chunk: fc1 recompute + dH 6-14 k, gelu + dY 6 k, transposes + dW MFMAs 8 k, the owner-wave reduction of the partial dW
-//     tiles with its atomics and two barriers 3-4 k -- for 32 tile steps = 6.1 kcycles of matrix-pipe time, ~20 % of the pipe with ONE wave
-//     per SIMD (256 VGPRs + 252 AGPRs, 147 KB of LDS) whose MFMA, VALU, LDS-transpose and barrier phases run strictly one after the other;
-//   * the pairs stream their 28 A bytes at 4.3-5.3 TB/s with four workgroups per CU.
-// (The first form folded the partial dW tiles into shared LDS accumulators with ds_add_f32: 73 of 98 kcycles per chunk, ~760 cycles per
-// LDS float-atomic wave instruction with four waves contending -- profiles/r04_m; the step was 5.58 ms.)
-// Kept as the measured record of the recomputing backward the round-3 verdict asked for (in-kernel weight gradients included).
-bool mswsa_fused_mlp_bwd_enabled() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SAST_MSWSA_FUSED_MLP_BWD"); on = e ? atoi(e) : 0; }
-  return on != 0;
-}
-// dY = dZ + dUG W1 and dW1 / db1 / raw dW2 / colsum(dZ) of one MS-WSA layer from the saved Y (see mswsa_fused_mlp_bwd_kernel)
-int mswsa_fused_mlp_bwd_launch(const SastMswsaArgs* a, const float* planes, float* dY, float* raw2, float* s2, int rows_max, hipStream_t st) {
-  using namespace fused;
-  const int C = a->C, inner = a->inner;
-  MlpBwdArgs m{};
-  m.Y = a->Y; m.dout = a->dout; m.dY = dY; m.row_tok = a->sel.row_tok; m.count = a->sel.counts;
-  m.wstream = reinterpret_cast<const char*>(planes) + (size_t)(fwd_stream_tiles(C, inner) + STREAM_PAD) * TILE_BYTES;
-  m.fc1_b = a->fc1_b; m.ls2 = a->ls2; m.d_fc1_w = a->d_fc1_w; m.d_fc1_b = a->d_fc1_b; m.raw2 = raw2; m.s2 = s2; m.rows_max = rows_max;
-  const dim3 grid((rows_max + 127) / 128), block(256);
-  if (prof_enabled()) {
-    int cnt = 0; hipEvent_t e0, e1;
-    hipMemcpyAsync(&cnt, a->sel.counts, sizeof(int), hipMemcpyDeviceToHost, st); hipStreamSynchronize(st);
-    const double rows = cnt < rows_max ? cnt : rows_max;
-    // algorithmic work of the MLP backward: dH, dY (dX), dW1, dW2 = 2 x 3 C inner x 2 flop per row (the recompute is not counted);
-    // bytes: Y and dZ read, dY written
-    prof_kernel_events_ex("mswsa_fused_mlp_bwd_kernel", 12.0 * C * inner * rows, 12.0 * C * rows, st, &e0, &e1);
-    SAST_EXT_LAUNCH((mswsa_fused_mlp_bwd_kernel<64, 160>), grid, block, 0, st, e0, e1, 0, m);
-  } else {
-    SAST_LAUNCH((mswsa_fused_mlp_bwd_kernel<64, 160>), grid, block, 0, st, m);
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;

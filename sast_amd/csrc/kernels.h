@@ -64,12 +64,11 @@ int select_pair_launch(const float* tok, int B, int H, int W, int ph, int pw, fl
                        const SastSel* grid, hipStream_t st);
 
 // k_attn_mfma.hip (T <= 128)
-// Kw: kept tokens per group (work accounting only); the kernels run per PACK (pack_rows / row_seg, see SastSel)
-int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, const int* pack_rows,
-                         const int* row_seg, int W, int T, int C, int dh, hipStream_t st);
+// Kw: kept tokens per group; one workgroup per (group, head)
+int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh, hipStream_t st);
 struct LsFinish;
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw,
-                         const int* pack_rows, const int* row_seg, int W, int T, int C, int dh, hipStream_t st,
+                         int W, int T, int C, int dh, hipStream_t st,
                          const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
 
 // k_dwconv.hip: depth-wise k x k convolution, zero padding k/2, stride 1 / 2 (input Hi x Wi -> output Ho x Wo)
@@ -83,7 +82,5 @@ bool mswsa_fused_supported(int C, int inner, int T, int dim_head, int cb_tps);
 size_t mswsa_fused_plane_floats(int C, int inner);
 int mswsa_fused_planes_launch(const SastMswsaArgs* a, float* planes, hipStream_t st);
 int mswsa_fused_fwd_launch(const SastMswsaArgs* a, const float* planes, hipStream_t st);
-bool mswsa_fused_mlp_bwd_enabled();
-int mswsa_fused_mlp_bwd_launch(const SastMswsaArgs* a, const float* planes, float* dY, float* raw2, float* s2, int rows_max, hipStream_t st);
 
 }  // namespace sast

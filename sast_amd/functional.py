@@ -102,12 +102,11 @@ def _g(p):
 
 
 def _like_view(flat: torch.Tensor, p: torch.Tensor):
-    """`flat` (1-D, p.numel() elements) seen with p's shape AND strides (dense contiguous or channels-last 4-D), else None"""
-    if p.is_contiguous():
-        return flat.view(p.shape)
-    if p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous():
-        co, ci, kh, kw = p.shape
-        return flat.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+    """`flat` (1-D, p.numel() elements) seen with p's shape AND its exact strides (dense contiguous or channels-last 4-D: the memory
+    orders the kernels accept), else None.  as_strided rather than view + permute: for size-1 dimensions several stride tuples describe
+    the same memory, and `.grad` is compared with its parameter stride for stride."""
+    if p.is_contiguous() or (p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous()):
+        return flat.as_strided(p.size(), p.stride())
     return None
 
 
@@ -660,7 +659,9 @@ _FUSED_ENABLE = True  # tools / tests switch the fused form off to compare the t
 # rows (B * L tokens of the layer) from which the one-kernel forward is used: a wave of it runs the whole layer for 32 tokens (~50 us of
 # dependent work), which only pays once the rows give every SIMD of the chip about two such waves.  Measured: 1Mpx B = 4 (61 440 rows)
 # -1.5 % of the training step, -4.2 % forward only; Gen1 B = 4 (20 480 rows) +1.9 % forward only (profiles/r04_k).  Tests set 0.
-_FUSED_MIN_ROWS = int(os.environ.get("SAST_MSWSA_FUSED_MIN_ROWS", "49152"))
+FUSED_MIN_ROWS_DEFAULT = int(os.environ.get("SAST_MSWSA_FUSED_MIN_ROWS", "49152"))
+_FUSED_MIN_ROWS = FUSED_MIN_ROWS_DEFAULT
+MSWSA_FORM_CALLS = {"fused": 0, "chain": 0}     # forward calls per form of the layer (tests assert which one the policy chose)
 
 
 class _MSWSA(torch.autograd.Function):
@@ -702,6 +703,7 @@ class _MSWSA(torch.autograd.Function):
         # True for trainable parameters under torch.no_grad() too -- `mswsa` samples the mode) and some input wants a gradient
         needs_bwd = bool(grad_on) and any(ctx.needs_input_grad)
         fws = None
+        MSWSA_FORM_CALLS["fused" if fused_floats else "chain"] += 1
         if fused_floats:
             fws = torch.empty(fused_floats, device=dev)
             _fill(a, fused_ws=fws)
