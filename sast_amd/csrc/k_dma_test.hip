@@ -1,0 +1,207 @@
+// Bounding experiment for the round-4 verdict's item 4 (tools library only, never the product path): a GEMM  C = A W^T + bias  whose
+// k-loop has NO VGPR staging, NO LDS stores and NO barrier:
+//   * the WEIGHT operand comes as pre-split bf16x3 planes in MFMA operand order ("weight image": per 32-row tile and k16 step 3 planes x
+//     64 lanes x 16 B = 3 KB, the layout of k_mswsa_fused.hip's tile stream), built once by weight_image_kernel;
+//   * the ACTIVATION operand stays fp32 rows in HBM (no producer has to change) and is split by the reading wave AFTER its LDS read
+//     (8 values per lane and k16 step);
+//   * both are moved global -> LDS by global_load_lds_dwordx4 into a wave-PRIVATE ring (a wave owns a 32 x (32 TN) output tile and a k
+//     range; the k-groups of a workgroup only meet for the final fold), waits are hand-counted s_waitcnt vmcnt.
+// A's LDS image: the 32 x 16 fp32 tile of a k16 step as 4 quarter-planes [q][row] of 16-byte slots (q = k / 4): DMA piece j (lane l)
+// fetches row l % 32, quarter 2 j + l / 32 and lands at slot 64 j + l; the reader (row r = lane % 32, half hf = lane / 32) needs k =
+// 8 hf .. 8 hf + 7 = slots 64 hf + r and 64 hf + 32 + r: two linear, conflict-free ds_read_b128.
+#include <hip/hip_runtime.h>
+#include "mfma_tiles.cuh"
+#include "kernels.h"
+using namespace sast;
+
+namespace {
+using u4 = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int WTILE = 3072;   // bytes of one weight tile (3 planes x 1 KB)
+
+__global__ __launch_bounds__(256) void weight_image_kernel(const float* __restrict__ w, int N, int K, u4* __restrict__ dst) {
+  const int nks = K / 16, ntiles = (N / 32) * nks;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= ntiles * 64) return;
+  const int tile = item >> 6, lane = item & 63;
+  const int nt = tile / nks, ks = tile % nks;
+  const float* src = w + (size_t)(nt * 32 + (lane & 31)) * K + ks * 16 + 8 * (lane >> 5);
+  const float4 lo = ld4(src), hi = ld4(src + 4);
+  const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  const Split3 s = split3(v);
+  u4* d = dst + (size_t)tile * (WTILE / 16) + lane;
+  d[0] = __builtin_bit_cast(u4, s.h);
+  d[64] = __builtin_bit_cast(u4, s.m);
+  d[128] = __builtin_bit_cast(u4, s.l);
+}
+
+template <int LGKM>
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  if constexpr (LGKM >= 0)
+    asm volatile("s_waitcnt lgkmcnt(%3)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst), "n"(LGKM) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int TN> struct Ops { float a[8]; Split3 b[TN]; };
+
+// TN: 32-column tiles per wave; D: ring depth in k16 steps (power of two); KS: k-groups (waves) per workgroup
+template <int TN, int D, int KS>
+__global__ __launch_bounds__(64 * KS) void dma_gemm_nt_kernel(const float* __restrict__ A, int lda, const char* __restrict__ wimg,
+                                                               const float* __restrict__ bias, float* __restrict__ Cm, int ldc, int M,
+                                                               int N, int K) {
+  constexpr int STAGE = 2048 + TN * WTILE;     // bytes of one k16 step: A tile (32 x 16 fp32) + TN weight tiles
+  constexpr int PER = 2 + 3 * TN;              // DMA pieces per step
+  constexpr int RINGB = D * STAGE;
+  static_assert((D & (D - 1)) == 0 && (D - 1) * PER <= 63, "ring depth");
+  static_assert(RINGB >= TN * 16 * 64 * 4, "the fold reuses a wave's ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, kg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int nbn = N / (32 * TN);
+  // consecutive blocks go round-robin to the 8 XCDs: give each XCD a contiguous range of work items (the column tiles of a row block
+  // share its A rows in that XCD's L2)
+  const int nblk = gridDim.x, per_x = nblk >> 3;
+  int work = blockIdx.x;
+  if ((nblk & 7) == 0) work = (blockIdx.x & 7) * per_x + (blockIdx.x >> 3);
+  const int bm = work / nbn, bn = work % nbn;
+  const int m0 = bm * 32, n0 = bn * 32 * TN;
+  const int nks = K / 16, per = (nks + KS - 1) / KS;
+  const int ks0 = kg * per, n = min(nks, ks0 + per) - ks0;      // this wave's k16 steps [ks0, ks0 + n)
+  char* ring = smem + kg * RINGB;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
+  // this lane's sources
+  const int arow = min(m0 + l31, M - 1);
+  const float* asrc = A + (size_t)arow * lda + 4 * hf;           // piece j adds 8 j floats, step s adds 16 s
+  const char* wsrc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) wsrc[t] = wimg + ((size_t)(bn * TN + t) * nks) * WTILE + lane * 16;
+
+  const auto issue = [&](int i, auto lgkm) {       // step i of this wave -> ring slot i % D (steps past the end re-read the last one)
+    constexpr int LG = decltype(lgkm)::value;
+    const int s = ks0 + min(i, n - 1);
+    const unsigned d = ring_lds + (unsigned)(i & (D - 1)) * STAGE;
+    const float* a = asrc + 16 * s;
+    dma16<LG>(a, d);
+    dma16<-1>(a + 8, d + 1024);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const char* g = wsrc[t] + (size_t)s * WTILE;
+      const unsigned db = d + 2048 + t * WTILE;
+      dma16<-1>(g, db); dma16<-1>(g + 1024, db + 1024); dma16<-1>(g + 2048, db + 2048);
+    }
+  };
+  const auto read = [&](int i) {
+    Ops<TN> o;
+    const char* p = ring + (i & (D - 1)) * STAGE;
+    const float4 x0 = *reinterpret_cast<const float4*>(p + 1024 * hf + 16 * l31), x1 = *reinterpret_cast<const float4*>(p + 1024 * hf + 512 + 16 * l31);
+    o.a[0] = x0.x; o.a[1] = x0.y; o.a[2] = x0.z; o.a[3] = x0.w; o.a[4] = x1.x; o.a[5] = x1.y; o.a[6] = x1.z; o.a[7] = x1.w;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const char* q = p + 2048 + t * WTILE + lane * 16;
+      o.b[t] = Split3{*reinterpret_cast<const bf16x8*>(q), *reinterpret_cast<const bf16x8*>(q + 1024), *reinterpret_cast<const bf16x8*>(q + 2048)};
+    }
+    return o;
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  if (n > 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) issue(i, std::integral_constant<int, -1>{});
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * PER) : "memory");
+    Ops<TN> cur = read(0);
+    for (int i = 0; i < n; ++i) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * PER) : "memory");     // step i + 1 has landed
+      const Ops<TN> nxt = read(i + 1);
+      // slot i % D (read one iteration ago) is refilled with step i + D once everything older than the reads just issued has returned
+      issue(i + D, std::integral_constant<int, PER>{});
+      const Split3 sa = split3(cur.a);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[t] = mfma6(sa, cur.b[t], acc[t]);
+      cur = nxt;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the steps still in flight must land before the ring is reused / released
+  if constexpr (KS > 1) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(ring) + lane;
+    if (kg > 0) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[(t * 16 + e) * 64] = acc[t][e];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+      const float* src = reinterpret_cast<const float*>(smem + g * RINGB) + lane;
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] += src[(t * 16 + e) * 64];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int j = n0 + t * 32 + l31;
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + crow(e, lane);
+      if (m < M) Cm[(size_t)m * ldc + j] = acc[t][e] + bj;
+    }
+  }
+}
+
+template <int TN, int D, int KS>
+int launch_dma(const float* a, const char* img, const float* bias, float* c, int M, int N, int K, hipStream_t st) {
+  if (N % (32 * TN) || K % 16) return SAST_EINVAL;
+  constexpr int LDS = KS * D * (2048 + TN * WTILE);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_gemm_nt_kernel<TN, D, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return SAST_EINVAL;
+    attr = true;
+  }
+  const int grid = ((M + 31) / 32) * (N / (32 * TN));
+  hipLaunchKernelGGL((dma_gemm_nt_kernel<TN, D, KS>), dim3(grid), dim3(64 * KS), LDS, st, a, K, img, bias, c, N, M, N, K);
+  return hipGetLastError() == hipSuccess ? SAST_OK : SAST_ELAUNCH;
+}
+}  // namespace
+
+extern "C" size_t sast_test_weight_image_bytes(int N, int K) { return (size_t)(N / 32) * (K / 16) * WTILE + 8 * WTILE; }
+
+extern "C" int sast_test_weight_image(const float* w, int N, int K, void* image, sast_stream_t stream) {
+  if (N % 32 || K % 16) return SAST_EINVAL;
+  const int items = (N / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(weight_image_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, N, K, reinterpret_cast<u4*>(image));
+  return hipGetLastError() == hipSuccess ? SAST_OK : SAST_ELAUNCH;
+}
+
+// cfg = 100 * TN + 10 * log2(D) + log2(KS)
+extern "C" int sast_test_dma_gemm_nt(const float* a, const void* image, const float* bias, float* c, int M, int N, int K, int cfg,
+                                     sast_stream_t stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const char* img = reinterpret_cast<const char*>(image);
+  switch (cfg) {
+    case 122: return launch_dma<1, 4, 4>(a, img, bias, c, M, N, K, st);
+    case 132: return launch_dma<1, 8, 4>(a, img, bias, c, M, N, K, st);
+    case 123: return launch_dma<1, 4, 8>(a, img, bias, c, M, N, K, st);
+    case 121: return launch_dma<1, 4, 2>(a, img, bias, c, M, N, K, st);
+    case 222: return launch_dma<2, 4, 4>(a, img, bias, c, M, N, K, st);
+    case 212: return launch_dma<2, 2, 4>(a, img, bias, c, M, N, K, st);
+    case 221: return launch_dma<2, 4, 2>(a, img, bias, c, M, N, K, st);
+    case 220: return launch_dma<2, 4, 1>(a, img, bias, c, M, N, K, st);
+    case 223: return launch_dma<2, 2, 8>(a, img, bias, c, M, N, K, st);
+    case 422: return launch_dma<4, 2, 4>(a, img, bias, c, M, N, K, st);
+    case 421: return launch_dma<4, 4, 2>(a, img, bias, c, M, N, K, st);
+    default: return SAST_EINVAL;
+  }
+}

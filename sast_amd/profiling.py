@@ -239,6 +239,10 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
                              "bytes_counter_over_algorithmic": (b_cnt / b_alg) if b_cnt else None,
                              "t_mfma_ms": t_m, "t_hbm_ms": t_h, "t_roof_ms": max(t_m, t_h), "bound": "mfma" if t_m >= t_h else "hbm",
                              "ms_per_step": ms_per_step, "frac": max(t_m, t_h) / ms_per_step,
+                             # against the pipe the default build EXECUTES the products on (6 bf16 MFMAs per fp32 product tile: 2516.6 / 6 =
+                             # 419.4 TFLOP/s of fp32-equivalent work) -- the stricter of the two fractions
+                             "t_executed_pipe_ms": (gflop / (PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS)) if split3 else t_m,
+                             "frac_of_executed_pipe": (max(gflop / (PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS), t_h) if split3 else max(t_m, t_h)) / ms_per_step,
                              "achieved_tflops": gflop / ms_per_step, "achieved_counter_tbs": (b_cnt / (ms_per_step * 1e-3) / 1e12) if b_cnt else None,
                              "note": "gflop: algorithmic 2*M*N*K of every GEMM / conv + 4*C*sum K_m^2 (x2.5 backward) of the attention launches, from "
                                      "device-side counts; bytes_algorithmic: SURVEY 8d rule (dense upper bound, backward = 2x forward, optimizer 28 B/param); "
