@@ -48,12 +48,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_dst) {
 template <int TN> struct Ops { float a[8]; Split3 b[TN]; };
 
 // TN: 32-column tiles per wave; D: ring depth in k16 steps (power of two); KS: k-groups (waves) per workgroup
-template <int TN, int D, int KS>
+// MODE (diagnostics, wrong results by design except bit 0): 1 = every row block starts its k range at another offset (do concurrent
+// workgroups that stream the same weight tiles in lockstep hot-spot a few L2 channels?), 2 = no A pieces, 4 = no weight pieces,
+// 8 = no MFMAs / split (what is left is the data movement)
+template <int TN, int D, int KS, int MODE = 0>
 __global__ __launch_bounds__(64 * KS) void dma_gemm_nt_kernel(const float* __restrict__ A, int lda, const char* __restrict__ wimg,
                                                                const float* __restrict__ bias, float* __restrict__ Cm, int ldc, int M,
                                                                int N, int K) {
   constexpr int STAGE = 2048 + TN * WTILE;     // bytes of one k16 step: A tile (32 x 16 fp32) + TN weight tiles
-  constexpr int PER = 2 + 3 * TN;              // DMA pieces per step
+  constexpr int PER = ((MODE & 2) ? 0 : 2) + ((MODE & 4) ? 0 : 3 * TN);              // DMA pieces per step
   constexpr int RINGB = D * STAGE;
   static_assert((D & (D - 1)) == 0 && (D - 1) * PER <= 63, "ring depth");
   static_assert(RINGB >= TN * 16 * 64 * 4, "the fold reuses a wave's ring");
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(64 * KS) void dma_gemm_nt_kernel(const float* __res
   const int m0 = bm * 32, n0 = bn * 32 * TN;
   const int nks = K / 16, per = (nks + KS - 1) / KS;
   const int ks0 = kg * per, n = min(nks, ks0 + per) - ks0;      // this wave's k16 steps [ks0, ks0 + n)
+  const int rot = n > 0 ? (bm * 5 + bn * 3) % n : 0;            // MODE & 1
   char* ring = smem + kg * RINGB;
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)ring);
   // this lane's sources
@@ -81,16 +85,23 @@ __global__ __launch_bounds__(64 * KS) void dma_gemm_nt_kernel(const float* __res
 
   const auto issue = [&](int i, auto lgkm) {       // step i of this wave -> ring slot i % D (steps past the end re-read the last one)
     constexpr int LG = decltype(lgkm)::value;
-    const int s = ks0 + min(i, n - 1);
+    int ii = min(i, n - 1);
+    if constexpr (MODE & 1) { ii += rot; if (ii >= n) ii -= n; }
+    const int s = ks0 + ii;
     const unsigned d = ring_lds + (unsigned)(i & (D - 1)) * STAGE;
     const float* a = asrc + 16 * s;
-    dma16<LG>(a, d);
-    dma16<-1>(a + 8, d + 1024);
+    if constexpr (!(MODE & 2)) {
+      dma16<LG>(a, d);
+      dma16<-1>(a + 8, d + 1024);
+    }
+    if constexpr (!(MODE & 4)) {
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      const char* g = wsrc[t] + (size_t)s * WTILE;
-      const unsigned db = d + 2048 + t * WTILE;
-      dma16<-1>(g, db); dma16<-1>(g + 1024, db + 1024); dma16<-1>(g + 2048, db + 2048);
+      for (int t = 0; t < TN; ++t) {
+        const char* g = wsrc[t] + (size_t)s * WTILE;
+        const unsigned db = d + 2048 + t * WTILE;
+        if ((MODE & 2) && t == 0) dma16<LG>(g, db); else dma16<-1>(g, db);
+        dma16<-1>(g + 1024, db + 1024); dma16<-1>(g + 2048, db + 2048);
+      }
     }
   };
   const auto read = [&](int i) {
@@ -121,10 +132,15 @@ __global__ __launch_bounds__(64 * KS) void dma_gemm_nt_kernel(const float* __res
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * PER) : "memory");     // step i + 1 has landed
       const Ops<TN> nxt = read(i + 1);
       // slot i % D (read one iteration ago) is refilled with step i + D once everything older than the reads just issued has returned
-      issue(i + D, std::integral_constant<int, PER>{});
-      const Split3 sa = split3(cur.a);
+      issue(i + D, std::integral_constant<int, 2 + 3 * TN>{});      // (lgkmcnt: the LDS reads just issued may stay outstanding)
+      if constexpr (MODE & 8) {
 #pragma unroll
-      for (int t = 0; t < TN; ++t) acc[t] = mfma6(sa, cur.b[t], acc[t]);
+        for (int t = 0; t < TN; ++t) acc[t][0] += cur.a[t] + __builtin_bit_cast(u4, cur.b[t].h)[0] * 1e-30f;      // keep the reads alive
+      } else {
+        const Split3 sa = split3(cur.a);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = mfma6(sa, cur.b[t], acc[t]);
+      }
       cur = nxt;
     }
   }
@@ -161,17 +177,17 @@ __global__ __launch_bounds__(64 * KS) void dma_gemm_nt_kernel(const float* __res
   }
 }
 
-template <int TN, int D, int KS>
+template <int TN, int D, int KS, int MODE = 0>
 int launch_dma(const float* a, const char* img, const float* bias, float* c, int M, int N, int K, hipStream_t st) {
   if (N % (32 * TN) || K % 16) return SAST_EINVAL;
   constexpr int LDS = KS * D * (2048 + TN * WTILE);
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_gemm_nt_kernel<TN, D, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return SAST_EINVAL;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dma_gemm_nt_kernel<TN, D, KS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return SAST_EINVAL;
     attr = true;
   }
   const int grid = ((M + 31) / 32) * (N / (32 * TN));
-  hipLaunchKernelGGL((dma_gemm_nt_kernel<TN, D, KS>), dim3(grid), dim3(64 * KS), LDS, st, a, K, img, bias, c, N, M, N, K);
+  hipLaunchKernelGGL((dma_gemm_nt_kernel<TN, D, KS, MODE>), dim3(grid), dim3(64 * KS), LDS, st, a, K, img, bias, c, N, M, N, K);
   return hipGetLastError() == hipSuccess ? SAST_OK : SAST_ELAUNCH;
 }
 }  // namespace
@@ -202,6 +218,15 @@ extern "C" int sast_test_dma_gemm_nt(const float* a, const void* image, const fl
     case 223: return launch_dma<2, 2, 8>(a, img, bias, c, M, N, K, st);
     case 422: return launch_dma<4, 2, 4>(a, img, bias, c, M, N, K, st);
     case 421: return launch_dma<4, 4, 2>(a, img, bias, c, M, N, K, st);
+    // diagnostics on the TN 2, ring 2 / 4, 4 k-group forms: cfg + 1000 MODE
+    case 1212: return launch_dma<2, 2, 4, 1>(a, img, bias, c, M, N, K, st);
+    case 1222: return launch_dma<2, 4, 4, 1>(a, img, bias, c, M, N, K, st);
+    case 2212: return launch_dma<2, 2, 4, 2>(a, img, bias, c, M, N, K, st);
+    case 4212: return launch_dma<2, 2, 4, 4>(a, img, bias, c, M, N, K, st);
+    case 8212: return launch_dma<2, 2, 4, 8>(a, img, bias, c, M, N, K, st);
+    case 10212: return launch_dma<2, 2, 4, 10>(a, img, bias, c, M, N, K, st);
+    case 12212: return launch_dma<2, 2, 4, 12>(a, img, bias, c, M, N, K, st);
+    case 6212: return launch_dma<2, 2, 4, 6>(a, img, bias, c, M, N, K, st);
     default: return SAST_EINVAL;
   }
 }
