@@ -188,7 +188,18 @@ def selection_margins(scores: Tensor, B: int, N: int, T: int, bounce: float):
 
 # --------------------------------------------------------------------------- a9
 # layers/create_act.py:62-79 (_ACT_LAYER_DEFAULT; torch >= 1.7 has nn.SiLU): the names the build implements
-GLU_ACTS = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, "swish": F.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh}
+def _hard_mish(x):
+    """layers/activations.py:104-112 (the memory-efficient variant get_act_layer picks, activations_me.py, has the same derivative
+    except on the two kinks)"""
+    return 0.5 * x * (x + 2).clamp(min=0, max=2)
+
+
+# every parameter-free name of get_act_layer (layers/create_act.py:62-98), mapped as the reference maps it on this torch: native
+# F.silu / F.mish / F.hardsigmoid / F.hardswish, module defaults for leaky_relu (0.01), elu / celu (alpha 1), selu
+GLU_ACTS = {"gelu": F.gelu, "relu": F.relu, "silu": F.silu, "swish": F.silu, "sigmoid": torch.sigmoid, "tanh": torch.tanh,
+            "mish": F.mish, "relu6": F.relu6, "leaky_relu": F.leaky_relu, "elu": F.elu, "celu": F.celu, "selu": F.selu,
+            "hard_sigmoid": F.hardsigmoid, "hardsigmoid": F.hardsigmoid, "hard_swish": F.hardswish, "hardswish": F.hardswish,
+            "hard_mish": _hard_mish}
 
 
 def drop_path(x: Tensor, cfg: "AttnCfg") -> Tensor:

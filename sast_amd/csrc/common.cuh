@@ -110,14 +110,26 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 
 // gate activation of the GLU-MLP (ops.py:111-137, act_layer from layers/create_act.py:62-79): SastMswsaArgs.mlp_act
 //   0 gelu (erf form: GeGLU, every shipped config)  1 relu (ReGLU)  2 silu / swish (SwiGLU)  3 sigmoid (GLU)  4 tanh
+//   round 5, the remaining parameter-free names of get_act_layer (torch module defaults):  5 mish  6 relu6  7 leaky_relu (slope 0.01)
+//   8 elu / celu (alpha 1: the two coincide)  9 selu  10 hard_sigmoid  11 hard_swish  12 hard_mish (HardMishMe: its own backward)
 // the code is wave-uniform (one layer per launch): the switch is a scalar branch
-constexpr int GLU_ACT_COUNT = 5;
+constexpr int GLU_ACT_COUNT = 13;
+constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f, SELU_SCALE = 1.0507009873554804934193349852946f;
+__device__ __forceinline__ float softplus_t20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }      // F.softplus(beta 1, threshold 20)
 __device__ __forceinline__ float glu_act(float g, int act) {
   switch (act) {
     case 1: return fmaxf(g, 0.0f);
     case 2: return g * sigmoid_exact(g);
     case 3: return sigmoid_exact(g);
     case 4: return tanhf(g);
+    case 5: return g * tanhf(softplus_t20(g));
+    case 6: return fminf(fmaxf(g, 0.0f), 6.0f);
+    case 7: return g > 0.0f ? g : 0.01f * g;
+    case 8: return g > 0.0f ? g : expm1f(g);
+    case 9: return SELU_SCALE * (g > 0.0f ? g : SELU_ALPHA * expm1f(g));
+    case 10: return fminf(fmaxf(g + 3.0f, 0.0f), 6.0f) / 6.0f;
+    case 11: return g * fminf(fmaxf(g + 3.0f, 0.0f), 6.0f) / 6.0f;
+    case 12: return 0.5f * g * fminf(fmaxf(g + 2.0f, 0.0f), 2.0f);
     default: return gelu_erf(g);
   }
 }
@@ -127,6 +139,14 @@ __device__ __forceinline__ float glu_act_grad(float g, int act) {
     case 2: { const float s = sigmoid_exact(g); return s * (1.0f + g * (1.0f - s)); }
     case 3: { const float s = sigmoid_exact(g); return s * (1.0f - s); }
     case 4: { const float t = tanhf(g); return 1.0f - t * t; }
+    case 5: { const float t = tanhf(softplus_t20(g)); return t + g * (1.0f - t * t) * (1.0f / (1.0f + expf(-g))); }
+    case 6: return (g > 0.0f && g < 6.0f) ? 1.0f : 0.0f;    // hardtanh_backward: 0 at and beyond both ends
+    case 7: return g > 0.0f ? 1.0f : 0.01f;
+    case 8: return g > 0.0f ? 1.0f : expf(g);
+    case 9: return g > 0.0f ? SELU_SCALE : SELU_SCALE * SELU_ALPHA * expf(g);
+    case 10: return (g > -3.0f && g < 3.0f) ? (1.0f / 6.0f) : 0.0f;
+    case 11: return g < -3.0f ? 0.0f : (g <= 3.0f ? g / 3.0f + 0.5f : 1.0f);      // hardswish_backward
+    case 12: return g < -2.0f ? 0.0f : (g <= 0.0f ? g + 1.0f : 1.0f);             // activations_me.py: hard_mish_jit_bwd
     default: return gelu_erf_grad(g);
   }
 }

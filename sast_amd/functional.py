@@ -780,7 +780,11 @@ class _MSWSA(torch.autograd.Function):
         return (dxin, None, None, None, None, None, None, None, None) + pg.out()
 
 
-GLU_ACTIVATIONS = {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4}     # include/sast_hip.h: SastMswsaArgs.mlp_act
+# include/sast_hip.h: SastMswsaArgs.mlp_act.  Every parameter-free name of the reference's get_act_layer (layers/create_act.py:62-79, with
+# the defaults of the torch modules it maps to); `prelu` carries a learnable slope (a parameter the reference's state_dict would gain)
+# and is refused.
+GLU_ACTIVATIONS = {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4, "mish": 5, "relu6": 6, "leaky_relu": 7, "elu": 8,
+                   "celu": 8, "selu": 9, "hard_sigmoid": 10, "hardsigmoid": 10, "hard_swish": 11, "hardswish": 11, "hard_mish": 12}
 
 
 def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32, fused: bool = True,

@@ -93,7 +93,9 @@ def _glu_activation_name(act) -> str:
     if isinstance(act, str):
         name = act
     else:
-        name = {nn.GELU: "gelu", nn.ReLU: "relu", nn.SiLU: "silu", nn.Sigmoid: "sigmoid", nn.Tanh: "tanh"}.get(act)
+        name = {nn.GELU: "gelu", nn.ReLU: "relu", nn.SiLU: "silu", nn.Sigmoid: "sigmoid", nn.Tanh: "tanh", nn.Mish: "mish", nn.ReLU6: "relu6",
+                nn.LeakyReLU: "leaky_relu", nn.ELU: "elu", nn.CELU: "celu", nn.SELU: "selu", nn.Hardsigmoid: "hard_sigmoid",
+                nn.Hardswish: "hard_swish"}.get(act)
     if name not in SF.GLU_ACTIVATIONS:
         raise NotImplementedError(f"sast_amd: MLP activation {act!r}: the GLU epilogues implement {sorted(SF.GLU_ACTIVATIONS)}")
     return name
@@ -104,8 +106,11 @@ class MS_WSA(nn.Module):
 
     def __init__(self, dim: int, dim_head: int = 32, bias: bool = True, sub_layer_params=None, norms=None):
         super().__init__()
-        if dim_head not in (24, 32):
-            raise NotImplementedError("sast_amd: the attention kernels are built for dim_head 32 and 24 (the widths the reference ships)")
+        if dim_head % 4 or not 4 <= dim_head <= 32 or dim % dim_head:
+            # SAST.py:35,171-179 accept any divisor of dim; the attention kernels hold a head's q / k / v in one 32-wide plane row
+            # (narrower heads are zero-padded), so heads of 4, 8, ... 32 channels run -- the shipped models use 32 (tiny / base / large: 24)
+            raise NotImplementedError(f"sast_amd: dim_head {dim_head} (dim {dim}): the attention kernels take head widths that are multiples "
+                                      "of 4 up to 32 and divide dim")
         self.num_heads = dim // dim_head
         self.dim_head = dim_head
         self.scale = dim_head ** -0.5

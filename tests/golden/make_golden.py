@@ -231,9 +231,20 @@ def gen_downsample_variants(ref):
     print("downsample_variants ok")
 
 
-def gen_acts(ref):
-    for act in ("relu", "silu", "sigmoid", "tanh"):
+ACTS_R4 = ("relu", "silu", "sigmoid", "tanh")
+# round 5: the remaining parameter-free names of get_act_layer (layers/create_act.py:62-98)
+ACTS_R5 = ("mish", "relu6", "leaky_relu", "elu", "celu", "selu", "hard_sigmoid", "hard_swish", "hard_mish")
+
+
+def gen_acts(ref, names=ACTS_R4 + ACTS_R5):
+    for act in names:
         gen_block(ref, "block_act_" + act, 1, 2e-2, C=32, act=act)
+
+
+def gen_dim_heads(ref):
+    """dim_head other than the shipped 32 / 24 (SAST.py:35,171-179 accept any divisor of dim): 16 and 8 at C = 32 (2 / 4 heads)"""
+    gen_block(ref, "block_dh16", 2, 2e-2, C=32, dim_head=16)
+    gen_block(ref, "block_dh8", 1, 2e-2, C=32, dim_head=8)
 
 
 def gen_two_blocks(ref):
@@ -770,6 +781,12 @@ def main():
     if "--acts-only" in sys.argv:    # the gate activations beside gelu (B=1, C=32: small fixtures)
         gen_acts(ref)
         return
+    if "--acts-r5-only" in sys.argv:
+        gen_acts(ref, ACTS_R5)
+        return
+    if "--dim-heads-only" in sys.argv:
+        gen_dim_heads(ref)
+        return
     if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
         gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
         gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
@@ -784,6 +801,7 @@ def main():
     gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
     gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
     gen_acts(ref)
+    gen_dim_heads(ref)
     gen_block_drop_path(ref)
     gen_block_drop_path(ref, "block_drop_mlp", pdrop=0.0, pmlp=0.2)
     gen_block_drop_path(ref, "block_drop_path_cb", pdrop=0.25, pmlp=0.2, enable_cb=True)

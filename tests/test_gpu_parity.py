@@ -130,7 +130,8 @@ def test_input_prep_one_launch(golden_dir, dev):
 
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
                                   "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
-                                  "block_act_tanh"])
+                                  "block_act_tanh", "block_act_mish", "block_act_relu6", "block_act_leaky_relu", "block_act_elu", "block_act_celu",
+                                  "block_act_selu", "block_act_hard_sigmoid", "block_act_hard_swish", "block_act_hard_mish", "block_dh16", "block_dh8"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine

@@ -43,7 +43,8 @@ def test_non_zero_ratio(golden_dir):
 
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
                                   "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
-                                  "block_act_tanh"])
+                                  "block_act_tanh", "block_act_mish", "block_act_relu6", "block_act_leaky_relu", "block_act_elu", "block_act_celu",
+                                  "block_act_selu", "block_act_hard_sigmoid", "block_act_hard_swish", "block_act_hard_mish", "block_dh16", "block_dh8"])
 def test_sast_block(golden_dir, name):
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
