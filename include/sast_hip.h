@@ -67,7 +67,7 @@ int sast_add_rows(const float* x, const float* table, float* y, int rows, int C,
 /* mean squares of up to 4 dense fp32 tensors in one launch: partials[t*SAST_MEAN_SQUARE_BLOCKS + b], whose sum is
    sum_t mean(x_t^2) -- the synthetic training objective of bench.py (the reference's benchmark.py has no loss; its real
    objective is sast_yolox_loss).  x / n / dx are HOST arrays of `count` device pointers / element counts (n % 4 == 0). */
-#define SAST_MEAN_SQUARE_BLOCKS 32
+#define SAST_MEAN_SQUARE_BLOCKS 128   /* (round 5: 32 workgroups per tensor left 160 CUs idle: 11.8 + 13.6 us for 14 MB) */
 int sast_mean_square_fwd(const float* const* x, const size_t* n, int count, float* partials, sast_stream_t stream);
 int sast_mean_square_bwd(const float* const* x, const size_t* n, int count, const float* d_partials, int d_stride, float* const* dx,
                          sast_stream_t stream);   /* d_stride 1: one gradient per partial; 0: d_partials[0] for all (the broadcast gradient of a .sum()) */

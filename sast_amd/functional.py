@@ -263,7 +263,7 @@ def as_nchw_view(x_nhwc: torch.Tensor) -> torch.Tensor:
     return x_nhwc.permute(0, 3, 1, 2)
 
 
-MEAN_SQUARE_BLOCKS = 32   # include/sast_hip.h: SAST_MEAN_SQUARE_BLOCKS
+MEAN_SQUARE_BLOCKS = 128   # include/sast_hip.h: SAST_MEAN_SQUARE_BLOCKS
 
 
 class _MeanSquares(torch.autograd.Function):
