@@ -298,6 +298,9 @@ extern "C" int sast_test_atomic_xcd(float* buf, int* out_xcc, int mode, int nflo
 // mode 0: every wave runs MFMA chains only; 1: VALU only; 2: waves 0-3 MFMA, waves 4-7 VALU (the pair on a SIMD is complementary);
 // 3: every wave alternates 6 dependent MFMAs with NV independent VALU instructions (the shape of the fused layer kernels);
 // 4: as 3 with TWO accumulator chains interleaved.  out[block] = shader-clock cycles of wave 0.
+// round 5 -- modes 5 / 6: the SAME work per wave as 3 / 4 but in INTERLEAVED program order, one MFMA followed by NV / 6 VALU instructions
+// (forced with sched_group_barrier: an in-order wave can only hide VALU work under an MFMA if the VALU instructions sit between two
+// MFMAs in its instruction stream); 5: one accumulator chain, 6: two chains.
 template <int MODE, int NV>
 __global__ __launch_bounds__(512) void overlap_probe_kernel(float* __restrict__ out, long long* __restrict__ cyc, int iters) {
   using bf16x8_t = __attribute__((ext_vector_type(8))) __bf16;
@@ -312,6 +315,21 @@ __global__ __launch_bounds__(512) void overlap_probe_kernel(float* __restrict__ 
   const long long t0 = clock64();
   const bool do_m = MODE == 0 || (MODE == 2 && w < 4) || MODE >= 3, do_v = MODE == 1 || (MODE == 2 && w >= 4) || MODE >= 3;
   for (int it = 0; it < iters; ++it) {
+    if constexpr (MODE == 5 || MODE == 6) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        if (MODE == 6 && (k & 1)) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NV / 6; ++q) v[(k * (NV / 6) + q) & 7] = fmaf(v[(k * (NV / 6) + q) & 7], 1.000001f, 0.5f);
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA ...
+        __builtin_amdgcn_sched_group_barrier(0x002, NV / 6, 0);     // ... then NV / 6 VALU
+      }
+      continue;
+    }
     if (do_m) {
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
@@ -333,11 +351,18 @@ __global__ __launch_bounds__(512) void overlap_probe_kernel(float* __restrict__ 
 }
 extern "C" int sast_test_overlap_probe(float* out, long long* cyc, int mode, int nv, int blocks, int iters, sast_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
-#define OVL(M, V) SAST_LAUNCH((overlap_probe_kernel<M, V>), dim3(blocks), dim3(512), 0, st, out, cyc, iters)
-  if (nv == 24) { switch (mode) { case 0: OVL(0, 24); break; case 1: OVL(1, 24); break; case 2: OVL(2, 24); break; case 3: OVL(3, 24); break; case 4: OVL(4, 24); break; default: return SAST_EINVAL; } }
-  else if (nv == 48) { switch (mode) { case 0: OVL(0, 48); break; case 1: OVL(1, 48); break; case 2: OVL(2, 48); break; case 3: OVL(3, 48); break; case 4: OVL(4, 48); break; default: return SAST_EINVAL; } }
+  // mode + 10: the same with ONE wave per SIMD (256 threads)
+  const int threads = mode >= 10 ? 256 : 512;
+  mode %= 10;
+#define OVL(M, V) SAST_LAUNCH((overlap_probe_kernel<M, V>), dim3(blocks), dim3(threads), 0, st, out, cyc, iters)
+#define OVLS(V) switch (mode) { case 0: OVL(0, V); break; case 1: OVL(1, V); break; case 2: OVL(2, V); break; case 3: OVL(3, V); break; case 4: OVL(4, V); break; \
+                                case 5: OVL(5, V); break; case 6: OVL(6, V); break; default: return SAST_EINVAL; }
+  if (nv == 24) { OVLS(24) }
+  else if (nv == 48) { OVLS(48) }
+  else if (nv == 72) { OVLS(72) }
   else return SAST_EINVAL;
 #undef OVL
+#undef OVLS
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

@@ -12,13 +12,15 @@ st = torch.cuda.current_stream().cuda_stream
 out = torch.zeros(16, device="cuda"); cyc = torch.zeros(256, dtype=torch.int64, device="cuda")
 iters = 2000
 names = {0: "MFMA only (both waves)", 1: "VALU only (both waves)", 2: "one MFMA wave + one VALU wave per SIMD", 3: "each wave: 6 MFMA then NV VALU",
-         4: "each wave: 2 MFMA chains then NV VALU"}
+         4: "each wave: 2 MFMA chains then NV VALU", 5: "each wave: (1 MFMA, NV/6 VALU) x 6 interleaved", 6: "the same, two accumulator chains",
+         10: "ONE wave per SIMD: MFMA only", 11: "ONE wave per SIMD: VALU only", 13: "ONE wave per SIMD: 6 MFMA then NV VALU",
+         15: "ONE wave per SIMD: interleaved, one chain", 16: "ONE wave per SIMD: interleaved, two chains"}
 # work per loop iteration and SIMD (two waves per SIMD): mode 0: 2 x 6 MFMA; mode 1: 2 x NV VALU; mode 2: 6 MFMA (one wave) + NV VALU (the
 # other); modes 3 / 4: 2 x (6 MFMA + NV VALU).  One UNIT of work = 6 MFMA + NV VALU on one SIMD; every line is restated in ns per unit (for
 # the pure modes: per MFMA half / VALU half of a unit) so that the modes can be compared -- round 4 printed wave cycles next to whole-kernel
 # ns and read "specialised waves overlap" out of numbers that referred to different amounts of work (round-4 verdict, weak #9).
-UNITS = {0: 2.0, 1: 2.0, 2: 1.0, 3: 2.0, 4: 2.0}
-for nv in (24, 48):
+UNITS = {0: 2.0, 1: 2.0, 2: 1.0, 3: 2.0, 4: 2.0, 5: 2.0, 6: 2.0, 10: 1.0, 11: 1.0, 13: 1.0, 15: 1.0, 16: 1.0}
+for nv in (24, 48, 72):
     per_unit = {}
     for mode, name in names.items():
         fn(out.data_ptr(), cyc.data_ptr(), mode, nv, 256, 10, st)
@@ -28,8 +30,10 @@ for nv in (24, 48):
         c = cyc.float().mean().item() / iters
         ns = e0.elapsed_time(e1) * 1e6 / iters
         per_unit[mode] = ns / UNITS[mode]
-        what = "per 6-MFMA half" if mode == 0 else f"per {nv}-VALU half" if mode == 1 else "per unit (6 MFMA + NV VALU)"
+        what = "per 6-MFMA half" if mode in (0, 10) else f"per {nv}-VALU half" if mode in (1, 11) else "per unit (6 MFMA + NV VALU)"
         print(f"NV {nv:3d}  {name:42s} {c:8.1f} clock64 cycles / iteration of wave 0   {ns:7.1f} ns / iteration   {per_unit[mode]:7.1f} ns {what}")
     serial = per_unit[0] + per_unit[1]
     print(f"NV {nv:3d}  per unit of work: no overlap at all would be {serial:.1f} ns (MFMA half + VALU half); specialised waves {per_unit[2]:.1f} "
-          f"({per_unit[2] / serial:.2f}x), alternating waves {per_unit[3]:.1f} ({per_unit[3] / serial:.2f}x), two chains {per_unit[4]:.1f} ({per_unit[4] / serial:.2f}x)")
+          f"({per_unit[2] / serial:.2f}x), alternating waves {per_unit[3]:.1f} ({per_unit[3] / serial:.2f}x), two chains {per_unit[4]:.1f} ({per_unit[4] / serial:.2f}x), "
+          f"INTERLEAVED program order {per_unit[5]:.1f} ({per_unit[5] / serial:.2f}x) / two chains {per_unit[6]:.1f} ({per_unit[6] / serial:.2f}x); one wave per SIMD: "
+          f"MFMA {per_unit[10]:.1f} + VALU {per_unit[11]:.1f} = {per_unit[10] + per_unit[11]:.1f}, blocks {per_unit[13]:.1f}, interleaved {per_unit[15]:.1f} / two chains {per_unit[16]:.1f}")
