@@ -136,6 +136,84 @@ def test_flat_params_allreduce_adamw_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+_INPLACE_DDP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from sast_amd import functional as SF
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+mode = sys.argv[2]
+SF.set_autograd_visible_grads(mode == "visible")
+
+
+class Lin(torch.autograd.Function):
+    """a linear layer under sast_amd's parameter-gradient contract (functional._ParamGrads): in-place mode = accumulate into `.grad`
+    and return None on the parameter's autograd edge; autograd-visible mode = return the buffer"""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        pg = SF._ParamGrads(ctx.w)
+        pg[0].add_(dy.t() @ x)                 # what the backward kernels do: "+=" into the buffer they are handed
+        return dy @ ctx.w, pg.out()[0]
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(4, 3))
+        self.w2 = torch.nn.Parameter(torch.randn(2, 4))
+
+    def forward(self, x):
+        return Lin.apply(Lin.apply(x, self.w1), self.w2)
+
+
+torch.manual_seed(0)
+net = Net()
+ddp = torch.nn.parallel.DistributedDataParallel(net, find_unused_parameters=False, gradient_as_bucket_view=True)     # train.py:96-98
+for it, set_to_none in enumerate((True, True, False)):
+    ddp.zero_grad(set_to_none=set_to_none)
+    torch.manual_seed(100 * it + rank)
+    x = torch.randn(5, 3)
+    ddp(x).pow(2).sum().backward()
+    xs = [torch.zeros_like(x) for _ in range(world)]
+    dist.all_gather(xs, x)
+    ref1, ref2 = 0, 0
+    for xx in xs:                              # DDP: the mean of the ranks' gradients
+        w1, w2 = net.w1.detach().clone().requires_grad_(True), net.w2.detach().clone().requires_grad_(True)
+        ((xx @ w1.t()) @ w2.t()).pow(2).sum().backward()
+        ref1, ref2 = ref1 + w1.grad / world, ref2 + w2.grad / world
+    assert torch.allclose(net.w1.grad, ref1, rtol=1e-5, atol=1e-6), (mode, it, float((net.w1.grad - ref1).abs().max()))
+    assert torch.allclose(net.w2.grad, ref2, rtol=1e-5, atol=1e-6), (mode, it)
+dist.destroy_process_group()
+print("rank", rank, mode, "ok")
+'''
+
+
+@pytest.mark.parametrize("mode", ["inplace", "visible"])
+def test_parameter_gradient_contract_under_ddp_gloo_world2(tmp_path, mode):
+    """the assumption the in-place gradient contract rests on, pinned for THIS torch: when a Function returns None for a parameter, the
+    parameter's AccumulateGrad node still runs (with an undefined gradient) and DistributedDataParallel's hooks on it fire -- after the
+    backward that filled `.grad` in place -- so DDP (find_unused_parameters=False, gradient_as_bucket_view=True: the reference's strategy,
+    train.py:96-98) reduces the right values over three iterations, with grads set to None and zeroed in place (bucket views).  The
+    autograd-visible mode must give the same.  (The real modules run the same scenario on the GPU:
+    test_reference_ddp_caller_with_sync_batchnorm.)"""
+    script = tmp_path / "worker.py"
+    script.write_text(_INPLACE_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29733" if mode == "inplace" else "29734", str(script), ROOT, mode],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
 def test_positive_linear_forward_matches_reference_expression():
     """SAST.py:325-328: F.linear(input, exp(weight), bias) -- the stand-alone module computes (inside SAST_block it is fused)"""
     import torch
