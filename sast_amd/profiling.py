@@ -41,13 +41,15 @@ def _norm_kernel(name: str) -> str:
 
 
 def csrc_sha() -> str:
-    """content hash of the kernel sources: stamped into the PMC summary by tools/rocpd_pmc.py, compared by bench.py so that a
-    traffic figure measured on older kernels is flagged instead of silently reported"""
+    """content hash of the PRODUCT kernel sources (what libsast_hip.so is built from: build.SOURCES + the headers; the tools-only
+    translation units k_test.hip / k_dma_test.hip do not count): stamped into the PMC summary by tools/rocpd_pmc.py, compared by bench.py
+    so that a traffic figure measured on older kernels is flagged instead of silently reported"""
     import hashlib
+    from .build import SOURCES
     h = hashlib.sha256()
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     for fn in sorted(os.listdir(d)):
-        if fn.endswith((".hip", ".cuh", ".h")):
+        if fn in SOURCES or fn.endswith((".cuh", ".h")):
             with open(os.path.join(d, fn), "rb") as f:
                 h.update(fn.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
