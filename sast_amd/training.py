@@ -217,6 +217,13 @@ class TrainStep:
         (never captured).  not segmented and world == 1: ONE graph including the optimizer update; not segmented and
         world > 1: one graph for forward + backward, all-reduce + update behind it."""
         self.flat.check_views()
+        if SF.AUTOGRAD_GRADS:
+            # with gradients returned on the autograd edges the parameters' AccumulateGrad nodes add them into the flat views -- on the
+            # stream each node was created on (an eager step before the capture), not on the capture stream: measured garbage in the
+            # segmented graphs (round 5).  The in-place contract has no AccumulateGrad work at all.
+            raise RuntimeError("sast_amd.TrainStep.capture needs the in-place gradient mode (functional.set_autograd_visible_grads(False)): "
+                               "the autograd-visible mode is for callers that own the backward (DDP, torch.autograd.grad), not for the "
+                               "captured flat-buffer step")
         for m in (self.fpn, self.head):
             grp = pass_sync_group(m) if m is not None else None
             if grp is not None and grp.active() and not grp.capturable():
