@@ -466,7 +466,8 @@ def main():
         # for ranks that are not there -- skipped, `roofline` is then absent from the line)
         if not args.no_roofline and not (tr.sync_bn and world > 1):
             from sast_amd.profiling import dominant_kernel_roofline
-            res["roofline"] = dominant_kernel_roofline(tr, ms_per_step=res["ms_per_step"] / max(args.seq_len, 1), hw=HW, batch=BATCH)
+            res["roofline"] = dominant_kernel_roofline(tr, ms_per_step=res["ms_per_step"], hw=HW, batch=BATCH, seq_len=max(args.seq_len, 1),
+                                                       pmc_applies=baseline_cfg and args.event_dtype == "int32" and not tr.sync_bn)
         if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy" and args.precision == "f32":
             parity, res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only, tr=tr)
             if parity is not None:

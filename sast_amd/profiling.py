@@ -168,7 +168,9 @@ def pmc_bytes_per_step():
         return None
 
 
-def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=None, batch=None):
+def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=None, batch=None, seq_len: int = 1, pmc_applies: bool = True):
+    """pmc_applies: the committed rocprofv3 --pmc summary (profiles/pmc_hbm_traffic_latest.json) was taken on THIS configuration (bench.py:
+    the BASELINE configuration); otherwise `traffic` / `bytes_counter` are null -- counter bytes of another shape say nothing here"""
     # rank-local on purpose: this leg runs on rank 0 only, after the timed region -- it must not enter a collective (the
     # other ranks are already past it), so it replays forward + backward without the gradient all-reduce / optimizer step
     def run(n):
@@ -213,8 +215,9 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
            **pipe,
            "achieved_tflops": achieved, "frac_of_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
            "achieved_algorithmic_gbs": 1e3 * achieved_tbs, "frac_of_hbm_peak": achieved_tbs / PEAK_HBM_TBS,
-           "traffic": pmc_traffic_bytes(name), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json)",
-           "traffic_over_algorithmic": (pmc_traffic_bytes(name) / (nbytes / calls)) if (pmc_traffic_bytes(name) and nbytes) else None,
+           "traffic": pmc_traffic_bytes(name) if pmc_applies else None,
+           "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/pmc_hbm_traffic_latest.json; null when that summary is of another configuration)",
+           "traffic_over_algorithmic": (pmc_traffic_bytes(name) / (nbytes / calls)) if (pmc_applies and pmc_traffic_bytes(name) and nbytes) else None,
            "traffic_profile_csrc_sha": stamp, "traffic_stale": stamp != csrc_sha(), "kernel": name,
            "launches_per_step": calls / n_steps, "avg_launch_us": 1e3 * ms / calls,
            "algorithmic_gflop_per_launch": flops / calls / 1e9, "algorithmic_mbytes_per_launch": nbytes / calls / 1e6,
@@ -235,8 +238,11 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
         gflop = sum(r["flops"] for r in rows) / n_steps / 1e9
         fwd_only = bool(getattr(trainer, "fwd_only", False))
         b_alg = algorithmic_bytes_per_step(hw, batch, n_params=n_params, fwd_only=fwd_only, with_fpn=not fwd_only or bool(getattr(trainer, "infer", False)))
+        if seq_len > 1:      # a BPTT step runs the backbone on every timestep (the measured gflop cover all of them); weights / optimizer once
+            once = (4.0 if fwd_only else 3.0 * 4.0 + 28.0) * n_params
+            b_alg = (b_alg - once) * seq_len + once
         t_m, t_h = gflop / PEAK_F32_MFMA_TFLOPS, b_alg / (PEAK_HBM_TBS * 1e12) * 1e3      # ms
-        b_cnt = pmc_bytes_per_step()
+        b_cnt = pmc_bytes_per_step() if pmc_applies else None
         out["whole_step"] = {"gflop": gflop, "bytes_algorithmic": b_alg, "bytes_counter": b_cnt,
                              "bytes_counter_over_algorithmic": (b_cnt / b_alg) if b_cnt else None,
                              "t_mfma_ms": t_m, "t_hbm_ms": t_h, "t_roof_ms": max(t_m, t_h), "bound": "mfma" if t_m >= t_h else "hbm",
@@ -248,5 +254,6 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
                              "achieved_tflops": gflop / ms_per_step, "achieved_counter_tbs": (b_cnt / (ms_per_step * 1e-3) / 1e12) if b_cnt else None,
                              "note": "gflop: algorithmic 2*M*N*K of every GEMM / conv + 4*C*sum K_m^2 (x2.5 backward) of the attention launches, from "
                                      "device-side counts; bytes_algorithmic: SURVEY 8d rule (dense upper bound, backward = 2x forward, optimizer 28 B/param); "
-                                     "bytes_counter: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per step, valid when traffic_stale is false"}
+                                     "bytes_counter: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per step of the HEADLINE configuration, valid when "
+                                     "traffic_stale is false; ms_per_step: one whole step (all timesteps of a sequence)"}
     return out
