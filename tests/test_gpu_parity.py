@@ -2079,6 +2079,52 @@ def test_autograd_visible_parameter_gradients_match_in_place(dev):
         SF.set_autograd_visible_grads(prev)
 
 
+def test_modules_under_autocast_and_gradscaler(dev):
+    """every shipped experiment of the reference trains with `precision: 16` (config/experiment/gen4/default.yaml:6): Lightning wraps the
+    step in `torch.autocast(device_type="cuda", dtype=torch.float16)` and scales the loss with a GradScaler.  The hot path here computes
+    in fp32 whatever the autocast state (the fp16 arithmetic class is out of scope; the C ABI takes fp32 rows) -- so
+    under the reference's AMP wrapper the modules must run unchanged: same outputs and, after `scaler.unscale_`, the same gradients as
+    without it, with nothing turning into fp16 on the way (backbone + PAFPN + YOLOX head, SimOTA loss)."""
+    from sast_amd.detection import RNNDetector, YOLOPAFPN, YOLOXHead
+    hw, part, E, chans = (128, 160), (4, 5), 32, (64, 128, 256)
+    ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, embed_dim=E, amp=2e-2)
+    net = RNNDetector(_rcfg(hw, part, E, 2e-2, 0.5)).to(dev)
+    fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=chans).to(dev).train()
+    head = YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=chans).to(dev).train()
+    load_params(net, O.init_backbone_params(ocfg, seed=3, ls_init=0.5))
+    load_params(fpn, O.init_pafpn_params(chans, seed=4))
+    load_params(head, O.init_head_params(chans, num_classes=3, seed=9))
+    x = O.count_events(2, hw, seed=1, density=0.05).to(dev)
+    labels = O.synthetic_labels(2, hw, 3, max_labels=6, seed=11)
+    labels[:, 0, :] = torch.tensor([1.0, 100.0, 90.0, 60.0, 50.0])
+    labels = labels.to(dev)
+    params = [p for m in (net, fpn, head) for p in m.parameters()]
+    sd = {k: v.clone() for m in (fpn, head) for k, v in m.state_dict().items()}       # running statistics move with every training pass
+
+    def run(amp):
+        for m in (fpn, head):
+            m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()}, strict=False)
+        for p in params:
+            p.grad = None
+        scaler = torch.amp.GradScaler("cuda", enabled=amp, init_scale=1024.0)
+        with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=amp):
+            out, _st, _P = net(x)
+            feats = fpn(out)
+            _pred, losses = head(feats, labels)
+            loss = losses["loss"]
+        assert loss.dtype == torch.float32 and all(f.dtype == torch.float32 for f in feats)
+        scaler.scale(loss).backward()
+        opt = torch.optim.SGD(params, lr=0.0)
+        scaler.unscale_(opt)
+        return float(loss), [p.grad.clone() for p in params]
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        maxnorm_close(a, b, 2e-5, f"param {i}, autocast + GradScaler vs plain")
+
+
 def test_fused_forward_under_no_grad_takes_the_inference_form(dev):
     """torch.no_grad() around a TRAINABLE model (validation of a model in training, bench.py --fwd-only): `needs_input_grad` still says
     True for the parameters, the grad mode decides -- the one-kernel MS-WSA forward must then write nothing but its output (no saved
