@@ -307,7 +307,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=50, help="untimed warm-up steps (reference protocol: 50)")
     ap.add_argument("--amp", type=float, default=2e-4, help="attention_cfg.AMP (controls the kept-token fraction)")
     ap.add_argument("--batch", type=int, default=BATCH, help="samples per GPU (BASELINE config: 4; sparsity sweep C5: 8)")
-    ap.add_argument("--res", choices=["1mpx", "gen1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10)")
+    ap.add_argument("--res", choices=["1mpx", "gen1", "1mpx-split1"], default="1mpx", help="1mpx: 384x640 partition (6,10); gen1: 256x320 (8,10); "
+                    "1mpx-split1: 384x640 with partition_split_32 1 (config/modifier.py:28-37) = partitions of 12x20 = 240 tokens")
     ap.add_argument("--seq-len", type=int, default=1, help="timesteps per step with recurrent state + BPTT (1 = BASELINE metric)")
     ap.add_argument("--fwd-only", action="store_true", help="backbone forward only (reference benchmark.py protocol; BASELINE config C2 with --res gen1)")
     ap.add_argument("--loss", choices=["proxy", "yolox"], default="proxy", help="proxy: sum mean(out^2) over the PAFPN outputs (BASELINE "
@@ -336,6 +337,8 @@ def main():
             raise SystemExit("--precision bf16 needs the opt-in library: python -m sast_amd.build --bf16")
     if args.res == "gen1":
         HW, PART = (256, 320), (8, 10)
+    elif args.res == "1mpx-split1":
+        PART = (12, 20)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -424,7 +427,7 @@ def main():
         metric = "frames/sec (B=4) SAST backbone fwd+bwd, 1Mpx 640x360" if baseline_cfg else (
             f"frames/sec (B={BATCH}) SAST " + ("backbone+PAFPN+head inference" if args.infer else "backbone fwd" if args.fwd_only else
                                                "backbone+PAFPN+YOLOX-loss fwd+bwd" if args.loss == "yolox" else "backbone fwd+bwd") +
-            (", 1Mpx 640x360" if args.res == "1mpx" else ", Gen1 304x240") + (f", {args.seq_len} timesteps BPTT" if args.seq_len > 1 else "") +
+            ({"1mpx": ", 1Mpx 640x360", "gen1": ", Gen1 304x240", "1mpx-split1": ", 1Mpx 640x360 partitions 12x20"}[args.res]) + (f", {args.seq_len} timesteps BPTT" if args.seq_len > 1 else "") +
             (", bf16 GEMM operands (reduced-precision library)" if args.precision == "bf16" else "") +
             " [not the BASELINE.json metric configuration]")
         res = {
@@ -432,7 +435,8 @@ def main():
             "value": BATCH * args.seq_len * world * args.steps / el, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "bf16 operands / f32 accumulate", "data": "synthetic",
-            "config": {"workload": ("1Mpx 640x360 (padded 384x640)" if args.res == "1mpx" else "Gen1 304x240 (padded 256x320)") +
+            "config": {"workload": ({"1mpx": "1Mpx 640x360 (padded 384x640)", "gen1": "Gen1 304x240 (padded 256x320)",
+                                    "1mpx-split1": "1Mpx 640x360 (padded 384x640), partition_split_32 1 (12x20 = 240-token partitions)"}[args.res]) +
                                    (" full SAST backbone + PAFPN + YOLOX head (3 classes), eval forward -> decoded predictions, " if args.infer else
                                     " full SAST backbone, forward only (benchmark.py protocol), " if args.fwd_only else
                                     " full SAST backbone + PAFPN + YOLOX head, SimOTA loss on 16 synthetic boxes/sample, fwd+bwd + AdamW, "

@@ -478,6 +478,240 @@ __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ?
 // launch through SAST_LAUNCH, or -- in the roofline leg of bench.py (prof_enabled) -- with kernel-exact start / stop events and the
 // algorithmic work of the launch from the device-side kept-token counts: QK^T and PV are 2 K_m^2 dh flop each per (group, head)
 // = 4 C sum_m K_m^2 per launch, the backward's five products 2.5x that; bytes = the compact rows read and written once
+// ------------------------------------------------------------------ partitions of 129 .. 256 tokens (round 5)
+// The one valid reference configuration beyond 128 tokens per partition is the gen4 model with partition_split_32: 1 (config/modifier.py:
+// 37: 384 x 640 -> (12, 20) = 240 tokens).  Eight 32-token tiles: the kernels above would need 128 score registers per wave in the forward,
+// 256 in the backward, and 196 KB of LDS for the backward's four operand images.  These kernels instead
+//   * keep ONE score tile in registers and sweep the key (query) tiles twice where a row statistic is needed first: the forward's
+//     softmax maximum / sum (online rescaling in sweep 1, P V in sweep 2), the backward's D_i (sweep 1) before dS (sweep 2) -- the
+//     score tiles are recomputed, 2 x 6 MFMAs per tile;
+//   * stage only the operands a wave reads ACROSS tiles in LDS (forward: K, V -- and Q, three images of 48 KB; backward: K, V for the
+//     dQ kernel, Q, dO for the dK / dV kernel: 96 KB each) and build the wave's OWN rows (its query tile, or its key tile) as MFMA operands
+//     straight from global memory (8 consecutive d of one token = one operand: split in registers);
+//   * split the backward into two launches around D_i, which travels through a [rows, heads] scratch in HBM.
+// Same split-exact products and the same masking rules as above; results agree with the small kernels' to rounding (other summation order).
+constexpr int BIGT = 8;                     // 32-token tiles of the images
+constexpr int BIG_MAT = 3 * 32 * BIGT * 64; // one staged matrix: 48 KB
+
+// the 8 consecutive d of chunk `chunk` (d = 8 chunk ..) of token `row` of a [rows, ld] matrix as a split operand, scaled by mul; rows that
+// do not exist and channels >= dh read as zeros (stage_commit's rule)
+__device__ __forceinline__ Split3 own_row_operand(const float* __restrict__ src, int ld, int coff, int row, bool valid, int chunk, int dh, float mul) {
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int d = 8 * chunk + 4 * q;
+    const float4 x = ld4(src + (size_t)row * ld + coff + min(d, dh - 4));
+    const float m = (valid && d < dh) ? mul : 0.f;
+    v[4 * q] = x.x * m; v[4 * q + 1] = x.y * m; v[4 * q + 2] = x.z * m; v[4 * q + 3] = x.w * m;
+  }
+  return split3(v);
+}
+
+__global__ __launch_bounds__(64 * BIGT) void attn_fwd_big_kernel(const float* __restrict__ qkv, float* __restrict__ o, float* __restrict__ lse,
+                                                                 const int* __restrict__ row_off, const int* __restrict__ Kw, int C, int heads,
+                                                                 float scale, int dh) {
+  __shared__ __attribute__((aligned(16))) char sm[2 * BIG_MAT];
+  const int g = blockIdx.x, h = blockIdx.y;
+  const int K = Kw[g];
+  if (K == 0) return;
+  const int r0 = row_off[g], nt = (K + 31) >> 5, KT = nt * 32;
+  char* Km = sm;
+  char* Vm = sm + BIG_MAT;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int C3 = 3 * C, coff = h * 3 * dh;
+  {
+    const Staged sk = stage_issue<BIGT>(qkv, C3, coff + dh, r0, K, dh), sv = stage_issue<BIGT>(qkv, C3, coff + 2 * dh, r0, K, dh);
+    stage_commit<BIGT>(Km, sk, K, KT, 1.f, dh);
+    stage_commit<BIGT>(Vm, sv, K, KT, 1.f, dh);
+  }
+  __syncthreads();
+  if (w >= nt) return;
+  const int i = w * 32 + l31;
+  const bool qv = i < K;
+  Split3 qb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) qb[u] = own_row_operand(qkv, C3, coff, r0 + min(i, K - 1), qv, 2 * u + hf, dh, scale);
+  const auto scores = [&](int t) {       // S^T tile t: rows = keys of tile t, column = this lane's query
+    f32x16 st;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) st = mfma6(rd_read<BIGT>(Km, t * 32 + l31, 2 * u + hf), qb[u], st);
+    return st;
+  };
+  // sweep 1: maximum and sum of exp over the keys (online rescaling)
+  float m = -INFINITY, l = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    const f32x16 st = scores(t);
+    float mt = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mt = fmaxf(mt, (t * 32 + crow(e, lane) < K) ? st[e] : -INFINITY);
+    mt = pair_max(mt);
+    const float mn = fmaxf(m, mt);
+    float pl = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pl += (t * 32 + crow(e, lane) < K) ? __expf(st[e] - mn) : 0.f;
+    l = l * __expf(m - mn) + pair_sum(pl);      // (first tile: l = 0, exp(-inf) = 0; every group has a key in tile 0, so mn is finite)
+    m = mn;
+  }
+  if (hf == 0 && qv) lse[(size_t)(r0 + i) * heads + h] = m + logf(l);
+  // sweep 2: O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    f32x16 st = scores(t);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = (t * 32 + crow(e, lane) < K) ? __expf(st[e] - m) : 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc = mfma6(tk_read<BIGT>(Vm, t * 32 + 16 * u, lane), c_tile_operand(st, u), acc);
+  }
+  if (qv) store_rows_per_lane(o + (size_t)(r0 + i) * C + h * dh, acc, 1.0f / l, lane, dh);
+}
+
+// backward, launch 1: wave w owns QUERY tile w.  D_i (to `dbuf` [rows, heads]) and dQ.
+__global__ __launch_bounds__(64 * BIGT) void attn_bwd_big_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                   const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                   float* __restrict__ dbuf, const int* __restrict__ row_off,
+                                                                   const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
+  __shared__ __attribute__((aligned(16))) char sm[2 * BIG_MAT];
+  const int g = blockIdx.x, h = blockIdx.y;
+  const int K = Kw[g];
+  if (K == 0) return;
+  const int r0 = row_off[g], nt = (K + 31) >> 5, KT = nt * 32;
+  char* Km = sm;
+  char* Vm = sm + BIG_MAT;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int C3 = 3 * C, coff = h * 3 * dh;
+  {
+    const Staged sk = stage_issue<BIGT>(qkv, C3, coff + dh, r0, K, dh), sv = stage_issue<BIGT>(qkv, C3, coff + 2 * dh, r0, K, dh);
+    stage_commit<BIGT>(Km, sk, K, KT, 1.f, dh);
+    stage_commit<BIGT>(Vm, sv, K, KT, 1.f, dh);
+  }
+  __syncthreads();
+  if (w >= nt) return;
+  const int i = w * 32 + l31;
+  const bool qv = i < K;
+  const int ri = r0 + min(i, K - 1);
+  Split3 qb[2], gb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    qb[u] = own_row_operand(qkv, C3, coff, ri, qv, 2 * u + hf, dh, scale);
+    gb[u] = own_row_operand(dout, C, h * dh, ri, qv, 2 * u + hf, dh, 1.f);
+  }
+  const float li = lse[(size_t)ri * heads + h];
+  const auto tiles = [&](int t, f32x16& st, f32x16& dpt) {      // P^T (masked) and dP^T of key tile t
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st = mfma6(rd_read<BIGT>(Km, t * 32 + l31, 2 * u + hf), qb[u], st);
+      dpt = mfma6(rd_read<BIGT>(Vm, t * 32 + l31, 2 * u + hf), gb[u], dpt);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st[e] = (qv && t * 32 + crow(e, lane) < K) ? __expf(st[e] - li) : 0.f;
+  };
+  float dloc = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    f32x16 st, dpt;
+    tiles(t, st, dpt);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dloc += st[e] * dpt[e];
+  }
+  const float D = pair_sum(dloc);
+  if (hf == 0 && qv) dbuf[(size_t)(r0 + i) * heads + h] = D;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int t = 0; t < nt; ++t) {
+    f32x16 st, dpt;
+    tiles(t, st, dpt);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dpt[e] = st[e] * (dpt[e] - D);          // dS^T
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc = mfma6(tk_read<BIGT>(Km, t * 32 + 16 * u, lane), c_tile_operand(dpt, u), acc);
+  }
+  if (qv) store_rows_per_lane(dqkv + (size_t)(r0 + i) * C3 + coff, acc, scale, lane, dh);
+}
+
+// backward, launch 2: wave w owns KEY tile w.  dV and dK from Q, dO (LDS), lse and D_i (LDS, from launch 1); the LayerScale gradient
+// finishes of the layer ride as side workgroups like in attn_bwd_mfma_kernel
+__global__ __launch_bounds__(64 * BIGT) void attn_bwd_big_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                    const float* __restrict__ dbuf, const int* __restrict__ row_off,
+                                                                    const int* __restrict__ Kw, int C, int heads, float scale, int dh, int W,
+                                                                    LsFinish f0, LsFinish f1, int fC) {
+  __shared__ __attribute__((aligned(16))) char sm[2 * BIG_MAT + 2 * 32 * BIGT * 4];
+  if (blockIdx.x >= W) {
+    if (blockIdx.y == 0) {
+      const int row = (blockIdx.x - W) * BIGT + (threadIdx.x >> 6);
+      if (row < fC) ls_finish_row(f0, row, threadIdx.x & 63);
+      else if (row < 2 * fC) ls_finish_row(f1, row - fC, threadIdx.x & 63);
+    }
+    return;
+  }
+  const int g = blockIdx.x, h = blockIdx.y;
+  const int K = Kw[g];
+  if (K == 0) return;
+  const int r0 = row_off[g], nt = (K + 31) >> 5, KT = nt * 32;
+  char* Qm = sm;                  // pre-scaled q
+  char* Gm = sm + BIG_MAT;        // dO
+  float* lse_s = reinterpret_cast<float*>(sm + 2 * BIG_MAT);
+  float* D_s = lse_s + 32 * BIGT;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int C3 = 3 * C, coff = h * 3 * dh;
+  {
+    const Staged sq = stage_issue<BIGT>(qkv, C3, coff, r0, K, dh), sg = stage_issue<BIGT>(dout, C, h * dh, r0, K, dh);
+    const int il = threadIdx.x;                        // 512 threads >= 256 rows: clamped, branch-free
+    const size_t ra = (size_t)(r0 + min(il, K - 1)) * heads + h;
+    const float lv = lse[ra], dv = dbuf[ra];
+    stage_commit<BIGT>(Qm, sq, K, KT, scale, dh);
+    stage_commit<BIGT>(Gm, sg, K, KT, 1.f, dh);
+    if (il < 32 * BIGT) { lse_s[il] = lv; D_s[il] = dv; }
+  }
+  __syncthreads();
+  if (w >= nt) return;
+  const int j = w * 32 + l31;
+  const bool kv = j < K;
+  const int rj = r0 + min(j, K - 1);
+  Split3 kb[2], vb[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    kb[u] = own_row_operand(qkv, C3, coff + dh, rj, kv, 2 * u + hf, dh, 1.f);
+    vb[u] = own_row_operand(qkv, C3, coff + 2 * dh, rj, kv, 2 * u + hf, dh, 1.f);
+  }
+  f32x16 av, ak;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { av[e] = 0.f; ak[e] = 0.f; }
+  for (int t = 0; t < nt; ++t) {
+    // S[i][j] = Q_t K_w^T, dP[i][j] = dO_t V_w^T  (column = key j, rows = queries of tile t)
+    f32x16 st, dpt;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { st[e] = 0.f; dpt[e] = 0.f; }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      st = mfma6(rd_read<BIGT>(Qm, t * 32 + l31, 2 * u + hf), kb[u], st);
+      dpt = mfma6(rd_read<BIGT>(Gm, t * 32 + l31, 2 * u + hf), vb[u], dpt);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = t * 32 + crow(e, lane);
+      const float pt = (kv && i < K) ? __expf(st[e] - lse_s[i]) : 0.f;
+      st[e] = pt;                                  // P
+      dpt[e] = pt * (dpt[e] - D_s[i]);             // dS
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      av = mfma6(tk_read<BIGT>(Gm, t * 32 + 16 * u, lane), c_tile_operand(st, u), av);
+      ak = mfma6(tk_read<BIGT>(Qm, t * 32 + 16 * u, lane), c_tile_operand(dpt, u), ak);
+    }
+  }
+  if (kv) {
+    store_rows_per_lane(dqkv + (size_t)(r0 + j) * C3 + coff + 2 * dh, av, 1.f, lane, dh);
+    store_rows_per_lane(dqkv + (size_t)(r0 + j) * C3 + coff + dh, ak, 1.f, lane, dh);
+  }
+}
+
 #define SAST_ATTN_LAUNCH(TAG, FLOPS_PER_K2, ROWS_X_C, KERNEL, GRID, BLOCK, ...)                                             \
   do {                                                                                                                    \
     if (prof_enabled()) {                                                                                                 \
@@ -499,14 +733,19 @@ __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ?
 int attn_pack_limit(int T) {
   static int lim = -1;
   if (lim < 0) { const char* e = getenv("SAST_ATTN_PACKS"); lim = e ? atoi(e) : 32; }
-  const int cap = T <= 64 ? 64 : (T <= 96 ? 96 : 128);      // what the kernels instantiated for T can hold
+  const int cap = T <= 64 ? 64 : (T <= 96 ? 96 : 128);      // what the kernels instantiated for T can hold (T > 128: no packs are used)
   return lim < cap ? lim : cap;
 }
 
 int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh, hipStream_t st) {
-  if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
+  if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 32 * BIGT) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
+  if (T > 128) {       // partitions of 129 .. 256 tokens: the two-sweep kernel (the sweeps recompute the score tiles: 6 instead of 4 C K^2 flop)
+    SAST_ATTN_LAUNCH("attn_fwd_big_kernel", 6.0, 4.0, attn_fwd_big_kernel, dim3(W, heads), dim3(64 * BIGT), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+    SAST_CHECK_LAUNCH();
+    return SAST_OK;
+  }
   // the LDS images are sized by the number of 32-token tiles a partition can need (36.9 KB for T <= 64: four workgroups per CU).
   // bytes: QKV (3C) read + O (C) written per kept row
   if (T <= 64) SAST_ATTN_LAUNCH("attn_fwd_mfma_kernel<2>", 4.0, 4.0, (attn_fwd_mfma_kernel<2>), dim3(W, heads), dim3(128), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
@@ -517,10 +756,24 @@ int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_
 }
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw,
                          int W, int T, int C, int dh, hipStream_t st, const LsFinish* f0,
-                         const LsFinish* f1, int fC) {
-  if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 128) return SAST_EINVAL;
+                         const LsFinish* f1, int fC, float* dbuf) {
+  if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 32 * BIGT) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
+  if (T > 128) {       // partitions of 129 .. 256 tokens: D_i + dQ, then dK / dV (+ the LayerScale finishes as side workgroups); dbuf: [rows, heads]
+    if (!dbuf) return SAST_EINVAL;
+    const LsFinish zb{};
+    const LsFinish& b0 = f0 ? *f0 : zb;
+    const LsFinish& b1 = f1 ? *f1 : zb;
+    if (!f0 || !f1) fC = 0;
+    const int sideb = (2 * fC + BIGT - 1) / BIGT;
+    SAST_ATTN_LAUNCH("attn_bwd_big_q_kernel", 8.0, 5.0, attn_bwd_big_q_kernel, dim3(W, heads), dim3(64 * BIGT), qkv, dout, lse, dqkv, dbuf, row_off, Kw, C,
+                     heads, scale, dh);
+    SAST_ATTN_LAUNCH("attn_bwd_big_kv_kernel", 8.0, 5.0, attn_bwd_big_kv_kernel, dim3(W + sideb, heads), dim3(64 * BIGT), qkv, dout, lse, dqkv, dbuf, row_off,
+                     Kw, C, heads, scale, dh, W, b0, b1, fC);
+    SAST_CHECK_LAUNCH();
+    return SAST_OK;
+  }
   const LsFinish z{};
   const LsFinish& a0 = f0 ? *f0 : z;
   const LsFinish& a1 = f1 ? *f1 : z;

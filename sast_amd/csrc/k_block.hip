@@ -10,7 +10,7 @@ using namespace sast;
 namespace {
 
 // largest partition (tokens per window / grid group) the attention kernels of k_attn_mfma.hip are instantiated for
-constexpr int ATTN_MAX_T = 128;
+constexpr int ATTN_MAX_T = 256;     // tokens per partition (k_select.hip: 4-word keep masks, k_attn_mfma.hip: the two-sweep kernels beyond 128)
 
 // ---------------------------------------------------------------- epilogues (protocol: col / pre / post, see gemm.cuh)
 struct EpBiasRelu {
@@ -294,9 +294,11 @@ size_t sast_mswsa_fused_ws_floats(int C, int inner, int T, int dim_head, int cb_
 }
 size_t sast_mswsa_raw_ws_floats(int C, int inner) { return (size_t)C * inner + (size_t)C * C + 2 * C; }
 
-size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) {
+static size_t mswsa_bwd_ws_base(int rows, int C, int inner) {
   return (size_t)rows * (2 * inner + C + C + 3 * C + C) + (size_t)C * inner + (size_t)C * C + 2 * C;
 }
+// (+ D_i of the attention backward, one float per row and head -- at most C / 4 heads --, used for partitions of more than 128 tokens)
+size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) { return mswsa_bwd_ws_base(rows, C, inner) + (size_t)rows * (C / 4); }
 
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
@@ -440,7 +442,8 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   {
     const LsFinish f2{a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner};
     const LsFinish f1{a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C};
-    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C);
+    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C,
+                              a->ws + mswsa_bwd_ws_base(R, C, inner));
   }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv

@@ -52,7 +52,10 @@ constexpr int SEL_WAVES = 16;   // windows per workgroup (one wave each)
 //   1. all waves together: mean token score of each of the sample's N windows (L1 norm / T, SAST.py:84-86) into LDS
 //      (recomputed by every workgroup of the sample: N/16 x redundant reads of a 4*L byte row that sits in L2);
 //   2. softmax over the N windows -> keep flag of the wave's own window (window_selection);
-//   3. softmax over the T <= 128 tokens of the own window, keep mask by ballot, K by popcount (token_selection).
+//   3. softmax over the T tokens of the own window, keep mask by ballot, K by popcount (token_selection).
+// SLOTS: tokens per lane (slot s = token lane + 64 s): 2 for partitions of up to 128 tokens, 4 for up to 256 (round 5: the gen4 model with
+// partition_split_32: 1 has T = 240, config/modifier.py:37); the keep mask of a group is SLOTS 64-bit words
+template <int SLOTS>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float* __restrict__ tok, PartMap pm, int L, float thr_win,
                                                                      float thr_tok, SelPair sp) {
   pm.mode = sp.mode[blockIdx.y];
@@ -67,13 +70,21 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float
   const int b = blockIdx.x / chunks, n_own = (blockIdx.x % chunks) * SEL_WAVES + (threadIdx.x >> 6);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const float* tb = tok + (size_t)b * L;
-  const bool h0 = lane < T, h1 = lane + 64 < T;
-  float v0 = 0.f, v1 = 0.f;     // the own window's token scores (kept from pass 1 when it is this wave's turn)
+  bool hs[SLOTS];
+  float v[SLOTS];               // the own window's token scores (kept from pass 1 when it is this wave's turn)
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) { hs[q] = lane + 64 * q < T; v[q] = 0.f; }
   for (int n = wave; n < N; n += SEL_WAVES) {
-    const float a0 = h0 ? tb[pm.token(n, lane)] : 0.f, a1 = h1 ? tb[pm.token(n, lane + 64)] : 0.f;
-    const double s = wave_sum_d((double)a0 + (double)a1);
+    float a[SLOTS];
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) { a[q] = hs[q] ? tb[pm.token(n, lane + 64 * q)] : 0.f; acc += (double)a[q]; }    // (SLOTS == 2: (double)a0 + (double)a1 as before)
+    const double s = wave_sum_d(acc);
     if (lane == 0) wv[n] = (float)s / (float)T;
-    if (n == n_own) { v0 = a0; v1 = a1; }
+    if (n == n_own) {
+#pragma unroll
+      for (int q = 0; q < SLOTS; ++q) v[q] = a[q];
+    }
   }
   __syncthreads();
   float lmax = -INFINITY;
@@ -97,23 +108,38 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float
   const int w = b * N + n_own;
   const bool keep = expf(wv[n_own] - mx) / sum >= thr_win;
   if (!keep) {
-    if (lane == 0) { win_keep[w] = 0; mask[2 * w] = 0ull; mask[2 * w + 1] = 0ull; Kout[w] = 0; }
+    if (lane == 0) {
+      win_keep[w] = 0; Kout[w] = 0;
+#pragma unroll
+      for (int q = 0; q < SLOTS; ++q) mask[SLOTS * (size_t)w + q] = 0ull;
+    }
     return;
   }
-  if (!h0) v0 = -INFINITY;
-  if (!h1) v1 = -INFINITY;
-  const float tmx = wave_max(fmaxf(v0, v1));
-  const float e0 = h0 ? expf(v0 - tmx) : 0.f, e1 = h1 ? expf(v1 - tmx) : 0.f;
-  const float tsum = (float)wave_sum_d((double)e0 + (double)e1);
-  const unsigned long long m0 = __ballot(h0 && (e0 / tsum >= thr_tok));
-  const unsigned long long m1 = __ballot(h1 && (e1 / tsum >= thr_tok));
-  if (lane == 0) { win_keep[w] = 1; mask[2 * w] = m0; mask[2 * w + 1] = m1; Kout[w] = __popcll(m0) + __popcll(m1); }
+  float lm = -INFINITY;
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) { if (!hs[q]) v[q] = -INFINITY; lm = fmaxf(lm, v[q]); }
+  const float tmx = wave_max(lm);
+  float e[SLOTS];
+  double es = 0.0;
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) { e[q] = hs[q] ? expf(v[q] - tmx) : 0.f; es += (double)e[q]; }
+  const float tsum = (float)wave_sum_d(es);
+  unsigned long long m[SLOTS];
+  int kk = 0;
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) { m[q] = __ballot(hs[q] && (e[q] / tsum >= thr_tok)); kk += __popcll(m[q]); }
+  if (lane == 0) {
+    win_keep[w] = 1; Kout[w] = kk;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) mask[SLOTS * (size_t)w + q] = m[q];
+  }
 }
 
 // exclusive scan over the W windows (flat b*N+n order == reference's ascending index order) + scatter of the compact row
 // ids, one wave per window (mbcnt-style rank = popcount of lower mask bits).  Every workgroup first sums K / win_keep of all
 // windows before its own SEL_WAVES (W <= a few thousand ints), so no separate scan launch is needed; the last workgroup
 // publishes the totals.
+template <int SLOTS>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm, int L, int W, int B, int pack_limit, SelPair sp) {
   pm.mode = sp.mode[blockIdx.y];
   const SelOut& o = sp.o[blockIdx.y];
@@ -157,32 +183,36 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm,
   const int seg = plo | ((plo + myk) << 16);
   const int N = pm.N(), T = pm.T();
   const int b = w / N, n = w % N;
-  const unsigned long long m0 = mask[2 * w], m1 = mask[2 * w + 1];
   const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  if (lane < T) {
-    const int p = b * L + pm.token(n, lane);
-    int slot = -1;
-    if ((m0 >> lane) & 1ull) { slot = base + __popcll(m0 & below); row_tok[slot] = p; o.row_seg[slot] = seg; }
-    tok_slot[p] = slot;
-  }
-  if (lane + 64 < T) {
-    const int p = b * L + pm.token(n, lane + 64);
-    int slot = -1;
-    if ((m1 >> lane) & 1ull) { slot = base + __popcll(m0) + __popcll(m1 & below); row_tok[slot] = p; o.row_seg[slot] = seg; }
-    tok_slot[p] = slot;
+  int before = base;                      // compact rows of the group in front of this word's tokens
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) {
+    const unsigned long long mq = mask[SLOTS * (size_t)w + q];
+    if (lane + 64 * q < T) {
+      const int p = b * L + pm.token(n, lane + 64 * q);
+      int slot = -1;
+      if ((mq >> lane) & 1ull) { slot = before + __popcll(mq & below); row_tok[slot] = p; o.row_seg[slot] = seg; }
+      tok_slot[p] = slot;
+    }
+    before += __popcll(mq);
   }
 }
 
 static int select_launch_n(const float* tok, int B, int H, int W_, int ph, int pw, float thr_win, float thr_tok, const SelPair& sp,
                            int nsel, hipStream_t st) {
   PartMap pm = make_part_map(H, W_, ph, pw, 0);
-  if (H % ph || W_ % pw || pm.T() > 128) return SAST_EINVAL;
+  if (H % ph || W_ % pw || pm.T() > 256) return SAST_EINVAL;
   const int L = H * W_, N = pm.N(), W = B * N;
   const int chunks = (N + SEL_WAVES - 1) / SEL_WAVES;
-  SAST_LAUNCH(select_mask_kernel, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win,
-                     thr_tok, sp);
   static_assert(SEL_WAVES == 16, "the pack blocks are the 16 groups of a select_fill workgroup");
-  SAST_LAUNCH(select_fill_kernel, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, attn_pack_limit(pm.T()), sp);
+  // the keep mask of a group is 2 words for partitions of up to 128 tokens, 4 words beyond (SastSel.mask: [W][2] or [W][4])
+  if (pm.T() <= 128) {
+    SAST_LAUNCH(select_mask_kernel<2>, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win, thr_tok, sp);
+    SAST_LAUNCH(select_fill_kernel<2>, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, attn_pack_limit(pm.T()), sp);
+  } else {
+    SAST_LAUNCH(select_mask_kernel<4>, dim3(B * chunks, nsel), dim3(64 * SEL_WAVES), sizeof(float) * N, st, tok, pm, L, thr_win, thr_tok, sp);
+    SAST_LAUNCH(select_fill_kernel<4>, dim3((W + SEL_WAVES - 1) / SEL_WAVES, nsel), dim3(64 * SEL_WAVES), 0, st, pm, L, W, B, attn_pack_limit(pm.T()), sp);
+  }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

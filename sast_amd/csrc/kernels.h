@@ -63,13 +63,14 @@ int attn_pack_limit(int T);   // rows an attention workgroup can hold: 32 x (tok
 int select_pair_launch(const float* tok, int B, int H, int W, int ph, int pw, float thr_win, float thr_tok, const SastSel* win,
                        const SastSel* grid, hipStream_t st);
 
-// k_attn_mfma.hip (T <= 128)
+// k_attn_mfma.hip (T <= 256: up to 128 tokens per partition one launch per direction, beyond it the two-sweep kernels)
 // Kw: kept tokens per group; one workgroup per (group, head)
 int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_off, const int* Kw, int W, int T, int C, int dh, hipStream_t st);
 struct LsFinish;
+// dbuf: fp32[rows, heads] scratch, needed for partitions of more than 128 tokens (D_i travels between the two backward launches)
 int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, float* dqkv, const int* row_off, const int* Kw,
                          int W, int T, int C, int dh, hipStream_t st,
-                         const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0);
+                         const LsFinish* f0 = nullptr, const LsFinish* f1 = nullptr, int fC = 0, float* dbuf = nullptr);
 
 // k_dwconv.hip: depth-wise k x k convolution, zero padding k/2, stride 1 / 2 (input Hi x Wi -> output Ho x Wo)
 struct DwGeom { int Hi, Wi, Ho, Wo, C, k, stride; };

@@ -456,6 +456,13 @@ def score_stp(xp, r, ws_w, ws_b, wc, amp) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------- a6-a8
+def mask_words(T: int) -> int:
+    """64-bit words of a group's kept-token mask (SastSel.mask): 2 for partitions of up to 128 tokens, 4 up to 256"""
+    if T > 256:
+        raise NotImplementedError("sast_amd: partitions of more than 256 tokens are not supported by the selection kernels")
+    return 2 if T <= 128 else 4
+
+
 class Selection:
     """device-resident result of the window/token selection (SastSel).  No host sync unless a
     reference-style index list is requested."""
@@ -473,7 +480,7 @@ class Selection:
         self.tok_slot = buf[o + 4:o + 4 + B * self.L]
         self.row_tok = buf[o + 4 + B * self.L:o + 4 + 2 * B * self.L]
         self.row_seg = buf[o + 4 + 2 * B * self.L:]
-        self.mask = torch.empty(nw, 2, device=device, dtype=torch.int64)
+        self.mask = torch.empty(nw, mask_words(self.T), device=device, dtype=torch.int64)
         self._buf = buf
         self.tok = None  # scores the selection was computed from (for index-list export)
 
@@ -511,9 +518,8 @@ class Selection:
 
     def _mask_bits(self) -> torch.Tensor:
         ar = torch.arange(64, device=self.mask.device, dtype=torch.int64)
-        lo = (self.mask[:, 0:1] >> ar) & 1
-        hi = (self.mask[:, 1:2] >> ar) & 1
-        return torch.cat([lo, hi], dim=1)[:, : self.T].bool()
+        words = [(self.mask[:, k:k + 1] >> ar) & 1 for k in range(self.mask.shape[1])]
+        return torch.cat(words, dim=1)[:, : self.T].bool()
 
     def group_token_ids(self) -> torch.Tensor:
         """(N, T) token index l = y*W + x of slot t of group n (ops.py:189-220 maps)."""
@@ -607,12 +613,12 @@ def selection_from_index_lists(index_window, asy_index, K, n_groups: int, T: int
     sel.row_tok = torch.zeros(n_groups * T, **i32)
     sel.row_tok[:total] = tokens.int()
     # kept-token bitmask of every group (two 64-bit words): the kernels test it to tell kept from passed-through tokens
-    bits = torch.zeros(n_groups, 128, device=device, dtype=torch.int64)
+    nwords = mask_words(T)
+    bits = torch.zeros(n_groups, 64 * nwords, device=device, dtype=torch.int64)
     bits[iw[asy // T], asy % T] = 1
     sh = torch.arange(64, device=device, dtype=torch.int64)
-    lo = (bits[:, :64] << sh).sum(1)        # bit 63 wraps into the sign: the same two's-complement word the device writes
-    hi = (bits[:, 64:] << sh).sum(1)
-    sel.mask = torch.stack([lo, hi], dim=1).contiguous()
+    # bit 63 wraps into the sign: the same two's-complement word the device writes
+    sel.mask = torch.stack([(bits[:, 64 * k:64 * (k + 1)] << sh).sum(1) for k in range(nwords)], dim=1).contiguous()
     sel.tok = None
     sel.build_packs()
     return sel

@@ -214,8 +214,7 @@ class SAST_block(nn.Module):
             partition_size = tuple(partition_size)
             assert len(partition_size) == 2
         self.partition_size = partition_size
-        if partition_size[0] * partition_size[1] > 128:
-            raise NotImplementedError("sast_amd: partitions of more than 128 tokens are not supported by the selection kernels")
+        SF.mask_words(partition_size[0] * partition_size[1])      # raises beyond 256 tokens (gen4 with partition_split_32 1 has 240)
         sub_layer_params = (ls_init_value, drop_path, mlp_expand_ratio, mlp_act_string, mlp_bias, drop_mlp)
         self.enable_CB = cfg_get(attention_cfg, 'enable_CB', False)
         mk_norm = lambda: LayerNorm(dim, eps=norm_eps)

@@ -84,10 +84,12 @@ def run_ref_block(ref, params, x, r, pe_mod, acfg, first=True, index_list=None, 
     return blk, xx, out, cnt, lists
 
 
-def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bias=True, act="gelu"):
+def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bias=True, act="gelu", hw=(16, 20), part=(4, 5)):
     """bias=False: attention_bias: False and mlp_bias: False (qkv / proj / MLP linears without bias vectors, SAST.py:180-181);
-    act: attention_cfg.mlp_activation (SAST.py:38,55: get_act_layer(name) -> the GLU's gate activation, ops.py:133-137)"""
-    H, W, part = 16, 20, (4, 5)
+    act: attention_cfg.mlp_activation (SAST.py:38,55: get_act_layer(name) -> the GLU's gate activation, ops.py:133-137);
+    hw / part: map size and partition size (round 5: (24, 40) / (12, 20) = 240 tokens per partition, the gen4 model with
+    partition_split_32: 1, config/modifier.py:37)"""
+    H, W = hw
     acfg = dict(partition_size=part, dim_head=dim_head, attention_bias=bias, mlp_activation=act, mlp_bias=bias,
                 mlp_ratio=4, drop_mlp=0, drop_path=0, ls_init_value=0.5, enable_CB=enable_cb, AMP=amp, BOUNCE=1e-3)
     ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=enable_cb, dim_head=dim_head, mlp_activation=act)
@@ -129,7 +131,8 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
     assert torch.allclose(xo.grad, xx.grad, atol=1e-7, rtol=1e-5)
     d = dict(x=np_(x), r=np_(r), out=np_(out), count=np.int64(cnt), seed=np.int64(seed), amp=np.float64(amp),
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)),
-             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head), bias=np.int64(bias), act=np.array(act))
+             enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head), bias=np.int64(bias), act=np.array(act),
+             part=np.array(part, dtype=np.int64))
     d.update(lists_to_np(lists, ""))
     named = dict(blk.named_parameters())
     for k, v in named.items():
@@ -239,6 +242,13 @@ ACTS_R5 = ("mish", "relu6", "leaky_relu", "elu", "celu", "selu", "hard_sigmoid",
 def gen_acts(ref, names=ACTS_R4 + ACTS_R5):
     for act in names:
         gen_block(ref, "block_act_" + act, 1, 2e-2, C=32, act=act)
+
+
+def gen_big_partitions(ref):
+    """partitions of more than 128 tokens: (12, 20) = 240 on a 24 x 40 map (4 partitions per sample), dense (every token kept: eight
+    32-token tiles) and sparse (AMP 2e-2: partitions of different kept counts); C = 32 with two heads of 16"""
+    gen_block(ref, "block_t240_dense", 2, 2e-4, C=32, dim_head=16, hw=(24, 40), part=(12, 20))
+    gen_block(ref, "block_t240_sparse", 2, 2e-2, C=32, dim_head=16, hw=(24, 40), part=(12, 20))
 
 
 def gen_dim_heads(ref):
@@ -787,6 +797,9 @@ def main():
     if "--dim-heads-only" in sys.argv:
         gen_dim_heads(ref)
         return
+    if "--big-partitions-only" in sys.argv:
+        gen_big_partitions(ref)
+        return
     if "--sizes-only" in sys.argv:   # the two fixtures added for the reference's other model sizes (small: dim_head 24, large: C=96)
         gen_block(ref, "block_small_dh24", 2, 2e-2, C=48, dim_head=24)
         gen_block(ref, "block_large_c96", 2, 2e-2, C=96)
@@ -802,6 +815,7 @@ def main():
     gen_block(ref, "block_nobias", 2, 2e-2, bias=False)
     gen_acts(ref)
     gen_dim_heads(ref)
+    gen_big_partitions(ref)
     gen_block_drop_path(ref)
     gen_block_drop_path(ref, "block_drop_mlp", pdrop=0.0, pmlp=0.2)
     gen_block_drop_path(ref, "block_drop_path_cb", pdrop=0.25, pmlp=0.2, enable_cb=True)

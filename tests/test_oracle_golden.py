@@ -44,7 +44,8 @@ def test_non_zero_ratio(golden_dir):
 @pytest.mark.parametrize("name", ["block_amp2e-4", "block_amp2e-2", "block_amp1", "block_b1", "block_cb", "block_small_dh24",
                                   "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
                                   "block_act_tanh", "block_act_mish", "block_act_relu6", "block_act_leaky_relu", "block_act_elu", "block_act_celu",
-                                  "block_act_selu", "block_act_hard_sigmoid", "block_act_hard_swish", "block_act_hard_mish", "block_dh16", "block_dh8"])
+                                  "block_act_selu", "block_act_hard_sigmoid", "block_act_hard_swish", "block_act_hard_mish", "block_dh16", "block_dh8",
+                                  "block_t240_dense", "block_t240_sparse"])
 def test_sast_block(golden_dir, name):
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
@@ -52,7 +53,8 @@ def test_sast_block(golden_dir, name):
     if "bias" in g and not int(g["bias"]):       # attention_bias: False, mlp_bias: False -- the linears have no bias vectors
         params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
-    cfg = O.AttnCfg(partition_size=(4, 5), amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]),
+    part = tuple(int(v) for v in g["part"]) if "part" in g else (4, 5)    # block_t240_*: partitions of 12 x 20 = 240 tokens
+    cfg = O.AttnCfg(partition_size=part, amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]),
                     dim_head=int(g["dim_head"]) if "dim_head" in g else 32,
                     mlp_activation=str(g["act"]) if "act" in g else "gelu")     # mlp_activation: relu / silu / sigmoid / tanh fixtures
     pe = O.position_embedding_sine(x.shape[1], x.shape[2], x.shape[3])

@@ -22,10 +22,11 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--fp64", action="store_true", help="oracle in double (arbiter)")
     ap.add_argument("--no-fpn", action="store_true")
+    ap.add_argument("--part", type=int, nargs=2, default=(6, 10), help="partition size: 6 10 (1Mpx default) / 12 20 (partition_split_32 1)")
     a = ap.parse_args()
     from sast_amd.detection import RNNDetector, YOLOPAFPN
     dev = torch.device("cuda:0")
-    hw, part = (384, 640), (6, 10)
+    hw, part = (384, 640), tuple(a.part)
     ocfg = O.BackboneCfg(in_res_hw=hw, partition_size=part, amp=a.amp)
     params = O.init_backbone_params(ocfg, seed=a.seed, ls_init=0.5)
     fparams = O.init_pafpn_params((128, 256, 512), seed=a.seed + 50)
