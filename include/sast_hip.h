@@ -126,7 +126,7 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream);
 /* a6-a8  window / token selection -- SAST.py:84-96, :258-281, :122.  All buffers caller-allocated. */
 typedef struct SastSel {
   int32_t* win_keep;   /* [B*N] 0/1 */
-  uint64_t* mask;      /* [B*N][2] kept-token bitmask of each group (T <= 128) */
+  uint64_t* mask;      /* [B*N][2] kept-token bitmask of each group for T <= 128, [B*N][4] for 128 < T <= 256 (the limit) */
   int32_t* K;          /* [B*N] kept tokens (0 for dropped windows) */
   int32_t* row_off;    /* [B*N] first compact row of the group */
   int32_t* win_rank;   /* [B*N] index among kept windows or -1 */

@@ -54,10 +54,32 @@ class BaseConv(nn.Module):
                 bn.num_batches_tracked.add_(1)
         return y
 
+    def sync_item(self, x, arena=None, sole=False, two_outputs=False):
+        """this unit's entry of a `forward_sync_group` call (same arguments as forward_nhwc)"""
+        bn = self.bn
+        return dict(x_nhwc=x, w=self.conv.weight, bn_w=bn.weight, bn_b=bn.bias, run_mean=bn.running_mean, run_var=bn.running_var,
+                    ksize=self.ksize, stride=self.stride, momentum=bn.momentum, eps=bn.eps, sole_consumer=sole, two_outputs=two_outputs,
+                    bn_ws=arena.take(SF.bn_ws_floats(bn.num_features)) if arena is not None else None)
+
     def forward(self, x):
         if isinstance(x, (tuple, list)):
             raise TypeError("sast_amd: the two-source (virtual concat) input is an internal NHWC feature; use forward_nhwc")
         return SF.as_nchw_view(self.forward_nhwc(SF.as_nhwc(x)))
+
+
+def forward_sync_group(grp, convs, xs, arena, sole=False):
+    """several INDEPENDENT BaseConv units under SyncBatchNorm (training mode, `grp.active()`, the pass exchanged its sample counts) with
+    ONE statistics all-reduce per direction for all of them (functional.conv_bn_silu_sync_group): the dependent chain of a multi-rank
+    step counts collectives, not units.  -> one output per unit"""
+    soles = sole if isinstance(sole, (tuple, list)) else (sole,) * len(convs)
+    ys = SF.conv_bn_silu_sync_group(grp, [c.sync_item(x, arena, sole=s) for c, x, s in zip(convs, xs, soles)])
+    for c in convs:
+        if c.bn.num_batches_tracked is not None:
+            if arena is not None:
+                arena.counters.append(c.bn.num_batches_tracked)
+            else:
+                c.bn.num_batches_tracked.add_(1)
+    return ys
 
 
 class DWConv(nn.Module):
@@ -206,6 +228,9 @@ class CSPLayer(nn.Module):
             x1, x2 = self._conv12(x, arena, sole_input)
         elif not self.training and SF.CONV_PAIR and not torch.is_grad_enabled():
             x1, x2 = SF.conv_bn_silu2_infer(x, self._pair_args()[0], self._pair_args()[1])     # inference: one launch for both
+        elif self.training and sync_active(self.conv1) and SF.SYNC_BN_GROUPS:
+            # SyncBatchNorm: the stacked launch sees one process's rows only; the two units still share ONE statistics all-reduce
+            x1, x2 = forward_sync_group(self.conv1.sync_group(), (self.conv1, self.conv2), (x, x), arena)
         else:
             x1 = self.conv1.forward_nhwc(x, arena)
             x2 = self.conv2.forward_nhwc(x, arena)

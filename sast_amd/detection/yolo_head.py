@@ -17,7 +17,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import functional as SF
-from .network_blocks import BaseConv, BnArena, DWConv, bn_scratch_floats, pass_sync_group
+from .network_blocks import BaseConv, BnArena, DWConv, bn_scratch_floats, forward_sync_group, pass_sync_group
 
 
 class _PredConv(nn.Module):
@@ -71,29 +71,41 @@ class YOLOXHead(nn.Module):
         sync = grp is not None and grp.active()
         if sync and not grp.same_pass(feats[0]):
             grp.exchange_batch(feats[0].shape[0], feats[0].device)
-        for k, (x, stride) in enumerate(zip(feats, self.strides)):
-            x = self.stems[k].forward_nhwc(x, ar)
-            if SF.CONV_PAIR and not sync and not self.depthwise:
-                # the first conv of both towers reads the stem output: one stacked 3x3 GEMM + shared BatchNorm launches, and (sole
-                # consumer of the stem output) the stem's BatchNorm-backward reduction in the pair's dX epilogue
-                c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]
-                args = [(c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.momentum, c.bn.eps) for c in (c0, r0)]
-                ws = tuple(ar.take(SF.bn_ws_floats(c.bn.num_features)) for c in (c0, r0))
-                cf, rf = SF.conv_bn_silu2(x, args[0], args[1], ws, sole_consumer=True, ksize=3)
-                ar.counters.extend(c.bn.num_batches_tracked for c in (c0, r0) if c.bn.num_batches_tracked is not None)
-                first = 1
-            else:
-                cf, rf = x, x          # the stem output feeds both towers; inside a tower every conv has one consumer
-                first = 0
-            for i, conv in enumerate(self.cls_convs[k]):
-                if i >= first:
-                    cf = conv.forward_nhwc(cf, ar, sole=i > 0)
-            for i, conv in enumerate(self.reg_convs[k]):
-                if i >= first:
-                    rf = conv.forward_nhwc(rf, ar, sole=i > 0)
-            cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
-            per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
-            levels.append((x.shape[1], x.shape[2], stride))
+        if sync and SF.SYNC_BN_GROUPS and not self.depthwise:
+            # SyncBatchNorm: the three levels are independent, and so are the two towers of a level -- the 15 units run as three sets
+            # (stems; first 3x3 of both towers; second 3x3) with ONE statistics all-reduce per set and direction instead of 15
+            n = len(feats)
+            xs = forward_sync_group(grp, list(self.stems), list(feats), ar)
+            t = forward_sync_group(grp, [self.cls_convs[k][0] for k in range(n)] + [self.reg_convs[k][0] for k in range(n)], xs + xs, ar)
+            t = forward_sync_group(grp, [self.cls_convs[k][1] for k in range(n)] + [self.reg_convs[k][1] for k in range(n)], t, ar, sole=True)
+            for k, (x, stride) in enumerate(zip(xs, self.strides)):
+                cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
+                per_level.append((t[n + k], t[k], rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
+                levels.append((x.shape[1], x.shape[2], stride))
+        else:
+            for k, (x, stride) in enumerate(zip(feats, self.strides)):
+                x = self.stems[k].forward_nhwc(x, ar)
+                if SF.CONV_PAIR and not sync and not self.depthwise:
+                    # the first conv of both towers reads the stem output: one stacked 3x3 GEMM + shared BatchNorm launches, and (sole
+                    # consumer of the stem output) the stem's BatchNorm-backward reduction in the pair's dX epilogue
+                    c0, r0 = self.cls_convs[k][0], self.reg_convs[k][0]
+                    args = [(c.conv.weight, c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var, c.bn.momentum, c.bn.eps) for c in (c0, r0)]
+                    ws = tuple(ar.take(SF.bn_ws_floats(c.bn.num_features)) for c in (c0, r0))
+                    cf, rf = SF.conv_bn_silu2(x, args[0], args[1], ws, sole_consumer=True, ksize=3)
+                    ar.counters.extend(c.bn.num_batches_tracked for c in (c0, r0) if c.bn.num_batches_tracked is not None)
+                    first = 1
+                else:
+                    cf, rf = x, x          # the stem output feeds both towers; inside a tower every conv has one consumer
+                    first = 0
+                for i, conv in enumerate(self.cls_convs[k]):
+                    if i >= first:
+                        cf = conv.forward_nhwc(cf, ar, sole=i > 0)
+                for i, conv in enumerate(self.reg_convs[k]):
+                    if i >= first:
+                        rf = conv.forward_nhwc(rf, ar, sole=i > 0)
+                cp, rp, op = self.cls_preds[k], self.reg_preds[k], self.obj_preds[k]
+                per_level.append((rf, cf, rp.weight, rp.bias, op.weight, op.bias, cp.weight, cp.bias))
+                levels.append((x.shape[1], x.shape[2], stride))
         ar.finish()
         losses, pred, fg, mg, piou = SF.head_pred_loss(labels, levels, self.num_classes, self.decode_in_inference, per_level, self.use_l1)
         self.last_assignment = (fg, mg, piou)      # SimOTA result of this step (device tensors), for inspection / tests

@@ -1027,6 +1027,23 @@ class SyncBatchNormGroup:
             self.dist.all_reduce(t, group=self.communicator())
         self.n_collectives += 1
 
+    def all_reduce_many(self, ts):
+        """the statistics of several independent units in ONE collective (coalesced: one launch / one wire round for all tensors)"""
+        if len(ts) == 1:
+            return self.all_reduce(ts[0])
+        if self.dist.is_initialized():
+            comm = self.communicator()
+            if self.dist.get_backend(self.group) == "nccl":      # ncclGroupStart / End around the per-tensor calls: one launch
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")          # (torch marks the coalesced entry point deprecated; ProcessGroupNCCL implements it)
+                    self.dist.all_reduce_coalesced(list(ts), group=comm)
+            else:                                            # host-side backends (gloo: the plumbing tests): one flat buffer
+                flat = torch.cat([t.reshape(-1) for t in ts])
+                self.dist.all_reduce(flat, group=comm)
+                torch._foreach_copy_([t.reshape(-1) for t in ts], list(flat.split([t.numel() for t in ts])))
+        self.n_collectives += 1
+
 
 _SYNC_GROUPS = {}
 
@@ -1048,35 +1065,93 @@ def _bn_ws_blocks(bn_ws, Cout):
     return raw[:4 * n].view(torch.float64), raw[4 * n:]      # write it like the kernels do, outside autograd's version counting
 
 
+def _cbs_fwd_args(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws):
+    """the argument block of one conv + BatchNorm + SiLU forward and what its backward keeps: (SastConvBnArgs, state dict)"""
+    _need_gpu(x, w)
+    x = x.contiguous()
+    if not is_channels_last_weight(w):
+        raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
+    B, H, W, Cin = x.shape
+    Cin1 = Cin
+    if x2 is not None:       # virtual channel concat [x | x2] (1x1 convs): read in place, never materialised
+        if ksize != 1 or stride != 1 or x2.shape[:3] != x.shape[:3]:
+            raise RuntimeError("sast_amd: a two-source input is supported for 1x1 stride-1 convs of equal spatial size")
+        x2 = x2.contiguous()
+        Cin = Cin1 + x2.shape[-1]
+    Cout = w.shape[0]
+    groups = _conv_groups(w, Cin, x2)
+    pad = (ksize - 1) // 2
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    M = B * Ho * Wo
+    dev = x.device
+    conv_out = torch.empty(M, Cout, device=dev)
+    stats = torch.empty(2 * Cout, device=dev)
+    y = torch.empty(B, Ho, Wo, Cout, device=dev)
+    if bn_ws is None:  # zero-filled reduction scratch (a whole FPN passes slices of one arena: one memset per step)
+        bn_ws = torch.zeros(bn_ws_floats(Cout), device=dev)
+    a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin1,
+              ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
+              run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1, groups=groups)
+    st = dict(saved=(x, x2, conv_out, stats, bn_ws), params=(w, bn_w, bn_b), groups=groups, y=y,
+              meta=(B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M))
+    return a, st
+
+
+def _cbs_fwd_links(st, training, producers, handle):
+    """the BatchNorm-backward folding links of one unit: (own handle filled, producers this unit's dX epilogue can serve)"""
+    x, x2, conv_out, stats, bn_ws = st["saved"]
+    w, bn_w, bn_b = st["params"]
+    B, H, W, Cin, Cin1, Cout, ksize, stride = st["meta"][:8]
+    own = handle.fill(conv_out, stats, bn_w, bn_b, bn_ws, Cout) if (training and handle is not None) else None
+    p1, p2 = producers if (training and stride == 1 and st["groups"] == 1) else (None, None)   # (the depth-wise stencil has no dX epilogue to fold into)
+    if p1 is not None and p1.cout != Cin1:
+        p1 = None
+    if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
+        p2 = None
+    return own, (p1, p2)
+
+
+def _cbs_bwd_args(saved, params, meta, groups, own, producers, need1, need2, dy, dy2):
+    """the argument block of one unit's backward: (SastConvBnArgs, dx, dx2, _ParamGrads, producers served, tensors to keep alive)"""
+    x, x2, conv_out, stats, bn_ws = saved
+    if dy is None:
+        dy, dy2 = dy2, None
+    if dy is None:
+        dy = torch.zeros(conv_out.shape, device=conv_out.device)
+    dy2 = dy2.contiguous() if dy2 is not None else None
+    w, bn_w, bn_b = params
+    B, H, W, Cin, Cin1, Cout, ksize, stride, training, momentum, eps, M = meta
+    dy = dy.contiguous()
+    need = need1 or (x2 is not None and need2)
+    dx = torch.empty_like(x) if need else None
+    dx2 = torch.empty_like(x2) if (need and x2 is not None) else None
+    ws = torch.empty(M * Cout, device=x.device)
+    p1, p2 = producers if need else (None, None)
+    if p1 is not None and p1.red_done:
+        p1 = None
+    if p2 is not None and (p2.red_done or dx2 is None):
+        p2 = None
+    pk = {}
+    for pre, h in (("p_", p1), ("p2_", p2)):
+        if h is not None:
+            pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
+                       pre + "bn_ws": h.bn_ws})
+    pg = _ParamGrads(w, bn_w, bn_b)
+    a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
+              ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
+              eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=pg[0],
+              d_bn_w=pg[1], d_bn_b=pg[2], bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2),
+              groups=groups, **pk)
+    return a, dx, dx2, pg, (p1, p2), (dy, dy2, ws)
+
+
 class _ConvBnSilu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws, producers, handle, two_y,
                 sync=None):
-        _need_gpu(x, w)
-        x = x.contiguous()
-        if not is_channels_last_weight(w):
-            raise RuntimeError("sast_amd: conv weights must be stored channels_last ([Cout][KH][KW][Cin])")
-        B, H, W, Cin = x.shape
-        Cin1 = Cin
-        if x2 is not None:       # virtual channel concat [x | x2] (1x1 convs): read in place, never materialised
-            if ksize != 1 or stride != 1 or x2.shape[:3] != x.shape[:3]:
-                raise RuntimeError("sast_amd: a two-source input is supported for 1x1 stride-1 convs of equal spatial size")
-            x2 = x2.contiguous()
-            Cin = Cin1 + x2.shape[-1]
-        Cout = w.shape[0]
-        groups = _conv_groups(w, Cin, x2)
-        pad = (ksize - 1) // 2
-        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
-        M = B * Ho * Wo
-        dev = x.device
-        conv_out = torch.empty(M, Cout, device=dev)
-        stats = torch.empty(2 * Cout, device=dev)
-        y = torch.empty(B, Ho, Wo, Cout, device=dev)
-        if bn_ws is None:  # zero-filled reduction scratch (a whole FPN passes slices of one arena: one memset per step)
-            bn_ws = torch.zeros(bn_ws_floats(Cout), device=dev)
-        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=int(training), ldx=Cin1,
-                  ldy=Cout, bn_ws_zeroed=1, momentum=momentum, eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, run_mean=_ptr(run_mean),
-                  run_var=_ptr(run_var), conv_out=conv_out, stats=stats, y=y, bn_ws=bn_ws, x2=_ptr(x2), Cin1=Cin1, ldx2=Cin - Cin1, groups=groups)
+        a, st = _cbs_fwd_args(x, x2, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum, eps, bn_ws)
+        M, B, Cout = st["meta"][11], st["meta"][0], st["meta"][5]
+        bn_ws = st["saved"][4]
         m_total = 0
         if sync is not None and training and sync.active():
             a.sync_phase = 1
@@ -1086,65 +1161,123 @@ class _ConvBnSilu(torch.autograd.Function):
             a.sync_phase, a.m_total = 2, m_total
         L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
         ctx.sync = (sync, m_total) if m_total else None
-        ctx.save_for_backward(x, x2, conv_out, stats, bn_ws)
-        ctx.params = (w, bn_w, bn_b)
-        ctx.meta = (B, H, W, Cin, Cin1, Cout, ksize, stride, int(training), momentum, eps, M)
-        ctx.groups = groups
-        ctx.handle = handle.fill(conv_out, stats, bn_w, bn_b, bn_ws, Cout) if (training and handle is not None) else None
-        p1, p2 = producers if (training and stride == 1 and groups == 1) else (None, None)   # (the depth-wise stencil has no dX epilogue to fold into)
-        if p1 is not None and p1.cout != Cin1:
-            p1 = None
-        if p2 is not None and (x2 is None or p2.cout != Cin - Cin1):
-            p2 = None
-        ctx.producers = (p1, p2)
+        ctx.save_for_backward(*st["saved"])
+        ctx.params, ctx.meta, ctx.groups = st["params"], st["meta"], st["groups"]
+        ctx.handle, ctx.producers = _cbs_fwd_links(st, training, producers, handle)
         ctx.two_y = bool(two_y)
+        y = st["y"]
         return (y, y.view_as(y)) if two_y else y     # two aliases for two consumers: see _LSTM.forward
 
     @staticmethod
     def backward(ctx, dy, dy2=None):
-        x, x2, conv_out, stats, bn_ws = ctx.saved_tensors
         _consume(ctx, "conv_bn_silu")
-        if dy is None:
-            dy, dy2 = dy2, None
-        if dy is None:
-            dy = torch.zeros(conv_out.shape, device=conv_out.device)
-        dy2 = dy2.contiguous() if dy2 is not None else None
-        w, bn_w, bn_b = ctx.params
-        B, H, W, Cin, Cin1, Cout, ksize, stride, training, momentum, eps, M = ctx.meta
-        dy = dy.contiguous()
-        need = ctx.needs_input_grad[0] or (x2 is not None and ctx.needs_input_grad[1])
-        dx = torch.empty_like(x) if need else None
-        dx2 = torch.empty_like(x2) if (need and x2 is not None) else None
-        ws = torch.empty(M * Cout, device=x.device)
-        p1, p2 = ctx.producers if need else (None, None)
-        if p1 is not None and p1.red_done:
-            p1 = None
-        if p2 is not None and (p2.red_done or dx2 is None):
-            p2 = None
-        pk = {}
-        for pre, h in (("p_", p1), ("p2_", p2)):
-            if h is not None:
-                pk.update({pre + "conv_out": h.conv_out, pre + "stats": h.stats, pre + "bn_w": h.bn_w, pre + "bn_b": h.bn_b,
-                           pre + "bn_ws": h.bn_ws})
-        own = ctx.handle
-        pg = _ParamGrads(w, bn_w, bn_b)
-        a = _fill(L.SastConvBnArgs(), B=B, H=H, W=W, Cin=Cin, Cout=Cout, ksize=ksize, stride=stride, training=training, ldx=Cin1,
-                  ldy=Cout, lddy=Cout, lddx=Cin1, bn_ws_zeroed=1, bn_red_done=int(own is not None and own.red_done), momentum=momentum,
-                  eps=eps, x=x, w=w, bn_w=bn_w, bn_b=bn_b, conv_out=conv_out, stats=stats, dy=dy, dx=_ptr(dx), dw=pg[0],
-                  d_bn_w=pg[1], d_bn_b=pg[2], bn_ws=bn_ws, ws=ws, x2=_ptr(x2), dx2=_ptr(dx2), Cin1=Cin1, ldx2=Cin - Cin1, dy2=_ptr(dy2),
-                  groups=ctx.groups, **pk)
+        Cout = ctx.meta[5]
+        a, dx, dx2, pg, served, _keep = _cbs_bwd_args(ctx.saved_tensors, ctx.params, ctx.meta, ctx.groups, ctx.handle, ctx.producers,
+                                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1], dy, dy2)
         if ctx.sync is not None:
             sync, m_total = ctx.sync
             a.sync_phase = 1
             L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
             # (phase 1 also added this process's (sum dz, sum dz * xhat) to d_bn_b / d_bn_w: the affine gradients stay local)
-            sync.all_reduce(_bn_ws_blocks(bn_ws, Cout)[1])
+            sync.all_reduce(_bn_ws_blocks(ctx.saved_tensors[4], Cout)[1])
             a.sync_phase, a.m_total, a.d_bn_w, a.d_bn_b = 2, m_total, None, None
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
-        for h in (p1, p2):
+        for h in served:
             if h is not None:
                 h.red_done = True
         return (dx, dx2) + pg.out() + (None,) * 12
+
+
+_CBS_UNIT_IN = 7      # tensors per unit of _ConvBnSiluSyncGroup.apply: x, x2, w, bn_w, bn_b, running_mean, running_var
+
+
+class _ConvBnSiluSyncGroup(torch.autograd.Function):
+    """SEVERAL independent conv + BatchNorm + SiLU units under SyncBatchNorm as one autograd node: phase 1 of every unit, ONE
+    (coalesced) statistics all-reduce, phase 2 of every unit -- forward and backward.  The dependent chain of a multi-rank step is the
+    number of collectives, not of units: CSPLayer.conv1 / conv2 (same input), the three levels of the YOLOX head (stems; first and second
+    3x3 of both towers) are such sets.  `units`: one tuple (ksize, stride, momentum, eps, bn_ws, producers, handle, two_y) per unit;
+    `tensors`: _CBS_UNIT_IN per unit.  Training mode only (the caller checked `sync.active()`)."""
+
+    @staticmethod
+    def forward(ctx, sync, units, *tensors):
+        n = len(units)
+        jobs, saved, outs = [], [], []
+        for i, (ksize, stride, momentum, eps, bn_ws, producers, handle, two_y) in enumerate(units):
+            x, x2, w, bn_w, bn_b, rm, rv = tensors[_CBS_UNIT_IN * i:_CBS_UNIT_IN * (i + 1)]
+            a, st = _cbs_fwd_args(x, x2, w, bn_w, bn_b, rm, rv, ksize, stride, True, momentum, eps, bn_ws)
+            a.sync_phase = 1
+            L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
+            jobs.append((a, st))
+        sync.all_reduce_many([_bn_ws_blocks(st["saved"][4], st["meta"][5])[0] for _a, st in jobs])
+        ctx.units = []
+        for (a, st), (ksize, stride, momentum, eps, bn_ws, producers, handle, two_y) in zip(jobs, units):
+            m_total = sync.rows_total(st["meta"][11], st["meta"][0])
+            a.sync_phase, a.m_total = 2, m_total
+            L.check(L.lib().sast_conv_bn_silu_fwd(C.byref(a), _stream()), "conv_bn_silu_fwd")
+            own, prods = _cbs_fwd_links(st, True, producers, handle)
+            ctx.units.append((st["params"], st["meta"], st["groups"], own, prods, bool(two_y), m_total, [t is not None for t in st["saved"]]))
+            saved.extend(t for t in st["saved"] if t is not None)
+            y = st["y"]
+            outs.extend((y, y.view_as(y)) if two_y else (y,))
+        ctx.sync = sync
+        ctx.save_for_backward(*saved)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        _consume(ctx, "conv_bn_silu (SyncBatchNorm group)")
+        sv, k, d = list(ctx.saved_tensors), 0, 0
+        jobs = []
+        for i, (params, meta, groups, own, prods, two_y, m_total, present) in enumerate(ctx.units):
+            saved = []
+            for has in present:
+                saved.append(sv[k] if has else None)
+                k += has
+            dy, dy2 = (dys[d], dys[d + 1]) if two_y else (dys[d], None)
+            d += 2 if two_y else 1
+            a, dx, dx2, pg, served, keep = _cbs_bwd_args(tuple(saved), params, meta, groups, own, prods,
+                                                         ctx.needs_input_grad[2 + _CBS_UNIT_IN * i], ctx.needs_input_grad[3 + _CBS_UNIT_IN * i], dy, dy2)
+            a.sync_phase = 1
+            L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
+            jobs.append((a, dx, dx2, pg, served, keep, saved[4], meta[5], m_total))
+        ctx.sync.all_reduce_many([_bn_ws_blocks(ws, cout)[1] for (_a, _dx, _dx2, _pg, _s, _k, ws, cout, _m) in jobs])
+        grads = [None, None]
+        for a, dx, dx2, pg, served, _keep, _ws, _cout, m_total in jobs:
+            a.sync_phase, a.m_total, a.d_bn_w, a.d_bn_b = 2, m_total, None, None
+            L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
+            for h in served:
+                if h is not None:
+                    h.red_done = True
+            grads.extend((dx, dx2) + pg.out() + (None, None))
+        return tuple(grads)
+
+
+def conv_bn_silu_sync_group(sync: "SyncBatchNormGroup", items):
+    """training-mode conv + BatchNorm + SiLU of SEVERAL independent units whose batch statistics span the ranks of `sync`, with one
+    statistics all-reduce per direction for all of them.  items: one dict per unit with the arguments of `conv_bn_silu` (x_nhwc, w, bn_w,
+    bn_b, run_mean, run_var, ksize, stride, momentum, eps, bn_ws, sole_consumer, two_outputs).  -> one output per unit (a (y, alias)
+    pair where two_outputs)."""
+    units, tensors = [], []
+    for it in items:
+        xin = it["x_nhwc"]
+        x, x2 = xin if isinstance(xin, (tuple, list)) else (xin, None)
+        two = bool(it.get("two_outputs", False)) and TWO_OUT and torch.is_grad_enabled()
+        handle = None if two else BnHandle()
+        units.append((int(it["ksize"]), int(it["stride"]), float(it.get("momentum", 0.1)), float(it.get("eps", 1e-5)), it.get("bn_ws"),
+                      _producers(x, x2, it.get("sole_consumer", False)), handle, two))
+        tensors.extend((x, x2, it["w"], it["bn_w"], it["bn_b"], it["run_mean"], it["run_var"]))
+    flat = _ConvBnSiluSyncGroup.apply(sync, units, *tensors)
+    outs, k = [], 0
+    for it, u in zip(items, units):
+        if u[7]:
+            outs.append((flat[k], flat[k + 1]))
+            k += 2
+        else:
+            y = flat[k]
+            y._sast_bn = u[6]      # lets a sole consumer of y fold this conv's BatchNorm-backward reduction into its dX epilogue
+            k += 1
+            outs.append((y, y) if it.get("two_outputs", False) else y)
+    return outs
 
 
 def _conv_groups(w, cin: int, x2=None) -> int:
@@ -1296,6 +1429,7 @@ def _producers(x, x2, sole):
 TWO_OUT = os.environ.get("SAST_TWO_OUT", "1") != "0"       # outputs with two consumers as two aliases (gradients summed inside the backward kernels)
 CONV_PAIR = os.environ.get("SAST_CONV_PAIR", "1") != "0"   # CSPLayer.conv1 / conv2 (same input) through conv_bn_silu2
 BN_FOLD = os.environ.get("SAST_BN_FOLD", "1") != "0"   # fold producers' BatchNorm-backward reductions into consumers' dX epilogues
+SYNC_BN_GROUPS = os.environ.get("SAST_SYNC_BN_GROUPS", "1") != "0"   # SyncBatchNorm: independent units share one statistics all-reduce (CSP conv1 / conv2, head levels)
 
 
 def conv_bn_silu(x_nhwc, w, bn_w, bn_b, run_mean, run_var, ksize, stride, training, momentum=0.1, eps=1e-5, bn_ws=None,

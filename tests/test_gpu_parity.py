@@ -1805,9 +1805,11 @@ for k, g in grads.items():
 sd = net.state_dict()
 for k, v in bufs.items():
     close(sd[k], v, 1e-5, k)
-assert net._sync_group.n_collectives == 1 + 2 * 32, net._sync_group.n_collectives
-# the YOLOX head under the same conversion (15 more units, stacked first tower convs replaced by the plain ones): SimOTA assignment of
-# this rank's images, running statistics and the num_fg-weighted loss against the oracle's head on the WHOLE batch
+# one sample-count exchange + one statistics all-reduce per unit and direction, CSPLayer.conv1 / conv2 (independent) sharing theirs: 32 - 4
+assert net._sync_group.n_collectives == 1 + 2 * 28, net._sync_group.n_collectives
+# the YOLOX head under the same conversion (15 more units as three sets of independent ones -- stems, first and second 3x3 of both towers
+# of the three levels -- with one all-reduce per set and direction): SimOTA assignment of this rank's images, running statistics, the
+# num_fg-weighted loss and its gradients against the oracle's head on the WHOLE batch
 from sast_amd.detection import YOLOXHead
 hp = O.init_head_params(chans, num_classes=3, seed=9)
 head = convert_sync_batchnorm(YOLOXHead(num_classes=3, strides=(8, 16, 32), in_channels=chans).to(dev))
@@ -1819,7 +1821,8 @@ labels = O.synthetic_labels(sum(splits), (hw[0] * 8, hw[1] * 8), 3, max_labels=6
 labels[:, 0, :] = torch.tensor([1.0, 100.0, 90.0, 60.0, 50.0])             # every image has at least one box
 _out, losses = head(tuple(f[lo:hi].to(dev) for f in hfull), labels[lo:hi].to(dev))
 hb = {k: v.clone() for k, v in hp.items() if "running_" in k}
-ref_h = O.yolox_head_train(hfull, labels, hp, bufs=hb)
+hpg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in hp.items()}
+ref_h = O.yolox_head_train(hfull, labels, hpg, bufs=hb)
 fg, mg, _piou = head.last_assignment
 for j, b in enumerate(range(lo, hi)):
     rfg, rmatched, _rp = ref_h["assign"][b]
@@ -1832,6 +1835,14 @@ nfg = torch.tensor([float(sum(int(ref_h["assign"][b][0].sum()) for b in range(lo
 acc = torch.tensor([float(losses["loss"]) * float(nfg), float(nfg)], dtype=torch.float64)
 dist.all_reduce(acc)
 assert abs(acc[0] / acc[1] - float(ref_h["loss"])) <= 2e-5 * abs(float(ref_h["loss"])), (float(acc[0] / acc[1]), float(ref_h["loss"]))
+# gradients: each rank normalises by ITS num_fg (yolo_head.py:399,417), the whole-batch loss by the total -> weight nfg_r / nfg_total, summed
+ref_h["loss"].backward()
+(losses["loss"] * (float(nfg) / float(acc[1]))).backward()
+for k, v in head.named_parameters():
+    g = v.grad.detach().cpu().clone()
+    dist.all_reduce(g)
+    worst = max(worst, close(g, hpg[k].grad, 3e-4, "head grad " + k))
+assert head._sync_group.n_collectives == 1 + 2 * 3, head._sync_group.n_collectives
 print(f"ok rank {rank} worst grad err {worst:.2e}")
 '''
 
@@ -1871,7 +1882,8 @@ with torch.cuda.stream(s):
     feats = {k: v.to(dev).requires_grad_(True) for k, v in full.items()}
     run(net, feats)                                       # the eager pass: fixes the sample counts, allocates the gradient buffers
     n_eager = net._sync_group.n_collectives
-    assert n_eager == 2 * n_units and n_units == (42 if dwise else 32), n_eager    # one per conv + BatchNorm unit and direction; the count exchange needs no call with one rank
+    # one per conv + BatchNorm unit and direction, CSPLayer.conv1 / conv2 of the four layers sharing theirs; the count exchange needs no call with one rank
+    assert n_eager == 2 * (n_units - 4) and n_units == (42 if dwise else 32), n_eager
     sd0 = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -1912,9 +1924,9 @@ print(f"ok captured worst grad err {worst:.2e}")
 def test_sync_batchnorm_statistics_allreduces_captured_into_hipgraph(dev, tmp_path, convs):
     """SyncBatchNorm inside the replayed step (the reference's DDP default, train.py:167): on RCCL the statistics all-reduces between the
     two phases of every conv + BatchNorm unit are stream-captured with the kernels around them.  One rank is what a one-GPU box can run:
-    a ONE-rank RCCL group with the two-phase path forced on (`convert_sync_batchnorm(force=True)`) -- 32 + 32 real collective calls inside
-    `torch.cuda.graph`, replayed twice -- must reproduce the unconverted PAFPN's outputs and gradients (one rank: the global statistics ARE
-    the local ones; the two forms differ only in where the fp64 sums are finished).  "depthwise": the same with DWConv units (42 + 42)."""
+    a ONE-rank RCCL group with the two-phase path forced on (`convert_sync_batchnorm(force=True)`) -- 28 + 28 real collective calls (four of
+    them coalesced over the two independent 1x1 units of a CSPLayer) inside `torch.cuda.graph`, replayed twice -- must reproduce the unconverted PAFPN's outputs and gradients (one rank: the global statistics ARE
+    the local ones; the two forms differ only in where the fp64 sums are finished).  "depthwise": the same with DWConv units (38 + 38)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -426,6 +426,46 @@ def test_sync_batchnorm_group_forced_and_capturable():
     t = torch.ones(4, dtype=torch.float64)
     f.all_reduce(t)                                        # no process group: the identity, but counted
     assert f.n_collectives == 1 and torch.equal(t, torch.ones(4, dtype=torch.float64))
+    f.all_reduce_many([t, torch.ones(2, dtype=torch.float64)])     # several independent units: ONE collective
+    assert f.n_collectives == 2
+
+
+_SYNC_MANY_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from sast_amd.functional import SyncBatchNormGroup
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+g = SyncBatchNormGroup()
+assert g.active() and g.world == world and not g.capturable()
+arena = torch.zeros(40, dtype=torch.float64)               # the units' blocks are slices of one arena, NOT adjacent (their backward blocks sit between)
+a, b, c = arena[0:6], arena[10:14], arena[30:40]
+for i, t in enumerate((a, b, c)):
+    t.fill_(float((rank + 1) * (i + 1)))
+g.all_reduce_many([a, b, c])
+tot = world * (world + 1) // 2
+assert g.n_collectives == 1
+assert torch.equal(a, torch.full((6,), 1.0 * tot, dtype=torch.float64)) and torch.equal(b, torch.full((4,), 2.0 * tot, dtype=torch.float64))
+assert torch.equal(c, torch.full((10,), 3.0 * tot, dtype=torch.float64))
+assert float(arena[6:10].abs().sum() + arena[14:30].abs().sum()) == 0.0      # nothing outside the blocks was touched
+g.all_reduce_many([a])
+assert g.n_collectives == 2 and float(a[0]) == tot * world
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sync_batchnorm_group_one_collective_for_independent_units_gloo_world2(tmp_path):
+    """SyncBatchNorm with several ranks: the statistics blocks of INDEPENDENT units (CSPLayer.conv1 / conv2, the YOLOX head's levels and
+    towers) travel in one collective (`SyncBatchNormGroup.all_reduce_many`; host-side backends: one flat buffer, RCCL: the coalesced
+    all-reduce) -- every block summed over the ranks, nothing around them touched, one call counted."""
+    script = tmp_path / "worker.py"
+    script.write_text(_SYNC_MANY_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29737", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
 
 
 def test_torch_sync_batchnorm_conversion_is_honoured_not_silently_local():

@@ -3,8 +3,9 @@
 # TWICE per N:
 #   default      rank-local BatchNorm statistics in the PAFPN (SURVEY 8e option (i): "all-reduce for gradients only", north_star) --
 #                the line the driver's `bench.py --gpus N` produces, and the one the >= 70 % 1 -> 8 efficiency target refers to
-#   --sync-bn    the reference's own DDP semantics (train.py:167 Trainer(sync_batchnorm=True)): 64 small statistics all-reduces per
-#                step captured into the hipGraphs; expected BELOW 70 % (62 dependent collectives x 20-30 us on a 4.8 ms step)
+#   --sync-bn    the reference's own DDP semantics (train.py:167 Trainer(sync_batchnorm=True)): 56 small statistics all-reduces per
+#                step captured into the hipGraphs (independent units share one); expected BELOW 70 % (56 dependent collectives x
+#                20-30 us on a 4.8 ms step)
 # usage: bash tools/scale.sh [steps] [warmup] > scale.jsonl      (needs an N-GPU node; nothing here can run on the 1-GPU boxes)
 steps=${1:-100}; warmup=${2:-20}
 export HSA_ENABLE_IPC_MODE_LEGACY=0
