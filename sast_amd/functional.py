@@ -29,7 +29,12 @@ from . import _lib as L
 _DT = {torch.float32: L.DT_F32, torch.int32: L.DT_I32, torch.uint8: L.DT_U8}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # the handle without building a torch.cuda.Stream object per launch
+
+
 def _stream():
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
