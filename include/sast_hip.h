@@ -157,9 +157,10 @@ typedef struct SastMswsaArgs {
   float eps;
   int32_t cb_tps;        /* Context Broadcasting (enable_CB, SAST.py:240-246): tokens per sample, 0 = off */
   int32_t dim_head;      /* attention head width (SAST.py:171-181): 32 (default when 0) or 24; heads = C / dim_head */
-  int32_t mlp_act;       /* gate activation of the GLU-MLP (attention_cfg.mlp_activation, SAST.py:38,55 -> ops.py:133-137):
-                            0 gelu (erf form; every shipped config)  1 relu  2 silu / swish  3 sigmoid  4 tanh; the one-kernel form
-                            (fused_ws) exists for 0 only */
+  int32_t mlp_act;       /* gate activation of the GLU-MLP (attention_cfg.mlp_activation, SAST.py:38,55 -> ops.py:133-137; the names of
+                            layers/create_act.py:62-79): 0 gelu (erf form; every shipped config)  1 relu  2 silu / swish  3 sigmoid  4 tanh
+                            5 mish  6 relu6  7 leaky_relu  8 elu / celu  9 selu  10 hard_sigmoid  11 hard_swish  12 hard_mish
+                            13 prelu (learnable slope: act_w / d_act_w below); the one-kernel form (fused_ws) exists for 0 only */
   const float* xin;      /* [B*L, C] image layout */
   float* out;            /* [B*L, C] */
   SastSel sel;
@@ -188,6 +189,8 @@ typedef struct SastMswsaArgs {
                             registers from LN to the scatter).  With S == NULL (inference) nothing else is written; with the saved-activation
                             buffers mean1 .. Hh present the same kernel also writes them, so that sast_mswsa_bwd runs unchanged.  The forward
                             fills fused_ws with the bf16x3 weight planes its kernel streams. */
+  const float* act_w;    /* mlp_act 13 (prelu; layers/activations.py:124-131: nn.PReLU, one slope, init 0.25): fp32[1] on the device */
+  float* d_act_w;        /* bwd, mlp_act 13: fp32[1], accumulated into (sum over the gate elements <= 0 of dh * value * gate) */
 } SastMswsaArgs;
 /* 0 = this layer shape has no fused form (the caller passes fused_ws = NULL and the saved-activation buffers) */
 size_t sast_mswsa_fused_ws_floats(int C, int inner, int T, int dim_head, int cb_tps);

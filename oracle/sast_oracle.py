@@ -224,7 +224,10 @@ def mlp_glu(x: Tensor, p: Params, pre: str, act: str = "gelu", cfg: Optional["At
     The dropout is the reference's torch call (same RNG draw); the mask goes through the same test plumbing as DropPath's factors."""
     y = F.linear(x, p[pre + "net.0.proj.weight"], p.get(pre + "net.0.proj.bias"))       # (mlp_bias: False -> no bias keys)
     val, gate = torch.tensor_split(y, 2, dim=-1)
-    h = val * GLU_ACTS[act](gate)
+    if act == "prelu":      # layers/activations.py:124-131: nn.PReLU with ONE learnable slope (init 0.25), `net.0.act_layer.weight`
+        h = val * F.prelu(gate, p[pre + "net.0.act_layer.weight"])
+    else:
+        h = val * GLU_ACTS[act](gate)
     if cfg is not None and cfg.drop_mlp > 0.0 and cfg.training:
         if cfg.drop_masks is not None:
             mask = cfg.drop_masks.pop(0).view_as(h)

@@ -47,7 +47,7 @@ SastMswsaArgs = _struct("SastMswsaArgs", [
     (P, "mean1 rstd1 mean2 rstd2 S QKV O lse Y UG Hh"),
     (P, "dout dxin"),
     (P, "d_ln1_w d_ln1_b d_ln2_w d_ln2_b d_qkv_w d_qkv_b d_proj_w d_proj_b d_ls1 d_fc1_w d_fc1_b d_fc2_w d_fc2_b d_ls2"),
-    (P, "ws cb_m cb_sum raw_ws drop1 drop2 drop_ws drop_mlp fused_ws"),
+    (P, "ws cb_m cb_sum raw_ws drop1 drop2 drop_ws drop_mlp fused_ws act_w d_act_w"),
 ])
 SastConvBn2Args = _struct("SastConvBn2Args", [
     (I32, "B H W Cin Cout ldx Cin1 ldx2 bn_ws_zeroed bn_red_done0 bn_red_done1 training ksize"), (F32, "momentum0 momentum1 eps0 eps1"),

@@ -112,12 +112,15 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 //   0 gelu (erf form: GeGLU, every shipped config)  1 relu (ReGLU)  2 silu / swish (SwiGLU)  3 sigmoid (GLU)  4 tanh
 //   round 5, the remaining parameter-free names of get_act_layer (torch module defaults):  5 mish  6 relu6  7 leaky_relu (slope 0.01)
 //   8 elu / celu (alpha 1: the two coincide)  9 selu  10 hard_sigmoid  11 hard_swish  12 hard_mish (HardMishMe: its own backward)
+//   13 prelu (nn.PReLU, ONE learnable slope `a`: SastMswsaArgs.act_w; torch: prelu'(0) = a, d a gets 0 from a gate of exactly 0)
 // the code is wave-uniform (one layer per launch): the switch is a scalar branch
-constexpr int GLU_ACT_COUNT = 13;
+constexpr int GLU_ACT_COUNT = 14;
+constexpr int GLU_ACT_PRELU = 13;
 constexpr float SELU_ALPHA = 1.6732632423543772848170429916717f, SELU_SCALE = 1.0507009873554804934193349852946f;
 __device__ __forceinline__ float softplus_t20(float x) { return x > 20.0f ? x : log1pf(expf(x)); }      // F.softplus(beta 1, threshold 20)
-__device__ __forceinline__ float glu_act(float g, int act) {
+__device__ __forceinline__ float glu_act(float g, int act, float a = 0.0f) {
   switch (act) {
+    case GLU_ACT_PRELU: return g > 0.0f ? g : a * g;
     case 1: return fmaxf(g, 0.0f);
     case 2: return g * sigmoid_exact(g);
     case 3: return sigmoid_exact(g);
@@ -133,8 +136,9 @@ __device__ __forceinline__ float glu_act(float g, int act) {
     default: return gelu_erf(g);
   }
 }
-__device__ __forceinline__ float glu_act_grad(float g, int act) {
+__device__ __forceinline__ float glu_act_grad(float g, int act, float a = 0.0f) {
   switch (act) {
+    case GLU_ACT_PRELU: return g > 0.0f ? 1.0f : a;
     case 1: return g > 0.0f ? 1.0f : 0.0f;                  // torch: relu'(0) = 0
     case 2: { const float s = sigmoid_exact(g); return s * (1.0f + g * (1.0f - s)); }
     case 3: { const float s = sigmoid_exact(g); return s * (1.0f - s); }

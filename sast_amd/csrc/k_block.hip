@@ -63,19 +63,31 @@ struct EpResidualLSScatterT {  // out[row_tok[m]] = res + [rs[m] *] gamma * (v +
 };
 // ANY = false: exact-erf GELU (every shipped config) compiled in; ANY = true: the gate activation is the run-time code `act`
 // (common.cuh glu_act) -- a separate instantiation, so that the GELU kernels do not carry the switch (measured: +2 / +7 us per launch)
+constexpr int PRELU_SLOTS = 1024;   // partial sums of the prelu slope gradient (tail of the backward workspace)
+__global__ void __launch_bounds__(PRELU_SLOTS) prelu_slope_finish_kernel(const float* __restrict__ slots, float* __restrict__ d) {
+  __shared__ float s[PRELU_SLOTS];
+  s[threadIdx.x] = slots[threadIdx.x];
+  __syncthreads();
+  for (int o = PRELU_SLOTS / 2; o; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) d[0] += s[0];
+}
 template <bool ANY>
 struct EpGluT {  // ops.py:136-137: value = first half, gate = second half
   float* ug; float* h; const float* bias; int inner; int act;
   const float* drop;   // ANY only: keep mask / (1 - p) of the MLP's nn.Dropout (ops.py:167, `drop_mlp`) on the hidden [rows, inner], NULL = none
-  struct Col { float bu, bg; };
+  const float* act_w;  // ANY only: the slope of prelu (fp32[1] on the device), NULL for every other activation
+  struct Col { float bu, bg, a; };
   using Aux = EpNone;
-  __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[inner + j]}; }
+  __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[inner + j], (ANY && act_w) ? act_w[0] : 0.0f}; }
   __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[2], const Col& k, const Aux&) const {
     const float u = v[0] + k.bu, g = v[1] + k.bg;
     ug[(size_t)m * 2 * inner + j] = u;
     ug[(size_t)m * 2 * inner + inner + j] = g;
-    if constexpr (ANY) h[(size_t)m * inner + j] = (u * glu_act(g, act)) * (drop ? drop[(size_t)m * inner + j] : 1.f);
+    if constexpr (ANY) h[(size_t)m * inner + j] = (u * glu_act(g, act, k.a)) * (drop ? drop[(size_t)m * inner + j] : 1.f);
     else h[(size_t)m * inner + j] = u * gelu_erf(g);
   }
 };
@@ -83,15 +95,18 @@ template <bool ANY>
 struct EpDGluT {  // v = dH -> d(value), d(gate)
   const float* ug; float* dug; int inner; int act;
   const float* drop;   // ANY only: see EpGluT (the hidden's gradient passes through the same mask)
-  using Col = EpNone;
+  const float* act_w;  // ANY only: prelu slope, and the PRELU_SLOTS partial sums of its gradient (sum over gates <= 0 of dh * value * gate;
+  float* slope_slots;  // spread over the slots by element index so that the atomics do not meet on one address), NULL otherwise
+  struct Col { float a; };
   struct Aux { float u, g; };
-  __device__ __forceinline__ Col col(int) const { return Col{}; }
+  __device__ __forceinline__ Col col(int) const { return Col{(ANY && act_w) ? act_w[0] : 0.0f}; }
   __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{ug[(size_t)m * 2 * inner + j], ug[(size_t)m * 2 * inner + inner + j]}; }
-  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col&, const Aux& x) const {
+  __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux& x) const {
     if constexpr (ANY) {
       const float dh = drop ? v[0] * drop[(size_t)m * inner + j] : v[0];
-      dug[(size_t)m * 2 * inner + j] = dh * glu_act(x.g, act);
-      dug[(size_t)m * 2 * inner + inner + j] = dh * x.u * glu_act_grad(x.g, act);
+      dug[(size_t)m * 2 * inner + j] = dh * glu_act(x.g, act, k.a);
+      dug[(size_t)m * 2 * inner + inner + j] = dh * x.u * glu_act_grad(x.g, act, k.a);
+      if (slope_slots && x.g < 0.0f) atomicAdd(slope_slots + (((size_t)m * inner + j) & (PRELU_SLOTS - 1)), dh * x.u * x.g);
     } else {
       dug[(size_t)m * 2 * inner + j] = v[0] * gelu_erf(x.g);
       dug[(size_t)m * 2 * inner + inner + j] = v[0] * x.u * gelu_erf_grad(x.g);
@@ -298,7 +313,8 @@ static size_t mswsa_bwd_ws_base(int rows, int C, int inner) {
   return (size_t)rows * (2 * inner + C + C + 3 * C + C) + (size_t)C * inner + (size_t)C * C + 2 * C;
 }
 // (+ D_i of the attention backward, one float per row and head -- at most C / 4 heads --, used for partitions of more than 128 tokens)
-size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) { return mswsa_bwd_ws_base(rows, C, inner) + (size_t)rows * (C / 4); }
+// (+ PRELU_SLOTS partial sums of the prelu slope gradient)
+size_t sast_mswsa_bwd_ws_floats(int rows, int C, int inner) { return mswsa_bwd_ws_base(rows, C, inner) + (size_t)rows * (C / 4) + PRELU_SLOTS; }
 
 int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   hipStream_t st = (hipStream_t)stream;
@@ -309,6 +325,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const int C = a->C, L = a->H * a->W, R = a->B * L, inner = a->inner;
   const int T = a->ph * a->pw, NW = a->B * (L / T);
   if (T > ATTN_MAX_T || a->mlp_act < 0 || a->mlp_act >= GLU_ACT_COUNT || (!a->drop1) != (!a->drop2)) return SAST_EINVAL;
+  const bool prelu = a->mlp_act == GLU_ACT_PRELU;
+  if (prelu && !a->act_w) return SAST_EINVAL;
   if (a->fused_ws) {   // one kernel for the whole layer (k_mswsa_fused.hip: GeGLU, no DropPath)
     if (!mswsa_fused_supported(C, inner, T, dh, a->cb_tps) || a->mlp_act != 0 || a->drop1 || a->drop_mlp || ((uintptr_t)a->fused_ws & 15)) return SAST_EINVAL;
     int rc = mswsa_fused_planes_launch(a, a->fused_ws, st);
@@ -337,8 +355,8 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
       if (mode && C >= 256) return launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
       return launch_gemm<TileG2>(la, lb, ep, R, inner, C, dR, nullptr, st);
     };
-    rc = (a->mlp_act || a->drop_mlp) ? fc1(EpGluT<true>{a->UG, a->Hh, a->fc1_b, inner, a->mlp_act, a->drop_mlp})
-                                     : fc1(EpGluT<false>{a->UG, a->Hh, a->fc1_b, inner, 0, nullptr});
+    rc = (a->mlp_act || a->drop_mlp) ? fc1(EpGluT<true>{a->UG, a->Hh, a->fc1_b, inner, a->mlp_act, a->drop_mlp, prelu ? a->act_w : nullptr})
+                                     : fc1(EpGluT<false>{a->UG, a->Hh, a->fc1_b, inner, 0, nullptr, nullptr});
     if (rc) return rc;
   }
   if (a->cb_tps <= 0)
@@ -413,9 +431,20 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     return a->ls2 ? gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNNS{a->fc2_w, inner, a->ls2}, ep, R, inner, C, dR, st)
                   : gemm_auto(LdRows{dz, C, dz_tok}, LdWeightNN{a->fc2_w, inner}, ep, R, inner, C, dR, st);
   };
-  rc = (a->mlp_act || a->drop_mlp) ? fc2_bwd(EpDGluT<true>{a->UG, dUG, inner, a->mlp_act, a->drop_mlp})
-                                   : fc2_bwd(EpDGluT<false>{a->UG, dUG, inner, 0, nullptr});
+  const bool prelu = a->mlp_act == GLU_ACT_PRELU;
+  float* slope_slots = (prelu && a->d_act_w) ? a->ws + mswsa_bwd_ws_base(R, C, inner) + (size_t)R * (C / 4) : nullptr;
+  if (prelu && !a->act_w) return SAST_EINVAL;
+  if (slope_slots) {
+    rc = zero_fill(slope_slots, PRELU_SLOTS * sizeof(float), st);
+    if (rc) return rc;
+  }
+  rc = (a->mlp_act || a->drop_mlp) ? fc2_bwd(EpDGluT<true>{a->UG, dUG, inner, a->mlp_act, a->drop_mlp, prelu ? a->act_w : nullptr, slope_slots})
+                                   : fc2_bwd(EpDGluT<false>{a->UG, dUG, inner, 0, nullptr, nullptr, nullptr});
   if (rc) return rc;
+  if (slope_slots) {
+    SAST_LAUNCH(prelu_slope_finish_kernel, dim3(1), dim3(PRELU_SLOTS), 0, st, slope_slots, a->d_act_w);
+    SAST_CHECK_LAUNCH();
+  }
   // fc1: dW1 / db1, and dY = dZ + dUG W1
   rc = gemm_pair(LdRowsT{dUG, 2 * inner}, LdRowsT{a->Y, C}, a->d_fc1_w, C, 2 * inner, C, R, dR, a->d_fc1_b,
                  LdRows{dUG, 2 * inner, nullptr}, LdWeightNN{a->fc1_w, C}, EpAddGather{dY, C, a->dout, row_tok, C}, R, C, 2 * inner, dR, st);

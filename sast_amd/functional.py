@@ -663,7 +663,7 @@ class DeviceCount:
 
 # ---------------------------------------------------------------------------------------------- a9
 _MSWSA_PARAMS = ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ls1",
-                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")
+                 "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "act_w")      # act_w: the slope of mlp_activation prelu (fp32[1]), None otherwise
 
 
 _FUSED_ENABLE = True  # tools / tests switch the fused form off to compare the two forms of the layer in one process
@@ -709,6 +709,8 @@ class _MSWSA(torch.autograd.Function):
                 _fill(a, drop_mlp=drop_mlp)
         # the layer's forward as ONE kernel (csrc/k_mswsa_fused.hip) where the library has that form for the shape; the scratch holds the
         # bf16x3 weight planes the kernel streams.  In training the same kernel also writes the activations the backward reads.
+        if (mlp_act == GLU_ACTIVATIONS["prelu"]) != (p["act_w"] is not None):
+            raise RuntimeError("sast_amd: mlp_activation prelu needs its slope parameter (act_w), every other activation none")
         fused_floats = L.lib().sast_mswsa_fused_ws_floats(Cc, inner, sel.ph * sel.pw, dim_head, cb_tps) if (_FUSED_ENABLE and fused and mlp_act == 0 and drop is None and drop_mlp is None and R >= _FUSED_MIN_ROWS) else 0
         # a backward can follow: grad mode was on at the call (it is always off inside Function.forward, and `needs_input_grad` says
         # True for trainable parameters under torch.no_grad() too -- `mswsa` samples the mode) and some input wants a gradient
@@ -791,11 +793,11 @@ class _MSWSA(torch.autograd.Function):
         return (dxin, None, None, None, None, None, None, None, None) + pg.out()
 
 
-# include/sast_hip.h: SastMswsaArgs.mlp_act.  Every parameter-free name of the reference's get_act_layer (layers/create_act.py:62-79, with
-# the defaults of the torch modules it maps to); `prelu` carries a learnable slope (a parameter the reference's state_dict would gain)
-# and is refused.
+# include/sast_hip.h: SastMswsaArgs.mlp_act.  Every name of the reference's get_act_layer (layers/create_act.py:62-79, with the defaults of
+# the torch modules it maps to); `prelu` carries ONE learnable slope (layers/activations.py:124-131: `...mlp.net.0.act_layer.weight` in the
+# reference's state_dict), handed to the kernels as `act_w`.
 GLU_ACTIVATIONS = {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4, "mish": 5, "relu6": 6, "leaky_relu": 7, "elu": 8,
-                   "celu": 8, "selu": 9, "hard_sigmoid": 10, "hardsigmoid": 10, "hard_swish": 11, "hardswish": 11, "hard_mish": 12}
+                   "celu": 8, "selu": 9, "hard_sigmoid": 10, "hardsigmoid": 10, "hard_swish": 11, "hardswish": 11, "hard_mish": 12, "prelu": 13}
 
 
 def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: int = 0, dim_head: int = 32, fused: bool = True,
@@ -814,7 +816,7 @@ def mswsa(xin, sel: Selection, eps: float, params: dict, cb_tokens_per_sample: i
     if mlp_activation not in GLU_ACTIVATIONS:
         raise NotImplementedError(f"sast_amd: mlp_activation {mlp_activation!r}: the GLU epilogues implement {sorted(GLU_ACTIVATIONS)}")
     return _MSWSA.apply(xin, sel, float(eps), int(cb_tokens_per_sample), int(dim_head), bool(fused), GLU_ACTIVATIONS[mlp_activation],
-                        drop_path, torch.is_grad_enabled(), *[params[k] for k in _MSWSA_PARAMS])
+                        drop_path, torch.is_grad_enabled(), *[params.get(k) if k == "act_w" else params[k] for k in _MSWSA_PARAMS])
 
 
 # ---------------------------------------------------------------------------------------------- a12

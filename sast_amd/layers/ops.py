@@ -105,6 +105,16 @@ class LayerScale(_FusedOnly):
         self.gamma = nn.Parameter(init_values * torch.ones(dim))
 
 
+class PReLUSlope(_FusedOnly):
+    """layers/activations.py:124-131 (nn.PReLU, num_parameters 1, init 0.25): the parameter holder of `mlp_activation: prelu` -- same name
+    (`act_layer.weight`) and shape as the reference's module, applied inside the GLU epilogues"""
+
+    def __init__(self, num_parameters: int = 1, init: float = 0.25, inplace: bool = False):
+        super().__init__()
+        assert num_parameters == 1
+        self.weight = nn.Parameter(torch.full((1,), float(init)))
+
+
 class GLU(_FusedOnly):
     """ops.py:111-137 (channel-last only): proj = Linear(dim_in, 2*dim_out); out = value * act(gate)."""
 
@@ -112,6 +122,8 @@ class GLU(_FusedOnly):
         super().__init__()
         assert channel_last, "sast_amd implements the channels-last MLP of MS_WSA only"
         self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+        if act_layer == "prelu" or act_layer is nn.PReLU or (isinstance(act_layer, type) and issubclass(act_layer, nn.PReLU)):
+            self.act_layer = PReLUSlope()      # (the parameter-free activations add nothing to the state_dict)
 
 
 class MLP(_FusedOnly):

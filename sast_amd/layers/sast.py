@@ -95,7 +95,9 @@ def _glu_activation_name(act) -> str:
     else:
         name = {nn.GELU: "gelu", nn.ReLU: "relu", nn.SiLU: "silu", nn.Sigmoid: "sigmoid", nn.Tanh: "tanh", nn.Mish: "mish", nn.ReLU6: "relu6",
                 nn.LeakyReLU: "leaky_relu", nn.ELU: "elu", nn.CELU: "celu", nn.SELU: "selu", nn.Hardsigmoid: "hard_sigmoid",
-                nn.Hardswish: "hard_swish"}.get(act)
+                nn.Hardswish: "hard_swish", nn.PReLU: "prelu"}.get(act)
+        if name is None and isinstance(act, type) and issubclass(act, nn.PReLU):       # the reference's own subclass (activations.py:124)
+            name = "prelu"
     if name not in SF.GLU_ACTIVATIONS:
         raise NotImplementedError(f"sast_amd: MLP activation {act!r}: the GLU epilogues implement {sorted(SF.GLU_ACTIVATIONS)}")
     return name
@@ -124,7 +126,7 @@ class MS_WSA(nn.Module):
         self.ls1 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop1 = DropPath(drop_path) if drop_path > 0 else nn.Identity()
         self.norm2 = norms[1]
-        self.mlp = MLP(dim=dim, channel_last=True, expansion_ratio=mlp_expand_ratio, act_layer=mlp_act_layer, bias=mlp_bias,
+        self.mlp = MLP(dim=dim, channel_last=True, expansion_ratio=mlp_expand_ratio, act_layer=self.mlp_activation, bias=mlp_bias,
                        drop_prob=drop_mlp)
         self.ls2 = LayerScale(dim=dim, init_values=ls_init_value) if ls_init_value > 0 else nn.Identity()
         self.drop2 = DropPath(drop_path) if drop_path > 0 else nn.Identity()
@@ -147,7 +149,7 @@ class MS_WSA(nn.Module):
                     ls1=getattr(self.ls1, "gamma", None), fc1_w=self.mlp.net[0].proj.weight,
                     fc1_b=self.mlp.net[0].proj.bias if self.mlp.net[0].proj.bias is not None else self._zero_fc1_b,
                     fc2_w=self.mlp.net[2].weight, fc2_b=self.mlp.net[2].bias if self.mlp.net[2].bias is not None else self._zero_fc2_b,
-                    ls2=getattr(self.ls2, "gamma", None))
+                    ls2=getattr(self.ls2, "gamma", None), act_w=getattr(getattr(self.mlp.net[0], "act_layer", None), "weight", None))
 
     def _drop_path_factors(self, rows: int, device):
         """training-mode randomness of the layer, in the reference's order (SAST.py:232-248): DropPath on the attention branch, nn.Dropout on

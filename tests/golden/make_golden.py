@@ -103,6 +103,9 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
         params = block_params(C, seed, 0.5)
         if not bias:
             params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
+        if act == "prelu":      # the one activation with a parameter (layers/activations.py:124-131): a slope per layer, away from the init value
+            for layer, slope in zip(("win_attn", "grid_attn"), PRELU_SLOPES):
+                params[f"att_blocks.0.att.{layer}.mlp.net.0.act_layer.weight"] = torch.tensor([slope])
         blk, xx, out, cnt, lists = run_ref_block(ref, params, x, r, pe_mod, acfg)
         # margins via the oracle's scores
         _o, _c, _l, sc = O.sast_block(x, pe, r, params, "att_blocks.0.att.", ocfg, return_scores=True)
@@ -133,6 +136,8 @@ def gen_block(ref, name, B, amp, enable_cb=False, seed0=0, C=64, dim_head=32, bi
              margin=np.float64(margin), dx=np_(xx.grad), param_checksum=np.float64(param_checksum(params)),
              enable_cb=np.int64(enable_cb), dim_head=np.int64(dim_head), bias=np.int64(bias), act=np.array(act),
              part=np.array(part, dtype=np.int64))
+    if act == "prelu":
+        d["prelu_slopes"] = np.array(PRELU_SLOPES, dtype=np.float32)
     d.update(lists_to_np(lists, ""))
     named = dict(blk.named_parameters())
     for k, v in named.items():
@@ -239,7 +244,10 @@ ACTS_R4 = ("relu", "silu", "sigmoid", "tanh")
 ACTS_R5 = ("mish", "relu6", "leaky_relu", "elu", "celu", "selu", "hard_sigmoid", "hard_swish", "hard_mish")
 
 
-def gen_acts(ref, names=ACTS_R4 + ACTS_R5):
+PRELU_SLOPES = (0.3, 0.15)
+
+
+def gen_acts(ref, names=ACTS_R4 + ACTS_R5 + ("prelu",)):
     for act in names:
         gen_block(ref, "block_act_" + act, 1, 2e-2, C=32, act=act)
 
@@ -790,6 +798,9 @@ def main():
         return
     if "--acts-only" in sys.argv:    # the gate activations beside gelu (B=1, C=32: small fixtures)
         gen_acts(ref)
+        return
+    if "--prelu-only" in sys.argv:
+        gen_acts(ref, ("prelu",))
         return
     if "--acts-r5-only" in sys.argv:
         gen_acts(ref, ACTS_R5)

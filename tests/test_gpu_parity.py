@@ -132,7 +132,7 @@ def test_input_prep_one_launch(golden_dir, dev):
                                   "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
                                   "block_act_tanh", "block_act_mish", "block_act_relu6", "block_act_leaky_relu", "block_act_elu", "block_act_celu",
                                   "block_act_selu", "block_act_hard_sigmoid", "block_act_hard_swish", "block_act_hard_mish", "block_dh16", "block_dh8",
-                                  "block_t240_dense", "block_t240_sparse"])
+                                  "block_t240_dense", "block_t240_sparse", "block_act_prelu"])
 def test_sast_block_vs_golden(golden_dir, dev, name):
     from sast_amd.layers import SAST_block
     from sast_amd.detection import PositionEmbeddingSine
@@ -146,6 +146,9 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     if not bias:
         params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
     act = str(g["act"]) if "act" in g else "gelu"           # attention_cfg.mlp_activation: the GLU's gate activation
+    if "prelu_slopes" in g:                                 # prelu: one learnable slope per layer (`mlp.net.0.act_layer.weight`)
+        for layer, slope in zip(("win_attn", "grid_attn"), g["prelu_slopes"]):
+            params[f"att_blocks.0.att.{layer}.mlp.net.0.act_layer.weight"] = torch.tensor([float(slope)])
     part = tuple(int(v) for v in g["part"]) if "part" in g else (4, 5)   # block_t240_*: 12 x 20 = 240 tokens (gen4, partition_split_32 1)
     acfg = attn_cfg(part, float(g["amp"]), cb=cb, dim_head=dh)
     acfg.update(attention_bias=bias, mlp_bias=bias, mlp_activation=act)
@@ -1215,6 +1218,9 @@ def test_ms_wsa_varlen_fwd_bwd(dev, T, Ks):
     xd = x.to(dev).requires_grad_(True)
     out = m(xd, *[l.to(dev) for l in lists[:4]], len(Ks), 1, False)
     abs_close(out.detach().cpu(), ref.detach(), FWD_ATOL, "")
+    with torch.no_grad():           # the inference form of the same layer (nothing saved for a backward)
+        out_ng = m(xd.detach(), *[l.to(dev) for l in lists[:4]], len(Ks), 1, False)
+    abs_close(out_ng.cpu(), ref.detach(), FWD_ATOL, "no_grad")
     (out * wgt.to(dev)).sum().backward()
     maxnorm_close(xd.grad, xo.grad, GRAD_RTOL, "dx")
     for k, v in m.named_parameters():

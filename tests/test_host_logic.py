@@ -534,22 +534,34 @@ def test_glu_activation_names():
     the activation CLASS; the mirror accepts the name, such a class, or None (= gelu), and refuses what the GLU epilogues do not implement"""
     from sast_amd.layers.sast import _glu_activation_name, SAST_block
     from sast_amd.functional import GLU_ACTIVATIONS
-    # every parameter-free name of the reference's get_act_layer (layers/create_act.py:62-98); elu / celu coincide at alpha = 1
+    # every name of the reference's get_act_layer (layers/create_act.py:62-98); elu / celu coincide at alpha = 1; prelu carries a parameter
     assert GLU_ACTIVATIONS == {"gelu": 0, "relu": 1, "silu": 2, "swish": 2, "sigmoid": 3, "tanh": 4, "mish": 5, "relu6": 6, "leaky_relu": 7,
                                "elu": 8, "celu": 8, "selu": 9, "hard_sigmoid": 10, "hardsigmoid": 10, "hard_swish": 11, "hardswish": 11,
-                               "hard_mish": 12}
+                               "hard_mish": 12, "prelu": 13}
     assert _glu_activation_name(None) == "gelu" and _glu_activation_name("swish") == "swish"
     assert [_glu_activation_name(c) for c in (torch.nn.GELU, torch.nn.ReLU, torch.nn.SiLU, torch.nn.Sigmoid, torch.nn.Tanh, torch.nn.Mish,
                                               torch.nn.Hardswish)] == ["gelu", "relu", "silu", "sigmoid", "tanh", "mish", "hard_swish"]
+    class RefPReLU(torch.nn.PReLU):                        # the reference's own subclass (layers/activations.py:124)
+        pass
+    assert _glu_activation_name(torch.nn.PReLU) == _glu_activation_name(RefPReLU) == "prelu"
     with pytest.raises(NotImplementedError):
-        _glu_activation_name(torch.nn.PReLU)               # a learnable slope: a parameter the reference's state_dict would gain
+        _glu_activation_name(torch.nn.Softplus)            # not a name of get_act_layer
     cfg = dict(partition_size=(4, 5), dim_head=32, attention_bias=True, mlp_activation="relu", mlp_bias=True, mlp_ratio=4, drop_mlp=0,
                drop_path=0, ls_init_value=1e-5, enable_CB=False, AMP=2e-4, BOUNCE=1e-3)
     blk = SAST_block(64, cfg, first_block=True)
     assert blk.win_attn.mlp_activation == blk.grid_attn.mlp_activation == "relu"
     assert SAST_block(64, dict(cfg, mlp_activation="hard_mish"), first_block=True).win_attn.mlp_activation == "hard_mish"
+    # prelu: ONE learnable slope per layer under the reference's state_dict name (nn.PReLU inside the GLU, init 0.25), also through the
+    # aliased `sub_layers` container (SAST.py:194); the parameter-free activations add no key
+    pre = SAST_block(64, dict(cfg, mlp_activation="prelu"), first_block=True)
+    sd = pre.state_dict()
+    for layer in ("win_attn", "grid_attn"):
+        for path in ("mlp.net.0.act_layer.weight", "sub_layers.3.net.0.act_layer.weight"):
+            assert tuple(sd[f"{layer}.{path}"].shape) == (1,) and float(sd[f"{layer}.{path}"]) == 0.25
+    assert pre.win_attn.kernel_params()["act_w"] is pre.win_attn.mlp.net[0].act_layer.weight
+    assert not any("act_layer" in k for k in blk.state_dict()) and blk.win_attn.kernel_params()["act_w"] is None
     with pytest.raises(NotImplementedError):
-        SAST_block(64, dict(cfg, mlp_activation="prelu"), first_block=True)
+        SAST_block(64, dict(cfg, mlp_activation="softplus"), first_block=True)
     # dim_head: any multiple of 4 up to 32 that divides dim (SAST.py:35,171-179 accept any divisor)
     assert SAST_block(64, dict(cfg, dim_head=16), first_block=True).win_attn.num_heads == 4
     for bad in (48, 6, 64):

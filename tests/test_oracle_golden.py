@@ -45,13 +45,16 @@ def test_non_zero_ratio(golden_dir):
                                   "block_large_c96", "block_nobias", "block_act_relu", "block_act_silu", "block_act_sigmoid",
                                   "block_act_tanh", "block_act_mish", "block_act_relu6", "block_act_leaky_relu", "block_act_elu", "block_act_celu",
                                   "block_act_selu", "block_act_hard_sigmoid", "block_act_hard_swish", "block_act_hard_mish", "block_dh16", "block_dh8",
-                                  "block_t240_dense", "block_t240_sparse"])
+                                  "block_t240_dense", "block_t240_sparse", "block_act_prelu"])
 def test_sast_block(golden_dir, name):
     g = _load(golden_dir, name)
     x, r = torch.from_numpy(g["x"]), torch.from_numpy(g["r"])
     params = _block_params(x.shape[-1], int(g["seed"]))
     if "bias" in g and not int(g["bias"]):       # attention_bias: False, mlp_bias: False -- the linears have no bias vectors
         params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
+    if "prelu_slopes" in g:                      # mlp_activation prelu: one learnable slope per layer (layers/activations.py:124-131)
+        for layer, slope in zip(("win_attn", "grid_attn"), g["prelu_slopes"]):
+            params[f"att_blocks.0.att.{layer}.mlp.net.0.act_layer.weight"] = torch.tensor([float(slope)])
     assert abs(_checksum(params) - float(g["param_checksum"])) < 1e-6 * float(g["param_checksum"])
     part = tuple(int(v) for v in g["part"]) if "part" in g else (4, 5)    # block_t240_*: partitions of 12 x 20 = 240 tokens
     cfg = O.AttnCfg(partition_size=part, amp=float(g["amp"]), bounce=1e-3, enable_cb=bool(g["enable_cb"]),
