@@ -741,8 +741,9 @@ int attn_fwd_mfma_launch(const float* qkv, float* o, float* lse, const int* row_
   if (dh < 4 || dh > ADH || dh % 4 || C % dh || T > 32 * BIGT) return SAST_EINVAL;
   const int heads = C / dh;
   const float scale = 1.0f / sqrtf((float)dh);
-  if (T > 128) {       // partitions of 129 .. 256 tokens: the two-sweep kernel (the sweeps recompute the score tiles: 6 instead of 4 C K^2 flop)
-    SAST_ATTN_LAUNCH("attn_fwd_big_kernel", 6.0, 4.0, attn_fwd_big_kernel, dim3(W, heads), dim3(64 * BIGT), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
+  if (T > 128) {       // partitions of 129 .. 256 tokens: the two-sweep kernel (the sweeps recompute the score tiles: it EXECUTES 6 C K^2 flop;
+                       // the profile hook prices the ALGORITHMIC 4 like the one-launch kernels)
+    SAST_ATTN_LAUNCH("attn_fwd_big_kernel", 4.0, 4.0, attn_fwd_big_kernel, dim3(W, heads), dim3(64 * BIGT), qkv, o, lse, row_off, Kw, C, heads, scale, dh);
     SAST_CHECK_LAUNCH();
     return SAST_OK;
   }
@@ -767,9 +768,10 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
     const LsFinish& b1 = f1 ? *f1 : zb;
     if (!f0 || !f1) fC = 0;
     const int sideb = (2 * fC + BIGT - 1) / BIGT;
-    SAST_ATTN_LAUNCH("attn_bwd_big_q_kernel", 8.0, 5.0, attn_bwd_big_q_kernel, dim3(W, heads), dim3(64 * BIGT), qkv, dout, lse, dqkv, dbuf, row_off, Kw, C,
+    // algorithmic flop of the backward = 10 C K^2 (S, dP, dV, dQ, dK); the second launch recomputes S and dP (executed: 6 + 8): priced 6 + 4
+    SAST_ATTN_LAUNCH("attn_bwd_big_q_kernel", 6.0, 5.0, attn_bwd_big_q_kernel, dim3(W, heads), dim3(64 * BIGT), qkv, dout, lse, dqkv, dbuf, row_off, Kw, C,
                      heads, scale, dh);
-    SAST_ATTN_LAUNCH("attn_bwd_big_kv_kernel", 8.0, 5.0, attn_bwd_big_kv_kernel, dim3(W + sideb, heads), dim3(64 * BIGT), qkv, dout, lse, dqkv, dbuf, row_off,
+    SAST_ATTN_LAUNCH("attn_bwd_big_kv_kernel", 4.0, 5.0, attn_bwd_big_kv_kernel, dim3(W + sideb, heads), dim3(64 * BIGT), qkv, dout, lse, dqkv, dbuf, row_off,
                      Kw, C, heads, scale, dh, W, b0, b1, fC);
     SAST_CHECK_LAUNCH();
     return SAST_OK;
