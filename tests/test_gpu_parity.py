@@ -177,6 +177,71 @@ def test_sast_block_vs_golden(golden_dir, dev, name):
     net_grads_close(blk.named_parameters(), lambda k: torch.from_numpy(g["g_" + k]), kl, log_prefix="att_blocks.0.att.")
 
 
+def _safe_block_case(C, hw, part, B, ocfg, bias, slopes, seed0):
+    """first seed whose window / token decisions all sit >= 3e-5 (relative) away from their thresholds in BOTH layers (the rule of
+    tests/golden/make_golden.py): x, r, parameters"""
+    H, W = hw
+    pe = O.position_embedding_sine(H, W, C)
+    T, N = part[0] * part[1], H * W // (part[0] * part[1])
+    for seed in range(seed0, seed0 + 200):
+        g = torch.Generator().manual_seed(4000 + seed)
+        x = torch.randn(B, H, W, C, generator=g)
+        r = torch.rand(B, 20, generator=g) * 0.05
+        params = block_params(C, seed)
+        if not bias:
+            params = {k: v for k, v in params.items() if not (k.endswith(".bias") and ("qkv." in k or "proj." in k or "mlp.net" in k))}
+        if slopes is not None:
+            for layer, a in zip(("win_attn", "grid_attn"), slopes):
+                params[f"att_blocks.0.att.{layer}.mlp.net.0.act_layer.weight"] = torch.tensor([a])
+        _o, _c, lists, sc = O.sast_block(x, pe, r, params, "att_blocks.0.att.", ocfg, return_scores=True)
+        mw, mt = O.selection_margins(sc, B, N, T, 1e-3)
+        scg = O.grid_partition(O.window_reverse(sc.view(B * N, part[0], part[1], C), part, (H, W)), part).view(B, N, -1, C)
+        mw2, mt2 = O.selection_margins(scg, B, N, T, 1e-3)
+        if float(min(mw.min(), mt.min(), mw2.min(), mt2.min())) >= 3e-5 and all(len(l[3]) > 0 for l in lists):
+            return x, r, params
+    raise RuntimeError("no seed with a safe selection margin")
+
+
+@pytest.mark.parametrize("case", ["t240-cb-dh8-prelu-nobias", "t80-cb-dh24-hardswish-b1", "t20-cb-selu-nobias-b3", "t240-dh32-c128-mish"])
+def test_sast_block_feature_combinations_vs_oracle(dev, case):
+    """feature COMBINATIONS no reference fixture holds, against the oracle (pinned to the reference feature by feature): partitions of 240
+    tokens with Context Broadcasting, 8-wide heads, the prelu gate and bias-free linears at once; Gen1-sized partitions with B = 1 (the
+    reference's batch-1 selection branch, SAST.py:262-268), 24-wide heads, CB and hard_swish; small partitions, three samples, selu, no
+    biases, CB; 240-token partitions at C = 128 with 32-wide heads (the attention kernels' full plane width) and mish.  Index lists exact,
+    outputs, input and every parameter gradient (kink-aware behind the scoring ReLU)."""
+    from sast_amd.layers import SAST_block
+    from sast_amd.detection import PositionEmbeddingSine
+    C, hw, part, B, dh, cb, act, bias, slopes, amp = {
+        "t240-cb-dh8-prelu-nobias": (32, (24, 40), (12, 20), 2, 8, True, "prelu", False, (0.3, -0.1), 2e-2),
+        "t80-cb-dh24-hardswish-b1": (48, (16, 20), (8, 10), 1, 24, True, "hard_swish", True, None, 2e-2),
+        "t20-cb-selu-nobias-b3": (64, (16, 20), (4, 5), 3, 32, True, "selu", False, None, 2e-2),
+        "t240-dh32-c128-mish": (128, (24, 40), (12, 20), 2, 32, False, "mish", True, None, 2e-2)}[case]
+    H, W = hw
+    ocfg = O.AttnCfg(partition_size=part, amp=amp, bounce=1e-3, enable_cb=cb, dim_head=dh, mlp_activation=act)
+    x, r, params = _safe_block_case(C, hw, part, B, ocfg, bias, slopes, seed0=0)
+    acfg = attn_cfg(part, amp, cb=cb, dim_head=dh)
+    acfg.update(attention_bias=bias, mlp_bias=bias, mlp_activation=act)
+    blk = SAST_block(C, acfg, first_block=True).to(dev)
+    load_params(blk, params, "att_blocks.0.att.")
+    pe = PositionEmbeddingSine(C // 2, normalize=True, input_size=(1, H, W))
+    xd = x.to(dev).requires_grad_(True)
+    out, cnt, lists = blk(xd, pe, r.to(dev), None)
+    kl = {}
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    xo = x.clone().requires_grad_(True)
+    oo, oc, ol = O.sast_block(xo, O.position_embedding_sine(H, W, C), r, po, "att_blocks.0.att.", ocfg, kink_log=kl)
+    assert int(cnt) == int(oc)
+    for li, sel in enumerate(lists):
+        got = sel.to_index_list()
+        for nm in ("index_window", "asy_index", "K"):
+            assert torch.equal(got[LIST_NAMES.index(nm)].cpu(), ol[li][LIST_NAMES.index(nm)]), (li, nm)
+    abs_close(out.detach().cpu(), oo.detach(), FWD_ATOL, "")
+    (out ** 2).mean().backward()
+    (oo ** 2).mean().backward()
+    maxnorm_close(xd.grad, xo.grad, GRAD_RTOL, "dx")
+    net_grads_close(blk.named_parameters(), lambda k: po["att_blocks.0.att." + k].grad, kl, log_prefix="att_blocks.0.att.")
+
+
 def test_downsample_no_overlap_no_affine_vs_golden(golden_dir, dev):
     """ConvDownsampling_Cf2Cl with downsample_cfg.overlap False (k = f, no padding: `SastDownArgs.no_overlap`) and norm_affine False (a
     LayerNorm without parameters) -- ops.py:69-76,87, in no shipped YAML -- against the reference module's outputs and gradients"""
