@@ -66,7 +66,7 @@ class Trainer:
     """bench harness around sast_amd.training.TrainStep (the reference's step is Lightning's, modules/detection.py:113-221)."""
 
     def __init__(self, dev, amp, world, use_graph, seq_len=1, fwd_only=False, infer=False, yolox_loss=False, segmented=None,
-                 label_every=0, sync_bn=False, event_dtype="int32"):
+                 label_every=0, sync_bn=False, event_dtype="int32", defer_dw=False, dw_rows=(0, 0), dw_discard=False, cuts=(3,)):
         from sast_amd.detection import RNNDetector, YOLOPAFPN
         from sast_amd.training import TrainStep
         torch.manual_seed(0)  # random init on the host, identical on every rank (weights never depend on device RNG)
@@ -110,7 +110,7 @@ class Trainer:
                 use_graph = False
         self.segmented = ((world > 1) and os.environ.get("SAST_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
         self.ts = TrainStep(self.net, self.fpn, self.head if yolox_loss else None, lr=2e-4, weight_decay=0.0, clip_value=1.0, world=world,
-                            segmented=self.segmented)
+                            segmented=self.segmented, defer_dw=defer_dw, dw_rows=dw_rows, dw_discard=dw_discard, cuts=cuts)
         self.flat, self.opt = self.ts.flat, self.ts.opt
         # seq_len > 1 (opt-in, --seq-len): the reference's BPTT step shape (modules/detection.py:141-177): L timesteps with the
         # recurrent states carried, PAFPN + loss on the last one, one backward through time.  Default 1 = BASELINE's metric.
@@ -142,6 +142,7 @@ class Trainer:
         self.ts.forward(self.xs, None, self.labels, self.indices)
         for i in range(self.ts.n_segments()):
             self.ts.backward_segment(i)
+        self.ts.flush_pending()       # deferred weight gradients: run what the segments parked, here on the same stream
         self.loss, self.P = self.ts.loss.detach(), self.ts.P
 
     def eager_step(self):
@@ -326,6 +327,13 @@ def main():
                     "the statistics all-reduces are captured into the hipGraphs on RCCL, eager step on gloo.  Default: per-rank batch statistics")
     ap.add_argument("--event-dtype", choices=["int32", "uint8"], default="int32", help="int32: the reference's benchmark.py protocol (`.int()`); "
                     "uint8: the dataset's storage type -- the event tensor stays bytes up to the stem conv's loaders")
+    ap.add_argument("--defer-dw", type=int, default=int(os.environ.get("SAST_DEFER_DW", "0")), help="1: weight gradients off the backward chain "
+                    "(training.TrainStep(defer_dw=True)): the dW jobs are parked and run on the side stream beside the next segment's chain")
+    ap.add_argument("--cuts", default="3", help="segment boundaries of the segmented backward: backbone stages (0-based) whose input is a cut, "
+                    "e.g. 3,2,1 = one segment per stage (default 3: PAFPN | stage 4 | stages 3-1)")
+    ap.add_argument("--dw-min-rows", type=int, default=0)
+    ap.add_argument("--dw-max-rows", type=int, default=0, help="only weight-gradient jobs over at most this many rows are deferred (0 = all)")
+    ap.add_argument("--dw-discard", action="store_true", help="TIMING PROBE: the parked jobs are dropped (the dX chain alone); gradients are wrong")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -382,7 +390,8 @@ def main():
     torch.cuda.set_stream(run_stream)
     tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, fwd_only=args.fwd_only, infer=args.infer,
                  yolox_loss=args.loss == "yolox", segmented=args.segmented, label_every=args.label_every, sync_bn=args.sync_bn,
-                 event_dtype=args.event_dtype)
+                 event_dtype=args.event_dtype, defer_dw=bool(args.defer_dw), dw_rows=(args.dw_min_rows, args.dw_max_rows), dw_discard=args.dw_discard,
+                 cuts=tuple(int(c) for c in args.cuts.split(",")))
     graphed = tr.capture()
     loss_first = tr.loss_first
     for _ in range(args.warmup):
@@ -406,7 +415,7 @@ def main():
     # N > 1: how much of the gradient exchange is NOT hidden behind the backward -- a few extra, un-timed steps on every rank with
     # event pairs (main stream idle, side stream done); max over ranks
     exposed_ms, bucket_ms = None, None
-    if (world > 1 or tr.segmented) and not tr.fwd_only:
+    if (world > 1 or tr.segmented or args.defer_dw) and not tr.fwd_only:
         tr.ts.measure_exposed = True
         for _ in range(20):
             tr.step()
@@ -449,6 +458,8 @@ def main():
                        "library": os.path.relpath(__import__("sast_amd._lib", fromlist=["lib"]).loaded_path(), ROOT),
                        "product_library": __import__("sast_amd._lib", fromlist=["lib"]).is_product_library(),
                        "segmented_backward_overlap": bool(tr.segmented and not tr.fwd_only),
+                       "deferred_weight_gradients": bool(args.defer_dw and not tr.fwd_only), "dw_rows_window": [args.dw_min_rows, args.dw_max_rows], "backward_cuts": args.cuts,
+                       "dw_discard_TIMING_PROBE_gradients_invalid": bool(args.dw_discard),
                        # the dim-64 MS-WSA layers (stage 1) run their forward as ONE kernel (csrc/k_mswsa_fused.hip) when the rows and the
                        # block's AMP allow it (sast_amd/functional.py: _FUSED_MIN_ROWS, layers/sast.py: FUSED_FORWARD_MAX_AMP)
                        "fused_mswsa_forward": _fused_forward_in_use(args.amp),

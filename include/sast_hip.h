@@ -397,6 +397,24 @@ int sast_adamw_onecycle(float* p, const float* g, float* m, float* v, size_t n, 
                         float weight_decay, float grad_scale, float clip_value, double initial_lr, double max_lr, double min_lr,
                         double end1, double end2, sast_stream_t stream);
 
+/* ---- deferred weight gradients (round 6; csrc/k_defer.hip).  Nothing reads a weight gradient before the optimizer, but the backward
+ * entry points above launch every layer's weight-gradient GEMM in one launch with its activation-gradient GEMM, so the next kernel of the
+ * backward chain waits for both (the reference has the same dependency shape: autograd computes grad_weight and grad_input of
+ * F.linear / conv2d in one node, models/layers/SAST/SAST.py:219-230, ops.py:111-175, yolox/models/network_blocks.py:29-54).
+ * sast_dw_defer(1): from now on the *_bwd entry points launch only what the backward CHAIN needs on their stream and PARK the
+ * weight-gradient jobs (and the LayerScale finishes that consume them) in a process-wide queue; sast_dw_flush(stream) enqueues
+ * every parked job on `stream` in parking order and empties the queue.  Contract: the caller keeps every buffer the parked jobs
+ * read (the upstream gradients, workspaces, saved activations, device-side row counts) or accumulate into (parameter gradients, the
+ * raw LayerScale accumulators) alive and unmodified until the flushed launches have RUN on the device, orders `stream` behind the
+ * backward kernels that produced those buffers, and orders the optimizer behind the flush.  Results are the same sums in a different
+ * atomic order.  sast_dw_defer_rows(min, max): only jobs whose reduction runs over min <= rows <= max are parked (0 = unbounded).
+ * sast_dw_defer returns the previous setting; sast_dw_pending the number of parked jobs; sast_dw_discard drops them (timing probes). */
+int sast_dw_defer(int on);
+int sast_dw_defer_rows(long min_rows, long max_rows);
+int sast_dw_pending(void);
+int sast_dw_discard(void);
+int sast_dw_flush(sast_stream_t stream);
+
 /* measurement aid (bench.py roofline leg): HIP-event timing of every launch of the GEMM-template kernels, recorded on
  * the launch stream; the report lists per kernel instantiation: calls, total ms, total algorithmic FLOPs (2*M*N*K with
  * the device-side row counts read back).  Enabling it adds host syncs -- never enable inside a timed region. */

@@ -125,6 +125,11 @@ _SIGNATURES = {
     "sast_zero_samples": (C.c_int, [P, C.c_int, C.c_size_t, C.POINTER(SastSampleMask), P]),
     "sast_adamw_onecycle": (C.c_int, [P, P, P, P, C.c_size_t, P, C.c_double, C.c_double, F32, F32, F32, F32, C.c_double, C.c_double, C.c_double,
                                       C.c_double, C.c_double, P]),
+    "sast_dw_defer": (C.c_int, [C.c_int]),
+    "sast_dw_defer_rows": (C.c_int, [C.c_long, C.c_long]),
+    "sast_dw_pending": (C.c_int, []),
+    "sast_dw_discard": (C.c_int, []),
+    "sast_dw_flush": (C.c_int, [P]),
     "sast_prof_enable": (C.c_int, [C.c_int]),
     "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),

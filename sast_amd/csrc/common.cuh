@@ -32,6 +32,17 @@ inline bool launch_failed_take() { const bool f = g_launch_failed != 0; g_launch
 // without consuming it (a failed launch inside a void helper, then `return rc`) must not be reported by this, unrelated, call
 #define SAST_ENTRY() ((void)sast::launch_failed_take())
 
+// Issue priority of the kernels of the backward CHAIN (experiment, round 6: with deferred weight gradients a side stream's workgroups
+// share the SIMDs with the chain's; -DSAST_MAIN_PRIO=n raises the chain's waves over the side stream's, which stay at the default 0)
+#ifndef SAST_MAIN_PRIO
+#define SAST_MAIN_PRIO 0
+#endif
+#if SAST_MAIN_PRIO > 0
+#define SAST_CHAIN_PRIO() __builtin_amdgcn_s_setprio(SAST_MAIN_PRIO)
+#else
+#define SAST_CHAIN_PRIO()
+#endif
+
 namespace sast {
 
 constexpr int WAVE = 64;
@@ -158,6 +169,27 @@ __device__ __forceinline__ float glu_act_grad(float g, int act, float a = 0.0f) 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// stores of activations that ONLY the backward pass reads (milliseconds later): -DSAST_NT_SAVED=1 gives them the non-temporal form
+// (round-5 verdict item 2: do ~0.7 GB per step of write-once data evict the weights and the next layer's operands from L2 / MALL?)
+#ifndef SAST_NT_SAVED
+#define SAST_NT_SAVED 0
+#endif
+__device__ __forceinline__ void st4_saved(float* p, float4 v) {
+#if SAST_NT_SAVED
+  typedef float f4v_ __attribute__((ext_vector_type(4)));
+  f4v_ t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<f4v_*>(p));
+#else
+  st4(p, v);
+#endif
+}
+__device__ __forceinline__ void st_saved(float* p, float v) {
+#if SAST_NT_SAVED
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 // exact n / d for n * d < 2^32 with mul = 2^32 / d + 1 (one v_mul_hi_u32 instead of the ~35-instruction integer division; the
 // weight-gradient im2col loader ran two of those per load inside its k-loop)

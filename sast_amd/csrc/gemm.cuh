@@ -833,6 +833,7 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
                                                               const int* __restrict__ dM, const int* __restrict__ dR,
                                                               float* __restrict__ colsum, int nsplit, int xcd_remap) {
   __shared__ __attribute__((aligned(16))) float smem[GemmSmem<T, LA, LB>::FLOATS];
+  SAST_CHAIN_PRIO();
   int nmain = gridDim.x;
   if constexpr (EpHasSide<EP>::value) {
     nmain -= ep.side_blocks;
@@ -856,6 +857,7 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
   constexpr int F1 = GemmSmem<typename J1::T, typename J1::LA, typename J1::LB>::FLOATS;
   constexpr int F2 = GemmSmem<typename J2::T, typename J2::LA, typename J2::LB>::FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
+  SAST_CHAIN_PRIO();
   if ((int)blockIdx.x < n1) {
     SAST_TL_JOB(1);
     if (threadIdx.x >= J1::T::NT) return;   // surplus waves of the larger workgroup shape (block-uniform per wave)
@@ -872,6 +874,30 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
     gemm_body<typename J2::T, typename J2::LA, typename J2::LB, typename J2::EP, J2::SPLIT>(
         b.la, b.lb, b.ep, b.M, b.NJ, b.R, b.dM, b.dR, b.colsum, b.nsplit, b.xcd_remap, blockIdx.x - n1, n2, smem);
   }
+}
+
+// ---- up to NMAX independent GEMMs of ONE instantiation in one launch (round 6: the deferred weight-gradient jobs of a backward
+// segment, gemm_dispatch.cuh: DwGroup).  The jobs travel as kernel arguments (the kernarg segment is addressable: a scalar loop finds
+// the job of a workgroup from the prefix sums of the per-job grids, then everything is gemm_body).  A weight-gradient job alone is one
+// wave of short-lived workgroups at its latency floor (launch + fill + k-loop + fold + atomic tail + drain: ~22 us for ~1 GFLOP); a
+// group of them is ONE grid of thousands of tiles that the dispatcher back-fills CU by CU, with no boundary between the jobs.
+template <class J, int NMAX>
+struct JobPack { J jobs[NMAX]; int start[NMAX + 1]; int n; };
+template <class J> struct JobPackSize {
+  // hipLaunchKernel arguments are limited to 4 KB: as many jobs as fit 3.5 KB, at most 32
+  static constexpr int RAW = (3584 - 8) / ((int)sizeof(J) + 4);
+  static constexpr int value = RAW > 32 ? 32 : (RAW < 1 ? 1 : RAW);
+};
+template <class J, int NMAX>
+__global__ __launch_bounds__(J::T::NT, J::T::MINW) void gemm_group_kernel(JobPack<J, NMAX> p) {
+  __shared__ __attribute__((aligned(16))) float smem[GemmSmem<typename J::T, typename J::LA, typename J::LB>::FLOATS];
+  const int b = blockIdx.x;
+  int k = 0;
+  while (k + 1 < p.n && b >= p.start[k + 1]) ++k;     // block-uniform: scalar loads from the kernarg segment
+  const J& a = p.jobs[k];
+  SAST_TL_JOB(k);
+  gemm_body<typename J::T, typename J::LA, typename J::LB, typename J::EP, J::SPLIT>(
+      a.la, a.lb, a.ep, a.M, a.NJ, a.R, a.dM, a.dR, a.colsum, a.nsplit, a.xcd_remap, b - p.start[k], p.start[k + 1] - p.start[k], smem);
 }
 
 // ---- optional per-launch HIP-event timing of the GEMM family (bench.py roofline leg; off by default).
@@ -978,6 +1004,42 @@ inline int launch_gemm_dual(const LA1& la1, const LB1& lb1, const EP1& ep1, int 
     SAST_EXT_LAUNCH((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, e0, e1, 0, a, b, n1);
   } else {
     SAST_LAUNCH((gemm_dual_kernel<J1, J2>), dim3(n1 + n2 + ep_side_blocks(ep2)), dim3(NTHREADS), 0, st, a, b, n1);
+  }
+  SAST_CHECK_LAUNCH();
+  return SAST_OK;
+}
+
+// a group of split-R jobs of one instantiation (see gemm_group_kernel); jobs[i].nsplit / .xcd_remap are set here
+template <class J>
+inline int launch_gemm_group(J* jobs, const int* splits, int n, hipStream_t st) {
+  constexpr int NMAX = JobPackSize<J>::value;
+  using T = typename J::T;
+  for (int i0 = 0; i0 < n; i0 += NMAX) {
+    JobPack<J, NMAX> p;
+    const int cnt = n - i0 < NMAX ? n - i0 : NMAX;
+    p.n = cnt;
+    p.start[0] = 0;
+    double flops = 0.0, bytes = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      J& j = jobs[i0 + i];
+      const int nt = ((j.M + T::BM - 1) / T::BM) * ((j.NJ + T::BJ - 1) / T::BJ);
+      int remap;
+      const int g = gemm_grid(nt, splits[i0 + i] < 1 ? 1 : splits[i0 + i], remap);
+      j.nsplit = splits[i0 + i] < 1 ? 1 : splits[i0 + i];
+      j.xcd_remap = remap;
+      p.jobs[i] = j;
+      p.start[i + 1] = p.start[i] + (g + 7) / 8 * 8;    // every job starts on a multiple of 8: its block -> XCD phase is the stand-alone one
+      flops += 2.0 * j.M * j.NJ * T::G * j.R;
+      bytes += 4.0 * ((double)j.M * j.R + (double)j.NJ * T::G * j.R + (double)j.M * j.NJ * T::G);
+    }
+    for (int i = cnt; i < NMAX; ++i) { p.jobs[i] = jobs[i0]; p.start[i + 1] = p.start[cnt]; }
+    if (prof_enabled()) {
+      hipEvent_t e0, e1;
+      prof_kernel_events_ex(__PRETTY_FUNCTION__, flops, bytes, st, &e0, &e1);
+      SAST_EXT_LAUNCH((gemm_group_kernel<J, NMAX>), dim3(p.start[cnt]), dim3(T::NT), 0, st, e0, e1, 0, p);
+    } else {
+      SAST_LAUNCH((gemm_group_kernel<J, NMAX>), dim3(p.start[cnt]), dim3(T::NT), 0, st, p);
+    }
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;

@@ -7,9 +7,19 @@
 // through the environment for A/B runs.
 #pragma once
 #include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <vector>
 #include "gemm.cuh"
 
 namespace sast {
+
+// ---- deferred weight gradients (k_defer.hip; include/sast_hip.h: sast_dw_defer / sast_dw_flush): while deferral is on, the
+// weight-gradient job of every gemm_pair / gemm_tn site is parked as a closure instead of launched, and the activation-gradient job
+// goes out alone (gemm_auto's stand-alone tile choice) -- the chain no longer waits for gradients nothing reads before the optimizer
+bool dw_defer_on();
+bool dw_defer_rows_ok(long R);
+void dw_defer_push(std::function<int(hipStream_t, bool)> job);     // job(stream, run): run == false drops the entry (sast_dw_discard)
 
 // the plain-GEMM tiles gemm_auto / the dX job of a paired launch choose from (overridable for A/B builds)
 #ifndef SAST_TILE_THIN
@@ -74,9 +84,65 @@ inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
   return splits < 1 ? 1 : splits;
 }
 
+// A DEFERRED weight-gradient job runs on the side stream beside the backward chain, never co-resident with its own dX job.
+// SAST_DW_GROUP (default 1): the parked jobs of one kernel instantiation leave as ONE launch (gemm.cuh: gemm_group_kernel) -- thousands
+// of tiles, no fill / drain per job -- and a job is split over the reduction into chunks of ~SAST_DW_ROWS_PER_SPLIT rows (long enough to
+// amortise a workgroup's prologue, fold and atomic tail; the group supplies the parallelism).  0: one launch per job, split into
+// ~SAST_TN_BLOCKS_DEFERRED workgroups.
+inline int deferred_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS_DEFERRED", 384); return v; }
+inline bool dw_group_enabled() { static int v = env_int("SAST_DW_GROUP", 1); return v != 0; }
+inline int dw_rows_per_split() { static int v = env_int("SAST_DW_ROWS_PER_SPLIT", 512); return v; }
+inline int dw_group_splits(int R) {
+  const int rps = dw_rows_per_split() > 16 ? dw_rows_per_split() : 16;
+  const int s = (R + rps / 2) / rps;
+  return s < 1 ? 1 : s;
+}
+template <class J>
+struct DwGroup {
+  struct State { std::mutex mu; std::vector<J> jobs; std::vector<int> splits; };
+  static State& state() { static State s; return s; }
+  static void push(const J& j, int sp) {
+    State& s = state();
+    bool first;
+    {
+      std::lock_guard<std::mutex> lk(s.mu);
+      first = s.jobs.empty();
+      s.jobs.push_back(j);
+      s.splits.push_back(sp);
+    }
+    if (first) dw_defer_push([](hipStream_t st, bool run) { return flush(st, run); });   // the group leaves where its first job was parked
+  }
+  static int flush(hipStream_t st, bool run) {
+    State& s = state();
+    std::vector<J> jobs;
+    std::vector<int> splits;
+    {
+      std::lock_guard<std::mutex> lk(s.mu);
+      jobs.swap(s.jobs);
+      splits.swap(s.splits);
+    }
+    if (!run || jobs.empty()) return SAST_OK;
+    return launch_gemm_group(jobs.data(), splits.data(), (int)jobs.size(), st);
+  }
+};
+// park one split-R job (the caller has checked dw_defer_rows_ok)
+template <class LA, class LB, class EP>
+inline int dw_park(const LA& la, const LB& lb, const EP& ep, int Mo, int NJ, int R, const int* dR, float* colsum) {
+  if (colsum != nullptr && LA::RC && GemmSmem<TileSplitR, LA, LB>::PSA) return SAST_EINVAL;   // see launch_gemm_split
+  if (dw_group_enabled()) {
+    using J = GemmJob<TileSplitR, LA, LB, EP, true>;
+    DwGroup<J>::push(J{la, lb, ep, Mo, NJ, R, nullptr, dR, colsum, 1, 0}, dw_group_splits(R));
+    return SAST_OK;
+  }
+  const int sp = tn_splits(Mo, NJ, R, deferred_tn_blocks());
+  dw_defer_push([=](hipStream_t s, bool run) { return run ? launch_gemm_split<TileSplitR>(la, lb, ep, Mo, NJ, R, dR, sp, colsum, s) : SAST_OK; });
+  return SAST_OK;
+}
+
 // weight-gradient form: out[Mo, NJ] += A^T B over R rows (dR: device-side count), optional column sums of A (bias gradient)
 template <class LA, class LB>
 int gemm_tn(const LA& la, const LB& lb, float* out, int ldc, int Mo, int NJ, int R, const int* dR, float* colsum, hipStream_t st) {
+  if (dw_defer_rows_ok(R) && Mo > 0 && NJ > 0 && R > 0) return dw_park(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, colsum);
   return launch_gemm_split<TileSplitR>(la, lb, EpAtomic{out, ldc}, Mo, NJ, R, dR, tn_splits(Mo, NJ, R), colsum, st);
 }
 template <class LA, class LB>
@@ -98,6 +164,11 @@ int gemm_pair(const LA1& la1, const LB1& lb1, float* out, int ldc, int Mo, int N
 template <class LA1, class LB1, class EP1, class LA2, class LB2, class EP2>
 int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1, int R1, const int* dR1, float* colsum,
                  const LA2& la2, const LB2& lb2, const EP2& ep2, int M2, int NJ2, int R2, const int* dM2, hipStream_t st, int tn_target) {
+  if (dw_defer_rows_ok(R1) && Mo > 0 && NJ1 > 0 && R1 > 0) {      // job 1 parked, job 2 alone with the stand-alone tile choice
+    const int rc = dw_park(la1, lb1, ep1, Mo, NJ1, R1, dR1, colsum);
+    if (rc) return rc;
+    return gemm_auto(la2, lb2, ep2, M2, NJ2, R2, dM2, st);
+  }
   const long nb2 = (long)((M2 + 63) / 64) * ((NJ2 + 63) / 64);
   const bool thin = nb2 <= pair_thin_nb() && R2 >= pair_ks_min_r(), k2 = nb2 <= pair_ks_nb() && R2 >= pair_ks_min_r();
   const int nb1 = ((Mo + 63) / 64) * ((NJ1 + 63) / 64);

@@ -446,6 +446,7 @@ __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ?
                                                                    int C, int heads, float scale, int dh, int W,
                                                                    LsFinish f0, LsFinish f1, int fC) {
   __shared__ __attribute__((aligned(16))) char sm[4 * 3 * 32 * NTMAX * 64 + 2 * 32 * NTMAX * 4];
+  SAST_CHAIN_PRIO();
   if (blockIdx.x >= W) {   // side workgroups: the LayerScale'd fc2 / proj gradient finish of the same MS-WSA layer (independent work
     if (blockIdx.y == 0) {  // that used to be a launch of its own), one wave per output channel
       const int row = (blockIdx.x - W) * (NTMAX * (SPLIT ? 2 : 1)) + (threadIdx.x >> 6);

@@ -85,8 +85,8 @@ struct EpGluT {  // ops.py:136-137: value = first half, gate = second half
   __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[2], const Col& k, const Aux&) const {
     const float u = v[0] + k.bu, g = v[1] + k.bg;
-    ug[(size_t)m * 2 * inner + j] = u;
-    ug[(size_t)m * 2 * inner + inner + j] = g;
+    st_saved(ug + (size_t)m * 2 * inner + j, u);             // [u|g]: read by the backward only
+    st_saved(ug + (size_t)m * 2 * inner + inner + j, g);
     if constexpr (ANY) h[(size_t)m * inner + j] = (u * glu_act(g, act, k.a)) * (drop ? drop[(size_t)m * inner + j] : 1.f);
     else h[(size_t)m * inner + j] = u * gelu_erf(g);
   }
@@ -137,7 +137,7 @@ struct EpLstm {  // rnn.py:57-67
     c1[(size_t)m * C + j] = c;
     h1[(size_t)m * C + j] = o * tanhf(c);
     float* gp = gates + (size_t)m * 4 * C + j;
-    gp[0] = f; gp[C] = i; gp[2 * C] = o; gp[3 * C] = g;
+    st_saved(gp, f); st_saved(gp + C, i); st_saved(gp + 2 * C, o); st_saved(gp + 3 * C, g);     // the gates: read by the backward only
   }
 };
 
@@ -468,11 +468,19 @@ int sast_mswsa_bwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
   if (rc) return rc;
   // raw (gamma-free) fc2 and proj gradients -> parameter gradients incl. the LayerScale gammas: side workgroups of the attention
   // backward launch
+  // (deferred weight gradients: the raw accumulators are only complete once the parked fc2 / proj jobs have run -- the finish is
+  // parked behind them as its own small launch and the attention backward goes without side workgroups)
   {
     const LsFinish f2{a->fc2_w, a->fc2_b, a->ls2, raw2, s2, a->d_fc2_w, a->d_fc2_b, a->d_ls2, inner};
     const LsFinish f1{a->proj_w, a->proj_b, a->ls1, raw1, s1, a->d_proj_w, a->d_proj_b, a->d_ls1, C};
-    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, &f2, &f1, C,
-                              a->ws + mswsa_bwd_ws_base(R, C, inner));
+    const bool parked = dw_defer_rows_ok(R);
+    if (parked)
+      dw_defer_push([=](hipStream_t s, bool run) {
+        return !run ? SAST_OK : ls_linear_finish2_launch(f2.w, f2.b, f2.gamma, f2.raw, f2.s, f2.dw, f2.db, f2.dgamma, f2.K,
+                                        f1.w, f1.b, f1.gamma, f1.raw, f1.s, f1.dw, f1.db, f1.dgamma, f1.K, C, s);
+      });
+    rc = attn_bwd_mfma_launch(a->QKV, dO, a->lse, dQKV, a->sel.row_off, a->sel.K, NW, T, C, dh, st, parked ? nullptr : &f2,
+                              parked ? nullptr : &f1, parked ? 0 : C, a->ws + mswsa_bwd_ws_base(R, C, inner));
   }
   if (rc) return rc;
   // qkv: dWqkv / dbqkv, and dS = dY + dQKV Wqkv

@@ -168,13 +168,15 @@ __device__ __forceinline__ void load_token(const float* __restrict__ row, int hf
       x[ct][4 * q] = v.x; x[ct][4 * q + 1] = v.y; x[ct][4 * q + 2] = v.z; x[ct][4 * q + 3] = v.w;
     }
 }
-template <int CT>
+template <int CT, bool SAVED = false>     // SAVED: an activation only the backward reads (common.cuh: st4_saved)
 __device__ __forceinline__ void store_token(float* __restrict__ row, int hf, const Tile (&x)[CT]) {
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      st4(row + ct * 32 + 8 * q + 4 * hf, make_float4(x[ct][4 * q], x[ct][4 * q + 1], x[ct][4 * q + 2], x[ct][4 * q + 3]));
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = make_float4(x[ct][4 * q], x[ct][4 * q + 1], x[ct][4 * q + 2], x[ct][4 * q + 3]);
+      if constexpr (SAVED) st4_saved(row + ct * 32 + 8 * q + 4 * hf, v); else st4(row + ct * 32 + 8 * q + 4 * hf, v);
+    }
 }
 // LayerNorm over the channels of this lane's token: its own CT x 16 values and its partner's (lane ^ 32)
 template <int CT>
@@ -304,7 +306,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     ln_token<CT>(s, vec + V::LN2W, vec + V::LN2B, a.eps, hf, mean, rstd);
     if (save) {
       if (hf == 0) { a.mean2[crow_g] = mean; a.rstd2[crow_g] = rstd; }
-      store_token<CT>(a.S + crow_g * C, hf, s);
+      store_token<CT, true>(a.S + crow_g * C, hf, s);
     }
   }
   FTL(1);
@@ -338,14 +340,14 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
       if (save) {
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-          st4(qrow + 8 * qd + 4 * hf, make_float4(q[4 * qd], q[4 * qd + 1], q[4 * qd + 2], q[4 * qd + 3]));
-          st4(qrow + 32 + 8 * qd + 4 * hf, make_float4(k[4 * qd], k[4 * qd + 1], k[4 * qd + 2], k[4 * qd + 3]));
+          st4_saved(qrow + 8 * qd + 4 * hf, make_float4(q[4 * qd], q[4 * qd + 1], q[4 * qd + 2], q[4 * qd + 3]));
+          st4_saved(qrow + 32 + 8 * qd + 4 * hf, make_float4(k[4 * qd], k[4 * qd + 1], k[4 * qd + 2], k[4 * qd + 3]));
         }
       }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {   // the V tile is [token][d]: register e = token row crow(e), this lane's d = l31
         const int ti = w * 32 + crow(e, lane);
-        if (ti < K) a.QKV[(size_t)(r0 + ti) * (3 * C) + h * 96 + 64 + l31] = v[e];
+        if (ti < K) st_saved(a.QKV + (size_t)(r0 + ti) * (3 * C) + h * 96 + 64 + l31, v[e]);
       }
     }
     if (NT > 1 && h > 0) __syncthreads();      // the other wave has finished reading the previous head's K / V
@@ -402,7 +404,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
     for (int e = 0; e < 16; ++e) o[e] = (o[e] + o2[e]) * inv;
     if (save) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) st4(a.O + crow_g * C + h * 32 + 8 * qd + 4 * hf, make_float4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]));
+      for (int qd = 0; qd < 4; ++qd) st4_saved(a.O + crow_g * C + h * 32 + 8 * qd + 4 * hf, make_float4(o[4 * qd], o[4 * qd + 1], o[4 * qd + 2], o[4 * qd + 3]));
     }
     FTL(5 + 4 * h);
     // proj: Y^T[c][t] += sum_d Wp[c][32 h + d] O^T[d][t]
@@ -429,7 +431,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) y[ct][e] = s[ct][e] + g1[e] * (y[ct][e] + bp[e]);
   }
-  if (save) store_token<CT>(a.Y + crow_g * C, hf, y);
+  if (save) store_token<CT, true>(a.Y + crow_g * C, hf, y);
   Split3 yop[KS];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) yop[ks] = c_tile_operand(y[ks >> 1], ks & 1);
@@ -458,15 +460,15 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
       float* ug = a.UG + crow_g * (2 * INNER) + kc * 32;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
-        st4(ug + 8 * qd + 4 * hf, make_float4(uu[4 * qd], uu[4 * qd + 1], uu[4 * qd + 2], uu[4 * qd + 3]));
-        st4(ug + INNER + 8 * qd + 4 * hf, make_float4(gg[4 * qd], gg[4 * qd + 1], gg[4 * qd + 2], gg[4 * qd + 3]));
+        st4_saved(ug + 8 * qd + 4 * hf, make_float4(uu[4 * qd], uu[4 * qd + 1], uu[4 * qd + 2], uu[4 * qd + 3]));
+        st4_saved(ug + INNER + 8 * qd + 4 * hf, make_float4(gg[4 * qd], gg[4 * qd + 1], gg[4 * qd + 2], gg[4 * qd + 3]));
       }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) uu[e] *= gelu_erf(gg[e]);
     if (save && a.Hh) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) st4(a.Hh + crow_g * INNER + kc * 32 + 8 * qd + 4 * hf, make_float4(uu[4 * qd], uu[4 * qd + 1], uu[4 * qd + 2], uu[4 * qd + 3]));
+      for (int qd = 0; qd < 4; ++qd) st4_saved(a.Hh + crow_g * INNER + kc * 32 + 8 * qd + 4 * hf, make_float4(uu[4 * qd], uu[4 * qd + 1], uu[4 * qd + 2], uu[4 * qd + 3]));
     }
     Split3 hop[2];
 #pragma unroll

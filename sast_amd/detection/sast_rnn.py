@@ -187,11 +187,13 @@ class RNNDetector(nn.Module):
         assert min(idx) >= 0 and max(idx) < len(self.stages), idx
         return tuple(self.strides[i] for i in idx)
 
-    def forward_nhwc(self, x: torch.Tensor, prev_states=None, token_mask=None, cut_before_stage: Optional[int] = None):
+    def forward_nhwc(self, x: torch.Tensor, prev_states=None, token_mask=None, cut_before_stage=None):
         """fused path: returns NHWC feature maps {stage: (B,H,W,C)}, states [(h,c)] NHWC, P list.
-        cut_before_stage (training.TrainStep): the input of that stage (0-based) enters it as a detached leaf, so the backward
-        pass can run in two segments around it; the pair (upstream tensor, leaf) is left in `self.last_cut`."""
-        self.last_cut = None
+        cut_before_stage (training.TrainStep; an int or several): the input of that stage (0-based) enters it as a detached leaf, so the
+        backward pass can run in segments around it; the pairs (upstream tensor, leaf) are left in `self.last_cuts` {stage: pair}
+        (`self.last_cut`: the pair of the LAST such stage)."""
+        self.last_cut, self.last_cuts = None, {}
+        cuts = () if cut_before_stage is None else ((cut_before_stage,) if isinstance(cut_before_stage, int) else tuple(cut_before_stage))
         if prev_states is None:
             prev_states = [None] * self.num_stages
         assert len(prev_states) == self.num_stages
@@ -205,9 +207,9 @@ class RNNDetector(nn.Module):
         r, xin = SF.input_prep(x, pad, self._prep_ws, keep_bytes=SF.STEM_U8)
         states, output, P = [], {}, []
         for i, stage in enumerate(self.stages):
-            if cut_before_stage is not None and i == cut_before_stage and torch.is_grad_enabled() and xin.requires_grad:
+            if i in cuts and torch.is_grad_enabled() and xin.requires_grad:
                 leaf = xin.detach().requires_grad_(True)
-                self.last_cut = (xin, leaf)
+                self.last_cut = self.last_cuts[i] = (xin, leaf)
                 xin = leaf
             xin, state, p = stage.forward_nhwc(xin, prev_states[i], r[:, i], token_mask if i == 0 else None)   # sast_rnn.py:157
             states.append(state)

@@ -155,6 +155,48 @@ class _ParamGrads:
         return tuple(self.ret)
 
 
+# ---- deferred weight gradients (include/sast_hip.h: sast_dw_defer ...; csrc/k_defer.hip).  Owned by training.TrainStep: while deferral is
+# on, the backward entry points park their weight-gradient jobs in the library's queue and the owner flushes them on a side stream.  The
+# parked jobs hold RAW pointers to the upstream gradients, workspaces, saved activations and row counts of the backward call that parked
+# them, so every backward that can park hands its locals to `_dw_hold`; the owner releases them (`dw_release`) once the stream it keeps
+# allocating on is ordered behind the flushed launches.
+_DW_DEFER = False
+_DW_HOLD = []
+
+
+def dw_defer(on: bool, min_rows: int = 0, max_rows: int = 0) -> bool:
+    """switch the library's deferral of weight-gradient jobs on / off (process-wide); returns the previous setting.
+    min_rows / max_rows: only jobs whose reduction runs over that many rows are parked (0 = unbounded)."""
+    global _DW_DEFER
+    prev, _DW_DEFER = _DW_DEFER, bool(on)
+    L.lib().sast_dw_defer_rows(int(min_rows), int(max_rows))
+    L.lib().sast_dw_defer(int(bool(on)))
+    return prev
+
+
+def dw_pending() -> int:
+    return int(L.lib().sast_dw_pending())
+
+
+def dw_flush():
+    """enqueue every parked weight-gradient job on the CURRENT stream (the caller has ordered it behind the backward kernels)"""
+    L.check(L.lib().sast_dw_flush(_stream()), "dw_flush")
+
+
+def dw_discard() -> int:
+    return int(L.lib().sast_dw_discard())
+
+
+def dw_release():
+    """drop the references held for parked jobs (the caller has ordered its allocating stream behind the flushed launches)"""
+    _DW_HOLD.clear()
+
+
+def _dw_hold(objs):
+    if _DW_DEFER:
+        _DW_HOLD.append(objs)
+
+
 def _consume(ctx, what: str):
     """the backward kernels of these ops CONSUME scratch accumulators that the forward kernels cleared (BatchNorm-backward sums,
     the LayerScale / fc2 / proj raw gradients, d(scale) of the STP controls): a second backward over the same forward
@@ -374,6 +416,7 @@ class _DownsampleLN(torch.autograd.Function):
                   conv_out=conv_out, mean=stats[0], rstd=stats[1], dy=dy, dx=_ptr(dx), dw=pg[0], d_ln_w=pg[1], d_ln_b=pg[2], ws=ws,
                   x_dtype=xdt, no_overlap=no_overlap)
         L.check(L.lib().sast_downsample_ln_bwd(C.byref(a), _stream()), "downsample_ln_bwd")
+        _dw_hold((x, conv_out, stats, dy, ws, pg))
         return (dx,) + pg.out() + (None, None)
 
 
@@ -453,6 +496,7 @@ class _ScoreSTP(torch.autograd.Function):
         a = _fill(L.SastScoreArgs(), B=B, L=Lt, C=Cc, r_stride=r.stride(0), amp=amp, xp=xp, r=r, ws_w=ws_w, ws_b=ws_b, wc=wc,
                   scale=scale, s=s, dxw=dxw, dxp=dxp, d_ws_w=pg[0], d_ws_b=pg[1], d_wc=pg[2], ws=ws, dscale_ws=dscale)
         L.check(L.lib().sast_score_stp_bwd(C.byref(a), _stream()), "score_stp_bwd")
+        _dw_hold((xp, r, scale, s, dscale, dxw, ws, pg))
         return (dxp, None) + pg.out() + (None,)
 
 
@@ -790,6 +834,7 @@ class _MSWSA(torch.autograd.Function):
         pg = _ParamGrads(*params)                          # held until the launch is enqueued (scratch buffers among them)
         _fill(a, **{"d_" + k: _ptr(pg[i]) for i, k in enumerate(_MSWSA_PARAMS)})
         L.check(L.lib().sast_mswsa_bwd(C.byref(a), _stream()), "mswsa_bwd")
+        _dw_hold((xin, stats, big, raw, fws, dout, ws, pg, sel, ctx.drop, ctx.drop_mlp, locals().get("drop_ws"), locals().get("cb_m"), locals().get("cb_sum")))
         return (dxin, None, None, None, None, None, None, None, None) + pg.out()
 
 
@@ -868,6 +913,7 @@ class _LSTM(torch.autograd.Function):
         a = _fill(L.SastLstmArgs(), B=B, L=Lt, C=Cc, x=x, h0=_ptr(h0), c0=_ptr(c0), w=w, b=b, c1=c1, gates=gates, dh1=dh1,
                   dc1=_ptr(dc1), dx=dx, dh0=_ptr(dh0), dc0=_ptr(dc0), dw=pg[0], db=pg[1], ws=ws, dh1b=_ptr(dh1b), drop=_ptr(drop))
         L.check(L.lib().sast_lstm_bwd(C.byref(a), _stream()), "lstm_bwd")
+        _dw_hold((x, h0, c0, c1, gates, drop, dh1, dh1b, dc1, ws, pg))
         return (dx, dh0, dc0) + pg.out() + (None,)
 
 
@@ -1189,6 +1235,7 @@ class _ConvBnSilu(torch.autograd.Function):
             sync.all_reduce(_bn_ws_blocks(ctx.saved_tensors[4], Cout)[1])
             a.sync_phase, a.m_total, a.d_bn_w, a.d_bn_b = 2, m_total, None, None
         L.check(L.lib().sast_conv_bn_silu_bwd(C.byref(a), _stream()), "conv_bn_silu_bwd")
+        _dw_hold((ctx.saved_tensors, _keep, pg))
         for h in served:
             if h is not None:
                 h.red_done = True
@@ -1256,6 +1303,7 @@ class _ConvBnSiluSyncGroup(torch.autograd.Function):
                 if h is not None:
                     h.red_done = True
             grads.extend((dx, dx2) + pg.out() + (None, None))
+        _dw_hold((sv, jobs))
         return tuple(grads)
 
 
@@ -1377,6 +1425,7 @@ class _ConvBnSilu2(torch.autograd.Function):
                   stats0=st0, stats1=st1, bn_ws0=ws0, bn_ws1=ws1, dy0=dy0, dy1=dy1, dw0=pg[0], dw1=pg[3], d_bn_w0=pg[1],
                   d_bn_w1=pg[4], d_bn_b0=pg[2], d_bn_b1=pg[5], ws0=dws, dx=_ptr(dx), dx2=_ptr(dx2), **pk)
         L.check(L.lib().sast_conv_bn_silu2_bwd(C.byref(a), _stream()), "conv_bn_silu2_bwd")
+        _dw_hold((x, x2, co0, co1, st0, st1, ws0, ws1, dy0, dy1, dws, pg))
         for h in (p1, p2):
             if h is not None:
                 h.red_done = True

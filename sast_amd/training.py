@@ -19,9 +19,18 @@ in the middle of the PAFPN / head passes.
 With world == 1 the all-reduce is a no-op and everything else is identical, so a single-GPU run exercises the same path.
 
 For sequences (seq_len > 1, BPTT) the backbone gradients only become final at the end of the backward: segments B and C merge.
+
+Round 6: DEFERRED WEIGHT GRADIENTS (`defer_dw=True`).  Nothing reads a weight gradient before AdamW, yet in the chain above every
+layer's backward launch carries its dW job beside its dX job and the next kernel waits for both.  With deferral the backward entry
+points launch only the dX chain on the main stream and park the dW jobs in the library (include/sast_hip.h: sast_dw_defer); after each
+segment the side stream waits for the segment's event, runs the parked jobs (`SF.dw_flush`; replayed as a hipGraph of its own -- kernel
+nodes of ONE graph never overlap on ROCm 7.2, separately instantiated graphs on two streams do) and then that segment's all-reduce +
+AdamW, while the main stream is already in the next segment's chain.  `dw_cuts` adds segment boundaries before backbone stages
+(more, shorter dW graphs: less weight-gradient work left exposed behind the last segment); buckets and their order are unchanged.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -34,9 +43,13 @@ from .dist import FlatParams, FusedAdamW, OneCycleLR
 
 class TrainStep:
     def __init__(self, net, fpn, head=None, *, lr: float = 2e-4, weight_decay: float = 0.0, clip_value: float = 0.0, eps: float = 1e-8,
-                 schedule: Optional[OneCycleLR] = None, world: int = 1, group=None, segmented: bool = True):
+                 schedule: Optional[OneCycleLR] = None, world: int = 1, group=None, segmented: bool = True, defer_dw: bool = False,
+                 dw_rows=(0, 0), dw_discard: bool = False, cuts: Sequence[int] = (3,)):
         self.net, self.fpn, self.head = net, fpn, head
         self.world, self.group = world, group
+        # defer_dw: weight gradients off the backward chain (module docstring); dw_rows = (min, max) reduction rows of the jobs that are
+        # parked (0 = unbounded); dw_discard: TIMING PROBE ONLY -- the parked jobs are dropped instead of run (the dX chain alone)
+        self.defer_dw, self.dw_rows, self.dw_discard = bool(defer_dw), tuple(dw_rows), bool(dw_discard)
         stages = list(net.stages)
         first = [fpn] + ([head] if head is not None else [])
         # The segmented backward is written for the topology of the shipped models: four backbone stages, the PAFPN reading stages up to
@@ -61,6 +74,12 @@ class TrainStep:
                 warnings.warn(f"sast_amd.TrainStep: segmented backward disabled ({why}); running the monolithic step")
                 segmented = False
         self.segmented = segmented
+        # cuts: the backbone stages (0-based) whose INPUT is a segment boundary of the single-timestep backward.  (3,) = the three
+        # segments of the module docstring; more cuts (e.g. (3, 2, 1)) only add boundaries -- the buckets stay the same three, a bucket
+        # is reduced + updated behind the segment that completes it; with defer_dw every segment's parked weight gradients leave behind it
+        self.cuts = tuple(sorted({int(c) for c in cuts}, reverse=True))
+        if segmented and (not self.cuts or self.cuts[0] != 3 or min(self.cuts) < 1):
+            raise ValueError(f"TrainStep(cuts={cuts}): the segmented backward needs the cut before the last stage (3) and cuts in 1 .. 3")
         if len(stages) == 4:
             buckets = [first, [stages[3]], [stages[2], stages[1], stages[0]]]
         else:
@@ -69,9 +88,13 @@ class TrainStep:
         self.opt = FusedAdamW(self.flat, lr=lr, weight_decay=weight_decay, clip_value=clip_value, eps=eps, schedule=schedule)
         dev = self.flat.flat.device
         self._one = torch.ones((), device=dev)
-        self.side = torch.cuda.Stream() if dev.type == "cuda" else None
+        # the side stream carries what the step does NOT wait for (bucket all-reduce + AdamW, deferred weight gradients): lowest priority
+        # with defer_dw, so that the dispatcher serves the backward chain's workgroups first and the parked jobs soak up what is left
+        prio = int(os.environ.get("SAST_SIDE_PRIORITY", "1" if defer_dw else "0"))
+        self.side = torch.cuda.Stream(priority=prio) if dev.type == "cuda" else None
         self.loss = self.P = self.losses = None
         self._graphs = None
+        self._dw_graphs = None
         self._seg_state = None
         # measure_exposed: every step records (main stream idle, side stream done) event pairs -- how long the step waits for the
         # last bucket's all-reduce + update AFTER its own backward has finished (bench.py: `allreduce_exposed_ms`)
@@ -89,10 +112,10 @@ class TrainStep:
         feats_seq, Ps = [], []
         for t, x in enumerate(xs):
             feats, states, P = self.net.forward_nhwc(x, states, token_masks[t] if token_masks is not None else None,
-                                                     cut_before_stage=3 if single else None)
+                                                     cut_before_stage=self.cuts if single else None)
             feats_seq.append(feats)
             Ps.append(P)
-        cut = self.net.last_cut if single else None
+        cut = dict(self.net.last_cuts) if (single and self.net.last_cuts) else None
         if indices is not None:
             from .detection.sequence import BackboneFeatureSelector
             sel = BackboneFeatureSelector()
@@ -115,12 +138,37 @@ class TrainStep:
         self._seg_state = (loss, fpn_in, leaves, cut)
         return loss
 
+    def _stage_groups(self):
+        """single-timestep segmented backward: the backbone stages (0-based) of segments 1, 2, ...: [[3], [2, 1, 0]] for cuts (3,)"""
+        cut = self._seg_state[3]
+        bounds = sorted(cut.keys(), reverse=True)           # e.g. [3, 2, 1]
+        groups, hi = [], len(self.net.stages) - 1
+        for c in bounds:
+            groups.append(list(range(hi, c - 1, -1)))
+            hi = c - 1
+        groups.append(list(range(hi, -1, -1)))
+        return groups
+
     def n_segments(self) -> int:
         if not self.segmented:
             return 1
-        return 3 if self._seg_state[3] is not None else 2
+        return 1 + len(self._stage_groups()) if self._seg_state[3] is not None else 2
+
+    def _side_path(self) -> bool:
+        """reduce + update (and the parked weight-gradient jobs) run on the side stream"""
+        return self.side is not None and (self.segmented or self.defer_dw)
 
     def backward_segment(self, i: int):
+        if self.defer_dw:
+            prev = SF.dw_defer(True, *self.dw_rows)
+            try:
+                self._backward_segment(i)
+            finally:
+                SF.dw_defer(prev)
+            return
+        self._backward_segment(i)
+
+    def _backward_segment(self, i: int):
         loss, fpn_in, leaves, cut = self._seg_state
         if i == 0:
             loss.backward(gradient=self._one)            # a resident 1.0 instead of a ones_like fill launch per step
@@ -129,20 +177,37 @@ class TrainStep:
         if cut is None:                                  # one backbone segment (sequences, or stage input without a graph)
             torch.autograd.backward([fpn_in[k] for k in keys], [leaves[k].grad for k in keys])
             return
-        top = keys[-1]                                   # the stage-4 feature map
-        if i == 1:
-            torch.autograd.backward([fpn_in[top]], [leaves[top].grad])
-        else:
-            rest = keys[:-1]
-            torch.autograd.backward([cut[0]] + [fpn_in[k] for k in rest], [cut[1].grad] + [leaves[k].grad for k in rest])
+        # segment i >= 1 runs the backward of a group of stages: its roots are the input of the stage above the group (the cut's
+        # upstream tensor, gradient = what the segment before left in the cut's leaf) and the group's own feature maps the FPN reads
+        grp = self._stage_groups()[i - 1]
+        roots, grads = [], []
+        above = max(grp) + 1
+        if above in cut:
+            roots.append(cut[above][0])
+            grads.append(cut[above][1].grad)
+        for k in keys:                                   # FPN input key k = output of stage k - 1
+            if k - 1 in grp:
+                roots.append(fpn_in[k])
+                grads.append(leaves[k].grad)
+        torch.autograd.backward(roots, grads)
 
     def bucket_of_segment(self, i: int) -> List[int]:
+        """the gradient buckets that are FINAL behind segment i"""
         n = self.n_segments()
         if n == 1:
             return list(range(len(self.flat.bucket_ranges)))
         if n == 2:
             return [[0], [1, 2]][i]
-        return [i]
+        if i == 0:
+            return [0]
+        groups = self._stage_groups()
+        done = {st for g in groups[:i] for st in g}
+        before = {st for g in groups[:i - 1] for st in g}
+        out = []
+        for b, stages in ((1, {3}), (2, {2, 1, 0})):     # bucket 1 = stage 4, bucket 2 = stages 3, 2, 1 (FlatParams order of __init__)
+            if stages <= done and not stages <= before:
+                out.append(b)
+        return out
 
     # ---------------------------------------------------------------- reduce + update
     def _reduce_update(self, buckets: List[int]):
@@ -164,9 +229,30 @@ class TrainStep:
         self._bucket_ev = {}
         return out
 
+    def _flush_dw(self, i: int):
+        """the weight-gradient jobs segment i parked, on the current (side) stream: the captured graph of the flush, or the launches"""
+        if not self.defer_dw:
+            return
+        if self._dw_graphs is not None:
+            if self._dw_graphs[i] is not None:
+                self._dw_graphs[i].replay()
+        elif self.dw_discard:
+            SF.dw_discard()
+        else:
+            SF.dw_flush()
+
+    def flush_pending(self):
+        """callers that run forward + backward_segment() themselves (no reduce / update): the parked jobs on the CURRENT stream"""
+        if self.defer_dw:
+            SF.dw_flush()
+            SF.dw_release()
+
     def _after_segment(self, i: int, first: bool):
-        """all-reduce + AdamW of the buckets that segment i completed; on the side stream when the step is segmented"""
-        if self.side is None or not self.segmented:
+        """(the parked weight-gradient jobs of segment i, then) all-reduce + AdamW of the buckets that segment i completed; on the side
+        stream when the step is segmented or defers its weight gradients"""
+        if not self._side_path():
+            if self.defer_dw:
+                self._flush_dw(i)
             if first:
                 self.opt.begin_step()
             self._reduce_update(self.bucket_of_segment(i))
@@ -176,12 +262,13 @@ class TrainStep:
         ev.record(main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ev)
+            self._flush_dw(i)
             if first:
                 self.opt.begin_step()
             self._reduce_update(self.bucket_of_segment(i))
 
     def finish(self):
-        if self.side is not None and self.segmented:
+        if self._side_path():
             main = torch.cuda.current_stream()
             if self.measure_exposed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -189,6 +276,8 @@ class TrainStep:
                 e1.record(self.side)       # ... the side stream still owes the last bucket's reduce + update
                 self._exposed.append((e0, e1))
             main.wait_stream(self.side)
+        if self.defer_dw and self._graphs is None:
+            SF.dw_release()          # eager: the allocating stream is now ordered behind the flushed launches
 
     def exposed_ms(self):
         """mean time per step by which the side stream (bucket all-reduce + AdamW) finished AFTER the main stream (0 when it was
@@ -230,7 +319,7 @@ class TrainStep:
                 raise RuntimeError("sast_amd.TrainStep.capture: the model was converted with convert_sync_batchnorm and the process group's "
                                    f"backend ({dist.get_backend(grp.group)}) runs its collectives on the host; the statistics all-reduces "
                                    "inside the PAFPN / head passes can only be captured into hipGraphs on RCCL (\"nccl\") -- run step()")
-        if not self.segmented:
+        if not self._side_path():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.forward(xs, states, labels, indices, token_masks)
@@ -241,22 +330,42 @@ class TrainStep:
             self.loss = self.loss.detach()
             return
         pool = torch.cuda.graph_pool_handle()
-        graphs = []
+        graphs, dw_graphs = [], []
+
+        def flush_graph():
+            """the jobs the segment just captured has parked, as a graph of their own (replayed on the side stream).  Everything they
+            read stays referenced (functional._DW_HOLD) until ALL graphs are captured: no later capture is handed their memory."""
+            if not self.defer_dw:
+                return None
+            if self.dw_discard:
+                SF.dw_discard()
+                return None
+            if SF.dw_pending() == 0:
+                return None
+            d = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(d, pool=pool, capture_error_mode="thread_local"):
+                SF.dw_flush()
+            return d
+
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
             self.forward(xs, states, labels, indices, token_masks)
             self.backward_segment(0)
         graphs.append(g)
+        dw_graphs.append(flush_graph())
         for i in range(1, self.n_segments()):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
                 self.backward_segment(i)
             graphs.append(g)
+            dw_graphs.append(flush_graph())
         self._graphs = graphs
+        self._dw_graphs = dw_graphs if self.defer_dw else None
+        SF.dw_release()
         self.loss = self.loss.detach()
 
     def replay(self):
-        if not self.segmented:
+        if not self._side_path():
             self._graphs[0].replay()
             if self.world > 1:
                 if self.measure_exposed:

@@ -1543,6 +1543,56 @@ def test_segmented_step_matches_monolithic(dev):
     assert float(segg.opt.lr_step[1]) == 4.0
 
 
+@pytest.mark.parametrize("segmented, cuts", [(True, (3,)), (False, (3,)), (True, (3, 2, 1))], ids=["segmented", "one-segment", "segment-per-stage"])
+def test_deferred_weight_gradients_match_monolithic(dev, segmented, cuts):
+    """training.TrainStep(defer_dw=True): the weight-gradient jobs leave the backward chain (parked in the library, run on the side stream
+    beside the next segment, csrc/k_defer.hip) -- same loss, gradients and parameters as the monolithic step over four updates, eager and as
+    hipGraphs (one graph per segment + one graph per flush); nothing stays parked, nothing stays held."""
+    from sast_amd import functional as SF
+    from sast_amd.config import backbone_config
+    from sast_amd.detection import RNNDetector, YOLOPAFPN
+    from sast_amd.dist import OneCycleLR
+    from sast_amd.training import TrainStep
+    hw, part, E = (128, 160), (4, 5), 32
+    x = O.count_events(2, hw, seed=2, density=0.05).to(dev)
+
+    def rig(**kw):
+        torch.manual_seed(0)
+        net = RNNDetector(backbone_config(hw, part, embed_dim=E, AMP=2e-4, ls_init_value=0.5)).to(dev)
+        fpn = YOLOPAFPN(depth=0.67, in_stages=(2, 3, 4), in_channels=(64, 128, 256)).to(dev)
+        return TrainStep(net, fpn, lr=1e-3, eps=1e-3, clip_value=1.0, schedule=OneCycleLR(1e-3, total_steps=20, pct_start=0.25), **kw)
+
+    mono, dfr, dfrg = rig(segmented=False), rig(segmented=segmented, defer_dw=True, cuts=cuts), rig(segmented=segmented, defer_dw=True, cuts=cuts)
+    ref = []
+    for _ in range(4):
+        mono.step([x])
+        ref.append((float(mono.loss), mono.flat.grad.clone(), mono.flat.flat.clone()))
+    for k in range(4):
+        dfr.step([x])
+        assert dfr.n_segments() == (2 + len(cuts) if segmented else 1)
+        assert SF.dw_pending() == 0 and not SF._DW_HOLD and not SF._DW_DEFER
+        torch.cuda.synchronize()
+        assert abs(float(dfr.loss) - ref[k][0]) <= 1e-5 * abs(ref[k][0])
+        maxnorm_close(dfr.flat.grad, ref[k][1], (1e-5, 1e-4, 1e-3, 3e-3)[k], f"deferred eager, gradient of step {k}")
+    maxnorm_close(dfr.flat.flat, ref[3][2], 1e-4, "deferred eager, parameters after 4 updates")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        dfrg.step([x])                                   # eager warm-up == step 0
+        torch.cuda.synchronize()
+        dfrg.capture([x])
+        assert SF.dw_pending() == 0 and not SF._DW_HOLD and not SF._DW_DEFER
+        assert len(dfrg._dw_graphs) == dfrg.n_segments() and all(d is not None for d in dfrg._dw_graphs)
+        for k in range(1, 4):
+            dfrg.replay()
+            torch.cuda.synchronize()
+            assert abs(float(dfrg.loss) - ref[k][0]) <= 1e-5 * abs(ref[k][0]), (k, float(dfrg.loss), ref[k][0])
+            maxnorm_close(dfrg.flat.grad, ref[k][1], (1e-4, 1e-3, 3e-3)[k - 1], f"deferred graphs, gradient of step {k}")
+    torch.cuda.current_stream().wait_stream(s)
+    maxnorm_close(dfrg.flat.flat, ref[3][2], 1e-4, "deferred graphs, parameters after 4 updates")
+    assert float(dfrg.opt.lr_step[1]) == 4.0
+
+
 def _train_rig(dev, hw, part, E, chans, eps):
     from sast_amd.config import backbone_config
     from sast_amd.detection import RNNDetector, YOLOPAFPN
