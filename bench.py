@@ -240,6 +240,20 @@ def parity_vs_oracle(tr, p, f, loss_cpu, P_cpu):
             "grad_max_rel_err_behind_scoring_relu": worst_kink[0], "note": "first step at the initial weights, max-norm relative error per tensor"}
 
 
+def _physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo (None where the file does not say)"""
+    try:
+        cores, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cores.add((phys, line.split(":")[1].strip()))
+        return len(cores) or None
+    except OSError:
+        return None
+
+
 def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False, tr=None):
     """the oracle (torch-CPU port of the reference path) timed on this box's host cores on a bounded sample,
     on the same initial weights and the same input as rank 0's GPU leg."""
@@ -286,10 +300,45 @@ def cpu_baseline(amp, init_state, seconds_budget=25.0, fwd_only=False, tr=None):
         el = time.perf_counter() - t0
         if el > seconds_budget or n >= (32 if fwd_only else 8):
             break
-    return parity, {"value": BATCH * n / el, "unit": "frames/s", "cores": cores, "kind": "port",
+    return parity, {"value": BATCH * n / el, "unit": "frames/s", "cores": cores, "threads": cores, "host_logical_cpus": os.cpu_count(),
+            "host_physical_cores": _physical_cores(), "kind": "port",
             "sample": (f"{n} backbone forward passes of the same workload (B={BATCH}, {HW[0]}x{HW[1]}), " if fwd_only else
                        f"{n} fwd+bwd steps of the same workload (B={BATCH}, {HW[0]}x{HW[1]}, backbone+PAFPN, proxy loss), ") +
-                      f"oracle/sast_oracle.py, torch {torch.__version__} CPU, {cores} threads, no optimizer step"}
+                      f"oracle/sast_oracle.py, torch {torch.__version__} CPU, {cores} threads (the fastest of 8 / 16 / 32 / 64 on this host), no optimizer step"}
+
+
+def batch_scan(args, dev, world, ms_at_batch, batches=(1, 2)):
+    """un-timed leg (round-5 verdict item 6): the same step at smaller batches -> least-squares line ms = a + b * B over B in {1, 2, BATCH}:
+    `a` is the batch-INDEPENDENT part of the step (the latency floor of its chain of dependent launches), `b` the cost per sample"""
+    global BATCH
+    pts = {BATCH: ms_at_batch}
+    keep = BATCH
+    try:
+        for b in batches:
+            if b >= keep:
+                continue
+            BATCH = b
+            tr = Trainer(dev, args.amp, world, use_graph=not args.no_graph, seq_len=args.seq_len, yolox_loss=args.loss == "yolox", segmented=args.segmented,
+                         sync_bn=args.sync_bn, event_dtype=args.event_dtype, defer_dw=bool(args.defer_dw), dw_rows=(args.dw_min_rows, args.dw_max_rows),
+                         cuts=tuple(int(c) for c in args.cuts.split(",")))
+            tr.capture()
+            for _ in range(10):
+                tr.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(40):
+                tr.step()
+            torch.cuda.synchronize()
+            pts[b] = 1e3 * (time.perf_counter() - t0) / 40
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        BATCH = keep
+    xs, ys = list(pts.keys()), list(pts.values())
+    n, sx, sy = len(xs), sum(xs), sum(ys)
+    sxx, sxy = sum(x * x for x in xs), sum(x * y for x, y in zip(xs, ys))
+    slope = (n * sxy - sx * sy) / (n * sxx - sx * sx)
+    return {"ms_at_batch": {str(k): round(v, 4) for k, v in sorted(pts.items())}, "batch_independent_ms": (sy - slope * sx) / n, "ms_per_sample": slope}
 
 
 def _fused_forward_in_use(amp):
@@ -337,6 +386,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-batch-scan", action="store_true", help="skip the un-timed B = 1, 2 legs behind roofline.whole_step.batch_independent_ms")
     args = ap.parse_args()
     BATCH = args.batch
     if args.precision == "bf16":       # before anything imports sast_amd._lib; opt-in build: `python -m sast_amd.build --bf16`
@@ -483,6 +533,11 @@ def main():
             from sast_amd.profiling import dominant_kernel_roofline
             res["roofline"] = dominant_kernel_roofline(tr, ms_per_step=res["ms_per_step"], hw=HW, batch=BATCH, seq_len=max(args.seq_len, 1),
                                                        pmc_applies=baseline_cfg and args.event_dtype == "int32" and not tr.sync_bn)
+            ws = res["roofline"].get("whole_step")
+            if ws is not None:
+                ws["peak_memory_bytes"] = {"allocated": int(torch.cuda.max_memory_allocated()), "reserved": int(torch.cuda.max_memory_reserved())}
+                if world == 1 and not args.no_batch_scan and not (args.fwd_only or args.infer) and BATCH > 2:
+                    ws.update(batch_scan(args, dev, world, res["ms_per_step"]))
         if not args.no_cpu_baseline and world == 1 and args.seq_len == 1 and not args.infer and args.loss == "proxy" and args.precision == "f32":
             parity, res["cpu_baseline"] = cpu_baseline(args.amp, tr.init_state, fwd_only=args.fwd_only, tr=tr)
             if parity is not None:

@@ -415,6 +415,16 @@ int sast_dw_pending(void);
 int sast_dw_discard(void);
 int sast_dw_flush(sast_stream_t stream);
 
+/* ---- tuning knobs.  Every SAST_* environment variable the library reads (tile / split / launch-shape choices, all defaulting to the
+ * measured-best setting: DESIGN.md section 7) goes through one registry: the value is read from the environment at first use and cached;
+ * sast_config_reload() makes every call site re-read its knob at its next use (a host that sets os.environ inside the process calls
+ * it), returns the number of knobs read so far.  sast_config_get(name, default): the value the library would use for `name` now.
+ * sast_config_report: "NAME=value (default d)" lines of the knobs read so far; returns the bytes needed. */
+unsigned long long sast_launch_count(void);   /* kernel launches this library has enqueued in this process (any thread, any stream) */
+int sast_config_reload(void);
+int sast_config_get(const char* name, int default_value);
+size_t sast_config_report(char* buf, size_t cap);
+
 /* measurement aid (bench.py roofline leg): HIP-event timing of every launch of the GEMM-template kernels, recorded on
  * the launch stream; the report lists per kernel instantiation: calls, total ms, total algorithmic FLOPs (2*M*N*K with
  * the device-side row counts read back).  Enabling it adds host syncs -- never enable inside a timed region. */

@@ -130,6 +130,10 @@ _SIGNATURES = {
     "sast_dw_pending": (C.c_int, []),
     "sast_dw_discard": (C.c_int, []),
     "sast_dw_flush": (C.c_int, [P]),
+    "sast_launch_count": (C.c_ulonglong, []),
+    "sast_config_reload": (C.c_int, []),
+    "sast_config_get": (C.c_int, [C.c_char_p, C.c_int]),
+    "sast_config_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "sast_prof_enable": (C.c_int, [C.c_int]),
     "sast_prof_calibrate": (C.c_float, [P, C.c_int]),
     "sast_prof_report": (C.c_size_t, [C.c_char_p, C.c_size_t]),
@@ -166,6 +170,23 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def reload_knobs() -> int:
+    """the library re-reads every SAST_* tuning knob from the environment at its next use (call after changing os.environ in-process)"""
+    return int(lib().sast_config_reload())
+
+
+def knobs() -> dict:
+    """{name: value in use} of the SAST_* knobs the library has read so far"""
+    n = lib().sast_config_report(None, 0)
+    buf = C.create_string_buffer(n)
+    lib().sast_config_report(buf, n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, v = line.split("=", 1)
+        out[k] = int(v.split(" ")[0])
+    return out
 
 
 def loaded_path() -> str:

@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libsast_hip.so")
 TOOLS_LIB = os.path.join(HERE, "libsast_hip_tools.so")
 BF16_LIB = os.path.join(HERE, "libsast_hip_bf16.so")
 ARCH = "gfx950"
-SOURCES = ["k_rows.hip", "k_select.hip", "k_attn_mfma.hip", "k_mswsa_fused.hip", "k_block.hip", "k_conv.hip", "k_dwconv.hip", "k_prof.hip", "k_head.hip", "k_defer.hip"]
+SOURCES = ["k_rows.hip", "k_select.hip", "k_attn_mfma.hip", "k_mswsa_fused.hip", "k_block.hip", "k_conv.hip", "k_dwconv.hip", "k_prof.hip", "k_head.hip", "k_defer.hip", "k_config.hip"]
 TOOLS_SOURCES = ["k_test.hip", "k_dma_test.hip", "k_ws_test.hip"]
 HEADERS = ["common.cuh", "gemm.cuh", "mfma_tiles.cuh", "gemm_dispatch.cuh", "kernels.h", os.path.join("..", "..", "include", "sast_hip.h")]
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SAST_EXTRA_FLAGS", "").split()

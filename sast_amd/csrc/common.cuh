@@ -17,6 +17,7 @@
 // sticky result of somebody else's hipEventQuery / hipStreamQuery on this thread (PyTorch's caching allocator polls events after H2D
 // copies).
 namespace sast {
+inline unsigned long long g_launch_count = 0;        // launches enqueued by this library (sast_launch_count: bench.py's dispatches per step)
 inline thread_local int g_launch_failed = 0;
 inline void launch_latch(hipError_t e, const char* file, int line) {
   if (e == hipSuccess || e == hipErrorNotReady) return;
@@ -25,12 +26,29 @@ inline void launch_latch(hipError_t e, const char* file, int line) {
 }
 inline bool launch_failed_take() { const bool f = g_launch_failed != 0; g_launch_failed = 0; return f; }
 }  // namespace sast
-#define SAST_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
-#define SAST_EXT_LAUNCH(...) do { (void)hipGetLastError(); hipExtLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
+#define SAST_LAUNCH(...) do { (void)hipGetLastError(); __atomic_fetch_add(&sast::g_launch_count, 1ull, __ATOMIC_RELAXED); hipLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
+#define SAST_EXT_LAUNCH(...) do { (void)hipGetLastError(); __atomic_fetch_add(&sast::g_launch_count, 1ull, __ATOMIC_RELAXED); hipExtLaunchKernelGGL(__VA_ARGS__); sast::launch_latch(hipGetLastError(), __FILE__, __LINE__); } while (0)
 #define SAST_CHECK_LAUNCH() do { if (sast::launch_failed_take()) return SAST_ELAUNCH; } while (0)
 // first statement of every extern "C" entry point: a latch left set by an EARLIER entry point that returned through an error path
 // without consuming it (a failed launch inside a void helper, then `return rc`) must not be reported by this, unrelated, call
 #define SAST_ENTRY() ((void)sast::launch_failed_take())
+
+// Every SAST_* tuning knob of the library is read through SAST_KNOB(name, default): the value comes from the environment, is cached
+// per call site, and is re-read after sast_config_reload() (include/sast_hip.h) -- a host that changes a knob inside the process
+// (tools, tests, A/B scripts) says so instead of being silently ignored by a value latched at first use.  k_prof.hip keeps the
+// registry of the knobs that have been read (sast_config_report).
+namespace sast {
+int knob_read(const char* name, int dflt);
+unsigned knob_generation();
+}  // namespace sast
+#define SAST_KNOB(NAME, DFLT)                                                   \
+  ([]() -> int {                                                               \
+    static int v_ = 0;                                                         \
+    static unsigned g_ = 0;                                                    \
+    const unsigned g = sast::knob_generation();                                \
+    if (g_ != g) { v_ = sast::knob_read(NAME, DFLT); g_ = g; }                 \
+    return v_;                                                                 \
+  }())
 
 // Issue priority of the kernels of the backward CHAIN (experiment, round 6: with deferred weight gradients a side stream's workgroups
 // share the SIMDs with the chain's; -DSAST_MAIN_PRIO=n raises the chain's waves over the side stream's, which stay at the default 0)
@@ -97,7 +115,7 @@ __device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, 
 
 // THE sigmoid of the library (SiLU, LSTM gates, STP weights, the silu / sigmoid GLU gates): on the hardware exp2 path
 // (v_exp_f32 is 1 ulp; the x*log2e pre-multiply adds ~|x|*6e-8 relative) -- measured inside the fp32 parity bars everywhere it is used
-__device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_hw(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) instead of libm's branchy erff:
 // the GLU epilogues evaluate it for every (token, inner channel) and were VALU-bound on erff.
@@ -133,8 +151,8 @@ __device__ __forceinline__ float glu_act(float g, int act, float a = 0.0f) {
   switch (act) {
     case GLU_ACT_PRELU: return g > 0.0f ? g : a * g;
     case 1: return fmaxf(g, 0.0f);
-    case 2: return g * sigmoid_exact(g);
-    case 3: return sigmoid_exact(g);
+    case 2: return g * sigmoid_hw(g);
+    case 3: return sigmoid_hw(g);
     case 4: return tanhf(g);
     case 5: return g * tanhf(softplus_t20(g));
     case 6: return fminf(fmaxf(g, 0.0f), 6.0f);
@@ -151,8 +169,8 @@ __device__ __forceinline__ float glu_act_grad(float g, int act, float a = 0.0f) 
   switch (act) {
     case GLU_ACT_PRELU: return g > 0.0f ? 1.0f : a;
     case 1: return g > 0.0f ? 1.0f : 0.0f;                  // torch: relu'(0) = 0
-    case 2: { const float s = sigmoid_exact(g); return s * (1.0f + g * (1.0f - s)); }
-    case 3: { const float s = sigmoid_exact(g); return s * (1.0f - s); }
+    case 2: { const float s = sigmoid_hw(g); return s * (1.0f + g * (1.0f - s)); }
+    case 3: { const float s = sigmoid_hw(g); return s * (1.0f - s); }
     case 4: { const float t = tanhf(g); return 1.0f - t * t; }
     case 5: { const float t = tanhf(softplus_t20(g)); return t + g * (1.0f - t * t) * (1.0f / (1.0f + expf(-g))); }
     case 6: return (g > 0.0f && g < 6.0f) ? 1.0f : 0.0f;    // hardtanh_backward: 0 at and beyond both ends

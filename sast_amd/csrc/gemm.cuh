@@ -1598,7 +1598,7 @@ struct BnCol { float mu, rs, g, b; };
 __device__ __forceinline__ BnCol bn_col(const BnProducer& p, int j) { return BnCol{p.stats[j], p.stats[p.C + j], p.gamma[j], p.beta[j]}; }
 __device__ __forceinline__ void bn_stat(float dy, float x, const BnCol& k, float& a, float& b) {
   const float xh = (x - k.mu) * k.rs;
-  const float z = xh * k.g + k.b, sg = sigmoid_exact(z);
+  const float z = xh * k.g + k.b, sg = sigmoid_hw(z);
   const float dz = dy * sg * (1.f + z * (1.f - sg));
   a += dz; b += dz * xh;
 }

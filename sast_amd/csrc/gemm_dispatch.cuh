@@ -35,17 +35,13 @@ using TileAutoThin = SAST_TILE_THIN;
 using TileAutoK2 = SAST_TILE_K2;
 using TileAutoK1 = SAST_TILE_K1;
 
-inline int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-inline bool gemm_pair_enabled() { static int v = env_int("SAST_GEMM_PAIR", 1); return v != 0; }
-inline int pair_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS", 768); return v; }
-inline int pair_ks_min_r() { static int v = env_int("SAST_KS_MINR", 256); return v; }
-inline int pair_thin_nb() { static int v = env_int("SAST_THIN_NB", 384); return v; }
-inline int pair_ks_nb() { static int v = env_int("SAST_KS_NB", 1000000); return v; }
+inline bool gemm_pair_enabled() { return SAST_KNOB("SAST_GEMM_PAIR", 1) != 0; }
+inline int pair_tn_blocks() { return SAST_KNOB("SAST_TN_BLOCKS", 768); }
+inline int pair_ks_min_r() { return SAST_KNOB("SAST_KS_MINR", 256); }
+inline int pair_thin_nb() { return SAST_KNOB("SAST_THIN_NB", 384); }
+inline int pair_ks_nb() { return SAST_KNOB("SAST_KS_NB", 1000000); }
 // 32x32 tiles with 8 k-groups when even the 32x64 tiling leaves more than half of the CUs idle (PAFPN level-32 convs, M = 960)
-inline int tiny_nb() { static int v = env_int("SAST_TINY_NB", 128); return v; }
+inline int tiny_nb() { return SAST_KNOB("SAST_TINY_NB", 128); }
 // (stand-alone launches only: as the dX job of a paired launch it measured slower, +0.02 ms/step)
 inline bool use_tiny(int M, int NJ, int R) { return (long)((M + 31) / 32) * ((NJ + 63) / 64) <= tiny_nb() && R >= 512; }
 
@@ -65,14 +61,14 @@ int gemm_auto(const LA& la, const LB& lb, const EP& ep, int M, int NJ, int R, hi
 // inside a paired launch the dW job shares the chip with the dX job: fewer, longer workgroups win (round 2, 4-wave split-R tile under the operand split: 192 measured best of 128 ... 512; round 1, 8-wave tile: 152; a target
 // that adapts to the dX job's grid size was not better)
 // the same for the k x k conv pairs (im2col / backward-data jobs)
-inline int pair_tn_blocks_conv() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_CONV", 192); return v; }
+inline int pair_tn_blocks_conv() { return SAST_KNOB("SAST_TN_BLOCKS_PAIRED_CONV", 192); }
 // and for the 1x1 conv pairs of the FPN / head (k_conv.hip)
-inline int pair_tn_blocks_1x1() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_1X1", 192); return v; }
-inline int pair_tn_blocks_paired() { static int v = env_int("SAST_TN_BLOCKS_PAIRED", 192); return v; }
+inline int pair_tn_blocks_1x1() { return SAST_KNOB("SAST_TN_BLOCKS_PAIRED_1X1", 192); }
+inline int pair_tn_blocks_paired() { return SAST_KNOB("SAST_TN_BLOCKS_PAIRED", 192); }
 // weight gradients of at most SAST_TN_SMALL_TILES output tiles (stage 1 / 2: 64x64 ... 128x128): every split adds its whole tile
 // atomically, a same-line chain of `splits` atomic instructions (~25 ns each) -- their own target (0 = the general one)
-inline int pair_tn_blocks_small() { static int v = env_int("SAST_TN_BLOCKS_PAIRED_SMALL", 0); return v; }
-inline int pair_tn_small_tiles() { static int v = env_int("SAST_TN_SMALL_TILES", 4); return v; }
+inline int pair_tn_blocks_small() { return SAST_KNOB("SAST_TN_BLOCKS_PAIRED_SMALL", 0); }
+inline int pair_tn_small_tiles() { return SAST_KNOB("SAST_TN_SMALL_TILES", 4); }
 
 // target: workgroups of the weight-gradient job (it is split over the reduction until it has about that many)
 inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
@@ -89,9 +85,9 @@ inline int tn_splits(int Mo, int NJ, int R, int target = 0) {
 // of tiles, no fill / drain per job -- and a job is split over the reduction into chunks of ~SAST_DW_ROWS_PER_SPLIT rows (long enough to
 // amortise a workgroup's prologue, fold and atomic tail; the group supplies the parallelism).  0: one launch per job, split into
 // ~SAST_TN_BLOCKS_DEFERRED workgroups.
-inline int deferred_tn_blocks() { static int v = env_int("SAST_TN_BLOCKS_DEFERRED", 384); return v; }
-inline bool dw_group_enabled() { static int v = env_int("SAST_DW_GROUP", 1); return v != 0; }
-inline int dw_rows_per_split() { static int v = env_int("SAST_DW_ROWS_PER_SPLIT", 512); return v; }
+inline int deferred_tn_blocks() { return SAST_KNOB("SAST_TN_BLOCKS_DEFERRED", 384); }
+inline bool dw_group_enabled() { return SAST_KNOB("SAST_DW_GROUP", 1) != 0; }
+inline int dw_rows_per_split() { return SAST_KNOB("SAST_DW_ROWS_PER_SPLIT", 512); }
 inline int dw_group_splits(int R) {
   const int rps = dw_rows_per_split() > 16 ? dw_rows_per_split() : 16;
   const int s = (R + rps / 2) / rps;

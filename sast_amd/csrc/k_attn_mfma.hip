@@ -732,8 +732,7 @@ __global__ __launch_bounds__(64 * BIGT) void attn_bwd_big_kv_kernel(const float*
 // 64 rows -- the masked off-diagonal score tiles double the MFMA work, and the number of workgroups was never the limiter) and are
 // kept as tools/experiments/r05_removed_experiments.patch.  SAST_ATTN_PACKS=<rows> overrides the budget (0: every group is its own pack).
 int attn_pack_limit(int T) {
-  static int lim = -1;
-  if (lim < 0) { const char* e = getenv("SAST_ATTN_PACKS"); lim = e ? atoi(e) : 32; }
+  const int lim = SAST_KNOB("SAST_ATTN_PACKS", 32);
   const int cap = T <= 64 ? 64 : (T <= 96 ? 96 : 128);      // what the kernels instantiated for T can hold (T > 128: no packs are used)
   return lim < cap ? lim : cap;
 }
@@ -784,8 +783,7 @@ int attn_bwd_mfma_launch(const float* qkv, const float* dout, const float* lse, 
   // SAST_ATTN_BWD_SPLIT (default 1): the two passes of the backward on 2 NTMAX waves side by side (attn_bwd_body_split; measured -0.7 ...
   // -1.5 % of the step on every configuration of the B = 8 sweep, B = 4 and B = 1, profiles/r04_z_ab_attn_bwd_split.txt); 0: one pass
   // after the other on NTMAX waves
-  static int split = -1;
-  if (split < 0) { const char* e = getenv("SAST_ATTN_BWD_SPLIT"); split = e ? atoi(e) : 1; }
+  const int split = SAST_KNOB("SAST_ATTN_BWD_SPLIT", 1);
   if (split && T <= 96) {      // (T > 96: eight waves of 256 registers spill -- those partitions keep the sequential form)
     const int wpb2 = T <= 64 ? 4 : 6, side2 = (2 * fC + wpb2 - 1) / wpb2;
     if (T <= 64) SAST_ATTN_LAUNCH("attn_bwd_mfma_kernel<2,split>", 10.0, 7.0, (attn_bwd_mfma_kernel<2, true>), dim3(W + side2, heads), dim3(256), qkv, dout, lse, dqkv, row_off, Kw, C, heads, scale, dh, W, a0, a1, fC);

@@ -131,8 +131,8 @@ struct EpLstm {  // rnn.py:57-67
   __device__ __forceinline__ Col col(int j) const { return Col{bias[j], bias[C + j], bias[2 * C + j], bias[3 * C + j]}; }
   __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{c0 ? c0[(size_t)m * C + j] : 0.f, drop ? drop[(size_t)m * C + j] : 1.f}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[4], const Col& k, const Aux& x) const {
-    const float f = sigmoid_exact(v[0] + k.bf), i = sigmoid_exact(v[1] + k.bi);
-    const float o = sigmoid_exact(v[2] + k.bo), g = tanhf(v[3] + k.bg);
+    const float f = sigmoid_hw(v[0] + k.bf), i = sigmoid_hw(v[1] + k.bi);
+    const float o = sigmoid_hw(v[2] + k.bo), g = tanhf(v[3] + k.bg);
     const float c = f * x.c + i * (g * x.d);
     c1[(size_t)m * C + j] = c;
     h1[(size_t)m * C + j] = o * tanhf(c);
@@ -302,8 +302,7 @@ int sast_score_stp_bwd(const SastScoreArgs* a, sast_stream_t stream) { SAST_ENTR
 
 // ------------------------------------------------------------------ MS-WSA
 size_t sast_mswsa_fused_ws_floats(int C, int inner, int T, int dim_head, int cb_tps) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("SAST_MSWSA_FUSED"); on = e ? atoi(e) : 1; }
+  const int on = SAST_KNOB("SAST_MSWSA_FUSED", 1);
   if (!on || !mswsa_fused_supported(C, inner, T, dim_head > 0 ? dim_head : 32, cb_tps)) return 0;
   return mswsa_fused_plane_floats(C, inner);
 }
@@ -348,8 +347,7 @@ int sast_mswsa_fwd(const SastMswsaArgs* a, sast_stream_t stream) { SAST_ENTRY();
     const LdRows la{a->Y, C, nullptr};
     const LdWeightNT lb{a->fc1_w, C, inner};
     const long nb = (long)((R + 63) / 64) * ((inner + 63) / 64);
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("SAST_GLU_TILE"); mode = e ? atoi(e) : 0; }
+    const int mode = SAST_KNOB("SAST_GLU_TILE", 0);
     auto fc1 = [&](auto ep) {
       if (mode && C >= 256 && nb <= 2 * pair_thin_nb()) return launch_gemm<TileG2K4>(la, lb, ep, R, inner, C, dR, nullptr, st);
       if (mode && C >= 256) return launch_gemm<TileG2K2>(la, lb, ep, R, inner, C, dR, nullptr, st);
@@ -502,8 +500,7 @@ int sast_lstm_fwd(const SastLstmArgs* a, sast_stream_t stream) { SAST_ENTRY();
   const LdRows2 la{a->x, C, C, a->h0, C};
   const LdWeightNT lb{a->w, 2 * C, C};
   const EpLstm ep{a->b, a->c0, a->h1, a->c1, a->gates, C, a->drop};
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("SAST_LSTM_TILE"); mode = e ? atoi(e) : 0; }
+  const int mode = SAST_KNOB("SAST_LSTM_TILE", 0);
   if (mode && Kred >= 256 && (long)((M + 63) / 64) * ((C + 31) / 32) <= 2 * pair_thin_nb())
     return launch_gemm<TileG4K4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);
   return launch_gemm<TileG4>(la, lb, ep, M, C, Kred, nullptr, nullptr, st);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJo
     const float4 mu = *(const float4*)(bn_sm + c), rs = *(const float4*)(bn_sm + C + c);
     float4 z = make_float4((v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z,
                            (v.w - mu.w) * rs.w * g.w + b.w);
-    z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
+    z.x *= sigmoid_hw(z.x); z.y *= sigmoid_hw(z.y); z.z *= sigmoid_hw(z.z); z.w *= sigmoid_hw(z.w);
     st4(y + m * ldy + c, z);
   }
 }
@@ -77,7 +77,7 @@ struct EpBnSilu {
   __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
     const float z = (v[0] - k.mu) * k.rs * k.g + k.b;
-    y[(size_t)m * ldy + j] = z * sigmoid_exact(z);
+    y[(size_t)m * ldy + j] = z * sigmoid_hw(z);
   }
 };
 // EpBnSilu for two convs evaluated as one GEMM over the stacked weights (columns [0, C) -> conv 0, [C, 2C) -> conv 1)
@@ -92,7 +92,7 @@ struct EpBnSilu2 {
   __device__ __forceinline__ Aux pre(int, int) const { return Aux{}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[1], const Col& k, const Aux&) const {
     const float z = (v[0] - k.mu) * k.rs * k.g + k.b;
-    (j < C ? y0 + (size_t)m * C + j : y1 + (size_t)m * C + (j - C))[0] = z * sigmoid_exact(z);
+    (j < C ? y0 + (size_t)m * C + j : y1 + (size_t)m * C + (j - C))[0] = z * sigmoid_hw(z);
   }
 };
 // forward batch statistics as a separate pass (alternative to the atomics in the conv epilogue): row-strip blocks,
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob 
         float* ap = &a.x; float* bp = &b.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float z = xh[e] * gg[e] + bb[e], sg = sigmoid_exact(z);
+          const float z = xh[e] * gg[e] + bb[e], sg = sigmoid_hw(z);
           const float dz = dd[e] * sg * (1.f + z * (1.f - sg));
           ap[e] += dz; bp[e] += dz * xh[e];
         }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
     for (int e = 0; e < 4; ++e) {
       const float mu = bsm[c + e], rs = bsm[C + c + e], g = bsm[2 * C + c + e];
       const float xh = ((&v.x)[e] - mu) * rs;
-      const float z = xh * g + bsm[3 * C + c + e], sg = sigmoid_exact(z);
+      const float z = xh * g + bsm[3 * C + c + e], sg = sigmoid_hw(z);
       const float dz = (&d.x)[e] * sg * (1.f + z * (1.f - sg));
       out[e] = training ? g * rs * (dz - bsm[4 * C + c + e] - xh * bsm[5 * C + c + e]) : g * rs * dz;
     }
@@ -334,8 +334,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 
 // (dz, dz * xhat) column sums of `njobs` convs of equal shape (blockIdx.y = job)
 void bn_bwd_reduce_launch(const BnBwdJob& j0, const BnBwdJob& j1, int njobs, int M, int C, hipStream_t st) {
-  static int target = -1;
-  if (target < 0) { const char* e = getenv("SAST_BN_BLOCKS"); target = e ? atoi(e) : 32; }
+  const int target = SAST_KNOB("SAST_BN_BLOCKS", 32);
   int rpb = (M + target - 1) / target;
   rpb = rpb < 8 ? 8 : (rpb > 512 ? 512 : rpb);
   const int c4n = C / 4, RP = BN_RED_THREADS / c4n > 0 ? BN_RED_THREADS / c4n : 1;
@@ -385,8 +384,7 @@ int conv_bwd_pair(const float* dconv, const float* x, const ConvGeom& g, int Cou
   const LdRowsT ta{dconv, Cout};
   const LdIm2colT tb{x, g};
   if (!dx) return gemm_tn(ta, tb, dw, K, Cout, K, M, st);
-  static int parity = -1;
-  if (parity < 0) { const char* e = getenv("SAST_CONVDX_PARITY"); parity = e ? atoi(e) : 1; }
+  const int parity = SAST_KNOB("SAST_CONVDX_PARITY", 1);
   const int Mc = g.B * (g.H / 2) * (g.W / 2);
   if (prod && prod->x) {   // stride-1 convs only (the caller checks): dX epilogue also reduces the producer's BatchNorm backward sums
     if (g.stride != 1 || lddx != g.Cin || prod->C != g.Cin) return SAST_EINVAL;
@@ -495,8 +493,7 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
   if (phase < 0 || phase > 2 || (phase == 2 && a->m_total < M)) return SAST_EINVAL;
   if (a->training && !a->bn_ws_zeroed && phase != 2) zero_fill(a->bn_ws, sizeof(float) * SAST_BN_WS_FLOATS(C), st);
   int rc = SAST_OK;
-  static int sep = -1;
-  if (sep < 0) { const char* e = getenv("SAST_BN_STATS_SEPARATE"); sep = e ? atoi(e) : 0; }
+  const int sep = SAST_KNOB("SAST_BN_STATS_SEPARATE", 0);
   const bool one = k == 1 && a->stride == 1;
   if (a->x2 && (!one || a->Cin1 % 4 || a->Cin1 <= 0 || a->Cin1 >= a->Cin)) return SAST_EINVAL;
   const LdRows2 la2{a->x, a->ldx, a->Cin1, a->x2, a->ldx2};    // virtual channel concat [x | x2]

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void dwconv_apply_kernel(const float* __restri
     const float4 mu = ld4(bn.mean + c), var = ld4(bn.var + c), ga = ld4(bn.gamma + c), be = ld4(bn.beta + c);
     float4 z = make_float4((acc.x - mu.x) * (1.0f / sqrtf(var.x + bn.eps)) * ga.x + be.x, (acc.y - mu.y) * (1.0f / sqrtf(var.y + bn.eps)) * ga.y + be.y,
                            (acc.z - mu.z) * (1.0f / sqrtf(var.z + bn.eps)) * ga.z + be.z, (acc.w - mu.w) * (1.0f / sqrtf(var.w + bn.eps)) * ga.w + be.w);
-    z.x *= sigmoid_exact(z.x); z.y *= sigmoid_exact(z.y); z.z *= sigmoid_exact(z.z); z.w *= sigmoid_exact(z.w);
+    z.x *= sigmoid_hw(z.x); z.y *= sigmoid_hw(z.y); z.z *= sigmoid_hw(z.z); z.w *= sigmoid_hw(z.w);
     acc = z;
   }
   st4(y + pix * C + c, acc);

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include "common.cuh"
 #include "../../include/sast_hip.h"
 
 namespace sast {
@@ -19,9 +20,7 @@ static std::vector<hipEvent_t> g_pending;
 bool prof_enabled() { return g_on; }
 
 bool xcd_remap_enabled() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SAST_XCD_REMAP"); v = e ? (atoi(e) != 0) : 1; }
-  return v != 0;
+  return SAST_KNOB("SAST_XCD_REMAP", 1) != 0;
 }
 
 void prof_record(const char* tag, int G, int M, int NJ, int R, const int* dM, const int* dR, hipStream_t st, bool begin) {

@@ -503,8 +503,7 @@ __global__ __launch_bounds__(ROWB) void ln_bwd_kernel(const float* __restrict__ 
 static inline int bwd_grid(int rows, int rpb) {
   // every block ends with one atomicAdd per channel per parameter-gradient vector: same-address float atomics serialise
   // at the memory side on MI355X, so the block count (not the row count) sets the tail -> keep it small
-  static int cap = -1;
-  if (cap < 0) { const char* e = getenv("SAST_LN_BLOCKS"); cap = e ? atoi(e) : 256; }
+  const int cap = SAST_KNOB("SAST_LN_BLOCKS", 256);
   int g = (rows + rpb - 1) / rpb;
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
@@ -656,7 +655,7 @@ __global__ __launch_bounds__(256) void stp_fwd_kernel(const float* __restrict__ 
       float inv = amp / cp[e];
       if (isinf(inv)) inv = 0.f;
       acc += (double)(inv * sp[e]);   // each product rounded to fp32 as in the reference, summed exactly-ish
-      xo[e] = (sigmoid_exact(cp[e]) * sigmoid_exact(sp[e])) * xo[e];
+      xo[e] = (sigmoid_hw(cp[e]) * sigmoid_hw(sp[e])) * xo[e];
     }
   }
   acc = group_reduce<GL>(acc, OpSum{});
@@ -683,7 +682,7 @@ __global__ __launch_bounds__(ROWB) void stp_bwd_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     ds[i] = zero4();
-    sc[i] = make_float4(sigmoid_exact(sc[i].x), sigmoid_exact(sc[i].y), sigmoid_exact(sc[i].z), sigmoid_exact(sc[i].w));
+    sc[i] = make_float4(sigmoid_hw(sc[i].x), sigmoid_hw(sc[i].y), sigmoid_hw(sc[i].z), sigmoid_hw(sc[i].w));
   }
   const int l0 = blockIdx.x * rows_per_block;
   const int l1 = min(L, l0 + rows_per_block);
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(ROWB) void stp_bwd_kernel(const float* __restrict__
       const float* cs = &sc[i].x; float* da = &ds[i].x;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float sg = sigmoid_exact(ss[e]);
+        const float sg = sigmoid_hw(ss[e]);
         const float gx = gs[e] * xs[e];
         dd[e] = ss[e] > 0.f ? gx * cs[e] * sg * (1.f - sg) : 0.f;
         da[e] += gx * sg;

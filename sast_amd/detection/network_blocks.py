@@ -72,6 +72,11 @@ def forward_sync_group(grp, convs, xs, arena, sole=False):
     ONE statistics all-reduce per direction for all of them (functional.conv_bn_silu_sync_group): the dependent chain of a multi-rank
     step counts collectives, not units.  -> one output per unit"""
     soles = sole if isinstance(sole, (tuple, list)) else (sole,) * len(convs)
+    if arena is None:
+        # units called on their own (a stand-alone CSPLayer.forward on a converted model: no PAFPN / head pass around them exchanged the
+        # sample counts of this batch): their own exchange, as BaseConv.forward_nhwc does -- never a stale ratio of an earlier pass
+        x0 = xs[0][0] if isinstance(xs[0], (tuple, list)) else xs[0]
+        grp.exchange_batch(x0.shape[0], x0.device)
     ys = SF.conv_bn_silu_sync_group(grp, [c.sync_item(x, arena, sole=s) for c, x, s in zip(convs, xs, soles)])
     for c in convs:
         if c.bn.num_batches_tracked is not None:
@@ -117,10 +122,10 @@ def pass_sync_group(module: nn.Module):
     (`module._sync_group`), else the one behind torch.nn.SyncBatchNorm modules left by torch's own conversion -- looked up when the
     module's first unit turns out to be converted (the conversion replaces every BatchNorm below a module, so one unit tells) and
     then installed on every unit below `module`."""
-    grp = module._sync_group
+    grp = getattr(module, "_sync_group", None)       # (a custom fpn / head without the attribute: nothing installed, torch's conversion below)
     if grp is None:
-        first = next((m for m in module.modules() if isinstance(m, BaseConv)), None)
-        if first is not None and isinstance(first.bn, nn.SyncBatchNorm):
+        units = [m for m in module.modules() if isinstance(m, BaseConv)]
+        if any(isinstance(m.bn, nn.SyncBatchNorm) for m in units):       # ANY converted unit: a partial conversion raises below, whichever unit comes first
             groups = {id(m.bn.process_group): m.bn.process_group for m in module.modules()
                       if isinstance(m, BaseConv) and isinstance(m.bn, nn.SyncBatchNorm)}
             if len(groups) != 1:
@@ -131,7 +136,8 @@ def pass_sync_group(module: nn.Module):
                     if not isinstance(m.bn, nn.SyncBatchNorm):
                         raise RuntimeError("sast_amd: only some BatchNorm modules of this PAFPN / head were converted to SyncBatchNorm")
                     m.sync_bn = grp
-            module._sync_group = grp
+            if hasattr(module, "_sync_group"):
+                module._sync_group = grp
     return grp
 
 

@@ -124,6 +124,12 @@ class _ParamGrads:
 
     def __init__(self, *params):
         self.bufs, self.ret = [], []
+        if AUTOGRAD_GRADS and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            # AccumulateGrad adds the returned gradients on the stream each node was CREATED on, not on the capture stream: a hipGraph
+            # captured around backward() in this mode replays garbage (measured, round 5).  Any capturing caller is refused, not only
+            # TrainStep.capture.
+            raise RuntimeError("sast_amd: the autograd-visible gradient mode (set_autograd_visible_grads / SAST_AUTOGRAD_GRADS=1) cannot run "
+                               "inside a stream capture: capture the backward in the in-place gradient mode")
         if not AUTOGRAD_GRADS:
             for p in params:
                 self.bufs.append(_g(p))
@@ -1007,9 +1013,21 @@ class SyncBatchNormGroup:
         self._comm = None           # the communicator the statistics travel on (see the class docstring); False = use self.group
         self.force = bool(force)
         self.n_collectives = 0
+        self._epoch = None          # identity of the default process group the cached world / communicator / ratio belong to
+
+    def _validate(self):
+        """destroy_process_group() + a new init_process_group() in the same process (Lightning fit -> test, the test suite) leaves this
+        object -- cached in `_SYNC_GROUPS`, installed on the modules -- with the world size, the private communicator and the sample
+        ratio of a group that no longer exists: drop them whenever the default group is gone or is another object (round-5 advice)"""
+        d = self.dist
+        cur = d.group.WORLD if d.is_initialized() else None
+        if cur is not self._epoch:
+            self._world = self._ratio = self._comm = None
+            self._epoch = cur
 
     @property
     def world(self) -> int:
+        self._validate()
         if self._world is None:
             if not self.dist.is_initialized():
                 return 1            # not cached: a later init_process_group must still switch the group on
@@ -1027,10 +1045,13 @@ class SyncBatchNormGroup:
         return self.dist.get_backend(self.group) == "nccl"
 
     def communicator(self):
-        """the process group the statistics all-reduces are issued on (created once, at the first eager collective)"""
+        """the process group the statistics all-reduces are issued on (created once, at the first eager collective).
+        SAST_SYNC_BN_PRIVATE_COMM=0: the gradient buckets' communicator (then the caller must order the side-stream bucket all-reduce
+        and the next segment's statistics all-reduces itself -- UNVERIFIED beyond one rank: no multi-GPU node was available to any round)"""
+        self._validate()
         if self._comm is None:
             d = self.dist
-            if d.get_backend(self.group) == "nccl":
+            if d.get_backend(self.group) == "nccl" and os.environ.get("SAST_SYNC_BN_PRIVATE_COMM", "1") != "0":
                 if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
                     raise RuntimeError("sast_amd: SyncBatchNormGroup needs one eager pass before a hipGraph capture (it creates the "
                                        "private RCCL communicator of the statistics all-reduces)")
@@ -1088,13 +1109,21 @@ class SyncBatchNormGroup:
             comm = self.communicator()
             if self.dist.get_backend(self.group) == "nccl":      # ncclGroupStart / End around the per-tensor calls: one launch
                 import warnings
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")          # (torch marks the coalesced entry point deprecated; ProcessGroupNCCL implements it)
-                    self.dist.all_reduce_coalesced(list(ts), group=comm)
-            else:                                            # host-side backends (gloo: the plumbing tests): one flat buffer
-                flat = torch.cat([t.reshape(-1) for t in ts])
-                self.dist.all_reduce(flat, group=comm)
-                torch._foreach_copy_([t.reshape(-1) for t in ts], list(flat.split([t.numel() for t in ts])))
+                coalesced = getattr(self.dist, "all_reduce_coalesced", None)      # deprecated in torch: may disappear
+                if coalesced is not None:
+                    try:
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")      # (torch marks the entry point deprecated; ProcessGroupNCCL implements it)
+                            coalesced(list(ts), group=comm)
+                        self.n_collectives += 1
+                        return
+                    except (AttributeError, NotImplementedError, TypeError):
+                        pass                                     # fall through to the flat buffer (capture-safe: cat, all_reduce, copies)
+            # host-side backends (gloo: the plumbing tests) and the fallback: one flat buffer (same dtype per call: the fp64 forward sums
+            # or the fp32 backward sums)
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            self.dist.all_reduce(flat, group=comm)
+            torch._foreach_copy_([t.reshape(-1) for t in ts], list(flat.split([t.numel() for t in ts])))
         self.n_collectives += 1
 
 

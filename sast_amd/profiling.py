@@ -168,6 +168,32 @@ def pmc_bytes_per_step():
         return None
 
 
+_KT_SUMMARY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "kernel_trace_latest.json")
+
+
+def kernel_trace_per_step():
+    """(kernel ms per step, dispatches per step, csrc stamp) of the committed rocprofv3 --kernel-trace summary of the headline step
+    (tools/rocpd_stats.py --json), or (None, None, None)"""
+    try:
+        with open(_KT_SUMMARY) as f:
+            d = json.load(f)
+        return float(d["kernel_ms_per_step"]), float(d["dispatches_per_step"]), d.get("csrc_sha")
+    except (OSError, ValueError, KeyError):
+        return None, None, None
+
+
+def library_launches_per_step(trainer, n: int = 2):
+    """kernel launches libsast_hip enqueues for ONE eager forward + backward (include/sast_hip.h: sast_launch_count; the optimizer's
+    launches and ATen's -- gradient clear, the loss's ones -- are not in it)"""
+    lib = L.lib()
+    trainer.fwd_bwd()
+    c0 = int(lib.sast_launch_count())
+    for _ in range(n):
+        trainer.fwd_bwd()
+    torch.cuda.synchronize()
+    return (int(lib.sast_launch_count()) - c0) / n
+
+
 def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=None, batch=None, seq_len: int = 1, pmc_applies: bool = True):
     """pmc_applies: the committed rocprofv3 --pmc summary (profiles/pmc_hbm_traffic_latest.json) was taken on THIS configuration (bench.py:
     the BASELINE configuration); otherwise `traffic` / `bytes_counter` are null -- counter bytes of another shape say nothing here"""
@@ -243,6 +269,7 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
             b_alg = (b_alg - once) * seq_len + once
         t_m, t_h = gflop / PEAK_F32_MFMA_TFLOPS, b_alg / (PEAK_HBM_TBS * 1e12) * 1e3      # ms
         b_cnt = pmc_bytes_per_step() if pmc_applies else None
+        kt_ms, kt_n, kt_sha = kernel_trace_per_step() if pmc_applies else (None, None, None)
         out["whole_step"] = {"gflop": gflop, "bytes_algorithmic": b_alg, "bytes_counter": b_cnt,
                              "bytes_counter_over_algorithmic": (b_cnt / b_alg) if b_cnt else None,
                              "t_mfma_ms": t_m, "t_hbm_ms": t_h, "t_roof_ms": max(t_m, t_h), "bound": "mfma" if t_m >= t_h else "hbm",
@@ -251,9 +278,16 @@ def dominant_kernel_roofline(trainer, n_steps: int = 3, ms_per_step=None, hw=Non
                              # 419.4 TFLOP/s of fp32-equivalent work) -- the stricter of the two fractions
                              "t_executed_pipe_ms": (gflop / (PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS)) if split3 else t_m,
                              "frac_of_executed_pipe": (max(gflop / (PEAK_BF16_MFMA_TFLOPS / SPLIT3_PRODUCTS), t_h) if split3 else max(t_m, t_h)) / ms_per_step,
+                             # the launch structure (round-5 verdict item 6): the step is a chain of dependent launches at their latency floor
+                             "kernel_ms_per_step": kt_ms, "dispatches_per_step": kt_n, "kernel_trace_csrc_sha": kt_sha,
+                             "kernel_trace_stale": (kt_sha != csrc_sha()) if kt_sha else None,
+                             "library_launches_fwd_bwd": library_launches_per_step(trainer),
                              "achieved_tflops": gflop / ms_per_step, "achieved_counter_tbs": (b_cnt / (ms_per_step * 1e-3) / 1e12) if b_cnt else None,
                              "note": "gflop: algorithmic 2*M*N*K of every GEMM / conv + 4*C*sum K_m^2 (x2.5 backward) of the attention launches, from "
                                      "device-side counts; bytes_algorithmic: SURVEY 8d rule (dense upper bound, backward = 2x forward, optimizer 28 B/param); "
                                      "bytes_counter: rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) per step of the HEADLINE configuration, valid when "
-                                     "traffic_stale is false; ms_per_step: one whole step (all timesteps of a sequence)"}
+                                     "traffic_stale is false; ms_per_step: one whole step (all timesteps of a sequence); kernel_ms_per_step / "
+                                     "dispatches_per_step: sum of kernel durations and dispatch count of one replayed step in the committed rocprofv3 "
+                                     "kernel trace (profiles/kernel_trace_latest.json, HEADLINE configuration); library_launches_fwd_bwd: launches "
+                                     "this library enqueued for one eager forward + backward, counted live"}
     return out

@@ -40,7 +40,11 @@ def scores_grads_close(prefix, gW, gb, rW, rb, records, rtol=None):
     hold x, z and g of every evaluation of this layer.  The elements with |z| < KINK_BAND * max|z| are taken OUT of the comparison on
     both sides: the reference loses the contributions of those it passed; the device's residual on a row must then be a 0/1
     combination of that row's ambiguous contributions (solved by least squares, rounded to {0, 1}) and is reduced by it.  What is
-    left is compared at the ordinary gradient tolerance.  The raw, unadjusted error is recorded as a diagnostic only."""
+    left is compared at the ordinary gradient tolerance.
+    The RAW, unadjusted error is capped too (round 6): element (c, i) of dWs may differ from the reference's by at most the sum of
+    |g * x_i| over the ambiguous elements of row c (what flipping every one of them could move it by) plus the ordinary tolerance, and
+    db likewise -- so the fit can only forgive what the kink itself can explain: a row without ambiguous elements sits at the plain
+    tolerance, and an error larger than the ambiguous contributions fails even where the 0/1 fit could have absorbed part of it."""
     from conftest import record_error
     rtol = GRAD_RTOL if rtol is None else rtol
     gW, gb = gW.detach().double().cpu(), gb.detach().double().cpu()
@@ -54,6 +58,16 @@ def scores_grads_close(prefix, gW, gb, rW, rb, records, rtol=None):
     amb = zs.abs() < KINK_BAND * float(zs.abs().max())
     n_amb = int(amb.sum())
     on = amb & (zs > 0)
+    # raw cap: |device - reference| <= sum over the row's ambiguous elements of |g x| (+ the ordinary tolerance), element by element
+    capW = (gs.abs() * amb).t() @ xs.abs()
+    capb = (gs.abs() * amb).sum(0)
+    rawW, rawb = (gW - rW).abs(), (gb - rb).abs()
+    overW, overb = float((rawW - capW).max()), float((rawb - capb).max())
+    record_error(_test_id(), prefix + "to_scores.weight [raw minus what the ambiguous elements can move]", max(overW, 0.0), scale_W, rtol)
+    assert overW <= rtol * scale_W + 1e-9, (f"{prefix}to_scores.weight: raw error exceeds what the {n_amb} ambiguous pre-activations can explain by "
+                                            f"{overW:.3e} (scale {scale_W:.3e}, rel {overW / scale_W:.2e} > {rtol:.1e})")
+    assert overb <= rtol * scale_b + 1e-9, (f"{prefix}to_scores.bias: raw error exceeds what the ambiguous pre-activations can explain by "
+                                            f"{overb:.3e} (scale {scale_b:.3e})")
     rW_off = rW - (gs * on).t() @ xs
     rb_off = rb - (gs * on).sum(0)
     gW_adj, gb_adj = gW.clone(), gb.clone()

@@ -1593,6 +1593,37 @@ def test_deferred_weight_gradients_match_monolithic(dev, segmented, cuts):
     assert float(dfrg.opt.lr_step[1]) == 4.0
 
 
+def test_knob_reload_reaches_the_launch_sites(dev, monkeypatch):
+    """sast_config_reload: a launch-shape knob changed in os.environ inside the process changes the NEXT launch (SAST_GEMM_PAIR=0 splits
+    the (dW || dX) pair of a conv backward into two launches: seen in the library's own launch profile) -- and back"""
+    from sast_amd import _lib as SL, functional as SF
+    from sast_amd.profiling import kernel_report
+    torch.manual_seed(0)
+    x = torch.randn(2, 16, 20, 32, device=dev, requires_grad=True)
+    w = (torch.randn(32, 32, 1, 1, device=dev) * 0.1).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bn_w, bn_b = torch.ones(32, device=dev, requires_grad=True), torch.zeros(32, device=dev, requires_grad=True)
+    rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
+
+    def steps(n):
+        for _ in range(n):
+            y = SF.conv_bn_silu(x, w, bn_w, bn_b, rm, rv, 1, 1, True)
+            y.sum().backward()
+
+    def names():
+        return " ".join(r["name"] for r in kernel_report(steps, 1))
+
+    monkeypatch.delenv("SAST_GEMM_PAIR", raising=False)
+    SL.reload_knobs()
+    assert "gemm_dual_kernel" in names()
+    monkeypatch.setenv("SAST_GEMM_PAIR", "0")
+    assert "gemm_dual_kernel" in names()          # not reloaded yet: the cached value is in use
+    SL.reload_knobs()
+    assert "gemm_dual_kernel" not in names() and SL.knobs()["SAST_GEMM_PAIR"] == 0
+    monkeypatch.delenv("SAST_GEMM_PAIR")
+    SL.reload_knobs()
+    assert "gemm_dual_kernel" in names()
+
+
 def _train_rig(dev, hw, part, E, chans, eps):
     from sast_amd.config import backbone_config
     from sast_amd.detection import RNNDetector, YOLOPAFPN

@@ -327,18 +327,20 @@ print("rank", rank, "ok", worst)
 '''
 
 
-def test_two_replicas_bucketed_allreduce_equals_averaged_single_process_gloo(tmp_path):
-    """SURVEY 8(e) parity for the data-parallel path, on CPU: 2 ranks (gloo), the REAL modules' parameters re-homed into the bucketed
+@pytest.mark.parametrize("world", [2, 8])
+def test_replicas_bucketed_allreduce_equals_averaged_single_process_gloo(tmp_path, world):
+    """SURVEY 8(e) parity for the data-parallel path, on CPU: 2 ranks, and the 8 ranks of BASELINE config C4 (bucket ranges, grad_scale =
+    1 / world and the bucket order have to hold there too) (gloo), the REAL modules' parameters re-homed into the bucketed
     flat buffers of training.TrainStep, per-rank gradients (oracle, rank-local BatchNorm statistics) injected into the flat views,
     per-bucket all-reduce + fused AdamW (OneCycleLR, clip by value)  ==  one process that evaluates both shards as independent replicas,
     averages the gradients and steps torch.optim.AdamW + torch OneCycleLR.  Three optimizer steps."""
     script = tmp_path / "ddp_worker.py"
     script.write_text(_DDP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29741", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2" if world == 2 else "1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29741 + world), str(script), ROOT], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def test_kink_aware_scores_gradient_comparison():
@@ -377,6 +379,11 @@ def test_kink_aware_scores_gradient_comparison():
     bad[9] += 2e-3 * float(rW.abs().max())                       # a row without ambiguous elements
     with pytest.raises(AssertionError):
         scores_grads_close("blk.", bad, db, rW, rb, rec)
+    bad = dW.clone()
+    bad[3] += 3.0 * s.grad[5, 3] * x[5]                          # more than flipping every ambiguous element of the row could move it
+    if float((2.0 * s.grad[5, 3] * x[5]).abs().max()) > 1e-3 * float(rW.abs().max()):
+        with pytest.raises(AssertionError, match="raw error exceeds"):
+            scores_grads_close("blk.", bad, db, rW, rb, rec)
     bad = dW.clone()
     bad[3] += 0.4 * s.grad[5, 3] * x[5]                          # a fractional (impossible) share of an ambiguous element
     if float((0.4 * s.grad[5, 3] * x[5]).abs().max()) > 1e-3 * float(rW.abs().max()):
@@ -450,22 +457,30 @@ assert torch.equal(c, torch.full((10,), 3.0 * tot, dtype=torch.float64))
 assert float(arena[6:10].abs().sum() + arena[14:30].abs().sum()) == 0.0      # nothing outside the blocks was touched
 g.all_reduce_many([a])
 assert g.n_collectives == 2 and float(a[0]) == tot * world
+# ragged per-rank sample counts (a label-sparse step keeps different numbers of samples per rank, modules/detection.py:161-171): every
+# BatchNorm of the pass sees rows = samples of ALL ranks x (H_out * W_out)
+n_local = rank % 3 + 1
+tok = g.exchange_batch(n_local, torch.device("cpu"))
+n_total = sum(r % 3 + 1 for r in range(world))
+assert tok == (g, n_local) and g._ratio == (n_total, n_local) and g.n_collectives == 3
+assert g.rows_total(n_local * 48 * 80, n_local) == n_total * 48 * 80
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
 
 
-def test_sync_batchnorm_group_one_collective_for_independent_units_gloo_world2(tmp_path):
-    """SyncBatchNorm with several ranks: the statistics blocks of INDEPENDENT units (CSPLayer.conv1 / conv2, the YOLOX head's levels and
+@pytest.mark.parametrize("world", [2, 8])
+def test_sync_batchnorm_group_one_collective_for_independent_units_gloo(tmp_path, world):
+    """SyncBatchNorm with several ranks (2, and the 8 of BASELINE config C4): the statistics blocks of INDEPENDENT units (CSPLayer.conv1 / conv2, the YOLOX head's levels and
     towers) travel in one collective (`SyncBatchNormGroup.all_reduce_many`; host-side backends: one flat buffer, RCCL: the coalesced
     all-reduce) -- every block summed over the ranks, nothing around them touched, one call counted."""
     script = tmp_path / "worker.py"
     script.write_text(_SYNC_MANY_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29737", str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29737 + world), str(script), ROOT], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert r.stdout.count("ok") == 2
+    assert r.stdout.count("ok") == world
 
 
 def test_torch_sync_batchnorm_conversion_is_honoured_not_silently_local():
@@ -615,3 +630,59 @@ def test_struct_sizes_and_offsets_match_a_c_compiler(tmp_path):
         st = getattr(_lib, n)
         assert C.sizeof(st) == int(size), (n, C.sizeof(st), size)
         assert [getattr(st, f).offset for f, _t in st._fields_] == [int(o) for o in offs], n
+
+
+def test_library_knobs_registry_and_reload(monkeypatch):
+    """include/sast_hip.h sast_config_*: the SAST_* tuning knobs are read through one registry; a value changed in os.environ inside the
+    process is seen after reload_knobs() (round-4 / round-5 advice: knobs latched at first use ignored in-process toggling silently)"""
+    from sast_amd import _lib as SL
+    lib = SL.lib()
+    monkeypatch.delenv("SAST_TN_BLOCKS", raising=False)
+    SL.reload_knobs()
+    assert lib.sast_config_get(b"SAST_TN_BLOCKS", 768) == 768
+    monkeypatch.setenv("SAST_TN_BLOCKS", "123")
+    n = SL.reload_knobs()
+    assert n >= 1
+    assert lib.sast_config_get(b"SAST_TN_BLOCKS", 768) == 123
+    assert SL.knobs()["SAST_TN_BLOCKS"] == 123
+    monkeypatch.delenv("SAST_TN_BLOCKS")
+    SL.reload_knobs()
+    assert lib.sast_config_get(b"SAST_TN_BLOCKS", 768) == 768
+
+
+def test_deferred_weight_gradient_queue_is_off_and_empty_by_default():
+    """include/sast_hip.h sast_dw_*: deferral is opt-in (training.TrainStep(defer_dw=True) owns the flush); the switch returns its
+    previous setting, nothing is parked without a backward call, flush / discard of an empty queue are no-ops (no GPU needed)"""
+    from sast_amd import _lib as SL, functional as SF
+    lib = SL.lib()
+    assert lib.sast_dw_pending() == 0
+    assert SF.dw_defer(True, 0, 16000) is False and SF._DW_DEFER
+    assert SF.dw_defer(False) is True and not SF._DW_DEFER
+    assert lib.sast_dw_defer(0) == 0
+    assert lib.sast_dw_discard() == 0 and lib.sast_dw_flush(None) == 0 and lib.sast_dw_pending() == 0
+    SF._dw_hold(("x",))
+    assert not SF._DW_HOLD           # nothing is held while deferral is off
+
+
+def test_sync_group_forgets_a_destroyed_process_group():
+    """functional.SyncBatchNormGroup is cached per process group (`sync_group_for`) and installed on the modules: after
+    destroy_process_group() + a new init_process_group() in the same process it must not keep the world size, the private communicator or
+    the sample ratio of the dead group (round-5 advice)"""
+    import torch.distributed as dist
+    from sast_amd.functional import sync_group_for
+    assert not dist.is_initialized()
+    g = sync_group_for(None)
+    assert g.world == 1 and g._world is None                  # nothing cached while no group exists
+    try:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1)
+        assert g.world == 1 and g._world == 1
+        g._world, g._ratio, g._comm = 5, (20, 4), object()    # what a 5-rank group would have left behind
+        dist.destroy_process_group()
+        assert g.world == 1 and g._world is None and g._ratio is None and g._comm is None
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29534", rank=0, world_size=1)
+        g._world = 5                                          # (stale value written behind the validation's back)
+        g._epoch = object()
+        assert g.world == 1
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
