@@ -177,7 +177,7 @@ int gemm_pair_ep(const LA1& la1, const LB1& lb1, const EP1& ep1, int Mo, int NJ1
     if (k2) return launch_gemm<TileAutoK2>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
     return launch_gemm<TileAutoK1>(la2, lb2, ep2, M2, NJ2, R2, dM2, nullptr, st);
   }
-  if (thin)
+  if (thin)      // (round 6: the 4-k-group dW tile beside a thin dX job -- the launch already pays its 72 KB of LDS -- measured +4.5 %: profiles/r06_f)
     return launch_gemm_dual<TileSplitR, LA1, LB1, EP1, TileAutoThin, LA2, LB2, EP2>(la1, lb1, ep1, Mo, NJ1, R1, dR1, splits, colsum, la2, lb2,
                                                                                       ep2, M2, NJ2, R2, dM2, st);
   if (k2)

@@ -1448,8 +1448,11 @@ def test_sequence_gather_vs_golden(golden_dir, dev):
     assert all(float(h.abs().max()) == 0.0 for h, _ in st.get_states(0))
 
 
-def test_label_sparse_sequence_step(dev):
-    """the model part of the reference's training step (modules/detection.py:139-177): L = 3 timesteps with carried states, labels
+@pytest.mark.parametrize("defer_dw", [False, True], ids=["paired", "deferred-dw"])
+def test_label_sparse_sequence_step(dev, defer_dw):
+    """(deferred-dw: the same with the weight-gradient jobs parked and flushed on the side stream, training.TrainStep(defer_dw=True) --
+    BPTT accumulates several timesteps' jobs into the same gradients, the head and the sample gather take part)
+    the model part of the reference's training step (modules/detection.py:139-177): L = 3 timesteps with carried states, labels
     on a subset of the (timestep, sample) pairs, the labelled features gathered into ONE PAFPN + head + SimOTA call, BPTT through
     everything -- losses, kept-token counts and every gradient against the oracle run the same way; then a second sequence that
     starts from the saved (detached) states with sample 1 reset."""
@@ -1467,7 +1470,7 @@ def test_label_sparse_sequence_step(dev):
     load_params(net, bp)
     load_params(fpn, fp)
     load_params(head, hp)
-    ts = TrainStep(net, fpn, head, lr=0.0, segmented=True)          # lr 0: the parameters stay put, gradients are what is compared
+    ts = TrainStep(net, fpn, head, lr=0.0, segmented=True, defer_dw=defer_dw)          # lr 0: the parameters stay put, gradients are what is compared
     xs = [O.count_events(B, hw, seed=70 + t, density=0.05) for t in range(L)]
     indices = [[0, 2], [], [1, 2, 0]]
     labels = O.synthetic_labels(5, hw, nc, max_labels=5, seed=64)
@@ -1701,8 +1704,10 @@ def test_graph_replay_matches_eager(dev):
         maxnorm_close(gr[2].grad, eager[k][1], (1e-4, 1e-3, 3e-3)[k - 1], f"flat gradient after {k} updates, replay vs eager")
 
 
-def test_training_step_with_every_optional_config_branch_as_hipgraphs(dev):
-    """the config branches no shipped YAML uses, all at once, through the product's training step: mlp_activation silu, drop_path, drop_mlp,
+@pytest.mark.parametrize("defer_dw", [False, True], ids=["paired", "deferred-dw"])
+def test_training_step_with_every_optional_config_branch_as_hipgraphs(dev, defer_dw):
+    """(deferred-dw: the same step with its weight gradients parked and flushed per segment on the side stream, one flush graph per segment)
+    the config branches no shipped YAML uses, all at once, through the product's training step: mlp_activation silu, drop_path, drop_mlp,
     cell_update_dropout and a depth-wise ConvLSTM in the backbone (downsampling without overlap / affine), depthwise PAFPN and head, the YOLOX
     loss -- first eagerly, then captured as segmented hipGraphs (the random masks are drawn by torch's graph-safe generator INSIDE the
     graphs: every replay sees fresh ones) and replayed.  No reference numbers here (each branch is pinned alone by its fixture): the
@@ -1722,7 +1727,7 @@ def test_training_step_with_every_optional_config_branch_as_hipgraphs(dev):
     head = YOLOXHead(num_classes=2, strides=(8, 16, 32), in_channels=chans, depthwise=True).to(dev)
     for m in (net, fpn, head):
         m.train()
-    ts = TrainStep(net, fpn, head, lr=2e-3, weight_decay=0.0, clip_value=1.0, eps=1e-3, segmented=True)
+    ts = TrainStep(net, fpn, head, lr=2e-3, weight_decay=0.0, clip_value=1.0, eps=1e-3, segmented=True, defer_dw=defer_dw, cuts=(3, 2) if defer_dw else (3,))
     xs = [O.count_events(2, hw, seed=21, density=0.05).to(dev)]
     labels = O.synthetic_labels(2, hw, 2, max_labels=4, seed=22)
     labels[:, 0, :] = torch.tensor([1.0, 70.0, 60.0, 50.0, 40.0])
