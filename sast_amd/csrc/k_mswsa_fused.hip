@@ -128,7 +128,9 @@ struct WStreamT {
   // stream is padded by RING tiles.  hipcc does not count an asm load: the vmcnt waits here are the only ones the ring has.
   __device__ __forceinline__ Split3 take() {
     const Split3 cur = pre;
+#ifndef SAST_FUSED_PROBE_NO_RING_WAIT     // (timing probe only, round 6: WRONG results -- does the ring's vmcnt wait also wait for the saved-activation stores?)
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (RG - 2)) : "memory");
+#endif
     pre = read(next + 1);
     issue<3>(next + RG);
     ++next;
