@@ -107,6 +107,10 @@ class TrainStep:
         """xs: the event tensors of the sequence (one timestep = BASELINE's metric).  labels None: proxy objective
         sum_k mean(out_k^2) on the PAFPN outputs of the last timestep; else the YOLOX / SimOTA loss on `labels`, with
         `indices` (per timestep the batch indices that carry labels, modules/detection.py:161-171) or on the last timestep."""
+        if self.defer_dw and SF.dw_pending():
+            # a backward of an earlier step died between parking and flushing: its jobs point at buffers that are gone -- never run them
+            SF.dw_discard()
+            SF.dw_release()
         self.flat.zero_grad()
         single = len(xs) == 1 and self.segmented
         feats_seq, Ps = [], []

@@ -9,7 +9,7 @@ timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/r06_z_pytest.t
 cp $O/parity_errors.json $O/r06_z_parity_errors.json
 bash tools/refresh_profiles.sh > $O/r06_z_refresh.log 2>&1
 timeout 1500 python tools/sparsity_sweep.py --pmc > $O/r06_z_sparsity_sweep.txt 2>&1
-SAST_SYNC_BN_FORCE=1 timeout 300 python bench.py --sync-bn --steps 100 --warmup 20 --no-cpu-baseline --no-roofline > $O/r06_z_sync_bn_one_rank_captured.json 2> $O/r06_z_sync_bn_one_rank.err
+SAST_SYNC_BN_FORCE=1 timeout 300 python bench.py --sync-bn --steps 100 --warmup 20 --no-cpu-baseline --no-roofline 2> $O/r06_z_sync_bn_one_rank.err | tail -1 > $O/r06_z_sync_bn_one_rank_captured.json
 # N > 1 plumbing on the one GPU over gloo (rank count proven by an all-reduce of ones; not a rate): 2 ranks, and the 8 ranks of BASELINE config C4
 SAST_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/r06_z_two_ranks_gloo_one_gpu.json
 SAST_DIST_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29618 bench.py --gpus 8 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>$O/r06_z_eight_ranks.err | tail -1 > $O/r06_z_eight_ranks_gloo_one_gpu.json
