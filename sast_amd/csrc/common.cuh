@@ -115,13 +115,43 @@ __device__ __forceinline__ float group_sum(float v) { return group_reduce<G>(v, 
 
 // THE sigmoid of the library (SiLU, LSTM gates, STP weights, the silu / sigmoid GLU gates): on the hardware exp2 path
 // (v_exp_f32 is 1 ulp; the x*log2e pre-multiply adds ~|x|*6e-8 relative) -- measured inside the fp32 parity bars everywhere it is used
-__device__ __forceinline__ float sigmoid_hw(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// Round 6: the IEEE division behind `1.0f / x` is ~20 VALU instructions on gfx950 (v_div_scale / v_rcp / 4 x fma / v_div_fmas / v_div_fixup);
+// the gate / activation epilogues evaluate one or more per output element and are VALU-bound there (the 4-gate LSTM epilogue: ~140
+// instructions per cell with libm's tanhf, MFMA pipe 12 % busy).  v_rcp_f32 is 1 ulp -- two orders of magnitude inside the fp32 parity
+// bars.  -DSAST_FAST_DIV=0 restores the divisions and libm's tanhf (A/B builds).
+#ifndef SAST_FAST_DIV
+#define SAST_FAST_DIV 1
+#endif
+__device__ __forceinline__ float rcp_hw(float x) {
+#if SAST_FAST_DIV
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+__device__ __forceinline__ float rsqrt_hw(float x) {       // v_rsq_f32 (1 ulp)
+#if SAST_FAST_DIV
+  return __builtin_amdgcn_rsqf(x);
+#else
+  return 1.0f / sqrtf(x);
+#endif
+}
+__device__ __forceinline__ float sigmoid_hw(float x) { return rcp_hw(1.0f + __expf(-x)); }
+// tanh on the same path: 1 - 2 / (1 + e^{2x}) (saturates correctly: e = inf -> 1, e = 0 -> -1; absolute error <= 1.2e-7, the ulp of the
+// 1 it is subtracted from -- libm's tanhf is ~37 instructions with branches)
+__device__ __forceinline__ float tanh_hw(float x) {
+#if SAST_FAST_DIV
+  return 1.0f - 2.0f * rcp_hw(1.0f + __expf(2.0f * x));
+#else
+  return tanhf(x);
+#endif
+}
 
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level) instead of libm's branchy erff:
 // the GLU epilogues evaluate it for every (token, inner channel) and were VALU-bound on erff.
 __device__ __forceinline__ float erf_as(float x) {
   const float ax = fabsf(x);
-  const float t = 1.0f / fmaf(0.3275911f, ax, 1.0f);
+  const float t = rcp_hw(fmaf(0.3275911f, ax, 1.0f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
   p = fmaf(p, t, 1.421413741f);
   p = fmaf(p, t, -0.284496736f);
@@ -153,8 +183,8 @@ __device__ __forceinline__ float glu_act(float g, int act, float a = 0.0f) {
     case 1: return fmaxf(g, 0.0f);
     case 2: return g * sigmoid_hw(g);
     case 3: return sigmoid_hw(g);
-    case 4: return tanhf(g);
-    case 5: return g * tanhf(softplus_t20(g));
+    case 4: return tanh_hw(g);
+    case 5: return g * tanh_hw(softplus_t20(g));
     case 6: return fminf(fmaxf(g, 0.0f), 6.0f);
     case 7: return g > 0.0f ? g : 0.01f * g;
     case 8: return g > 0.0f ? g : expm1f(g);
@@ -171,8 +201,8 @@ __device__ __forceinline__ float glu_act_grad(float g, int act, float a = 0.0f) 
     case 1: return g > 0.0f ? 1.0f : 0.0f;                  // torch: relu'(0) = 0
     case 2: { const float s = sigmoid_hw(g); return s * (1.0f + g * (1.0f - s)); }
     case 3: { const float s = sigmoid_hw(g); return s * (1.0f - s); }
-    case 4: { const float t = tanhf(g); return 1.0f - t * t; }
-    case 5: { const float t = tanhf(softplus_t20(g)); return t + g * (1.0f - t * t) * (1.0f / (1.0f + expf(-g))); }
+    case 4: { const float t = tanh_hw(g); return 1.0f - t * t; }
+    case 5: { const float t = tanh_hw(softplus_t20(g)); return t + g * (1.0f - t * t) * (1.0f / (1.0f + expf(-g))); }
     case 6: return (g > 0.0f && g < 6.0f) ? 1.0f : 0.0f;    // hardtanh_backward: 0 at and beyond both ends
     case 7: return g > 0.0f ? 1.0f : 0.01f;
     case 8: return g > 0.0f ? 1.0f : expf(g);

@@ -132,10 +132,10 @@ struct EpLstm {  // rnn.py:57-67
   __device__ __forceinline__ Aux pre(int m, int j) const { return Aux{c0 ? c0[(size_t)m * C + j] : 0.f, drop ? drop[(size_t)m * C + j] : 1.f}; }
   __device__ __forceinline__ void post(int m, int j, const float (&v)[4], const Col& k, const Aux& x) const {
     const float f = sigmoid_hw(v[0] + k.bf), i = sigmoid_hw(v[1] + k.bi);
-    const float o = sigmoid_hw(v[2] + k.bo), g = tanhf(v[3] + k.bg);
+    const float o = sigmoid_hw(v[2] + k.bo), g = tanh_hw(v[3] + k.bg);
     const float c = f * x.c + i * (g * x.d);
     c1[(size_t)m * C + j] = c;
-    h1[(size_t)m * C + j] = o * tanhf(c);
+    h1[(size_t)m * C + j] = o * tanh_hw(c);
     float* gp = gates + (size_t)m * 4 * C + j;
     st_saved(gp, f); st_saved(gp + C, i); st_saved(gp + 2 * C, o); st_saved(gp + 3 * C, g);     // the gates: read by the backward only
   }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_pointwise_kernel(const float* __
   const size_t m = fast_div((int)e, C, c_mul); const int j = (int)(e - m * C);   // n < 2^31 (launcher)
   const float* gp = gates + m * 4 * C + j;
   const float f = gp[0], i = gp[C], o = gp[2 * C], g = gp[3 * C];
-  const float tc = tanhf(c1[e]);
+  const float tc = tanh_hw(c1[e]);
   const float dh = dh1[e] + (dh1b ? dh1b[e] : 0.f);   // h1 may have been handed out twice (next stage and FPN): the gradients are summed here
   const float dc = (dc1 ? dc1[e] : 0.f) + dh * o * (1.f - tc * tc);
   const float cp = c0 ? c0[e] : 0.f;

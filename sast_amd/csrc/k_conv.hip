@@ -16,12 +16,16 @@ namespace {
 // copies, added here); every block derives (mean, rstd) of all channels into LDS once and then streams `iters` x 256
 // float4 of the image; block 0 also publishes (mean, rstd) for the backward and updates the running statistics (torch
 // BatchNorm2d semantics: momentum, unbiased variance).  eval: running statistics.
+inline double bn_unbias(long M) { return M > 1 ? (double)M / (double)(M - 1) : 1.0; }
 struct BnFwdJob {
   const float* x; const double* sums; float* run_mean; float* run_var; float* stats; const float* gamma; const float* beta;
   float* y; int ldy; float momentum, eps;
 };
 // blockIdx.y selects the job: one conv, or the two convs of sast_conv_bn_silu2 (same M, C)
-__global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJob j1, int M, size_t n4, int C, int training, int iters,
+// invM = 1 / rows behind the sums, unbias = M / (M - 1) (1 for M = 1), both from the host: every block recomputes the statistics of all C
+// channels in front of its element pass, so a double division or square root there is latency of all 28 launches of a PAFPN step (round 6:
+// three v_div_f64 sequences and a v_sqrt_f64 + reciprocal per channel became two multiplications and one v_rsq_f32)
+__global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJob j1, double invM, double unbias, size_t n4, int C, int training, int iters,
                                                             unsigned c4_mul) {
   const BnFwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const double* __restrict__ sums = jb.sums;
@@ -35,13 +39,17 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJo
       double s = 0.0, q = 0.0;
 #pragma unroll
       for (int k = 0; k < BN_STAT_COPIES; ++k) { s += sums[(size_t)k * 2 * C + c]; q += sums[(size_t)k * 2 * C + C + c]; }
-      const double mean = s / M;
-      double var = q / M - mean * mean;
+      const double mean = s * invM;
+      double var = q * invM - mean * mean;
       if (var < 0) var = 0;
       mu = (float)mean;
+#if SAST_FAST_DIV
+      rs = rsqrt_hw((float)var + eps);
+#else
       rs = (float)(1.0 / sqrt(var + (double)eps));
+#endif
       if (blockIdx.x == 0 && run_mean) {
-        const double unb = M > 1 ? var * M / (M - 1) : var;
+        const double unb = var * unbias;
         run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
       }
@@ -546,7 +554,8 @@ int sast_conv_bn_silu_fwd(const SastConvBnArgs* a, sast_stream_t stream) { SAST_
   {
     const BnFwdJob jb{a->conv_out, sums, a->run_mean, a->run_var, a->stats, a->bn_w, a->bn_b, a->y, a->ldy, a->momentum, a->eps};
     SAST_LAUNCH(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 1), dim3(256), sizeof(float) * 2 * C, st,
-                       jb, jb, phase == 2 ? a->m_total : M, n4, C, a->training, iters, div_mul_of((unsigned)(C / 4), n4));
+                       jb, jb, 1.0 / (double)(phase == 2 ? a->m_total : M), bn_unbias(phase == 2 ? a->m_total : M), n4, C, a->training, iters,
+                       div_mul_of((unsigned)(C / 4), n4));
   }
   SAST_CHECK_LAUNCH();
   return SAST_OK;
@@ -649,7 +658,7 @@ int sast_conv_bn_silu2_fwd(const SastConvBn2Args* a, sast_stream_t stream) { SAS
   const BnFwdJob j0{a->conv_out0, (const double*)a->bn_ws0, a->run_mean0, a->run_var0, a->stats0, a->bn_w0, a->bn_b0, a->y0, C, a->momentum0, a->eps0};
   const BnFwdJob j1{a->conv_out1, (const double*)a->bn_ws1, a->run_mean1, a->run_var1, a->stats1, a->bn_w1, a->bn_b1, a->y1, C, a->momentum1, a->eps1};
   SAST_LAUNCH(bn_silu_apply_kernel, dim3((unsigned)((n4 + 256 * iters - 1) / (256 * iters)), 2), dim3(256), sizeof(float) * 2 * C, st, j0, j1,
-                     M, n4, C, 1, iters, div_mul_of((unsigned)(C / 4), n4));
+                     1.0 / (double)M, bn_unbias(M), n4, C, 1, iters, div_mul_of((unsigned)(C / 4), n4));
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }

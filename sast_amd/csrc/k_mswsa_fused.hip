@@ -200,7 +200,7 @@ __device__ __forceinline__ void ln_token(Tile (&x)[CT], const float* __restrict_
       x[ct][e] = d0; x[ct][e + 1] = d1; x[ct][e + 2] = d2; x[ct][e + 3] = d3;
       ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
     }
-  rstd = 1.0f / sqrtf(pair_sum(ss) * INV + eps);
+  rstd = rsqrt_hw(pair_sum(ss) * INV + eps);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
     float wv[16], bv[16];
@@ -264,7 +264,7 @@ __device__ __forceinline__ void ln1_unkept(const FwdArgs& a, const float* __rest
     float4 x = v[it];
     const float mean = group_sum<GL>((x.x + x.y) + (x.z + x.w)) * (1.0f / C);
     x.x -= mean; x.y -= mean; x.z -= mean; x.w -= mean;
-    const float rstd = 1.0f / sqrtf(group_sum<GL>((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w)) * (1.0f / C) + a.eps);
+    const float rstd = rsqrt_hw(group_sum<GL>((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w)) * (1.0f / C) + a.eps);
     if (act) {
       st4(a.out + row[it] * C + 4 * gl, make_float4(x.x * rstd * w.x + bb.x, x.y * rstd * w.y + bb.y, x.z * rstd * w.z + bb.z, x.w * rstd * w.w + bb.w));
       if (a.mean1 && gl == 0) { a.mean1[row[it]] = mean; a.rstd1[row[it]] = rstd; }
@@ -396,7 +396,7 @@ __device__ __forceinline__ void fwd_body(const FwdArgs& a, const float* __restri
         ploc += pt;
       }
     const float psum = pair_sum(ploc);
-    const float inv = 1.0f / psum;
+    const float inv = rcp_hw(psum);
     if (save && hf == 0) a.lse[crow_g * H + h] = m + logf(psum);
     Tile o = tzero(), o2 = tzero();                     // O^T[d][i], over two accumulator chains
 #pragma unroll

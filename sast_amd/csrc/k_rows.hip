@@ -377,7 +377,7 @@ __device__ __forceinline__ void ln_row(float4 (&v)[VPL], const float4 (&gm)[VPL]
 #pragma unroll
   for (int i = 0; i < VPL; ++i) ss += (d[i].x * d[i].x + d[i].y * d[i].y) + (d[i].z * d[i].z + d[i].w * d[i].w);
   ss = group_sum<GL>(ss);
-  rstd = 1.0f / sqrtf(ss * (1.0f / IO::C) + eps);
+  rstd = rsqrt_hw(ss * (1.0f / IO::C) + eps);
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     v[i].x = d[i].x * rstd * gm[i].x + bt[i].x; v[i].y = d[i].y * rstd * gm[i].y + bt[i].y;
