@@ -1088,7 +1088,41 @@ __host__ __device__ inline int small_div_mul(int d) { return 65536 / d + 1; }
 // with a select.  (A predicated `cond ? ld4(p) : 0` becomes an exec-masked branch around the global_load; hipcc then
 // cannot count outstanding loads across the join and emits s_waitcnt vmcnt(0) at the top of every k-loop phase, which
 // serialised the two-tile prefetch -- seen in the ISA of the first version of this kernel.)
-__device__ __forceinline__ float4 sel4(bool ok, float4 v) { return ok ? v : zero4(); }
+// Round 6 (SAST_ZERO_PAGE): an invalid slot used to read a CLAMPED in-bounds address and was replaced by zeros with a select at the
+// LDS store (4 v_cndmask per float4, 11-16 % of the k-loop's VALU instructions, plus the clamps).  Now it reads a 16-byte page of
+// zeros instead: the validity decides the ADDRESS (one 64-bit select), the loaded value needs no select.  Still branch-free.
+#ifndef SAST_ZERO_PAGE
+#define SAST_ZERO_PAGE 1
+#endif
+static __device__ __attribute__((aligned(16))) float sast_zero_page[4];        // device globals are zero-initialised
+// the load of one slot: `valid` is the address of a slot whose flag is set (it may be out of bounds when the flag is not),
+// `clamped` the always-in-bounds address of the older form
+__device__ __forceinline__ float4 ldz(bool ok, const float* valid, const float* clamped) {
+#if SAST_ZERO_PAGE
+  (void)clamped;
+  return ld4(ok ? valid : sast_zero_page);
+#else
+  (void)ok; (void)valid;
+  return ld4(clamped);
+#endif
+}
+__device__ __forceinline__ float ldz1(bool ok, const void* valid, const void* clamped) {     // the 4-byte form (uint8 event tensors)
+#if SAST_ZERO_PAGE
+  (void)clamped;
+  return *reinterpret_cast<const float*>(ok ? valid : (const void*)sast_zero_page);
+#else
+  (void)ok; (void)valid;
+  return *reinterpret_cast<const float*>(clamped);
+#endif
+}
+__device__ __forceinline__ float4 sel4(bool ok, float4 v) {
+#if SAST_ZERO_PAGE
+  (void)ok;
+  return v;
+#else
+  return ok ? v : zero4();
+#endif
+}
 #define SAST_DEFAULT_FINISH \
   __device__ __forceinline__ float4 finish(float4 v, float, bool ok) const { return sel4(ok, v); }
 
@@ -1104,7 +1138,7 @@ struct LdRows {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(c.row + (ok ? r : 0));
+    v = ldz(ok, c.row + r, c.row + (ok ? r : 0));
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1123,7 +1157,7 @@ struct LdRows2 {
     const bool second = r >= R1;
     ok = c.ok && r < Reff && (!second || p2 != nullptr);
     const float* q = second ? c.b : c.a;
-    v = ld4(ok ? q + r : c.a);
+    v = ldz(ok, q + r, ok ? q + r : c.a);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1139,7 +1173,7 @@ struct LdRowsT {
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(p + (size_t)min(r, Reff - 1) * ld + c.i);
+    v = ldz(ok, p + (size_t)r * ld + c.i, p + (size_t)min(r, Reff - 1) * ld + c.i);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1152,7 +1186,7 @@ struct LdRowsTG {  // gathered rows: row(r) = idx[r] (a dependent load per k-til
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{j < NJ ? j : 0, j < NJ}; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(p + (size_t)idx[min(r, Reff - 1)] * ld + c.i);
+    { const float* q = p + (size_t)idx[min(r, Reff - 1)] * ld + c.i; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1169,7 +1203,7 @@ struct LdRowsT2 {  // dual source along j (for d[W_x | W_h])
   __device__ __forceinline__ Ctx prep(int i, int Ieff) const { return prep(i, 0, Ieff); }   // as the A operand
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(c.base + (size_t)min(r, Reff - 1) * c.ld);
+    v = ldz(ok, c.base + (size_t)r * c.ld, c.base + (size_t)min(r, Reff - 1) * c.ld);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1185,7 +1219,7 @@ struct LdWeightNT {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(c.row + (ok ? r : 0));
+    v = ldz(ok, c.row + r, c.row + (ok ? r : 0));
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1203,7 +1237,7 @@ struct LdWeightNT2 {
   }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(c.row + (ok ? r : 0));
+    v = ldz(ok, c.row + r, c.row + (ok ? r : 0));
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1216,7 +1250,7 @@ struct LdWeightNN {
   __device__ __forceinline__ Ctx prep(int j, int, int NJ) const { return Ctx{w + (j < NJ ? j : 0), j < NJ}; }
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     ok = c.ok && r < Reff;
-    v = ld4(c.col + (size_t)min(r, Reff - 1) * ldw);
+    v = ldz(ok, c.col + (size_t)r * ldw, c.col + (size_t)min(r, Reff - 1) * ldw);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1231,7 +1265,7 @@ struct LdWeightNN2 {
     ok = c.ok && r < Reff;
     const int rr = min(r, Reff - 1);
     const float* row = rr < R1 ? w1 + (size_t)rr * ldw : w2 + (size_t)(rr - R1) * ldw;   // address select, not a branch
-    v = ld4(row + c.j);
+    v = ldz(ok, row + c.j, row + c.j);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1245,11 +1279,11 @@ struct LdWeightNNS {
   __device__ __forceinline__ void load(const Ctx& c, int r, int Reff, float4& v, float& aux, bool& ok) const {
     const int rr = min(r, Reff - 1);
     ok = c.ok && r < Reff;
-    v = ld4(c.col + (size_t)rr * ldw);
+    v = ldz(ok, c.col + (size_t)rr * ldw, c.col + (size_t)rr * ldw);
     aux = rscale[rr];
   }
   __device__ __forceinline__ float4 finish(float4 v, float aux, bool ok) const {
-    return ok ? make_float4(v.x * aux, v.y * aux, v.z * aux, v.w * aux) : zero4();
+    return sel4(ok, make_float4(v.x * aux, v.y * aux, v.z * aux, v.w * aux));        // (zero page: v is already zero where !ok, aux is a clamped, finite load)
   }
 };
 
@@ -1288,7 +1322,7 @@ struct LdIm2col {
     const int iy = c.iy0 + kh, ix = c.ix0 + kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
-    v = ld4(c.img + ((size_t)cy * g.W + cx) * g.ldx + ch);
+    { const float* q = c.img + ((size_t)cy * g.W + cx) * g.ldx + ch; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1316,7 +1350,7 @@ struct LdIm2colQ8 {
     const int iy = c.iy0 + kh, ix = c.ix0 + kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
-    v.x = *reinterpret_cast<const float*>(c.img + ((size_t)cy * g.W + cx) * g.ldx + ch);
+    { const unsigned char* q = c.img + ((size_t)cy * g.W + cx) * g.ldx + ch; v.x = ldz1(ok, q, q); }
     aux = 0.f;
   }
   __device__ __forceinline__ float4 finish(float4 v, float, bool ok) const { return sel4(ok, widen_u8x4(v.x)); }
@@ -1338,7 +1372,7 @@ struct LdIm2colTQ8 {
     const int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
-    v.x = *reinterpret_cast<const float*>(x + ((size_t)(b * g.H + cy) * g.W + cx) * g.ldx + c.c);
+    { const unsigned char* q = x + ((size_t)(b * g.H + cy) * g.W + cx) * g.ldx + c.c; v.x = ldz1(ok, q, q); }
     aux = 0.f;
   }
   __device__ __forceinline__ float4 finish(float4 v, float, bool ok) const { return sel4(ok, widen_u8x4(v.x)); }
@@ -1356,7 +1390,7 @@ struct LdIm2colU : LdIm2col {
     const int iy = c.iy0 + kh, ix = c.ix0 + kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r0 < Reff && (g.replicate || (cy == iy && cx == ix));
-    v = ld4(c.img + ((size_t)cy * g.W + cx) * g.ldx + ch0 + off);
+    { const float* q = c.img + ((size_t)cy * g.W + cx) * g.ldx + ch0 + off; v = ldz(ok, q, q); }
     aux = 0.f;
   }
 };
@@ -1378,7 +1412,7 @@ struct LdIm2colT {
     const int iy = oy * g.stride - g.pad + c.kh, ix = ox * g.stride - g.pad + c.kw;
     const int cy = min(max(iy, 0), g.H - 1), cx = min(max(ix, 0), g.W - 1);
     ok = c.ok && r < Reff && (g.replicate || (cy == iy && cx == ix));
-    v = ld4(x + ((size_t)(b * g.H + cy) * g.W + cx) * g.ldx + c.c);
+    { const float* q = x + ((size_t)(b * g.H + cy) * g.W + cx) * g.ldx + c.c; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1411,7 +1445,7 @@ struct LdConvDx {
     int oy, ox;
     const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
     ok = c.ok && r < Reff && vy && vx;
-    v = ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co);
+    { const float* q = c.img + ((size_t)oy * g.Wo + ox) * lddy + co; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1425,7 +1459,7 @@ struct LdConvDxU : LdConvDx {   // Cout a multiple of the k-tile: uniform tap, s
     int oy, ox;
     const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
     ok = c.ok && r0 < Reff && vy && vx;
-    v = ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co0 + off);
+    { const float* q = c.img + ((size_t)oy * g.Wo + ox) * lddy + co0 + off; v = ldz(ok, q, q); }
     aux = 0.f;
   }
 };
@@ -1439,7 +1473,7 @@ struct LdWeightConvDx {
     const int rr = min(r, Reff - 1);
     const int tap = (int)__umulhi((unsigned)rr, cout_mul), co = rr - tap * Cout;
     ok = c.ok && r < Reff;
-    v = ld4(c.col + ((size_t)co * taps + tap) * Cin);
+    { const float* q = c.col + ((size_t)co * taps + tap) * Cin; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1451,7 +1485,7 @@ struct LdWeightConvDxU : LdWeightConvDx {   // Cout a multiple of the k-tile: th
     const int rc = min(r0, Reff - bk);
     const int tap = (int)__umulhi((unsigned)rc, cout_mul), co0 = rc - tap * Cout;
     ok = c.ok && r0 < Reff;
-    v = ld4(c.col + ((size_t)co0 * taps + tap) * Cin + (size_t)off * (taps * Cin));
+    { const float* q = c.col + ((size_t)co0 * taps + tap) * Cin + (size_t)off * (taps * Cin); v = ldz(ok, q, q); }
     aux = 0.f;
   }
 };
@@ -1466,7 +1500,7 @@ struct LdWeightConvDx2 {
     const int tap = (int)__umulhi((unsigned)rr, cout_mul), co = rr - tap * Cout;
     ok = c.ok && r < Reff;
     const float* row = co < C1 ? w0 + ((size_t)co * taps + tap) * Cin : w1 + ((size_t)(co - C1) * taps + tap) * Cin;   // address select
-    v = ld4(row + c.j);
+    v = ldz(ok, row + c.j, row + c.j);
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1521,7 +1555,7 @@ struct LdConvDxP {
     int oy, ox;
     const bool vy = src(c.iy, kh, g.Ho, oy), vx = src(c.ix, kw, g.Wo, ox);
     ok = c.ok && r < Reff && vy && vx;
-    v = ld4(c.img + ((size_t)oy * g.Wo + ox) * lddy + co);
+    { const float* q = c.img + ((size_t)oy * g.Wo + ox) * lddy + co; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
@@ -1544,7 +1578,7 @@ struct LdWeightConvDxP {
     const int kh = (c.kh >> (4 * slot)) & 15, kw = (c.kw >> (4 * slot)) & 15;
     const bool empty = kh == 15 || kw == 15;
     ok = c.ok && r < Reff && !empty;
-    v = ld4(c.col + ((size_t)co * taps + (empty ? 0 : kh * KW + kw)) * Cin);
+    { const float* q = c.col + ((size_t)co * taps + (empty ? 0 : kh * KW + kw)) * Cin; v = ldz(ok, q, q); }
     aux = 0.f;
   }
   SAST_DEFAULT_FINISH
