@@ -61,6 +61,36 @@ unsigned knob_generation();
 #define SAST_CHAIN_PRIO()
 #endif
 
+// Round 6: kernel-argument warm-up.  hipcc sinks the scalar loads of by-value struct arguments next to their uses, behind the early-exit
+// branches: the prologue of a GEMM workgroup is a chain of ~7 `s_load -> s_waitcnt lgkmcnt(0)` round trips (seen in the ISA), and the
+// first touch of every 64-byte line of the kernel-argument segment is a scalar-cache miss -- paid by the first wave of every CU, i.e. by
+// every workgroup of a one-wave-per-CU launch, one line after the other.  kernarg_warm<BYTES>() requests the lines of the kernel's OWN
+// EXPLICIT arguments (BYTES = sum of their sizes: never past the segment) with back-to-back scalar loads at kernel entry: one miss
+// latency instead of one per line.  Measured -1.3 % of the step (profiles/r06_s).  SAST_KERNARG_WARM: most lines warmed (0 = off; 8
+// measured neutral: lines nobody reads cost what they save).
+#ifndef SAST_KERNARG_WARM
+#define SAST_KERNARG_WARM 5
+#endif
+template <int BYTES>
+__device__ __forceinline__ void kernarg_warm() {
+#if SAST_KERNARG_WARM > 0
+  constexpr int LINES_IN = BYTES >= 4 ? (BYTES - 4) / 64 + 1 : 0;                   // lines whose first dword lies inside the explicit arguments
+  constexpr int LINES = LINES_IN < SAST_KERNARG_WARM ? LINES_IN : SAST_KERNARG_WARM;
+  if constexpr (LINES >= 2) {                                                      // a single line is one round trip either way
+    using cptr = const __attribute__((address_space(4))) unsigned*;
+    cptr ka = (cptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < LINES; ++i) acc |= ka[16 * i];
+    asm volatile("" :: "s"(acc));
+  }
+#endif
+}
+// explicit-argument bytes of a kernel from its own type (padding ignored: an underestimate)
+template <class F> struct KernargBytes;
+template <class... A> struct KernargBytes<void (*)(A...)> { static constexpr int value = (0 + ... + (int)sizeof(A)); };
+#define SAST_KERNARG_WARM_SELF(...) kernarg_warm<KernargBytes<decltype(&__VA_ARGS__)>::value>()
+
 namespace sast {
 
 constexpr int WAVE = 64;

@@ -833,6 +833,7 @@ __global__ __launch_bounds__(T::NT, T::MINW) void gemm_kernel(LA la, LB lb, EP e
                                                               const int* __restrict__ dM, const int* __restrict__ dR,
                                                               float* __restrict__ colsum, int nsplit, int xcd_remap) {
   __shared__ __attribute__((aligned(16))) float smem[GemmSmem<T, LA, LB>::FLOATS];
+  kernarg_warm<(int)(sizeof(LA) + sizeof(LB) + sizeof(EP) + 3 * sizeof(int) + 3 * sizeof(void*) + 2 * sizeof(int))>();
   SAST_CHAIN_PRIO();
   int nmain = gridDim.x;
   if constexpr (EpHasSide<EP>::value) {
@@ -857,6 +858,7 @@ __global__ __launch_bounds__((J1::T::NT > J2::T::NT ? J1::T::NT : J2::T::NT)) vo
   constexpr int F1 = GemmSmem<typename J1::T, typename J1::LA, typename J1::LB>::FLOATS;
   constexpr int F2 = GemmSmem<typename J2::T, typename J2::LA, typename J2::LB>::FLOATS;
   __shared__ __attribute__((aligned(16))) float smem[F1 > F2 ? F1 : F2];
+  kernarg_warm<(int)(sizeof(J1) + sizeof(J2) + sizeof(int))>();
   SAST_CHAIN_PRIO();
   if ((int)blockIdx.x < n1) {
     SAST_TL_JOB(1);

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(64 * NTMAX * (SPLIT ? 2 : 1), SPLIT ? (NTMAX == 2 ?
                                                                    const int* __restrict__ row_off, const int* __restrict__ Kw,
                                                                    int C, int heads, float scale, int dh, int W,
                                                                    LsFinish f0, LsFinish f1, int fC) {
+  SAST_KERNARG_WARM_SELF(attn_bwd_mfma_kernel<NTMAX, SPLIT>);
   __shared__ __attribute__((aligned(16))) char sm[4 * 3 * 32 * NTMAX * 64 + 2 * 32 * NTMAX * 4];
   SAST_CHAIN_PRIO();
   if (blockIdx.x >= W) {   // side workgroups: the LayerScale'd fc2 / proj gradient finish of the same MS-WSA layer (independent work
@@ -575,6 +576,7 @@ __global__ __launch_bounds__(64 * BIGT) void attn_bwd_big_q_kernel(const float* 
                                                                    const float* __restrict__ lse, float* __restrict__ dqkv,
                                                                    float* __restrict__ dbuf, const int* __restrict__ row_off,
                                                                    const int* __restrict__ Kw, int C, int heads, float scale, int dh) {
+  SAST_KERNARG_WARM_SELF(attn_bwd_big_q_kernel);
   __shared__ __attribute__((aligned(16))) char sm[2 * BIG_MAT];
   const int g = blockIdx.x, h = blockIdx.y;
   const int K = Kw[g];
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(64 * BIGT) void attn_bwd_big_kv_kernel(const float*
                                                                     const float* __restrict__ dbuf, const int* __restrict__ row_off,
                                                                     const int* __restrict__ Kw, int C, int heads, float scale, int dh, int W,
                                                                     LsFinish f0, LsFinish f1, int fC) {
+  SAST_KERNARG_WARM_SELF(attn_bwd_big_kv_kernel);
   __shared__ __attribute__((aligned(16))) char sm[2 * BIG_MAT + 2 * 32 * BIGT * 4];
   if (blockIdx.x >= W) {
     if (blockIdx.y == 0) {

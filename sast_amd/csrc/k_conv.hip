@@ -27,6 +27,7 @@ struct BnFwdJob {
 // three v_div_f64 sequences and a v_sqrt_f64 + reciprocal per channel became two multiplications and one v_rsq_f32)
 __global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJob j1, double invM, double unbias, size_t n4, int C, int training, int iters,
                                                             unsigned c4_mul) {
+  SAST_KERNARG_WARM_SELF(bn_silu_apply_kernel);
   const BnFwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const double* __restrict__ sums = jb.sums;
   float* __restrict__ run_mean = jb.run_mean; float* __restrict__ run_var = jb.run_var; float* __restrict__ stats = jb.stats;
@@ -153,6 +154,7 @@ __device__ __forceinline__ float4 bn_ld_dy(const float* __restrict__ dy, const f
   return d;
 }
 __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob j0, BnBwdJob j1, int M, int C, int rows_per_block) {
+  SAST_KERNARG_WARM_SELF(bn_bwd_reduce_kernel);
   const BnBwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const float* __restrict__ stats = jb.stats; const float* __restrict__ gamma = jb.gamma;
   const float* __restrict__ beta = jb.beta; const float* __restrict__ dy = jb.dy; const int lddy = jb.lddy;
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob 
 // block 0 also publishes the affine gradients.
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob j1, size_t n4, int C, float invM, int training, int iters,
                                                            unsigned c4_mul) {
+  SAST_KERNARG_WARM_SELF(bn_bwd_apply_kernel);
   const BnBwdJob& jb = blockIdx.y == 0 ? j0 : j1;
   const float* __restrict__ x = jb.x; const float* __restrict__ stats = jb.stats; const float* __restrict__ gamma = jb.gamma;
   const float* __restrict__ beta = jb.beta; const float* __restrict__ dy = jb.dy; const int lddy = jb.lddy;
@@ -304,6 +307,7 @@ struct OneCycle { int on; double initial_lr, max_lr, min_lr, end1, end2; };
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, size_t n4, const float* __restrict__ lr_step, double b1d,
                                                     double b2d, float eps, float wd, float gscale, float clip, OneCycle oc) {
+  SAST_KERNARG_WARM_SELF(adamw_kernel);
   // bias corrections in DOUBLE from the double betas, once per workgroup: torch.optim.AdamW evaluates 1 - beta**step with python
   // doubles; 1 - powf(0.999f, t) loses ~1e-5 relative at small t (cancellation, and 0.999f itself is off by 1.3e-8)
   __shared__ float s_bc[3];

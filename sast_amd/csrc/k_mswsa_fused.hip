@@ -509,6 +509,7 @@ __device__ __forceinline__ void barriers_only() {
 // NTW = ceil(T / 32) waves (1Mpx T = 60: two, Gen1 T = 80: three)
 template <int C, int INNER, int NTW>
 __global__ __launch_bounds__(64 * NTW, 2) void mswsa_fused_fwd_kernel(FwdArgs a) {
+  SAST_KERNARG_WARM_SELF(mswsa_fused_fwd_kernel<C, INNER, NTW>);
   using V = Vec<C, INNER>;
   __shared__ __attribute__((aligned(16))) char ring_s[NTW * RING * TILE_BYTES];
   __shared__ __attribute__((aligned(16))) char xk[NTW * XTILE_BYTES];

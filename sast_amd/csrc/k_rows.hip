@@ -465,6 +465,7 @@ __global__ __launch_bounds__(ROWB) void ln_bwd_kernel(const float* __restrict__ 
                                                      const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                      const float* __restrict__ rstd_i, float* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+  SAST_KERNARG_WARM_SELF(ln_bwd_kernel<GL, VPL>);
   using IO = RowIO<GL, VPL>;
   extern __shared__ float red[];
   const int gl = threadIdx.x % GL;
@@ -536,6 +537,7 @@ __global__ __launch_bounds__(256) void ln1_gather_fwd_kernel(const float* __rest
                                                              float* __restrict__ mean1, float* __restrict__ rstd1,
                                                              float* __restrict__ mean2, float* __restrict__ rstd2,
                                                              int rows, float eps, float* __restrict__ zero_ptr, size_t zero_n4) {
+  SAST_KERNARG_WARM_SELF(ln1_gather_fwd_kernel<GL, VPL>);
   using IO = RowIO<GL, VPL>;
   // side job: clear the accumulators the backward of this layer will add into (saves a launch there)
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < zero_n4; i += (size_t)gridDim.x * 256) st4(zero_ptr + 4 * i, zero4());
@@ -569,6 +571,7 @@ __global__ __launch_bounds__(ROWB) void ln1_gather_bwd_kernel(const float* __res
                                                              const float* __restrict__ mean2, const float* __restrict__ rstd2,
                                                              float* __restrict__ dxin, float* __restrict__ dg1, float* __restrict__ db1,
                                                              float* __restrict__ dg2, float* __restrict__ db2, int rows) {
+  SAST_KERNARG_WARM_SELF(ln1_gather_bwd_kernel<GL, VPL>);
   using IO = RowIO<GL, VPL>;
   extern __shared__ float red[];
   const int gl = threadIdx.x % GL;
@@ -672,6 +675,7 @@ __global__ __launch_bounds__(ROWB) void stp_bwd_kernel(const float* __restrict__
                                                       const float* __restrict__ scale, const float* __restrict__ g,
                                                       float* __restrict__ direct, float* __restrict__ dz,
                                                       float* __restrict__ dscale, int L, int rows_per_block) {
+  SAST_KERNARG_WARM_SELF(stp_bwd_kernel<GL, VPL>);
   using IO = RowIO<GL, VPL>;
   extern __shared__ float red[];
   const int gl = threadIdx.x % GL;

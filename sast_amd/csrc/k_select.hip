@@ -58,6 +58,7 @@ constexpr int SEL_WAVES = 16;   // windows per workgroup (one wave each)
 template <int SLOTS>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float* __restrict__ tok, PartMap pm, int L, float thr_win,
                                                                      float thr_tok, SelPair sp) {
+  SAST_KERNARG_WARM_SELF(select_mask_kernel<SLOTS>);
   pm.mode = sp.mode[blockIdx.y];
   int* __restrict__ win_keep = sp.o[blockIdx.y].win_keep;
   unsigned long long* __restrict__ mask = sp.o[blockIdx.y].mask;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(64 * SEL_WAVES) void select_mask_kernel(const float
 // publishes the totals.
 template <int SLOTS>
 __global__ __launch_bounds__(64 * SEL_WAVES) void select_fill_kernel(PartMap pm, int L, int W, int B, int pack_limit, SelPair sp) {
+  SAST_KERNARG_WARM_SELF(select_fill_kernel<SLOTS>);
   pm.mode = sp.mode[blockIdx.y];
   const SelOut& o = sp.o[blockIdx.y];
   const int* __restrict__ win_keep = o.win_keep;
