@@ -790,32 +790,44 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
   float cs[T::TJ], cq[T::TJ];
 #pragma unroll
   for (int tj = 0; tj < T::TJ; ++tj) { cs[tj] = 0.f; cq[tj] = 0.f; }
+  // Round 6: a workgroup whose tile lies inside the output takes a copy of the element loop WITHOUT the bounds predicate.  Predicated, an
+  // element costs 11 instructions (v_or, v_cmp, s_and, s_and_saveexec, s_cbranch_execz, a 64-bit v_mad for m * ldc, the arithmetic, a 64-bit
+  // add, the store, s_or exec) and a branch; without it the compiler strength-reduces the row addresses and issues the 16 stores of a tile
+  // back to back.  The epilogue of a small GEMM is ~0.6 us of pure instruction issue (tools/gemm_timeline.py).
+  auto emit = [&](auto inside) {
+    constexpr bool INSIDE = decltype(inside)::value;
 #pragma unroll
-  for (int ta = 0; ta < T::TM; ++ta)
+    for (int ta = 0; ta < T::TM; ++ta)
 #pragma unroll
-    for (int tj = 0; tj < T::TJ; ++tj) {
-      const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
-      const int jc = min(j, NJ - 1);
-      const int mb = m0 + wm * T::WTM + ta * 32 + 4 * (lane >> 5);
-      const typename EP::Col col = ecol[tj];
-      typename EP::Aux aux[16];
+      for (int tj = 0; tj < T::TJ; ++tj) {
+        const int j = j0 + (wn * T::TJ + tj) * 32 + (lane & 31);
+        const int jc = INSIDE ? j : min(j, NJ - 1);
+        const int mb = m0 + wm * T::WTM + ta * 32 + 4 * (lane >> 5);
+        const typename EP::Col col = ecol[tj];
+        typename EP::Aux aux[16];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        if constexpr (EARLY_AUX) aux[reg] = eaux[reg];
-        else aux[reg] = ep.pre(min(mb + (reg & 3) + 8 * (reg >> 2), Meff - 1), jc);
-      }
+        for (int reg = 0; reg < 16; ++reg) {
+          if constexpr (EARLY_AUX) aux[reg] = eaux[reg];
+          else aux[reg] = ep.pre(INSIDE ? mb + (reg & 3) + 8 * (reg >> 2) : min(mb + (reg & 3) + 8 * (reg >> 2), Meff - 1), jc);
+        }
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int m = mb + (reg & 3) + 8 * (reg >> 2);
-        if (m < Meff && j < NJ) {
-          float v[G];
+        for (int reg = 0; reg < 16; ++reg) {
+          const int m = mb + (reg & 3) + 8 * (reg >> 2);
+          if (INSIDE || (m < Meff && j < NJ)) {
+            float v[G];
 #pragma unroll
-          for (int g = 0; g < G; ++g) v[g] = acc[ta][tj * G + g][reg];
-          ep.post(m, j, v, col, aux[reg]);
-          if constexpr (STATS) ep.stat(v[0], col, aux[reg], cs[tj], cq[tj]);
+            for (int g = 0; g < G; ++g) v[g] = acc[ta][tj * G + g][reg];
+            ep.post(m, j, v, col, aux[reg]);
+            if constexpr (STATS) ep.stat(v[0], col, aux[reg], cs[tj], cq[tj]);
+          }
         }
       }
-    }
+  };
+#ifndef SAST_EPILOGUE_INSIDE
+#define SAST_EPILOGUE_INSIDE 1
+#endif
+  if (SAST_EPILOGUE_INSIDE && m0 + BM <= Meff && j0 + BJ <= NJ) emit(std::true_type{});      // block-uniform
+  else emit(std::false_type{});
   if constexpr (STATS) {
 #pragma unroll
     for (int tj = 0; tj < T::TJ; ++tj) {

@@ -248,42 +248,52 @@ __global__ __launch_bounds__(256) void bn_publish_affine_kernel(const float* __r
   dgamma[c] += s2;
 }
 // ---------------------------------------------------------------- upsample / concat
+// IDX: unsigned when every element index fits 32 bits (the launcher checks): a 64-bit integer division is ~120 VALU instructions on
+// gfx950, a 32-bit one ~35, and the index decode below has five of them IN FRONT of the first load (round 6: 517 instructions before the
+// first vector memory operation of a 6 us kernel)
+template <class IDX>
 __global__ __launch_bounds__(256) void upsample_cat_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                float* __restrict__ out, int H, int W, int C1, int C2, size_t n4) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) return;
-  const int Ct = C1 + C2, c4n = Ct / 4;
-  const size_t row = e / c4n; const int c = (int)(e % c4n) * 4;
+  const size_t e64 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e64 >= n4) return;
+  const IDX e = (IDX)e64;
+  const int Ct = C1 + C2;
+  const IDX c4n = (IDX)(Ct / 4);
+  const IDX row = e / c4n; const int c = (int)(e - row * c4n) * 4;
   float4 v;
   if (c < C1) {
-    const int W2 = 2 * W, H2 = 2 * H;
-    const int x = (int)(row % W2); const size_t t = row / W2; const int y = (int)(t % H2); const size_t bb = t / H2;
-    v = ld4(a + ((bb * H + (y >> 1)) * W + (x >> 1)) * C1 + c);
+    const IDX W2 = (IDX)(2 * W), H2 = (IDX)(2 * H);
+    const IDX t = row / W2; const int x = (int)(row - t * W2); const IDX bb = t / H2; const int y = (int)(t - bb * H2);
+    v = ld4(a + (((size_t)bb * H + (y >> 1)) * W + (x >> 1)) * C1 + c);
   } else {
-    v = ld4(b + row * C2 + (c - C1));
+    v = ld4(b + (size_t)row * C2 + (c - C1));
   }
-  st4(out + row * Ct + c, v);
+  st4(out + (size_t)row * Ct + c, v);
 }
 // backward of upsample + concat in one launch: elements [0, n4) reduce the 2x2 children of the upsampled half into da, elements
 // [n4, n4 + n4b) copy the other half of the channels into db
+template <class IDX>
 __global__ __launch_bounds__(256) void upsample_cat_bwd_kernel(const float* __restrict__ dout, float* __restrict__ da, float* __restrict__ db,
                                                                int H, int W, int C1, int Ct, size_t n4, size_t n4b) {
-  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n4) {
-    const size_t eb = e - n4;
-    if (eb >= n4b) return;
-    const int C2 = Ct - C1, c4b = C2 / 4;
-    const size_t row = eb / c4b; const int c = (int)(eb % c4b) * 4;
-    st4(db + row * C2 + c, ld4(dout + row * Ct + C1 + c));
+  const size_t e64 = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e64 >= n4) {
+    const size_t eb64 = e64 - n4;
+    if (eb64 >= n4b) return;
+    const IDX eb = (IDX)eb64;
+    const int C2 = Ct - C1;
+    const IDX c4b = (IDX)(C2 / 4);
+    const IDX row = eb / c4b; const int c = (int)(eb - row * c4b) * 4;
+    st4(db + (size_t)row * C2 + c, ld4(dout + (size_t)row * Ct + C1 + c));
     return;
   }
-  const int c4n = C1 / 4;
-  const size_t row = e / c4n; const int c = (int)(e % c4n) * 4;
-  const int x = (int)(row % W); const size_t t = row / W; const int y = (int)(t % H); const size_t bb = t / H;
-  const size_t base = ((bb * 2 * H + 2 * y) * 2 * W + 2 * x);
+  const IDX e = (IDX)e64;
+  const IDX c4n = (IDX)(C1 / 4);
+  const IDX row = e / c4n; const int c = (int)(e - row * c4n) * 4;
+  const IDX t = row / (IDX)W; const int x = (int)(row - t * (IDX)W); const IDX bb = t / (IDX)H; const int y = (int)(t - bb * (IDX)H);
+  const size_t base = (((size_t)bb * 2 * H + 2 * y) * 2 * W + 2 * x);
   const float4 p = ld4(dout + base * Ct + c), q = ld4(dout + (base + 1) * Ct + c);
   const float4 r = ld4(dout + (base + 2 * W) * Ct + c), s = ld4(dout + (base + 2 * W + 1) * Ct + c);
-  st4(da + row * C1 + c, make_float4((p.x + q.x) + (r.x + s.x), (p.y + q.y) + (r.y + s.y), (p.z + q.z) + (r.z + s.z), (p.w + q.w) + (r.w + s.w)));
+  st4(da + (size_t)row * C1 + c, make_float4((p.x + q.x) + (r.x + s.x), (p.y + q.y) + (r.y + s.y), (p.z + q.z) + (r.z + s.z), (p.w + q.w) + (r.w + s.w)));
 }
 // copy a channel slice: dst[row, 0:Cs] = src[row*lds + off : +Cs]   (or the reverse with dst stride)
 __global__ __launch_bounds__(256) void slice_copy_kernel(const float* __restrict__ src, int lds, int soff, float* __restrict__ dst,
@@ -728,7 +738,8 @@ int sast_conv_bn_silu2_bwd(const SastConvBn2Args* a, sast_stream_t stream) { SAS
 int sast_upsample_cat_fwd(const float* a, const float* b, float* out, int B, int H, int W, int C1, int C2, sast_stream_t stream) { SAST_ENTRY();
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   const size_t n4 = (size_t)B * 4 * H * W * ((C1 + C2) / 4);
-  SAST_LAUNCH(upsample_cat_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
+  if (n4 < (1ull << 32)) SAST_LAUNCH(upsample_cat_fwd_kernel<unsigned>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
+  else SAST_LAUNCH(upsample_cat_fwd_kernel<size_t>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, H, W, C1, C2, n4);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
 }
@@ -736,7 +747,9 @@ int sast_upsample_cat_bwd(const float* dout, float* da, float* db, int B, int H,
   hipStream_t st = (hipStream_t)stream;
   if (C1 % 4 || C2 % 4) return SAST_EINVAL;
   const size_t n4 = (size_t)B * H * W * (C1 / 4), n4b = (size_t)B * 4 * H * W * (C2 / 4);
-  SAST_LAUNCH(upsample_cat_bwd_kernel, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, st, dout, da, db, H, W, C1, C1 + C2, n4,
+  if (n4 + n4b < (1ull << 32)) SAST_LAUNCH(upsample_cat_bwd_kernel<unsigned>, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, st, dout, da, db, H, W, C1, C1 + C2, n4,
+                     n4b);
+  else SAST_LAUNCH(upsample_cat_bwd_kernel<size_t>, dim3((unsigned)((n4 + n4b + 255) / 256)), dim3(256), 0, st, dout, da, db, H, W, C1, C1 + C2, n4,
                      n4b);
   SAST_CHECK_LAUNCH();
   return SAST_OK;
