@@ -33,13 +33,31 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJo
   float* __restrict__ run_mean = jb.run_mean; float* __restrict__ run_var = jb.run_var; float* __restrict__ stats = jb.stats;
   const float* __restrict__ gamma = jb.gamma; const float* __restrict__ beta = jb.beta; float* __restrict__ y = jb.y;
   const int ldy = jb.ldy; const float momentum = jb.momentum, eps = jb.eps;
-  extern __shared__ float bn_sm[];   // [2C]: scale = rstd * gamma, shift = beta - mean * scale
+  extern __shared__ float bn_sm[];   // [2C]: mean, rstd
+  // Round 6: the statistics prologue issues all loads of a channel before the first is used (ISA before: two dependent rounds behind a
+  // branch), -0.25 % of the step.  Requesting the first ELEMENT of every thread in front of the prologue as well (-DSAST_BN_EARLY_LOADS=1)
+  // measured the same (profiles/r06_v): off.
+  const int c4 = C / 4;
+  const size_t e0 = (size_t)blockIdx.x * 256 * iters + threadIdx.x;
+#ifndef SAST_BN_EARLY_LOADS
+#define SAST_BN_EARLY_LOADS 0
+#endif
+  float4 v0 = zero4(), g0 = zero4(), b0 = zero4();
+  size_t m0 = 0; int cc0 = 0;
+  if (SAST_BN_EARLY_LOADS) {
+    const size_t ec = e0 < n4 ? e0 : 0;                                  // clamped: a thread past the end reads element 0 and stores nothing
+    m0 = fast_div((int)ec, c4, c4_mul); cc0 = (int)(ec - m0 * c4) * 4;
+    v0 = ld4(x + m0 * C + cc0); g0 = ld4(gamma + cc0); b0 = ld4(beta + cc0);
+  }
   for (int c = threadIdx.x; c < C; c += 256) {
     float mu, rs;
     if (training) {
+      double sk[BN_STAT_COPIES], qk[BN_STAT_COPIES];
+#pragma unroll
+      for (int k = 0; k < BN_STAT_COPIES; ++k) { sk[k] = sums[(size_t)k * 2 * C + c]; qk[k] = sums[(size_t)k * 2 * C + C + c]; }
       double s = 0.0, q = 0.0;
 #pragma unroll
-      for (int k = 0; k < BN_STAT_COPIES; ++k) { s += sums[(size_t)k * 2 * C + c]; q += sums[(size_t)k * 2 * C + C + c]; }
+      for (int k = 0; k < BN_STAT_COPIES; ++k) { s += sk[k]; q += qk[k]; }
       const double mean = s * invM;
       double var = q * invM - mean * mean;
       if (var < 0) var = 0;
@@ -56,19 +74,18 @@ __global__ __launch_bounds__(256) void bn_silu_apply_kernel(BnFwdJob j0, BnFwdJo
       }
     } else {
       mu = run_mean[c];
-      rs = 1.0f / sqrtf(run_var[c] + eps);
+      rs = rsqrt_hw(run_var[c] + eps);
     }
     if (blockIdx.x == 0) { stats[c] = mu; stats[C + c] = rs; }
     bn_sm[c] = mu; bn_sm[C + c] = rs;
   }
   __syncthreads();
-  const int c4 = C / 4;
-  const size_t e0 = (size_t)blockIdx.x * 256 * iters + threadIdx.x;
   for (int it = 0; it < iters; ++it) {
     const size_t e = e0 + (size_t)it * 256;
     if (e >= n4) return;
-    const size_t m = fast_div((int)e, c4, c4_mul); const int c = (int)(e - m * c4) * 4;   // n4 < 2^31 (launcher)
-    const float4 v = ld4(x + m * C + c), g = ld4(gamma + c), b = ld4(beta + c);
+    size_t m; int c; float4 v, g, b;
+    if (SAST_BN_EARLY_LOADS && it == 0) { m = m0; c = cc0; v = v0; g = g0; b = b0; }
+    else { m = fast_div((int)e, c4, c4_mul); c = (int)(e - m * c4) * 4; v = ld4(x + m * C + c); g = ld4(gamma + c); b = ld4(beta + c); }
     const float4 mu = *(const float4*)(bn_sm + c), rs = *(const float4*)(bn_sm + C + c);
     float4 z = make_float4((v.x - mu.x) * rs.x * g.x + b.x, (v.y - mu.y) * rs.y * g.y + b.y, (v.z - mu.z) * rs.z * g.z + b.z,
                            (v.w - mu.w) * rs.w * g.w + b.w);
@@ -149,8 +166,12 @@ struct BnBwdJob {
   int lddconv;        // row stride of dconv (two stacked convs write the halves of one [M, 2C] buffer)
 };
 __device__ __forceinline__ float4 bn_ld_dy(const float* __restrict__ dy, const float* __restrict__ dy2, size_t off) {
+  // branch-free (round 6): a load under `if (dy2)` makes hipcc drain vmcnt(0) behind it, which serialises every load issued before it;
+  // without a second gradient the second load re-reads dy (an L1 hit) and is multiplied away
   float4 d = ld4(dy + off);
-  if (dy2) { const float4 e = ld4(dy2 + off); d.x += e.x; d.y += e.y; d.z += e.z; d.w += e.w; }
+  const float4 e = ld4((dy2 ? dy2 : dy) + off);
+  const float k = dy2 ? 1.f : 0.f;
+  d.x = fmaf(k, e.x, d.x); d.y = fmaf(k, e.y, d.y); d.z = fmaf(k, e.z, d.z); d.w = fmaf(k, e.w, d.w);
   return d;
 }
 __global__ __launch_bounds__(BN_RED_THREADS) void bn_bwd_reduce_kernel(BnBwdJob j0, BnBwdJob j1, int M, int C, int rows_per_block) {
@@ -208,22 +229,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdJob j0, BnBwdJob
   const float* __restrict__ sums = jb.sums; float* __restrict__ dconv = jb.dconv;
   float* __restrict__ dgamma = jb.dgamma; float* __restrict__ dbeta = jb.dbeta;
   extern __shared__ float bsm[];   // [6][C]: mean, rstd, gamma, beta, mean(dz), mean(dz*xhat)
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < BN_STAT_COPIES; ++k) { s1 += sums[(size_t)k * 2 * C + c]; s2 += sums[(size_t)k * 2 * C + C + c]; }
-    if (blockIdx.x == 0 && dbeta) { dbeta[c] += s1; dgamma[c] += s2; }   // NULL: the host already published them (SyncBatchNorm: LOCAL sums)
-    bsm[c] = stats[c]; bsm[C + c] = stats[C + c]; bsm[2 * C + c] = gamma[c]; bsm[3 * C + c] = beta[c];
-    bsm[4 * C + c] = s1 * invM; bsm[5 * C + c] = s2 * invM;
-  }
-  __syncthreads();
+  // (round 6, as in bn_silu_apply_kernel: the first element's loads are requested before the statistics prologue, and all 12 loads of a
+  // channel of the prologue are issued before the first is used -- the block-0 publication of the affine gradients sits behind them)
   const int c4 = C / 4;
   const size_t e0 = (size_t)blockIdx.x * 256 * iters + threadIdx.x;
+  float4 v0 = zero4(), d0 = zero4();
+  size_t m0 = 0; int cc0 = 0;
+  if (SAST_BN_EARLY_LOADS) {
+    const size_t ec = e0 < n4 ? e0 : 0;
+    m0 = fast_div((int)ec, c4, c4_mul); cc0 = (int)(ec - m0 * c4) * 4;
+    v0 = ld4(x + m0 * C + cc0); d0 = bn_ld_dy(dy, jb.dy2, m0 * lddy + cc0);
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a1[BN_STAT_COPIES], a2[BN_STAT_COPIES];
+#pragma unroll
+    for (int k = 0; k < BN_STAT_COPIES; ++k) { a1[k] = sums[(size_t)k * 2 * C + c]; a2[k] = sums[(size_t)k * 2 * C + C + c]; }
+    const float st_mu = stats[c], st_rs = stats[C + c], gm = gamma[c], bt = beta[c];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < BN_STAT_COPIES; ++k) { s1 += a1[k]; s2 += a2[k]; }
+    bsm[c] = st_mu; bsm[C + c] = st_rs; bsm[2 * C + c] = gm; bsm[3 * C + c] = bt;
+    bsm[4 * C + c] = s1 * invM; bsm[5 * C + c] = s2 * invM;
+    if (blockIdx.x == 0 && dbeta) { dbeta[c] += s1; dgamma[c] += s2; }   // NULL: the host already published them (SyncBatchNorm: LOCAL sums)
+  }
+  __syncthreads();
   for (int it = 0; it < iters; ++it) {
     const size_t e4 = e0 + (size_t)it * 256;
     if (e4 >= n4) return;
-    const size_t m = fast_div((int)e4, c4, c4_mul); const int c = (int)(e4 - m * c4) * 4;   // n4 < 2^31 (launcher)
-    const float4 v = ld4(x + m * C + c), d = bn_ld_dy(dy, jb.dy2, m * lddy + c);
+    size_t m; int c; float4 v, d;
+    if (SAST_BN_EARLY_LOADS && it == 0) { m = m0; c = cc0; v = v0; d = d0; }
+    else { m = fast_div((int)e4, c4, c4_mul); c = (int)(e4 - m * c4) * 4; v = ld4(x + m * C + c); d = bn_ld_dy(dy, jb.dy2, m * lddy + c); }
     float out[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
