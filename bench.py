@@ -219,12 +219,11 @@ def parity_vs_oracle(tr, p, f, loss_cpu, P_cpu):
         for k, v in mod.named_parameters():
             names.setdefault(id(v), pre + k)
     worst, worst_kink, off, n = (0.0, None), (0.0, None), 0, 0
-    for prm in tr.flat.params:
+    for prm, off in zip(tr.flat.params, tr.flat.offsets):
         k = prm.numel()
         name = names[id(prm)]
         from sast_amd.dist import _phys_view
         g = _phys_view(s0["grad"][off:off + k], prm)
-        off += (k + 3) // 4 * 4
         ref = (p if name.startswith("net.") else f)[name[4:]].grad
         if ref is None:
             continue

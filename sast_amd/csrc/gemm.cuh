@@ -73,40 +73,71 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 // middle 8 and bottom 8 significand bits; truncation, so the residuals are exact), packed as the 8-element operands of
 // v_mfma_f32_32x32x16_bf16 (element j in bits [16j, 16j+16))
 struct Split3 { bf16x8 h, m, l; };
-__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
-  unsigned h[8], m[8], l[8];
+// SAST_SPLIT_PK=1 (A/B builds): the two residuals of a PAIR of values as one packed subtraction each (v_pk_add_f32; the residuals are
+// exact, so the packed form gives the same bits) -- 4.5 VALU instructions per value instead of 5.5, and MEASURED SLOWER: +1.2 % on the
+// step (profiles/r06_w_ab_split_pk_and_weight_planes.txt); packed fp32 beside MFMAs costs more than the issue slot it saves.
+#ifndef SAST_SPLIT_PK
+#define SAST_SPLIT_PK 0
+#endif
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+// x[0..1] -> the packed (element 1 << 16 | element 0) bf16 pairs of the three terms
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& ph, unsigned& pm, unsigned& pl) {
+#if SAST_SPLIT_PK
+  const f32x2 x = {x0, x1};
+  const u32x2 h = __builtin_bit_cast(u32x2, x) & 0xffff0000u;
+  const f32x2 r1 = x - __builtin_bit_cast(f32x2, h);
+  const u32x2 m = __builtin_bit_cast(u32x2, r1) & 0xffff0000u;
+  const u32x2 l = __builtin_bit_cast(u32x2, r1 - __builtin_bit_cast(f32x2, m));   // <= 8 significant bits left: its high half IS the bf16
+#else
+  unsigned h[2], m[2], l[2];
+  const float xs[2] = {x0, x1};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    h[i] = __float_as_uint(x[i]) & 0xffff0000u;
-    const float r1 = x[i] - __uint_as_float(h[i]);
+  for (int i = 0; i < 2; ++i) {
+    h[i] = __float_as_uint(xs[i]) & 0xffff0000u;
+    const float r1 = xs[i] - __uint_as_float(h[i]);
     m[i] = __float_as_uint(r1) & 0xffff0000u;
     l[i] = __float_as_uint(r1 - __uint_as_float(m[i]));      // <= 8 significant bits left: its high half IS the bf16
   }
+#endif
+  ph = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u);      // (hi16 of element 1) << 16 | hi16 of element 0
+  pm = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u);
+  pl = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u);
+}
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
   u32x4 ph, pm, pl;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {      // (hi16 of element 2i+1) << 16 | hi16 of element 2i
-    ph[i] = __builtin_amdgcn_perm(h[2 * i + 1], h[2 * i], 0x07060302u);
-    pm[i] = __builtin_amdgcn_perm(m[2 * i + 1], m[2 * i], 0x07060302u);
-    pl[i] = __builtin_amdgcn_perm(l[2 * i + 1], l[2 * i], 0x07060302u);
+  for (int i = 0; i < 4; ++i) {
+    unsigned a, b, c;
+    split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
+    ph[i] = a; pm[i] = b; pl[i] = c;
   }
   return Split3{__builtin_bit_cast(bf16x8, ph), __builtin_bit_cast(bf16x8, pm), __builtin_bit_cast(bf16x8, pl)};
 }
 
 // the same split for the 4 consecutive k-values a thread stores to LDS: three 8-byte pieces, one per plane (plane stride in floats)
 __device__ __forceinline__ void store_split3(float* dst, int plane_floats, float4 v) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = __float_as_uint(x[i]) & 0xffff0000u;
-    const float r1 = x[i] - __uint_as_float(h[i]);
-    m[i] = __float_as_uint(r1) & 0xffff0000u;
-    l[i] = __float_as_uint(r1 - __uint_as_float(m[i]));
-  }
-  using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-  *reinterpret_cast<u32x2*>(dst) = u32x2{__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
-  *reinterpret_cast<u32x2*>(dst + plane_floats) = u32x2{__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
-  *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = u32x2{__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+  u32x2 h, m, l;
+  { unsigned a, b, c; split3_pair(v.x, v.y, a, b, c); h[0] = a; m[0] = b; l[0] = c; }
+  { unsigned a, b, c; split3_pair(v.z, v.w, a, b, c); h[1] = a; m[1] = b; l[1] = c; }
+  *reinterpret_cast<u32x2*>(dst) = h;
+  *reinterpret_cast<u32x2*>(dst + plane_floats) = m;
+  *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = l;
+}
+
+// TIMING PROBE ONLY (-DSAST_PROBE_B_SPLIT_FREE=1, wrong numbers): the B operand of the non-split-R GEMMs -- always a weight -- is
+// stored as its top plane and two copies of it, i.e. what staging would cost if the weights arrived already split AT THE SAME LOAD
+// COUNT (-3.7 % on the step; every real layout of pre-split weights in HBM needs 1.5 loads per 4 values and measured slower:
+// profiles/r06_w_ab_split_pk_and_weight_planes.txt, tools/experiments/r06_weight_planes.patch)
+#ifndef SAST_PROBE_B_SPLIT_FREE
+#define SAST_PROBE_B_SPLIT_FREE 0
+#endif
+__device__ __forceinline__ void store_split3_probe(float* dst, int plane_floats, float4 v) {
+  const u32x2 h = {__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u),
+                   __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u)};
+  *reinterpret_cast<u32x2*>(dst) = h;
+  *reinterpret_cast<u32x2*>(dst + plane_floats) = h;
+  *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = h;
 }
 
 // a lane's MFMA operand (8 consecutive k of index c0 + lane % 32, k = 8 * (lane / 32) + j) from the three [k][W] bf16 planes of an
@@ -429,7 +460,8 @@ __device__ __forceinline__ void gemm_body(const LA& la, const LB& lb, const EP& 
 #pragma unroll
     for (int it = 0; it < B_PER; ++it)
       if (B_SLOTS % NT == 0 || tid + it * NT < B_SLOTS) {
-        if constexpr (PSB) store_split3(bs + lb_off[it], BN * 8, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+        if constexpr (PSB && SAST_PROBE_B_SPLIT_FREE && !SPLIT) store_split3_probe(bs + lb_off[it], BN * 8, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
+        else if constexpr (PSB) store_split3(bs + lb_off[it], BN * 8, lb.finish(rb[set][it], ab[set][it], ob[set][it]));
         else st4(bs + lb_off[it], lb.finish(rb[set][it], ab[set][it], ob[set][it]));
       }
   };

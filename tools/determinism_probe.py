@@ -53,13 +53,12 @@ def main():
         return float(loss), [int(p) for p in P], [o.detach().clone() for o in outs]
 
     def per_param(flat, names, ga, gb, top=8):
-        rows, off = [], 0
-        for p, n in zip(flat.params, names):
+        rows = []
+        for p, n, off in zip(flat.params, names, flat.offsets):
             k = p.numel()
             a, b = ga[off:off + k], gb[off:off + k]
             sc = float(b.abs().max())
             rows.append((float((a - b).abs().max()) / (sc + 1e-30), n, sc))
-            off += (k + 3) // 4 * 4
         rows.sort(reverse=True)
         return rows[:top]
 
