@@ -548,6 +548,13 @@ def main():
         print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+        if world > 1:
+            # the result is out and the group is gone: leave without the interpreter's teardown.  With 8 ranks the communicator /
+            # socket destructors that run at exit abort now and then when the peers close together (seen with gloo on the CPU
+            # tests: SIGABRT after every rank had finished) -- torch.distributed.run would report that as a failed run
+            _flush_c_stdio()
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":

@@ -120,8 +120,12 @@ for step in range(3):
     ropt.zero_grad(); sum((ref(x) ** 2).mean() for x in xs).div(world).backward(); ropt.step()
 for a, b in zip(m.parameters(), ref.parameters()):
     assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
+import os as _os, sys as _sys
+_sys.stdout.flush()
+_os._exit(0)      # (skip interpreter teardown: gloo's pair destructors abort now and then when 8 peers close their sockets together)
 '''
 
 
@@ -191,8 +195,12 @@ for it, set_to_none in enumerate((True, True, False)):
         ref1, ref2 = ref1 + w1.grad / world, ref2 + w2.grad / world
     assert torch.allclose(net.w1.grad, ref1, rtol=1e-5, atol=1e-6), (mode, it, float((net.w1.grad - ref1).abs().max()))
     assert torch.allclose(net.w2.grad, ref2, rtol=1e-5, atol=1e-6), (mode, it)
+dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, mode, "ok")
+import os as _os, sys as _sys
+_sys.stdout.flush()
+_os._exit(0)      # (skip interpreter teardown: gloo's pair destructors abort now and then when 8 peers close their sockets together)
 '''
 
 
@@ -322,8 +330,12 @@ for prm in flat.params:
     n = names[id(prm)]
     worst = max(worst, float((prm.detach() - ref_all[n].detach()).abs().max()))
 assert worst <= 1e-5, worst      # updates are lr-sized (up to 1e-3 per step): <= 1 % of one update after 3 steps (measured 2.6e-6)
+dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok", worst)
+import os as _os, sys as _sys
+_sys.stdout.flush()
+_os._exit(0)      # (skip interpreter teardown: gloo's pair destructors abort now and then when 8 peers close their sockets together)
 '''
 
 
@@ -464,8 +476,12 @@ tok = g.exchange_batch(n_local, torch.device("cpu"))
 n_total = sum(r % 3 + 1 for r in range(world))
 assert tok == (g, n_local) and g._ratio == (n_total, n_local) and g.n_collectives == 3
 assert g.rows_total(n_local * 48 * 80, n_local) == n_total * 48 * 80
+dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
+import os as _os, sys as _sys
+_sys.stdout.flush()
+_os._exit(0)      # (skip interpreter teardown: gloo's pair destructors abort now and then when 8 peers close their sockets together)
 '''
 
 
