@@ -125,19 +125,21 @@ __device__ __forceinline__ void store_split3(float* dst, int plane_floats, float
   *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = l;
 }
 
-// TIMING PROBE ONLY (-DSAST_PROBE_B_SPLIT_FREE=1, wrong numbers): the B operand of the non-split-R GEMMs -- always a weight -- is
-// stored as its top plane and two copies of it, i.e. what staging would cost if the weights arrived already split AT THE SAME LOAD
-// COUNT (-3.7 % on the step; every real layout of pre-split weights in HBM needs 1.5 loads per 4 values and measured slower:
-// profiles/r06_w_ab_split_pk_and_weight_planes.txt, tools/experiments/r06_weight_planes.patch)
+// TIMING PROBE ONLY (-DSAST_PROBE_B_SPLIT_FREE=1, approximate numbers): the B operand of the non-split-R GEMMs -- always a weight -- is
+// stored as its top plane only (middle and bottom planes zero: the products lose ~2^-8 relative, the selection stays where it was --
+// bench.py prints the kept-token fractions), i.e. what staging would cost if the weights arrived already split AT THE SAME LOAD COUNT.
+// Every real layout of pre-split weights in HBM needs 1.5 loads per 4 values and measured slower:
+// profiles/r06_w_ab_split_pk_and_weight_planes.txt, tools/experiments/r06_weight_planes.patch
 #ifndef SAST_PROBE_B_SPLIT_FREE
 #define SAST_PROBE_B_SPLIT_FREE 0
 #endif
 __device__ __forceinline__ void store_split3_probe(float* dst, int plane_floats, float4 v) {
   const u32x2 h = {__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u),
                    __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u)};
+  const u32x2 z = {0u, 0u};
   *reinterpret_cast<u32x2*>(dst) = h;
-  *reinterpret_cast<u32x2*>(dst + plane_floats) = h;
-  *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = h;
+  *reinterpret_cast<u32x2*>(dst + plane_floats) = z;
+  *reinterpret_cast<u32x2*>(dst + 2 * plane_floats) = z;
 }
 
 // a lane's MFMA operand (8 consecutive k of index c0 + lane % 32, k = 8 * (lane / 32) + j) from the three [k][W] bf16 planes of an
